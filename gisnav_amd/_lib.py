@@ -1,0 +1,81 @@
+"""ctypes binding of libgisnav_amd.so (the C ABI declared in include/gisnav_amd.h).
+
+There is no fallback path: if the shared library is missing or a symbol cannot be resolved
+this module raises, so a GPU box can never silently run anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgisnav_amd.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+VP = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gisnav_amd.h one to one
+SIGNATURES = {
+    "gn_version": (C.c_char_p, []),
+    "gn_last_error": (C.c_char_p, [VP]),
+    "gn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
+    "gn_destroy": (None, [VP]),
+    "gn_load_tensor": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
+    "gn_missing_tensors": (C.c_int, [VP]),
+    "gn_set_num_layers": (C.c_int, [VP, C.c_int]),
+    "gn_set_filter_threshold": (C.c_int, [VP, C.c_float]),
+    "gn_match": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, VP]),
+    "gn_kmax": (C.c_int, [VP]),
+    "gn_gather_points": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),
+    "gn_pnp_ransac": (C.c_int, [VP, C.c_int, VP, VP, VP, C.c_int, c_f64p, C.c_int, C.c_float, C.c_double, C.c_int,
+                                VP, VP, VP, VP, VP]),
+    "gn_estimate": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, VP, C.c_int, C.c_int,
+                              c_f64p, C.c_int, VP, VP, VP, VP, VP, VP]),
+    "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
+    "gn_debug_gemm": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
+    "gn_debug_attention": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, VP, C.c_int,
+                                     VP, VP, C.c_int, VP]),
+    "gn_set_stage_timing": (C.c_int, [VP, C.c_int]),
+    "gn_get_stage_ms": (C.c_int, [VP, c_f32p, C.c_int]),
+}
+
+STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")
+
+GN_PREC_F32 = 0
+GN_PREC_BF16_ATTN = 1
+GN_KPT_LAF = 0
+GN_KPT_XYSA = 1
+
+
+class GnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnError(f"{LIB_PATH} not found: build it with `python -m gisnav_amd.build` "
+                      "(there is no CPU fallback for the product path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc: int, what: str) -> None:
+    if rc < 0:
+        msg = load().gn_last_error(ctx)
+        raise GnError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

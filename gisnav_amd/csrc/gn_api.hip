@@ -1,0 +1,562 @@
+// C ABI of libgisnav_amd.so: context, weight loading, and the stream-ordered schedule of the
+// PoseNode hot path (ros/gisnav/gisnav/core/pose_node.py:246-308, core/_shared.py:89-125).
+// See include/gisnav_amd.h for the contract of every entry point.
+#include "gn_common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+using namespace gn;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+
+struct Block {       // one SelfBlock or CrossBlock
+  Linear proj_in;    // self: Wqkv re-ordered to [q|k|v][head][d] (768x256); cross: [to_qk ; to_v] (512x256)
+  Linear proj_out;   // out_proj / to_out
+  Linear ffn0;       // 512x512
+  float* ln_g = nullptr; float* ln_b = nullptr;
+  Linear ffn3;       // 256x512
+};
+
+enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, ST_COUNT };
+
+}  // namespace
+
+struct gn_ctx {
+  int device = 0, max_batch = 0, npad = 0, precision = 0;
+  int n_layers = kMaxLayers;
+  float threshold = 0.5f;
+  std::string err;
+  // weights
+  Linear input_proj;
+  float* wr = nullptr;
+  Block self_blk[kMaxLayers], cross_blk[kMaxLayers];
+  Linear final_proj[kMaxLayers], matchability[kMaxLayers];
+  std::map<std::string, bool> loaded;
+  std::vector<std::string> required;
+  // workspace
+  float *desc = nullptr, *cos_t = nullptr, *sin_t = nullptr, *extent = nullptr;
+  int32_t* nvalid = nullptr;
+  float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *h = nullptr, *md = nullptr, *ls = nullptr;
+  float* sim = nullptr;
+  float *rowmax = nullptr, *rowlog = nullptr, *colmax = nullptr, *collog = nullptr, *max0 = nullptr;
+  int32_t *m0 = nullptr, *m1 = nullptr;
+  // pipeline scratch for gn_estimate
+  int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
+  uint8_t* mask_ws = nullptr;
+  std::vector<void*> allocs;
+  // stage timing
+  bool timing = false;
+  hipEvent_t ev[2 * 128];
+  int ev_stage[128]; int n_ev = 0; bool ev_ready = false;
+  float stage_ms[ST_COUNT] = {0};
+};
+
+namespace {
+
+#define GN_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      char buf_[512];                                                                             \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      if (ctx) ctx->err = buf_;                                                                   \
+      g_err = buf_;                                                                               \
+      return GN_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+int fail(gn_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_err = msg;
+  return code;
+}
+
+template <typename T>
+int dalloc(gn_ctx* ctx, T** p, size_t count) {
+  void* q = nullptr;
+  GN_HIP(hipMalloc(&q, count * sizeof(T)));
+  GN_HIP(hipMemset(q, 0, count * sizeof(T)));
+  ctx->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return GN_OK;
+}
+
+std::string canonical(const std::string& k) {
+  for (const char* kind : {"self_attn.", "cross_attn."}) {
+    const size_t L = strlen(kind);
+    if (k.compare(0, L, kind) == 0) {
+      const size_t dot = k.find('.', L);
+      if (dot == std::string::npos) return k;
+      return "transformers." + k.substr(L, dot - L) + "." + std::string(kind) + k.substr(dot + 1);
+    }
+  }
+  return k;
+}
+
+struct StageTimer {
+  gn_ctx* c; hipStream_t s; int st;
+  StageTimer(gn_ctx* c_, hipStream_t s_, int st_) : c(c_), s(s_), st(st_) {
+    if (c->timing && c->n_ev < 128) { hipEventRecord(c->ev[2 * c->n_ev], s); }
+  }
+  ~StageTimer() {
+    if (c->timing && c->n_ev < 128) { hipEventRecord(c->ev[2 * c->n_ev + 1], s); c->ev_stage[c->n_ev] = st; ++c->n_ev; }
+  }
+};
+
+void gemm(gn_ctx* c, int epi, GemmArgs& g, hipStream_t s) {
+  g.strideA = g.strideW = g.strideY = 0;
+  launch_gemm_f32(epi, g, 1, s);
+}
+
+GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, int M) {
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.lda = lda; g.A2 = nullptr; g.lda2 = 0; g.K1 = L.in;
+  g.W = L.w; g.ldw = L.in; g.bias = L.b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = L.out; g.K = L.in;
+  return g;
+}
+
+void attention(gn_ctx* c, const AttnArgs& a, hipStream_t s) {
+  if (c->precision == GN_PREC_BF16_ATTN) launch_attention_bf16(a, s); else launch_attention_f32(a, s);
+}
+
+// x += ffn3(gelu(ln(ffn0([x | msg]))))
+void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
+  GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
+  g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
+  gemm(c, EPI_BIAS, g, s);
+  launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s);
+  GemmArgs g3 = gemm_args(c->h, 2 * kDim, blk.ffn3, c->x, kDim, T);
+  g3.resid = c->x; g3.ldr = kDim;
+  gemm(c, EPI_RESIDUAL, g3, s);
+}
+
+int run_matcher(gn_ctx* c, int B, int kpt_format,
+                const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                int64_t* idx, float* score, int32_t* n_match, hipStream_t s) {
+  const int np = c->npad, T = B * 2 * np, BS = B * 2;
+  {
+    StageTimer tm(c, s, ST_PREP);
+    PrepArgs p;
+    p.desc_q = desc_q; p.kpt_q = kpt_q; p.n_q = n_q; p.stride_q = stride_q;
+    p.desc_r = desc_r; p.kpt_r = kpt_r; p.n_r = n_r; p.stride_r = stride_r;
+    p.kpt_format = kpt_format; p.B = B; p.npad = np; p.wr = c->wr;
+    p.desc = c->desc; p.kxy = nullptr; p.cos_t = c->cos_t; p.sin_t = c->sin_t; p.nvalid = c->nvalid; p.extent = c->extent;
+    launch_prep(p, s);
+    GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
+    gemm(c, EPI_BIAS, g, s);
+  }
+  for (int i = 0; i < c->n_layers; ++i) {
+    {  // SelfBlock on both sides at once
+      const Block& blk = c->self_blk[i];
+      {
+        StageTimer tm(c, s, ST_PROJ);
+        GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 3 * kDim, T);
+        g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
+        gemm(c, EPI_ROTARY, g, s);
+      }
+      {
+        StageTimer tm(c, s, ST_ATTN);
+        AttnArgs a;
+        a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
+        a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
+        attention(c, a, s);
+      }
+      {
+        StageTimer tm(c, s, ST_PROJ);
+        GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
+        gemm(c, EPI_BIAS, g, s);
+      }
+      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s); }
+    }
+    {  // CrossBlock
+      const Block& blk = c->cross_blk[i];
+      {
+        StageTimer tm(c, s, ST_PROJ);
+        GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 2 * kDim, T);
+        g.scale = 0.35355339059327373f;  // (dim_head ** -0.5) ** 0.5 applied to both qk sides
+        g.scale_cols = kDim;
+        gemm(c, EPI_SCALE_COLS, g, s);
+      }
+      {
+        StageTimer tm(c, s, ST_ATTN);
+        AttnArgs a;
+        a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
+        a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
+        attention(c, a, s);
+      }
+      {
+        StageTimer tm(c, s, ST_PROJ);
+        GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
+        gemm(c, EPI_BIAS, g, s);
+      }
+      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s); }
+    }
+  }
+  {
+    StageTimer tm(c, s, ST_HEAD);
+    const int li = c->n_layers - 1;
+    GemmArgs g = gemm_args(c->x, kDim, c->final_proj[li], c->md, kDim, T);
+    g.scale = 0.25f; g.scale_cols = kDim;  // / d ** 0.25
+    gemm(c, EPI_SCALE_COLS, g, s);
+    launch_matchability(c->x, c->matchability[li].w, c->matchability[li].b, c->ls, T, s);
+    GemmArgs gs;
+    memset(&gs, 0, sizeof gs);
+    gs.A = c->md; gs.lda = kDim; gs.K1 = kDim; gs.W = c->md + (size_t)np * kDim; gs.ldw = kDim;
+    gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim;
+    gs.strideA = gs.strideW = 2LL * np * kDim; gs.strideY = (long long)np * np;
+    launch_gemm_f32(EPI_PLAIN, gs, B, s);
+    HeadArgs hd;
+    hd.sim = c->sim; hd.ls = c->ls; hd.nvalid = c->nvalid; hd.B = B; hd.npad = np; hd.threshold = c->threshold;
+    hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
+    hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
+    hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = np;
+    launch_match_head(hd, s);
+  }
+  return GN_OK;
+}
+
+int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
+  if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
+  if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
+    return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
+  if (gn_missing_tensors(ctx) != 0) return fail(ctx, GN_ERR_WEIGHTS, "weights not fully loaded");
+  return GN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gn_version(void) { return "gisnav_amd 0.1.0 gfx950"; }
+
+const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out) {
+  gn_ctx* ctx = nullptr;
+  if (!out || max_batch < 1 || max_kpts < 2) return fail(nullptr, GN_ERR_ARG, "bad gn_create argument");
+  if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN) return fail(nullptr, GN_ERR_ARG, "bad precision");
+  GN_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  GN_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, GN_ERR_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  ctx = new gn_ctx();
+  ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision;
+  ctx->npad = ((max_kpts + 127) / 128) * 128;
+  const size_t np = ctx->npad, T = (size_t)max_batch * 2 * np, B = max_batch;
+#define GN_ALLOC(field, count)                                     \
+  do { int rc_ = dalloc(ctx, &ctx->field, (count)); if (rc_ != GN_OK) { gn_destroy(ctx); return rc_; } } while (0)
+  GN_ALLOC(desc, T * kInDim); GN_ALLOC(cos_t, T * kFreq); GN_ALLOC(sin_t, T * kFreq);
+  GN_ALLOC(extent, B * 4); GN_ALLOC(nvalid, B * 2);
+  GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
+  GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
+  GN_ALLOC(sim, B * np * np);
+  GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
+  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
+  GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
+  GN_ALLOC(mask_ws, B * np * 2);
+#undef GN_ALLOC
+  for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
+  ctx->ev_ready = true;
+  // required tensor names
+  auto req = [&](const std::string& n) { ctx->required.push_back(n + ".weight"); ctx->required.push_back(n + ".bias"); };
+  req("input_proj");
+  ctx->required.push_back("posenc.Wr.weight");
+  for (int i = 0; i < kMaxLayers; ++i) {
+    const std::string ps = "transformers." + std::to_string(i) + ".self_attn.", pc = "transformers." + std::to_string(i) + ".cross_attn.";
+    req(ps + "Wqkv"); req(ps + "out_proj"); req(ps + "ffn.0"); req(ps + "ffn.1"); req(ps + "ffn.3");
+    req(pc + "to_qk"); req(pc + "to_v"); req(pc + "to_out"); req(pc + "ffn.0"); req(pc + "ffn.1"); req(pc + "ffn.3");
+    req("log_assignment." + std::to_string(i) + ".final_proj");
+    req("log_assignment." + std::to_string(i) + ".matchability");
+  }
+  *out = ctx;
+  return GN_OK;
+}
+
+void gn_destroy(gn_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  for (void* p : ctx->allocs) hipFree(p);
+  if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
+  delete ctx;
+}
+
+int gn_missing_tensors(const gn_ctx* ctx) {
+  if (!ctx) return -1;
+  int missing = 0;
+  for (const auto& n : ctx->required) {
+    // log_assignment.{i} for i other than the last configured layer is optional
+    if (n.compare(0, 15, "log_assignment.") == 0) {
+      const int i = atoi(n.c_str() + 15);
+      if (i != ctx->n_layers - 1) continue;
+    }
+    if (n.compare(0, 13, "transformers.") == 0) {
+      const int i = atoi(n.c_str() + 13);
+      if (i >= ctx->n_layers) continue;
+    }
+    if (!ctx->loaded.count(n)) ++missing;
+  }
+  return missing;
+}
+
+int gn_set_num_layers(gn_ctx* ctx, int n_layers) {
+  if (!ctx || n_layers < 1 || n_layers > kMaxLayers) return fail(ctx, GN_ERR_ARG, "n_layers must be in 1..9");
+  ctx->n_layers = n_layers;
+  return GN_OK;
+}
+
+int gn_set_filter_threshold(gn_ctx* ctx, float th) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->threshold = th;
+  return GN_OK;
+}
+
+int gn_kmax(const gn_ctx* ctx) { return ctx ? ctx->npad : GN_ERR_ARG; }
+
+int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int64_t* shape, int ndim) {
+  if (!ctx || !name_c || !host || !shape || ndim < 1 || ndim > 2) return fail(ctx, GN_ERR_ARG, "bad gn_load_tensor argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  const std::string name = canonical(name_c);
+  if (name.compare(0, 17, "token_confidence.") == 0 || name == "confidence_thresholds") return GN_OK;  // dead in the live config
+  const int64_t d0 = shape[0], d1 = ndim == 2 ? shape[1] : 1;
+  auto upload = [&](float** dst, const float* src, size_t count) -> int {
+    if (*dst == nullptr) { int rc = dalloc(ctx, dst, count); if (rc != GN_OK) return rc; }
+    GN_HIP(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+    return GN_OK;
+  };
+  auto shape_err = [&]() { return fail(ctx, GN_ERR_SHAPE, "shape mismatch for " + name); };
+  const bool is_w = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+  const bool is_b = name.size() > 5 && name.compare(name.size() - 5, 5, ".bias") == 0;
+  if (!is_w && !is_b) return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
+  const std::string base = name.substr(0, name.size() - (is_w ? 7 : 5));
+
+  auto load_linear = [&](Linear& L, int out, int in, int row_off, int rows_total) -> int {
+    // loads rows [row_off, row_off + out) of a (rows_total x in) fused matrix
+    if (is_w) {
+      if (ndim != 2 || d0 != out || d1 != in) return shape_err();
+      if (!L.w) { int rc = dalloc(ctx, &L.w, (size_t)rows_total * in); if (rc != GN_OK) return rc; }
+      GN_HIP(hipMemcpy(L.w + (size_t)row_off * in, host, (size_t)out * in * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      if (d0 != out || d1 != 1) return shape_err();
+      if (!L.b) { int rc = dalloc(ctx, &L.b, (size_t)rows_total); if (rc != GN_OK) return rc; }
+      GN_HIP(hipMemcpy(L.b + row_off, host, (size_t)out * sizeof(float), hipMemcpyHostToDevice));
+    }
+    L.out = rows_total; L.in = in;
+    return GN_OK;
+  };
+
+  int rc = GN_ERR_NAME;
+  if (base == "input_proj") rc = load_linear(ctx->input_proj, kDim, kInDim, 0, kDim);
+  else if (base == "posenc.Wr") {
+    if (!is_w || ndim != 2 || d0 != kFreq || d1 != 4) return shape_err();
+    rc = upload(&ctx->wr, host, kFreq * 4);
+  } else if (base.compare(0, 13, "transformers.") == 0) {
+    const int i = atoi(base.c_str() + 13);
+    if (i < 0 || i >= kMaxLayers) return fail(ctx, GN_ERR_NAME, "layer index out of range in " + name);
+    const size_t p1 = base.find('.', 13);
+    const std::string rest = base.substr(p1 + 1);  // e.g. self_attn.Wqkv
+    const bool self = rest.compare(0, 10, "self_attn.") == 0;
+    const bool cross = rest.compare(0, 11, "cross_attn.") == 0;
+    if (!self && !cross) return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
+    const std::string leaf = rest.substr(self ? 10 : 11);
+    Block& blk = self ? ctx->self_blk[i] : ctx->cross_blk[i];
+    if (self && leaf == "Wqkv") {
+      // kornia splits the 768 outputs as unflatten(-1, (heads, 64, 3)): flat = h*192 + d*3 + s.
+      // Re-order rows to [s][h][d] so q, k, v are contiguous 256-wide panels (numerically identical:
+      // every output feature keeps its own weight row and bias).
+      if (is_w) { if (ndim != 2 || d0 != 3 * kDim || d1 != kDim) return shape_err(); }
+      else if (d0 != 3 * kDim || d1 != 1) return shape_err();
+      const int in = is_w ? kDim : 1;
+      std::vector<float> tmp((size_t)3 * kDim * in);
+      for (int hh = 0; hh < kHeads; ++hh)
+        for (int d = 0; d < kHeadDim; ++d)
+          for (int s3 = 0; s3 < 3; ++s3) {
+            const int src = hh * 192 + d * 3 + s3, dst = s3 * kDim + hh * kHeadDim + d;
+            memcpy(&tmp[(size_t)dst * in], host + (size_t)src * in, in * sizeof(float));
+          }
+      Linear& L = blk.proj_in;
+      if (is_w) { rc = upload(&L.w, tmp.data(), tmp.size()); } else { rc = upload(&L.b, tmp.data(), tmp.size()); }
+      L.out = 3 * kDim; L.in = kDim;
+    } else if (self && leaf == "out_proj") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
+    else if (cross && leaf == "to_qk") rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim);
+    else if (cross && leaf == "to_v") rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim);
+    else if (cross && leaf == "to_out") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
+    else if (leaf == "ffn.0") rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim);
+    else if (leaf == "ffn.3") rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim);
+    else if (leaf == "ffn.1") {
+      if (d0 != 2 * kDim || d1 != 1) return shape_err();
+      rc = upload(is_w ? &blk.ln_g : &blk.ln_b, host, 2 * kDim);
+    } else return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
+  } else if (base.compare(0, 15, "log_assignment.") == 0) {
+    const int i = atoi(base.c_str() + 15);
+    if (i < 0 || i >= kMaxLayers) return fail(ctx, GN_ERR_NAME, "layer index out of range in " + name);
+    const std::string leaf = base.substr(base.find('.', 15) + 1);
+    if (leaf == "final_proj") rc = load_linear(ctx->final_proj[i], kDim, kDim, 0, kDim);
+    else if (leaf == "matchability") {
+      if (is_w) { if (ndim != 2 || d0 != 1 || d1 != kDim) return shape_err(); rc = upload(&ctx->matchability[i].w, host, kDim); }
+      else { if (d0 != 1) return shape_err(); rc = upload(&ctx->matchability[i].b, host, 1); }
+    } else return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
+  } else {
+    return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
+  }
+  if (rc == GN_OK) ctx->loaded[name] = true;
+  return rc;
+}
+
+int gn_match(gn_ctx* ctx, int B, int kpt_format,
+             const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+             const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+             int64_t* idx, float* score, int32_t* n_match, void* stream) {
+  int rc = check_fwd(ctx, B, stride_q, stride_r);
+  if (rc != GN_OK) return rc;
+  if (!desc_q || !kpt_q || !n_q || !desc_r || !kpt_r || !n_r || !idx || !score || !n_match)
+    return fail(ctx, GN_ERR_ARG, "null pointer passed to gn_match");
+  if ((kpt_format & 0xff) != GN_KPT_LAF && (kpt_format & 0xff) != GN_KPT_XYSA) return fail(ctx, GN_ERR_ARG, "bad kpt_format");
+  GN_HIP(hipSetDevice(ctx->device));
+  ctx->n_ev = 0;
+  rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
+                   (hipStream_t)stream);
+  if (rc != GN_OK) return rc;
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_gather_points(gn_ctx* ctx, int B, int kpt_format, const float* kpt_q, int stride_q, const float* kpt_r, int stride_r,
+                     const int64_t* idx, const int32_t* n_match, const uint8_t* dem, int H, int W,
+                     float* mkp_q, float* obj, void* stream) {
+  if (!ctx || !kpt_q || !kpt_r || !idx || !n_match || !mkp_q || !obj || B < 1 || B > ctx->max_batch)
+    return fail(ctx, GN_ERR_ARG, "bad gn_gather_points argument");
+  if (dem && (H < 1 || W < 1)) return fail(ctx, GN_ERR_ARG, "bad DEM shape");
+  GN_HIP(hipSetDevice(ctx->device));
+  GatherArgs g;
+  g.kpt_q = kpt_q; g.stride_q = stride_q; g.kpt_r = kpt_r; g.stride_r = stride_r; g.kpt_format = kpt_format & 0xff;
+  g.idx = idx; g.n_match = n_match; g.kmax = ctx->npad; g.B = B; g.dem = dem; g.H = H; g.W = W; g.mkp_q = mkp_q; g.obj = obj;
+  StageTimer tm(ctx, (hipStream_t)stream, ST_GATHER);
+  launch_gather(g, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const int32_t* n_pts, int kstride,
+                  const double* K9, int iterations_count, float reproj_error_px, double confidence, int min_pts,
+                  double* R, double* t, int32_t* n_inliers, uint8_t* ok, void* stream) {
+  if (!ctx || !obj || !img || !n_pts || !K9 || !R || !t || !n_inliers || !ok || B < 1 || B > ctx->max_batch)
+    return fail(ctx, GN_ERR_ARG, "bad gn_pnp_ransac argument");
+  if (kstride < 1 || kstride > ctx->npad) return fail(ctx, GN_ERR_ARG, "kstride exceeds max_kpts of this context");
+  GN_HIP(hipSetDevice(ctx->device));
+  PnpArgs a;
+  a.obj = obj; a.img = img; a.n_pts = n_pts; a.kstride = kstride; a.B = B;
+  a.fx = K9[0]; a.fy = K9[4]; a.cx = K9[2]; a.cy = K9[5];
+  a.iterations = iterations_count; a.reproj = reproj_error_px; a.confidence = confidence; a.min_pts = min_pts;
+  a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws;
+  StageTimer tm(ctx, (hipStream_t)stream, ST_PNP);
+  launch_pnp(a, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
+                const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                const uint8_t* dem, int H, int W, const double* K9, int min_matches,
+                double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
+  if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  int rc = gn_match(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r,
+                    ctx->e_idx, ctx->e_score, n_match, stream);
+  if (rc != GN_OK) return rc;
+  rc = gn_gather_points(ctx, B, kpt_format, kpt_q, stride_q, kpt_r, stride_r, ctx->e_idx, n_match, dem, H, W,
+                        ctx->e_mkp, ctx->e_obj, stream);
+  if (rc != GN_OK) return rc;
+  return gn_pnp_ransac(ctx, B, ctx->e_obj, ctx->e_mkp, n_match, ctx->npad, K9, 10, 8.0f, 0.99, min_matches,
+                       R, t, n_inliers, ok, stream);
+}
+
+int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream) {
+  if (!ctx || !name || !host_out) return GN_ERR_ARG;
+  hipSetDevice(ctx->device);
+  const size_t np = ctx->npad, T = (size_t)ctx->max_batch * 2 * np, B = ctx->max_batch;
+  struct Ent { const char* n; const void* p; size_t count; };
+  const Ent tab[] = {
+      {"desc", ctx->desc, T * kInDim}, {"cos", ctx->cos_t, T * kFreq}, {"sin", ctx->sin_t, T * kFreq},
+      {"x", ctx->x, T * kDim}, {"qkv", ctx->qkv, T * 3 * kDim}, {"ctx", ctx->ctx, T * kDim}, {"msg", ctx->msg, T * kDim},
+      {"h", ctx->h, T * 2 * kDim}, {"md", ctx->md, T * kDim}, {"ls", ctx->ls, T}, {"sim", ctx->sim, B * np * np},
+      {"rowmax", ctx->rowmax, B * np}, {"rowlog", ctx->rowlog, B * np}, {"colmax", ctx->colmax, B * np},
+      {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
+      {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
+      {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np}};
+  for (const Ent& e : tab)
+    if (strcmp(e.n, name) == 0) {
+      size_t count = e.count;
+      if ((int64_t)(count * 4) > max_bytes) count = (size_t)max_bytes / 4;
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GN_ERR_HIP;
+      if (hipMemcpy(host_out, e.p, count * 4, hipMemcpyDeviceToHost) != hipSuccess) return GN_ERR_HIP;
+      return (int64_t)count;
+    }
+  if (strcmp(name, "e_idx") == 0) {
+    size_t count = B * np * 2;
+    if ((int64_t)(count * 8) > max_bytes) count = (size_t)max_bytes / 8;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GN_ERR_HIP;
+    if (hipMemcpy(host_out, ctx->e_idx, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return GN_ERR_HIP;
+    return (int64_t)count;
+  }
+  return fail(ctx, GN_ERR_NAME, std::string("unknown debug tensor ") + name);
+}
+
+int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float* W, const float* bias, float* Y, void* stream) {
+  if (!ctx || !A || !W || !Y || M % 128 || N % 128 || K % 32 || M < 128 || N < 128 || K < 32)
+    return fail(ctx, GN_ERR_ARG, "gn_debug_gemm needs M,N multiples of 128 and K a multiple of 32");
+  GN_HIP(hipSetDevice(ctx->device));
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.lda = K; g.K1 = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = K;
+  launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, const float* q, int ldq, const float* k, int ldk,
+                       const float* v, int ldv, const int32_t* nkv, float* out, int ldo, void* stream) {
+  if (!ctx || !q || !k || !v || !nkv || !out || npad % 128 || BS < 1 || (cross && (BS & 1)))
+    return fail(ctx, GN_ERR_ARG, "bad gn_debug_attention argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  AttnArgs a;
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
+  a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
+  attention(ctx, a, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_set_stage_timing(gn_ctx* ctx, int enable) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->timing = enable != 0;
+  ctx->n_ev = 0;
+  return GN_OK;
+}
+
+int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages) {
+  if (!ctx || !host_ms) return GN_ERR_ARG;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < ST_COUNT; ++i) ctx->stage_ms[i] = 0.f;
+  if (ctx->n_ev > 0) {
+    if (hipEventSynchronize(ctx->ev[2 * (ctx->n_ev - 1) + 1]) != hipSuccess) return GN_ERR_HIP;
+    for (int i = 0; i < ctx->n_ev; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ctx->stage_ms[ctx->ev_stage[i]] += ms;
+    }
+  }
+  const int n = max_stages < ST_COUNT ? max_stages : (int)ST_COUNT;
+  for (int i = 0; i < n; ++i) host_ms[i] = ctx->stage_ms[i];
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// Fused softmax(Q K^T) V for LightGlue's self- and cross-attention blocks (4 heads x 64) on gfx950.
+//
+// Stands in for kornia's `Attention.forward` (F.scaled_dot_product_attention / einsum-softmax-einsum)
+// as used by SelfBlock and CrossBlock, reached from ros/gisnav/gisnav/core/pose_node.py:285-287.
+// Cross attention is issued as two launches (q=qk0,k=qk1,v=v1 and q=qk1,k=qk0,v=v0) exactly like
+// kornia's flash path; the second softmax is over the columns of the same sim matrix because
+// (qk1 qk0^T) = (qk0 qk1^T)^T term by term.
+//
+// Wave-level plan (64-wide wavefront, no cross-lane traffic inside the tile loop):
+//   * a wave owns 32 query rows; the block (4 waves) shares 64-key K/V tiles staged in LDS;
+//   * S^T = K Q^T is computed with the operands swapped (A = K rows, B = Q rows), so in the MFMA
+//     C layout (col = lane & 31) every lane holds the scores of ONE query for 32 of the tile's 64 keys:
+//     the online-softmax max / sum are in-lane reductions plus a single lane<->lane+32 exchange;
+//   * O^T = V^T P^T reuses those score registers directly as the B operand (no shuffle, no LDS
+//     round trip for P), and every O register of a lane belongs to that same query, so the running
+//     rescale by exp(m_old - m_new) is lane-local as well.
+// f32 variant: v_mfma_f32_32x32x2_f32 (exact f32).  bf16 variant: v_mfma_f32_32x32x16_bf16 with f32
+// scores, softmax statistics and accumulators (GN_PREC_BF16_ATTN).
+#include "gn_common.h"
+
+namespace gn {
+
+namespace {
+constexpr int KT = 64;        // keys per LDS tile
+constexpr int KLS = 68;       // K tile row stride (floats): conflict-free ds_read_b128 across 16 rows
+constexpr int QB = 128;       // query rows per block
+
+__global__ __launch_bounds__(256) void k_attn_f32(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[KT * KLS + KT * 64];
+  float* Ks = smem;
+  float* Vs = smem + KT * KLS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, bs = blockIdx.z;
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  // Q fragment: lane (query ql, half hh) keeps Q[q][8j + 4hh + s], j = 0..7, s = 0..3.
+  float qf[8][4];
+  {
+    const float* qp = a.q + ((size_t)bs * a.npad + q0 + ql) * a.ldq + h * 64 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 8 * j);
+      qf[j][0] = t.x * a.qscale; qf[j][1] = t.y * a.qscale;
+      qf[j][2] = t.z * a.qscale; qf[j][3] = t.w * a.qscale;
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const float* kbase = a.k + (size_t)kvs * a.npad * a.ldk + h * 64;
+  const float* vbase = a.v + (size_t)kvs * a.npad * a.ldv + h * 64;
+  const int ntiles = (nkv + KT - 1) / KT;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+
+  for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 16 * p;
+      const size_t grow = (size_t)(t * KT + r);
+      *reinterpret_cast<float4*>(&Ks[r * KLS + lc]) = *reinterpret_cast<const float4*>(kbase + grow * a.ldk + lc);
+      *reinterpret_cast<float4*>(&Vs[r * 64 + lc]) = *reinterpret_cast<const float4*>(vbase + grow * a.ldv + lc);
+    }
+    __syncthreads();
+
+    // S^T[key][query] for the tile's two 32-key halves
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt * 32 + ql) * KLS + 8 * j + 4 * hh]);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[j][0], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[j][1], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[j][2], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[j][3], st[kt], 0, 0, 0);
+      }
+    }
+    if (t * KT + KT > nkv) {  // ragged tail: keys >= nkv never contribute
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= nkv) st[kt][r] = -INFINITY;
+        }
+    }
+    float mloc = st[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(st[kt][r] - m_new);
+        st[kt][r] = p;
+        l_run += p;
+      }
+    m_run = m_new;
+
+    // O^T[d][query] += V^T[d][key] P^T[key][query]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float v0 = Vs[key * 64 + ql];
+        const float v1 = Vs[key * 64 + 32 + ql];
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[kt][r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[kt][r], o[1], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
+      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 variant.  K tile is staged as bf16 [64 keys][64 d] (row stride 72 halves = 144 B), V tile is
+// staged TRANSPOSED as bf16 [64 d][64 keys] (row stride 72) so that the A operand of O^T = V^T P^T
+// (8 consecutive keys for one d) is contiguous.  Each lane's 16 f32 scores per 32-key half are
+// packed to bf16 in the order the MFMA wants: step u of a half uses registers 8u..8u+7, i.e. keys
+// {8u*2.. } as laid out by the C layout (keys (r&3) + 8(r>>2) + 4hh).  Any consistent permutation of
+// k between A and B is legal, so V^T is read at exactly those key positions.
+constexpr int HLS = 72;  // halves per LDS row
+
+__device__ inline unsigned short f2bf(float x) {
+  // round-to-nearest-even f32 -> bf16 (inputs are finite here)
+  unsigned int u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * KT * HLS];
+  unsigned short* Ks = smem;           // [key][d]
+  unsigned short* Vt = smem + KT * HLS;  // [d][key]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, bs = blockIdx.z;
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  // Q fragment as MFMA B operand: lane (query ql, half hh) holds Q[q][16c + 8hh + 0..7], c = 0..3.
+  bf16x8 qf[4];
+  {
+    const float* qp = a.q + ((size_t)bs * a.npad + q0 + ql) * a.ldq + h * 64 + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * c);
+      const float4 t1 = *reinterpret_cast<const float4*>(qp + 16 * c + 4);
+      qf[c][0] = (short)f2bf(t0.x * a.qscale); qf[c][1] = (short)f2bf(t0.y * a.qscale);
+      qf[c][2] = (short)f2bf(t0.z * a.qscale); qf[c][3] = (short)f2bf(t0.w * a.qscale);
+      qf[c][4] = (short)f2bf(t1.x * a.qscale); qf[c][5] = (short)f2bf(t1.y * a.qscale);
+      qf[c][6] = (short)f2bf(t1.z * a.qscale); qf[c][7] = (short)f2bf(t1.w * a.qscale);
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const float* kbase = a.k + (size_t)kvs * a.npad * a.ldk + h * 64;
+  const float* vbase = a.v + (size_t)kvs * a.npad * a.ldv + h * 64;
+  const int ntiles = (nkv + KT - 1) / KT;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+
+  for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 16 * p;
+      const size_t grow = (size_t)(t * KT + r);
+      const float4 kv = *reinterpret_cast<const float4*>(kbase + grow * a.ldk + lc);
+      const float4 vv = *reinterpret_cast<const float4*>(vbase + grow * a.ldv + lc);
+      ushort4 kb;
+      kb.x = f2bf(kv.x); kb.y = f2bf(kv.y); kb.z = f2bf(kv.z); kb.w = f2bf(kv.w);
+      *reinterpret_cast<ushort4*>(&Ks[r * HLS + lc]) = kb;
+      Vt[(lc + 0) * HLS + r] = f2bf(vv.x);
+      Vt[(lc + 1) * HLS + r] = f2bf(vv.y);
+      Vt[(lc + 2) * HLS + r] = f2bf(vv.z);
+      Vt[(lc + 3) * HLS + r] = f2bf(vv.w);
+    }
+    __syncthreads();
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + ql) * HLS + 16 * c + 8 * hh]);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[kt], 0, 0, 0);
+      }
+    }
+    if (t * KT + KT > nkv) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= nkv) st[kt][r] = -INFINITY;
+        }
+    }
+    float mloc = st[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+    // P -> bf16, packed 8 per MFMA step; the row sum uses the ROUNDED probabilities so that the
+    // normaliser matches what is multiplied into V.
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = expf(st[kt][8 * u + e] - m_new);
+          const unsigned short pb = f2bf(p);
+          pf[kt][u][e] = (short)pb;
+          l_run += __uint_as_float(((unsigned int)pb) << 16);
+        }
+    m_run = m_new;
+
+    // O^T[d][q] += sum over the 8 keys of step (kt,u): keys kt*32 + 16u + {0..3, 8..11} + 4hh
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kb = kt * 32 + 16 * u + 4 * hh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const unsigned short* vp = &Vt[(d * 32 + ql) * HLS + kb];
+          const ushort4 lo = *reinterpret_cast<const ushort4*>(vp);
+          const ushort4 hi = *reinterpret_cast<const ushort4*>(vp + 8);
+          bf16x8 vf;
+          vf[0] = (short)lo.x; vf[1] = (short)lo.y; vf[2] = (short)lo.z; vf[3] = (short)lo.w;
+          vf[4] = (short)hi.x; vf[5] = (short)hi.y; vf[6] = (short)hi.z; vf[7] = (short)hi.w;
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
+      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
+    }
+}
+}  // namespace
+
+void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
+  dim3 grid(a.npad / QB, kHeads, a.BS), block(256);
+  hipLaunchKernelGGL(k_attn_f32, grid, block, 0, s, a);
+}
+
+void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
+  dim3 grid(a.npad / QB, kHeads, a.BS), block(256);
+  hipLaunchKernelGGL(k_attn_bf16, grid, block, 0, s, a);
+}
+
+}  // namespace gn

@@ -1,0 +1,106 @@
+// Internal declarations shared by the gfx950 kernels and the C ABI (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/gisnav_amd.h"
+
+namespace gn {
+
+constexpr int kDim = 256;       // descriptor_dim
+constexpr int kHeads = 4;
+constexpr int kHeadDim = 64;
+constexpr int kInDim = 128;     // SIFT descriptor length
+constexpr int kFreq = 32;       // rotary frequencies per head (head_dim / 2)
+constexpr int kMaxLayers = 9;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- GEMM -----------------------------------------------------------------------------------
+enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4 };
+
+struct GemmArgs {
+  const float* A;    int lda;      // A[M][K1] (k < K1)
+  const float* A2;   int lda2;     // optional second source for k >= K1 (concat), else nullptr
+  int K1;
+  const float* W;    int ldw;      // W[N][K]
+  const float* bias;               // [N] or nullptr
+  float* Y;          int ldy;      // Y[M][N]
+  int M, N, K;
+  // batching over blockIdx.z
+  long long strideA, strideW, strideY;
+  // epilogue extras
+  float scale; int scale_cols;     // EPI_SCALE_COLS: cols < scale_cols multiplied by scale (after bias)
+  const float* cos_t; const float* sin_t; int rot_cols;  // EPI_ROTARY: [M][32] tables, cols < rot_cols rotated
+  const float* resid; int ldr;     // EPI_RESIDUAL
+};
+void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
+
+// ---- attention --------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* q; int ldq;   // rows = tokens, head h at column offset h*64 from the given pointer
+  const float* k; int ldk;
+  const float* v; int ldv;
+  float* out; int ldo;
+  const int32_t* nvalid;     // [BS] valid token count per (pair, side)
+  int npad;                  // tokens per (pair, side) slot
+  int cross;                 // 1: keys/values come from the other side of the same pair (bs ^ 1)
+  float qscale;              // multiplied into q before QK^T
+  int BS;                    // number of (pair, side) slots
+};
+void launch_attention_f32(const AttnArgs& a, hipStream_t s);
+void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
+
+// ---- elementwise / small kernels ----------------------------------------------------------------
+struct PrepArgs {
+  const float* desc_q; const float* kpt_q; const int32_t* n_q; int stride_q;
+  const float* desc_r; const float* kpt_r; const int32_t* n_r; int stride_r;
+  int kpt_format; int B; int npad;
+  const float* wr;          // posenc.Wr.weight [32][4]
+  float* desc;              // [B*2*npad][128] RootSIFT (zeros in padding)
+  float* kxy;               // [B*2*npad][2] keypoint centres (for the gather)
+  float* cos_t; float* sin_t;  // [B*2*npad][32]
+  int32_t* nvalid;          // [B*2] (n_q[b], n_r[b]) interleaved
+  float* extent;            // [B*2][2] (max_x, max_y)
+};
+void launch_prep(const PrepArgs& a, hipStream_t s);
+void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s);
+void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s);
+
+struct HeadArgs {
+  const float* sim;         // [B][npad][npad]
+  const float* ls;          // [B*2*npad] logsigmoid(matchability)
+  const int32_t* nvalid;    // [B*2]
+  int B; int npad; float threshold;
+  float* rowmax; float* rowlog; float* colmax; float* collog;   // [B][npad] each
+  int32_t* m0; float* max0; int32_t* m1;                        // [B][npad]
+  int64_t* idx; float* score; int32_t* n_match; int kmax;       // outputs
+};
+void launch_match_head(const HeadArgs& a, hipStream_t s);
+
+struct GatherArgs {
+  const float* kpt_q; int stride_q; const float* kpt_r; int stride_r; int kpt_format;
+  const int64_t* idx; const int32_t* n_match; int kmax; int B;
+  const uint8_t* dem; int H; int W;
+  float* mkp_q; float* obj;
+};
+void launch_gather(const GatherArgs& a, hipStream_t s);
+
+struct PnpArgs {
+  const float* obj; const float* img; const int32_t* n_pts; int kstride; int B;
+  double fx, fy, cx, cy;
+  int iterations; float reproj; double confidence; int min_pts;
+  double* R; double* t; int32_t* n_inliers; uint8_t* ok;
+  uint8_t* mask_ws;          // [B][kstride] scratch for inlier masks (2 per pair)
+};
+void launch_pnp(const PnpArgs& a, hipStream_t s);
+
+// ---- bf16 helpers -------------------------------------------------------------------------------
+void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
+
+}  // namespace gn

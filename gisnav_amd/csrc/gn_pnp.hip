@@ -1,0 +1,1015 @@
+// Batched PnP + RANSAC + Rodrigues on gfx950: one 64-lane wavefront per frame<->tile pair.
+//
+// Stands in for `cv2.solvePnPRansac(obj, img, K, zeros(4,1), useExtrinsicGuess=False,
+// iterationsCount=10)` + `cv2.Rodrigues` as called by `compute_pose`
+// (ros/gisnav/gisnav/core/_shared.py:104-117).  Algorithm restated from OpenCV 4.x calib3d
+// (SURVEY.md Appendix B): cv::RNG(-1) multiply-with-carry stream, 5-point subsets with redraw on
+// duplicates, EPnP minimal solver on normalised image points, float32 squared reprojection error
+// tested `<= 64.0f`, the `good > max(maxGood, 4)` update with RANSACUpdateNumIters, then
+// SOLVEPNP_ITERATIVE on the inliers: planar-homography or 12x12 DLT initialisation followed by
+// CvLevMarq (<= 20 iterations, eps = FLT_EPSILON) on (rvec, tvec), all in float64.
+//
+// Mapping to the wavefront:
+//   * RANSAC control flow, RNG and the small dense algebra are wave-uniform; register-resident
+//     3x3 / 6x6 kernels are fully unrolled, the 9x9 / 12x12 symmetric eigenproblems run as a
+//     lane-parallel cyclic Jacobi on LDS-resident matrices (lane k owns row/column k);
+//   * hypothesis scoring strides the K correspondences over the 64 lanes and counts inliers with
+//     __ballot + popcount; the DLT / homography normal matrices and the Levenberg-Marquardt
+//     J^T J, J^T e, |e|^2 are per-lane partial sums combined with a butterfly of wave shuffles.
+// Deviations (documented in DESIGN.md): findHomography's 10-iteration LM polish of the planar
+// initial guess is omitted (the pose LM that follows converges to the same optimum), and where
+// OpenCV's SVD leaves a basis implementation-defined (rank-deficient 3x3 alignment) the third
+// singular pair is completed as u0 x u1, v0 x v1.
+#include "gn_common.h"
+
+namespace gn {
+
+namespace {
+
+constexpr double kDblEps = 2.220446049250313e-16;
+constexpr double kFltEps = 1.1920928955078125e-07;
+constexpr double kDblMin = 2.2250738585072014e-308;
+
+__device__ inline double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+struct Shared {
+  double A[144];
+  double V[144];
+  int ord[12];
+  double L[60];
+  double rho[6];
+  double alphas[20];
+  double us[10];
+  double pws[15];
+  double cws[12];
+};
+
+// ------------------------------------------------------------------------------------------------
+// register-resident 3x3 symmetric eigen solver (wave-uniform), eigenvalues DESCENDING, V columns.
+template <int P, int Q>
+__device__ inline void rot3(double a[3][3], double v[3][3]) {
+  const double apq = a[P][Q];
+  if (fabs(apq) < 1e-300) return;
+  const double tau = (a[Q][Q] - a[P][P]) / (2.0 * apq);
+  const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = a[k][P], akq = a[k][Q];
+    a[k][P] = c * akp - s * akq; a[k][Q] = s * akp + c * akq;
+    const double vkp = v[k][P], vkq = v[k][Q];
+    v[k][P] = c * vkp - s * vkq; v[k][Q] = s * vkp + c * vkq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = a[P][k], aqk = a[Q][k];
+    a[P][k] = c * apk - s * aqk; a[Q][k] = s * apk + c * aqk;
+  }
+}
+
+template <int I, int J>
+__device__ inline void cswap3(double w[3], double v[3][3]) {
+  if (w[I] < w[J]) {
+    const double t = w[I]; w[I] = w[J]; w[J] = t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double u = v[k][I]; v[k][I] = v[k][J]; v[k][J] = u; }
+  }
+}
+
+__device__ inline void eig3(const double S[3][3], double w[3], double v[3][3]) {
+  double a[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a[i][j] = S[i][j]; v[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    const double dg = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-32 * dg || off == 0.0) break;
+    rot3<0, 1>(a, v); rot3<0, 2>(a, v); rot3<1, 2>(a, v);
+  }
+  w[0] = a[0][0]; w[1] = a[1][1]; w[2] = a[2][2];
+  cswap3<0, 1>(w, v); cswap3<0, 2>(w, v); cswap3<1, 2>(w, v);
+}
+
+__device__ inline void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline double det3(const double m[3][3]) {
+  return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+         m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+// R = U V^T of the SVD of M (closest orthogonal matrix); singular pair 2 completed by cross
+// products when M is rank deficient.
+__device__ inline void polar3(const double M[3][3], double R[3][3]) {
+  double S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];
+  double w[3], v[3][3];
+  eig3(S, w, v);
+  double u[3][3];  // u[i] = i-th left singular vector
+  double vv[3][3];  // vv[i] = i-th right singular vector
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vv[i][k] = v[k][i];
+  const double s0 = sqrt(fmax(w[0], 0.0));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double si = sqrt(fmax(w[i], 0.0));
+    const double inv = si > 0 ? 1.0 / si : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[i][k] = (M[k][0] * vv[i][0] + M[k][1] * vv[i][1] + M[k][2] * vv[i][2]) * inv;
+  }
+  // re-orthonormalise u1 against u0 (guards nearly equal singular values)
+  {
+    double n0 = sqrt(u[0][0] * u[0][0] + u[0][1] * u[0][1] + u[0][2] * u[0][2]);
+    n0 = n0 > 0 ? 1.0 / n0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[0][k] *= n0;
+    const double d = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[1][k] -= d * u[0][k];
+    double n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+    n1 = n1 > 0 ? 1.0 / n1 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[1][k] *= n1;
+  }
+  const double s2 = sqrt(fmax(w[2], 0.0));
+  if (s2 > 1e-9 * s0) {
+    const double inv = 1.0 / s2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[2][k] = (M[k][0] * vv[2][0] + M[k][1] * vv[2][1] + M[k][2] * vv[2][2]) * inv;
+  } else {
+    cross3(u[0], u[1], u[2]);
+    double t[3];
+    cross3(vv[0], vv[1], t);
+    vv[2][0] = t[0]; vv[2][1] = t[1]; vv[2][2] = t[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i][j] = u[0][i] * vv[0][j] + u[1][i] * vv[1][j] + u[2][i] * vv[2][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// cvRodrigues2
+__device__ inline void rodrigues_v2m(const double r[3], double R[3][3], double J[3][9], bool want_j) {
+  const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (theta < kDblEps) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[i][j] = (i == j) ? 1.0 : 0.0;
+    if (want_j) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) J[i][k] = 0.0;
+      J[0][5] = -1; J[0][7] = 1; J[1][2] = 1; J[1][6] = -1; J[2][1] = -1; J[2][3] = 1;
+    }
+    return;
+  }
+  const double c = cos(theta), s = sin(theta), c1 = 1.0 - c, itheta = 1.0 / theta;
+  const double rx = r[0] * itheta, ry = r[1] * itheta, rz = r[2] * itheta;
+  const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+  const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k / 3][k % 3] = c * eye[k] + c1 * rrt[k] + s * r_x[k];
+  if (!want_j) return;
+  const double drrt[3][9] = {{rx + rx, ry, rz, ry, 0, 0, rz, 0, 0},
+                             {0, rx, 0, rx, ry + ry, rz, 0, rz, 0},
+                             {0, 0, rx, 0, 0, ry, rx, ry, rz + rz}};
+  const double d_r_x[3][9] = {{0, 0, 0, 0, 0, -1, 0, 1, 0}, {0, 0, 1, 0, 0, 0, -1, 0, 0}, {0, -1, 0, 1, 0, 0, 0, 0, 0}};
+  const double rv[3] = {rx, ry, rz};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double ri = rv[i];
+    const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+    const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) J[i][k] = a0 * eye[k] + a1 * rrt[k] + a2 * drrt[i][k] + a3 * r_x[k] + a4 * d_r_x[i][k];
+  }
+}
+
+__device__ inline void rodrigues_m2v(const double Rin[3][3], double r[3]) {
+  double R[3][3];
+  polar3(Rin, R);
+  r[0] = R[2][1] - R[1][2]; r[1] = R[0][2] - R[2][0]; r[2] = R[1][0] - R[0][1];
+  const double s = sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+  double c = (R[0][0] + R[1][1] + R[2][2] - 1) * 0.5;
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  double theta = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { r[0] = r[1] = r[2] = 0.0; return; }
+    double t = (R[0][0] + 1) * 0.5;
+    r[0] = sqrt(fmax(t, 0.0));
+    t = (R[1][1] + 1) * 0.5;
+    r[1] = sqrt(fmax(t, 0.0)) * (R[0][1] < 0 ? -1.0 : 1.0);
+    t = (R[2][2] + 1) * 0.5;
+    r[2] = sqrt(fmax(t, 0.0)) * (R[0][2] < 0 ? -1.0 : 1.0);
+    if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && ((R[1][2] > 0) != (r[1] * r[2] > 0))) r[2] = -r[2];
+    theta /= sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] *= theta; r[1] *= theta; r[2] *= theta;
+  } else {
+    const double vth = theta / (2 * s);
+    r[0] *= vth; r[1] *= vth; r[2] *= vth;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPD solve (LDL^T, no pivoting), fully unrolled; a vanishing pivot zeroes that unknown.
+template <int K>
+__device__ inline void spd_solve(const double N[K][K], const double b[K], double x[K]) {
+  double L[K][K], d[K], inv[K];
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) scale = fmax(scale, fabs(N[i][i]));
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    double dj = N[j][j];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k < j) dj -= L[j][k] * L[j][k] * d[k];
+    const bool good = dj > 1e-15 * scale;
+    d[j] = good ? dj : 0.0;
+    inv[j] = good ? 1.0 / dj : 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (i > j) {
+        double v = N[i][j];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k < j) v -= L[i][k] * L[j][k] * d[k];
+        L[i][j] = v * inv[j];
+      }
+  }
+  double y[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k < i) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    double v = y[i] * inv[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k > i) v -= L[k][i] * x[k];
+    x[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lane-parallel cyclic Jacobi for an n x n symmetric matrix in LDS (n <= 12).  On return the
+// eigenvalues are on the diagonal of A, eigenvectors are the COLUMNS of V, and ord[] lists the
+// column indices by ASCENDING eigenvalue.  Called by the whole (single-wave) block.
+__device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
+  for (int idx = lane; idx < n * n; idx += 64) V[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const double v = A[idx];
+      if (idx / n == idx % n) dg += v * v; else off += v * v;
+    }
+    off = wsum(off); dg = wsum(dg);
+    if (off <= 1e-30 * dg || off == 0.0) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p * n + q];
+        const double app = A[p * n + p], aqq = A[q * n + q];
+        if (fabs(apq) <= 1e-18 * sqrt(fabs(app * aqq)) || fabs(apq) < 1e-300) continue;  // wave-uniform
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        __syncthreads();
+        if (lane < n) {
+          const int k = lane;
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+        }
+        __syncthreads();
+        if (lane < n) {
+          const int k = lane;
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+        }
+        __syncthreads();
+      }
+  }
+  if (lane == 0) {
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    for (int i = 1; i < n; ++i) {
+      const int oi = ord[i];
+      const double wi = A[oi * n + oi];
+      int j = i - 1;
+      while (j >= 0 && A[ord[j] * n + ord[j]] > wi) { ord[j + 1] = ord[j]; --j; }
+      ord[j + 1] = oi;
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// EPnP on the 5 correspondences staged in sh.pws / sh.us (normalised image coordinates).
+__device__ inline void epnp_Ab(const Shared& sh, const double be[4], double A[6][4], double b[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double* l = &sh.L[i * 10];
+    A[i][0] = 2 * l[0] * be[0] + l[1] * be[1] + l[3] * be[2] + l[6] * be[3];
+    A[i][1] = l[1] * be[0] + 2 * l[2] * be[1] + l[4] * be[2] + l[7] * be[3];
+    A[i][2] = l[3] * be[0] + l[4] * be[1] + 2 * l[5] * be[2] + l[8] * be[3];
+    A[i][3] = l[6] * be[0] + l[7] * be[1] + l[8] * be[2] + 2 * l[9] * be[3];
+    b[i] = sh.rho[i] - (l[0] * be[0] * be[0] + l[1] * be[0] * be[1] + l[2] * be[1] * be[1] + l[3] * be[0] * be[2] +
+                        l[4] * be[1] * be[2] + l[5] * be[2] * be[2] + l[6] * be[0] * be[3] + l[7] * be[1] * be[3] +
+                        l[8] * be[2] * be[3] + l[9] * be[3] * be[3]);
+  }
+}
+
+template <int K>
+__device__ inline void lsq6(const double A[6][K], const double b[6], double x[K]) {
+  double N[K][K], r[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double v = 0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) v += A[m][i] * b[m];
+    r[i] = v;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      double u = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) u += A[m][i] * A[m][j];
+      N[i][j] = u;
+    }
+  }
+  spd_solve<K>(N, r, x);
+}
+
+__device__ inline double epnp_Rt(const Shared& sh, const double be[4], double R[3][3], double t[3]) {
+  double ccs[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v += be[m] * sh.V[(3 * i + k) * 12 + sh.ord[m]];
+      ccs[i][k] = v;
+    }
+  double pcs[5][3];
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v += sh.alphas[p * 4 + j] * ccs[j][k];
+      pcs[p][k] = v;
+    }
+  if (pcs[0][2] < 0) {
+#pragma unroll
+    for (int p = 0; p < 5; ++p)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pcs[p][k] = -pcs[p][k];
+  }
+  double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pc0[k] += pcs[p][k]; pw0[k] += sh.pws[p * 3 + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pc0[k] *= 0.2; pw0[k] *= 0.2; }
+  double abt[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = 0;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) v += (pcs[p][j] - pc0[j]) * (sh.pws[p * 3 + k] - pw0[k]);
+      abt[j][k] = v;
+    }
+  polar3(abt, R);
+  if (det3(R) < 0) { R[2][0] = -R[2][0]; R[2][1] = -R[2][1]; R[2][2] = -R[2][2]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = pc0[k] - (R[k][0] * pw0[0] + R[k][1] * pw0[1] + R[k][2] * pw0[2]);
+  double err = 0;
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double* w = &sh.pws[p * 3];
+    const double X = R[0][0] * w[0] + R[0][1] * w[1] + R[0][2] * w[2] + t[0];
+    const double Y = R[1][0] * w[0] + R[1][1] * w[1] + R[1][2] * w[2] + t[1];
+    const double Z = R[2][0] * w[0] + R[2][1] * w[1] + R[2][2] * w[2] + t[2];
+    const double du = sh.us[2 * p] - X / Z, dv = sh.us[2 * p + 1] - Y / Z;
+    err += sqrt(du * du + dv * dv);
+  }
+  return err * 0.2;
+}
+
+__device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3]) {
+  // control points: centroid + PCA axes
+  double c0[3] = {0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c0[k] += sh.pws[p * 3 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c0[k] *= 0.2;
+  double S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = 0;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) v += (sh.pws[p * 3 + i] - c0[i]) * (sh.pws[p * 3 + j] - c0[j]);
+      S[i][j] = v;
+    }
+  double dc[3], uc[3][3];
+  eig3(S, dc, uc);
+  double kk[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) kk[i] = sqrt(fmax(dc[i], 0.0) / 5.0);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh.cws[k] = c0[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sh.cws[3 * (i + 1) + k] = c0[k] + kk[i] * uc[k][i];
+    // barycentric coordinates through the pseudo-inverse of CC = U diag(kk)
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      double a123 = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v += uc[k][i] * (sh.pws[p * 3 + k] - c0[k]);
+        v = kk[i] > 1e-15 * kk[0] ? v / kk[i] : 0.0;
+        sh.alphas[p * 4 + 1 + i] = v;
+        a123 += v;
+      }
+      sh.alphas[p * 4] = 1.0 - a123;
+    }
+  }
+  __syncthreads();
+  // M^T M (12 x 12), M is 10 x 12 with fu = fv = 1, uc = vc = 0
+  for (int idx = lane; idx < 144; idx += 64) {
+    const int r = idx / 12, c = idx % 12;
+    const int jr = r / 3, kr = r % 3, jc = c / 3, kc = c % 3;
+    double v = 0;
+    for (int p = 0; p < 5; ++p) {
+      const double ar = sh.alphas[p * 4 + jr], ac = sh.alphas[p * 4 + jc];
+      const double u = sh.us[2 * p], w = sh.us[2 * p + 1];
+      // row 2p:   [a, 0, -a u]   row 2p+1: [0, a, -a w]
+      const double m0r = kr == 0 ? ar : (kr == 2 ? -ar * u : 0.0), m0c = kc == 0 ? ac : (kc == 2 ? -ac * u : 0.0);
+      const double m1r = kr == 1 ? ar : (kr == 2 ? -ar * w : 0.0), m1c = kc == 1 ? ac : (kc == 2 ? -ac * w : 0.0);
+      v += m0r * m0c + m1r * m1c;
+    }
+    sh.A[idx] = v;
+  }
+  __syncthreads();
+  sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+  // L (6 x 10) and rho
+  if (lane < 60) {
+    const int j = lane / 10, m = lane % 10;
+    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    const int ia[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, ib[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
+    int a_ = 0, b_ = 0, x_ = 0, y_ = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (q == j) { a_ = pa[q]; b_ = pb[q]; }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) if (q == m) { x_ = ia[q]; y_ = ib[q]; }
+    const int cx = sh.ord[x_], cy = sh.ord[y_];
+    double d = 0;
+    for (int k = 0; k < 3; ++k) {
+      const double dx = sh.V[(3 * a_ + k) * 12 + cx] - sh.V[(3 * b_ + k) * 12 + cx];
+      const double dy = sh.V[(3 * a_ + k) * 12 + cy] - sh.V[(3 * b_ + k) * 12 + cy];
+      d += dx * dy;
+    }
+    sh.L[lane] = (x_ == y_) ? d : 2.0 * d;
+    if (m == 0) {
+      double rr = 0;
+      for (int k = 0; k < 3; ++k) { const double e = sh.cws[3 * a_ + k] - sh.cws[3 * b_ + k]; rr += e * e; }
+      sh.rho[j] = rr;
+    }
+  }
+  __syncthreads();
+
+  double best_err = 0; bool have = false;
+  double rho[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rho[i] = sh.rho[i];
+#pragma unroll 1
+  for (int cand = 0; cand < 3; ++cand) {
+    double be[4] = {0, 0, 0, 0};
+    if (cand == 0) {  // betas10 -> [B11 B12 B13 B14]
+      double A4[6][4], b4[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { A4[i][0] = sh.L[i * 10 + 0]; A4[i][1] = sh.L[i * 10 + 1]; A4[i][2] = sh.L[i * 10 + 3]; A4[i][3] = sh.L[i * 10 + 6]; }
+      lsq6<4>(A4, rho, b4);
+      if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
+      else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
+    } else if (cand == 1) {  // [B11 B12 B22]
+      double A3[6][3], b3[3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { A3[i][0] = sh.L[i * 10 + 0]; A3[i][1] = sh.L[i * 10 + 1]; A3[i][2] = sh.L[i * 10 + 2]; }
+      lsq6<3>(A3, rho, b3);
+      if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = b3[2] < 0 ? sqrt(-b3[2]) : 0.0; }
+      else { be[0] = sqrt(b3[0]); be[1] = b3[2] > 0 ? sqrt(b3[2]) : 0.0; }
+      if (b3[1] < 0) be[0] = -be[0];
+    } else {  // [B11 B12 B22 B13 B23]
+      double A5[6][5], b5[5];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) A5[i][k] = sh.L[i * 10 + k];
+      lsq6<5>(A5, rho, b5);
+      if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = b5[2] < 0 ? sqrt(-b5[2]) : 0.0; }
+      else { be[0] = sqrt(b5[0]); be[1] = b5[2] > 0 ? sqrt(b5[2]) : 0.0; }
+      if (b5[1] < 0) be[0] = -be[0];
+      be[2] = b5[3] / be[0];
+    }
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {  // gauss_newton
+      double A[6][4], b[6], x[4];
+      epnp_Ab(sh, be, A, b);
+      lsq6<4>(A, b, x);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) be[k] += x[k];
+    }
+    double R[3][3], t[3];
+    const double err = epnp_Rt(sh, be, R, t);
+    if (err == err && (!have || err < best_err)) {
+      have = true; best_err = err;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { tb[i] = t[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rb[i][j] = R[i][j]; }
+    }
+  }
+  bool fin = have;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { fin = fin && isfinite(tb[i]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fin = fin && isfinite(Rb[i][j]); }
+  return fin;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Cam { double fx, fy, cx, cy; };
+
+// |e|^2, and optionally J^T J (upper, 21) and J^T e (6), over the masked points
+__device__ inline double lm_accumulate(const float* obj, const float* img, const uint8_t* mask, int n, int lane,
+                                       const Cam& cam, const double p[6], bool want_j, double JtJ[21], double Jte[6]) {
+  double R[3][3], dR[3][9];
+  rodrigues_v2m(p, R, dR, want_j);
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    if (!mask[i]) continue;
+    const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
+    const double X = R[0][0] * M0 + R[0][1] * M1 + R[0][2] * M2 + p[3];
+    const double Y = R[1][0] * M0 + R[1][1] * M1 + R[1][2] * M2 + p[4];
+    const double Z = R[2][0] * M0 + R[2][1] * M1 + R[2][2] * M2 + p[5];
+    const double z = Z != 0 ? 1.0 / Z : 1.0;
+    const double x = X * z, y = Y * z;
+    const double ex = x * cam.fx + cam.cx - (double)img[2 * i], ey = y * cam.fy + cam.cy - (double)img[2 * i + 1];
+    acc[27] += ex * ex + ey * ey;
+    if (want_j) {
+      double jx[6], jy[6];
+      // d(x,y)/dX
+      const double ax0 = cam.fx * z, ax2 = -cam.fx * x * z;
+      const double ay1 = cam.fy * z, ay2 = -cam.fy * y * z;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double dX = dR[k][0] * M0 + dR[k][1] * M1 + dR[k][2] * M2;
+        const double dY = dR[k][3] * M0 + dR[k][4] * M1 + dR[k][5] * M2;
+        const double dZ = dR[k][6] * M0 + dR[k][7] * M1 + dR[k][8] * M2;
+        jx[k] = ax0 * dX + ax2 * dZ;
+        jy[k] = ay1 * dY + ay2 * dZ;
+      }
+      jx[3] = ax0; jx[4] = 0.0; jx[5] = ax2;
+      jy[3] = 0.0; jy[4] = ay1; jy[5] = ay2;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = r; c < 6; ++c) { acc[q] += jx[r] * jx[c] + jy[r] * jy[c]; ++q; }
+        acc[21 + r] += jx[r] * ex + jy[r] * ey;
+      }
+    }
+  }
+  const int lo = want_j ? 0 : 27;
+#pragma unroll
+  for (int k = 0; k < 28; ++k)
+    if (k >= lo) acc[k] = wsum(acc[k]);
+  if (want_j) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) JtJ[k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jte[k] = acc[21 + k];
+  }
+  return acc[27];
+}
+
+__device__ inline void lm_step(const double JtJ[21], const double Jte[6], const double prev[6], int lambda_lg10, double out[6]) {
+  const double lam = exp(lambda_lg10 * 2.302585092994046);
+  double N[6][6];
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) { N[r][c] = JtJ[q]; N[c][r] = JtJ[q]; ++q; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) N[r][r] *= 1.0 + lam;
+  double d[6];
+  spd_solve<6>(N, Jte, d);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k] = prev[k] - d[k];
+}
+
+// CvLevMarq(6, 2n, TermCriteria(20, FLT_EPSILON)) driven as in cvFindExtrinsicCameraParams2
+__device__ void levmarq_pose(const float* obj, const float* img, const uint8_t* mask, int n, int lane, const Cam& cam, double p[6]) {
+  double prev[6], JtJ[21], Jte[6];
+  int lambda_lg10 = -3, iters = 0;
+  double prev_err = 0.0;
+  double e2 = lm_accumulate(obj, img, mask, n, lane, cam, p, true, JtJ, Jte);
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) prev[k] = p[k];
+    lm_step(JtJ, Jte, prev, lambda_lg10, p);
+    if (iters == 0) prev_err = sqrt(e2);
+    double err_norm;
+    for (;;) {
+      err_norm = sqrt(lm_accumulate(obj, img, mask, n, lane, cam, p, false, JtJ, Jte));
+      if (err_norm > prev_err) {
+        if (++lambda_lg10 <= 16) { lm_step(JtJ, Jte, prev, lambda_lg10, p); continue; }
+      }
+      break;
+    }
+    lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+    ++iters;
+    double dn = 0, pn = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { dn += (p[k] - prev[k]) * (p[k] - prev[k]); pn += prev[k] * prev[k]; }
+    const double rel = sqrt(dn) / (pn > 0 ? sqrt(pn) : 1.0);
+    if (iters >= 20 || rel < kFltEps) break;
+    prev_err = err_norm;
+    e2 = lm_accumulate(obj, img, mask, n, lane, cam, p, true, JtJ, Jte);
+  }
+}
+
+__device__ inline int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+  p = fmin(fmax(p, 0.0), 1.0); ep = fmin(fmax(ep, 0.0), 1.0);
+  double num = fmax(1.0 - p, kDblMin);
+  double denom = 1.0 - pow(1.0 - ep, (double)model_points);
+  if (denom < kDblMin) return 0;
+  num = log(num); denom = log(denom);
+  return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)rint(num / denom);
+}
+
+__device__ inline unsigned rng_next(unsigned long long& st) {
+  st = (unsigned long long)(unsigned)st * 4164903690ull + (st >> 32);
+  return (unsigned)st;
+}
+
+__global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
+  __shared__ Shared sh;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = a.n_pts[b];
+  const float* obj = a.obj + (size_t)b * a.kstride * 3;
+  const float* img = a.img + (size_t)b * a.kstride * 2;
+  uint8_t* mask_cur = a.mask_ws + (size_t)b * 2 * a.kstride;
+  uint8_t* mask_best = mask_cur + a.kstride;
+  double* Rout = a.R + (size_t)b * 9;
+  double* tout = a.t + (size_t)b * 3;
+  const Cam cam = {a.fx, a.fy, a.cx, a.cy};
+
+  auto fail = [&]() {
+    if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
+    if (lane < 3) tout[lane] = 0.0;
+    if (lane == 0) { a.ok[b] = 0; a.n_inliers[b] = 0; }
+  };
+  if (n < a.min_pts || n < 5) { fail(); return; }
+
+  // ---- RANSAC ---------------------------------------------------------------------------------
+  unsigned long long rng = 0xFFFFFFFFFFFFFFFFull;
+  int niters = a.iterations, max_good = 0;
+  double bestR[3][3], bestT[3];
+  const float thr = a.reproj * a.reproj;
+  for (int it = 0; it < niters; ++it) {
+    int idx[5];
+    if (n > 5) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        for (;;) {
+          const int v = (int)(rng_next(rng) % (unsigned)n);
+          bool dup = false;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) if (j < i && idx[j] == v) dup = true;
+          if (!dup) { idx[i] = v; break; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) idx[i] = i;
+    }
+    __syncthreads();
+    if (lane < 5) {
+      int id = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) if (i == lane) id = idx[i];
+      sh.pws[lane * 3 + 0] = obj[3 * id]; sh.pws[lane * 3 + 1] = obj[3 * id + 1]; sh.pws[lane * 3 + 2] = obj[3 * id + 2];
+      sh.us[2 * lane] = ((double)img[2 * id] - cam.cx) / cam.fx;
+      sh.us[2 * lane + 1] = ((double)img[2 * id + 1] - cam.cy) / cam.fy;
+    }
+    __syncthreads();
+    double R[3][3], t[3];
+    if (!epnp5(sh, lane, R, t)) continue;
+    // hypothesis scoring: float32 squared reprojection error <= thr
+    int good = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      bool inl = false;
+      if (i < n) {
+        const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
+        const double X = R[0][0] * M0 + R[0][1] * M1 + R[0][2] * M2 + t[0];
+        const double Y = R[1][0] * M0 + R[1][1] * M1 + R[1][2] * M2 + t[1];
+        const double Z = R[2][0] * M0 + R[2][1] * M1 + R[2][2] * M2 + t[2];
+        const double z = Z != 0 ? 1.0 / Z : 1.0;
+        const float pu = (float)(X * z * cam.fx + cam.cx), pv = (float)(Y * z * cam.fy + cam.cy);
+        const float dx = img[2 * i] - pu, dy = img[2 * i + 1] - pv;
+        const float e = dx * dx + dy * dy;
+        inl = e <= thr;
+        mask_cur[i] = inl ? 1 : 0;
+      }
+      good += __popcll(__ballot(inl));
+    }
+    if (good > (max_good > 4 ? max_good : 4)) {
+      uint8_t* tmp = mask_cur; mask_cur = mask_best; mask_best = tmp;
+      max_good = good;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { bestT[i] = t[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bestR[i][j] = R[i][j]; }
+      niters = ransac_update_iters(a.confidence, (double)(n - good) / n, 5, niters);
+    }
+  }
+  if (max_good == 0) { fail(); return; }
+  __syncthreads();  // mask_best writes visible to the whole wave (global memory, same wave: ordered)
+
+  // ---- solvePnP(SOLVEPNP_ITERATIVE) on the inliers ---------------------------------------------
+  const uint8_t* mask = mask_best;
+  const int ninl = max_good;
+  double p[6];
+  // PCA of the inlier object points
+  double mc[3] = {0, 0, 0};
+  for (int i = lane; i < n; i += 64)
+    if (mask[i]) { mc[0] += obj[3 * i]; mc[1] += obj[3 * i + 1]; mc[2] += obj[3 * i + 2]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mc[k] = wsum(mc[k]) / ninl;
+  double mm[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < n; i += 64)
+    if (mask[i]) {
+      const double d0 = obj[3 * i] - mc[0], d1 = obj[3 * i + 1] - mc[1], d2 = obj[3 * i + 2] - mc[2];
+      mm[0] += d0 * d0; mm[1] += d0 * d1; mm[2] += d0 * d2; mm[3] += d1 * d1; mm[4] += d1 * d2; mm[5] += d2 * d2;
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mm[k] = wsum(mm[k]);
+  double MM[3][3] = {{mm[0], mm[1], mm[2]}, {mm[1], mm[3], mm[4]}, {mm[2], mm[4], mm[5]}};
+  double W[3], Vc[3][3];
+  eig3(MM, W, Vc);
+  bool init_ok = true;
+  if (W[2] / W[1] < 1e-3) {
+    // planar structure: homography from the model plane to the normalised image
+    double Rt[3][3];  // rows = principal axes (V^T)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rt[i][j] = Vc[j][i];
+    if (Rt[0][2] * Rt[0][2] + Rt[1][2] * Rt[1][2] < 1e-10) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rt[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    if (det3(Rt) < 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rt[i][j] = -Rt[i][j];
+    }
+    double Tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Tt[i] = -(Rt[i][0] * mc[0] + Rt[i][1] * mc[1] + Rt[i][2] * mc[2]);
+    // findHomography(method 0) works on float32 copies of both point sets
+    auto plane_xy = [&](int i, double& X, double& Y, double& x, double& y) {
+      const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
+      X = (double)(float)(Rt[0][0] * M0 + Rt[0][1] * M1 + Rt[0][2] * M2 + Tt[0]);
+      Y = (double)(float)(Rt[1][0] * M0 + Rt[1][1] * M1 + Rt[1][2] * M2 + Tt[1]);
+      x = (double)(float)(((double)img[2 * i] - cam.cx) / cam.fx);
+      y = (double)(float)(((double)img[2 * i + 1] - cam.cy) / cam.fy);
+    };
+    double s4[4] = {0, 0, 0, 0};
+    for (int i = lane; i < n; i += 64)
+      if (mask[i]) { double X, Y, x, y; plane_xy(i, X, Y, x, y); s4[0] += X; s4[1] += Y; s4[2] += x; s4[3] += y; }
+    double cM[2], cm[2];
+    cM[0] = wsum(s4[0]) / ninl; cM[1] = wsum(s4[1]) / ninl; cm[0] = wsum(s4[2]) / ninl; cm[1] = wsum(s4[3]) / ninl;
+    double d4[4] = {0, 0, 0, 0};
+    for (int i = lane; i < n; i += 64)
+      if (mask[i]) { double X, Y, x, y; plane_xy(i, X, Y, x, y);
+        d4[0] += fabs(X - cM[0]); d4[1] += fabs(Y - cM[1]); d4[2] += fabs(x - cm[0]); d4[3] += fabs(y - cm[1]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d4[k] = wsum(d4[k]);
+    if (fabs(d4[0]) < kDblEps || fabs(d4[1]) < kDblEps || fabs(d4[2]) < kDblEps || fabs(d4[3]) < kDblEps) {
+      init_ok = false;
+    } else {
+      const double sM[2] = {ninl / d4[0], ninl / d4[1]}, sm[2] = {ninl / d4[2], ninl / d4[3]};
+      // L^T L blocks: S1 = sum QQ^T, Sx = sum x QQ^T, Sy = sum y QQ^T, Sw = sum (x^2+y^2) QQ^T, Q = [X Y 1]
+      double q24[24];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) q24[k] = 0.0;
+      for (int i = lane; i < n; i += 64)
+        if (mask[i]) {
+          double X, Y, x, y; plane_xy(i, X, Y, x, y);
+          x = (x - cm[0]) * sm[0]; y = (y - cm[1]) * sm[1]; X = (X - cM[0]) * sM[0]; Y = (Y - cM[1]) * sM[1];
+          const double qq[6] = {X * X, X * Y, X, Y * Y, Y, 1.0};
+          const double w = x * x + y * y;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { q24[k] += qq[k]; q24[6 + k] += x * qq[k]; q24[12 + k] += y * qq[k]; q24[18 + k] += w * qq[k]; }
+        }
+#pragma unroll
+      for (int k = 0; k < 24; ++k) q24[k] = wsum(q24[k]);
+      __syncthreads();
+      for (int idx = lane; idx < 81; idx += 64) {
+        const int r = idx / 9, c = idx % 9, br = r / 3, bc = c / 3, ir = r % 3, ic = c % 3;
+        const int lo = ir < ic ? ir : ic, hi = ir < ic ? ic : ir;
+        const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);  // (0,0)0 (0,1)1 (0,2)2 (1,1)3 (1,2)4 (2,2)5
+        double v = 0.0;
+        if (br == bc && br < 2) v = q24[sidx];
+        else if (br == 2 && bc == 2) v = q24[18 + sidx];
+        else if ((br == 0 && bc == 2) || (br == 2 && bc == 0)) v = -q24[6 + sidx];
+        else if ((br == 1 && bc == 2) || (br == 2 && bc == 1)) v = -q24[12 + sidx];
+        sh.A[idx] = v;
+      }
+      __syncthreads();
+      sym_eig_lds(sh.A, sh.V, sh.ord, 9, lane);
+      double H0[3][3];
+      const int c0 = sh.ord[0];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H0[k / 3][k % 3] = sh.V[k * 9 + c0];
+      // H = invHnorm * H0 * Hnorm2, then / H[2][2]
+      const double ih[3][3] = {{1.0 / sm[0], 0, cm[0]}, {0, 1.0 / sm[1], cm[1]}, {0, 0, 1}};
+      const double hn[3][3] = {{sM[0], 0, -cM[0] * sM[0]}, {0, sM[1], -cM[1] * sM[1]}, {0, 0, 1}};
+      double T1[3][3], H[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T1[i][j] = ih[i][0] * H0[0][j] + ih[i][1] * H0[1][j] + ih[i][2] * H0[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[i][j] = T1[i][0] * hn[0][j] + T1[i][1] * hn[1][j] + T1[i][2] * hn[2][j];
+      const double h22 = 1.0 / H[2][2];
+      bool fin = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { H[i][j] *= h22; fin = fin && isfinite(H[i][j]); }
+      if (!fin) init_ok = false;
+      else {
+        const double h1n = sqrt(H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]);
+        const double h2n = sqrt(H[0][1] * H[0][1] + H[1][1] * H[1][1] + H[2][1] * H[2][1]);
+        const double i1 = 1.0 / fmax(h1n, kDblEps), i2 = 1.0 / fmax(h2n, kDblEps), it3 = 2.0 / fmax(h1n + h2n, kDblEps);
+        double h1[3] = {H[0][0] * i1, H[1][0] * i1, H[2][0] * i1}, h2[3] = {H[0][1] * i2, H[1][1] * i2, H[2][1] * i2}, h3[3];
+        double tt[3] = {H[0][2] * it3, H[1][2] * it3, H[2][2] * it3};
+        cross3(h1, h2, h3);
+        double Rh[3][3] = {{h1[0], h2[0], h3[0]}, {h1[1], h2[1], h3[1]}, {h1[2], h2[2], h3[2]}};
+        double rv[3], dummy[3][9];
+        rodrigues_m2v(Rh, rv);
+        rodrigues_v2m(rv, Rh, dummy, false);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tt[i] += Rh[i][0] * Tt[0] + Rh[i][1] * Tt[1] + Rh[i][2] * Tt[2];
+        double Rf[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Rf[i][j] = Rh[i][0] * Rt[0][j] + Rh[i][1] * Rt[1][j] + Rh[i][2] * Rt[2][j];
+        rodrigues_m2v(Rf, p);
+        p[3] = tt[0]; p[4] = tt[1]; p[5] = tt[2];
+      }
+    }
+    if (!init_ok) { p[0] = p[1] = p[2] = p[3] = p[4] = p[5] = 0.0; init_ok = true; }
+  } else if (ninl >= 6) {
+    // DLT: L^T L from 4 weighted sums of P P^T, P = [X Y Z 1]
+    double s40[40];
+#pragma unroll
+    for (int k = 0; k < 40; ++k) s40[k] = 0.0;
+    for (int i = lane; i < n; i += 64)
+      if (mask[i]) {
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        const double x = -(((double)img[2 * i] - cam.cx) / cam.fx), y = -(((double)img[2 * i + 1] - cam.cy) / cam.fy);
+        const double pp[10] = {X * X, X * Y, X * Z, X, Y * Y, Y * Z, Y, Z * Z, Z, 1.0};
+        const double w = x * x + y * y;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { s40[k] += pp[k]; s40[10 + k] += x * pp[k]; s40[20 + k] += y * pp[k]; s40[30 + k] += w * pp[k]; }
+      }
+#pragma unroll
+    for (int k = 0; k < 40; ++k) s40[k] = wsum(s40[k]);
+    __syncthreads();
+    for (int idx = lane; idx < 144; idx += 64) {
+      const int r = idx / 12, c = idx % 12, br = r / 4, bc = c / 4, ir = r % 4, ic = c % 4;
+      const int lo = ir < ic ? ir : ic, hi = ir < ic ? ic : ir;
+      const int sidx = lo == 0 ? hi : (lo == 1 ? 3 + hi : (lo == 2 ? 5 + hi : 9));  // upper-tri index of 4x4
+      double v = 0.0;
+      if (br == bc && br < 2) v = s40[sidx];
+      else if (br == 2 && bc == 2) v = s40[30 + sidx];
+      else if ((br == 0 && bc == 2) || (br == 2 && bc == 0)) v = s40[10 + sidx];
+      else if ((br == 1 && bc == 2) || (br == 2 && bc == 1)) v = s40[20 + sidx];
+      sh.A[idx] = v;
+    }
+    __syncthreads();
+    sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+    const int c0 = sh.ord[0];
+    double RR[3][3], tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) RR[i][j] = sh.V[(4 * i + j) * 12 + c0];
+      tt[i] = sh.V[(4 * i + 3) * 12 + c0];
+    }
+    if (det3(RR) < 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { tt[i] = -tt[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) RR[i][j] = -RR[i][j]; }
+    }
+    double sc = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sc += RR[i][j] * RR[i][j];
+    sc = sqrt(sc);
+    double Rq[3][3];
+    polar3(RR, Rq);
+    double rn = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rn += Rq[i][j] * Rq[i][j];
+    rn = sqrt(rn);
+    rodrigues_m2v(Rq, p);
+    p[3] = tt[0] * (rn / sc); p[4] = tt[1] * (rn / sc); p[5] = tt[2] * (rn / sc);
+  } else {
+    init_ok = false;  // < 6 non-planar inliers: OpenCV >= 4.5 falls back to the RANSAC model
+  }
+
+  double Rf[3][3], dummy[3][9];
+  if (init_ok) {
+    levmarq_pose(obj, img, mask, n, lane, cam, p);
+    rodrigues_v2m(p, Rf, dummy, false);
+  } else {
+    // rvec = Rodrigues(bestR) then back, as the reference applies cv2.Rodrigues to the returned rvec
+    double rv[3];
+    rodrigues_m2v(bestR, rv);
+    rodrigues_v2m(rv, Rf, dummy, false);
+    p[3] = bestT[0]; p[4] = bestT[1]; p[5] = bestT[2];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { tout[i] = p[3 + i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rout[3 * i + j] = Rf[i][j]; }
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fin = fin && isfinite(p[k]);
+    a.ok[b] = fin ? 1 : 0;
+    a.n_inliers[b] = ninl;
+  }
+}
+}  // namespace
+
+void launch_pnp(const PnpArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_pnp_ransac, dim3(a.B), dim3(64), 0, s, a);
+}
+
+}  // namespace gn

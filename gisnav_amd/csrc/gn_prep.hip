@@ -1,0 +1,175 @@
+// Input preparation and the row-wise pieces of the LightGlue blocks (HBM-bound, one pass each).
+//
+//   k_extent        keypoint extent (max_x, max_y) per (pair, side): kornia's LightGlueMatcher passes
+//                   image_size = keypoints.max(dim=1) when hw is None (call site pose_node.py:285-287)
+//   k_prep          RootSIFT (pose_node.py:278-284), LAF -> (centre, scale, orientation)
+//                   (pose_node.py:267-276 + kornia get_laf_*), normalize_keypoints, and the learnable
+//                   Fourier positional encoding cos/sin(Wr [x^,y^,scale,ori]) cached for all 9 layers
+//   k_ln_gelu       LayerNorm(512, eps 1e-5, affine) + exact-erf GELU of the FFN hidden (ffn.1, ffn.2)
+//   k_matchability  logsigmoid(Linear(256 -> 1)) per keypoint (MatchAssignment.matchability)
+#include "gn_common.h"
+
+namespace gn {
+
+namespace {
+constexpr float kPi = 3.14159265358979323846f;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ inline void read_kpt(const float* kp, int fmt, float& x, float& y, float& scale, float& ori) {
+  float a00, a01, a10, a11;
+  if (fmt == GN_KPT_LAF) {
+    a00 = kp[0]; a01 = kp[1]; x = kp[2]; a10 = kp[3]; a11 = kp[4]; y = kp[5];
+  } else {
+    x = kp[0]; y = kp[1];
+    const float size = kp[2];
+    const float ang = kp[3] * kPi / 180.0f;  // kornia deg2rad
+    const float c = cosf(ang), s = sinf(ang);
+    a00 = size * c; a01 = size * s; a10 = size * (-s); a11 = size * c;
+  }
+  scale = sqrtf(fabsf(a00 * a11 - a10 * a01));             // get_laf_scale
+  const float deg = 180.0f * atan2f(a01, a00) / kPi;       // get_laf_orientation (rad2deg)
+  ori = deg * kPi / 180.0f;                                // deg2rad in LightGlueMatcher.forward
+  if (ori < 0.f) ori += 2.0f * kPi;
+}
+
+__global__ __launch_bounds__(256) void k_extent(PrepArgs a) {
+  const int bs = blockIdx.x, b = bs >> 1, side = bs & 1;
+  const int n = side ? a.n_r[b] : a.n_q[b];
+  const int stride = side ? a.stride_r : a.stride_q;
+  const int fmt = a.kpt_format & 0xff;
+  const int w = fmt == GN_KPT_LAF ? 6 : 4;
+  const int xo = fmt == GN_KPT_LAF ? 2 : 0, yo = fmt == GN_KPT_LAF ? 5 : 1;
+  const float* kp = (side ? a.kpt_r : a.kpt_q) + (size_t)b * stride * w;
+  float mx = -INFINITY, my = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    mx = fmaxf(mx, kp[(size_t)i * w + xo]);
+    my = fmaxf(my, kp[(size_t)i * w + yo]);
+  }
+  mx = wave_max(mx); my = wave_max(my);
+  __shared__ float sx[4], sy[4];
+  if ((threadIdx.x & 63) == 0) { sx[threadIdx.x >> 6] = mx; sy[threadIdx.x >> 6] = my; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.extent[bs * 2 + 0] = fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3]));
+    a.extent[bs * 2 + 1] = fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3]));
+    a.nvalid[bs] = n;
+  }
+}
+
+// one wave per token slot
+__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bs = blockIdx.y, b = bs >> 1, side = bs & 1;
+  const int i = blockIdx.x * 4 + wave;
+  const int n = side ? a.n_r[b] : a.n_q[b];
+  const int stride = side ? a.stride_r : a.stride_q;
+  const size_t tok = (size_t)bs * a.npad + i;
+  float* dout = a.desc + tok * kInDim;
+  if (i >= n) {  // padding slot: finite, inert values
+    dout[lane] = 0.f; dout[lane + 64] = 0.f;
+    if (lane < kFreq) { a.cos_t[tok * kFreq + lane] = 1.f; a.sin_t[tok * kFreq + lane] = 0.f; }
+    return;
+  }
+  const float* din = (side ? a.desc_r : a.desc_q) + ((size_t)b * stride + i) * kInDim;
+  const float d0 = din[lane], d1 = din[lane + 64];
+  if (a.kpt_format & GN_DESC_ROOTSIFT) {
+    dout[lane] = d0; dout[lane + 64] = d1;
+  } else {
+    const float l1 = wave_sum(fabsf(d0) + fabsf(d1));
+    const float den = fmaxf(l1, 1e-12f);  // F.normalize(p=1, eps=1e-12)
+    dout[lane] = sqrtf(d0 / den);
+    dout[lane + 64] = sqrtf(d1 / den);
+  }
+
+  if (lane < kFreq) {
+    const int fmt = a.kpt_format & 0xff;
+    const int w = fmt == GN_KPT_LAF ? 6 : 4;
+    const float* kp = (side ? a.kpt_r : a.kpt_q) + ((size_t)b * stride + i) * w;
+    float x, y, scale, ori;
+    read_kpt(kp, fmt, x, y, scale, ori);
+    const float sx = a.extent[bs * 2], sy = a.extent[bs * 2 + 1];
+    const float sc = fmaxf(sx, sy) / 2.0f;
+    const float xn = (x - sx / 2.0f) / sc, yn = (y - sy / 2.0f) / sc;  // normalize_keypoints
+    const float* wr = a.wr + lane * 4;
+    const float e = wr[0] * xn + wr[1] * yn + wr[2] * scale + wr[3] * ori;
+    a.cos_t[tok * kFreq + lane] = cosf(e);
+    a.sin_t[tok * kFreq + lane] = sinf(e);
+  }
+}
+
+// one wave per 512-wide row, in place
+__global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* p = h + (size_t)row * 512;
+  float4 v0 = *reinterpret_cast<const float4*>(p + lane * 4);
+  float4 v1 = *reinterpret_cast<const float4*>(p + 256 + lane * 4);
+  const float mean = wave_sum(v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w) * (1.0f / 512.0f);
+  v0.x -= mean; v0.y -= mean; v0.z -= mean; v0.w -= mean;
+  v1.x -= mean; v1.y -= mean; v1.z -= mean; v1.w -= mean;
+  const float var = wave_sum(v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w +
+                             v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w) * (1.0f / 512.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 g1 = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + lane * 4);
+  const float4 b1 = *reinterpret_cast<const float4*>(beta + 256 + lane * 4);
+  auto f = [rstd](float x, float g, float b) {
+    const float y = x * rstd * g + b;
+    return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+  };
+  v0.x = f(v0.x, g0.x, b0.x); v0.y = f(v0.y, g0.y, b0.y); v0.z = f(v0.z, g0.z, b0.z); v0.w = f(v0.w, g0.w, b0.w);
+  v1.x = f(v1.x, g1.x, b1.x); v1.y = f(v1.y, g1.y, b1.y); v1.z = f(v1.z, g1.z, b1.z); v1.w = f(v1.w, g1.w, b1.w);
+  *reinterpret_cast<float4*>(p + lane * 4) = v0;
+  *reinterpret_cast<float4*>(p + 256 + lane * 4) = v1;
+}
+
+// one wave per 256-wide row
+__global__ __launch_bounds__(256) void k_matchability(const float* x, const float* w, const float* b, float* ls, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * kDim + lane * 4);
+  const float4 ww = *reinterpret_cast<const float4*>(w + lane * 4);
+  const float z = wave_sum(v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w) + b[0];
+  // logsigmoid(z) = min(z, 0) - log1p(exp(-|z|))
+  if (lane == 0) ls[row] = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
+}
+
+__global__ void k_cast_bf16(const float* in, uint16_t* out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    unsigned int u = __float_as_uint(in[i]);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    out[i] = (uint16_t)(u >> 16);
+  }
+}
+}  // namespace
+
+void launch_prep(const PrepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_extent, dim3(a.B * 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_prep, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
+}
+void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows);
+}
+void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(k_matchability, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, ls, rows);
+}
+void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_cast_bf16, dim3(2048), dim3(256), 0, s, in, out, n);
+}
+
+}  // namespace gn

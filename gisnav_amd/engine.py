@@ -1,0 +1,203 @@
+"""Device-side engine: one `PoseEngine` per GPU wraps a `gn_ctx` of libgisnav_amd.so.
+
+PyTorch is used here only for device memory, streams and (in `dist.py`) the RCCL process
+group; every numeric step of the hot path runs in the hand-written gfx950 kernels behind the
+C ABI.  The engine mirrors the state PoseNode builds in its constructor
+(ros/gisnav/gisnav/core/pose_node.py:81-122): a device, a LightGlue("sift") matcher with 9
+layers / threshold 0.5 / no early exit, and the solvePnPRansac settings of
+core/_shared.py:109-116.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import canonical_state_dict
+
+MIN_MATCHES = 15          # PoseNode.MIN_MATCHES, pose_node.py:63
+FILTER_THRESHOLD = 0.5    # PoseNode.CONFIDENCE_THRESHOLD, pose_node.py:60
+RANSAC_ITERATIONS = 10    # _shared.py:115
+RANSAC_REPROJ_PX = 8.0    # cv2.solvePnPRansac default
+RANSAC_CONFIDENCE = 0.99  # cv2.solvePnPRansac default
+
+_PRECISIONS = {"f32": _lib.GN_PREC_F32, "bf16_attn": _lib.GN_PREC_BF16_ATTN}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev_tensor(t, dtype, device) -> torch.Tensor:
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    t = t.to(device=device, dtype=dtype, non_blocking=True)
+    return t.contiguous()
+
+
+class PoseEngine:
+    """Batched frame<->tile matcher + PnP solver on one MI355X."""
+
+    def __init__(self, device: int = 0, max_batch: int = 32, max_kpts: int = 1024,
+                 precision: str = "f32", state_dict: Optional[Dict[str, np.ndarray]] = None,
+                 n_layers: int = 9, filter_threshold: float = FILTER_THRESHOLD):
+        if not torch.cuda.is_available():
+            raise _lib.GnError("PoseEngine needs a HIP device; the product path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        self.max_batch, self.precision = max_batch, precision
+        ctx = C.c_void_p()
+        _lib.check(None, self.lib.gn_create(device, max_batch, max_kpts, _PRECISIONS[precision], C.byref(ctx)), "gn_create")
+        self.ctx = ctx
+        self.kmax = self.lib.gn_kmax(ctx)
+        _lib.check(ctx, self.lib.gn_set_num_layers(ctx, n_layers), "gn_set_num_layers")
+        _lib.check(ctx, self.lib.gn_set_filter_threshold(ctx, filter_threshold), "gn_set_filter_threshold")
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def __del__(self):
+        ctx, self.ctx = getattr(self, "ctx", None), None
+        if ctx:
+            self.lib.gn_destroy(ctx)
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd) -> None:
+        for name, arr in canonical_state_dict(sd).items():
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
+            rc = self.lib.gn_load_tensor(self.ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, max(arr.ndim, 1))
+            _lib.check(self.ctx, rc, f"gn_load_tensor({name})")
+        missing = self.lib.gn_missing_tensors(self.ctx)
+        if missing:
+            raise _lib.GnError(f"{missing} required LightGlue tensors missing from the state dict")
+
+    def set_num_layers(self, n: int) -> None:
+        _lib.check(self.ctx, self.lib.gn_set_num_layers(self.ctx, n), "gn_set_num_layers")
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def stage_inputs(self, pairs, kpt_format: int = _lib.GN_KPT_XYSA):
+        """Pack a list of `synthetic.Pair`-like objects into device tensors (host -> HBM once)."""
+        B = len(pairs)
+        nq = max(len(p.kp_q) for p in pairs)
+        nr = max(len(p.kp_r) for p in pairs)
+        dq = np.zeros((B, nq, 128), np.float32); kq = np.zeros((B, nq, 4), np.float32)
+        dr = np.zeros((B, nr, 128), np.float32); kr = np.zeros((B, nr, 4), np.float32)
+        n_q = np.zeros(B, np.int32); n_r = np.zeros(B, np.int32)
+        h, w = pairs[0].dem.shape
+        dem = np.zeros((B, h, w), np.uint8)
+        for b, p in enumerate(pairs):
+            a, c = len(p.kp_q), len(p.kp_r)
+            n_q[b], n_r[b] = a, c
+            dq[b, :a], dr[b, :c] = p.desc_q, p.desc_r
+            kq[b, :a] = np.column_stack([p.kp_q, p.size_q, p.angle_q])
+            kr[b, :c] = np.column_stack([p.kp_r, p.size_r, p.angle_r])
+            dem[b] = p.dem
+        f = lambda a, dt: _dev_tensor(a, dt, self.device)  # noqa: E731
+        return dict(desc_q=f(dq, torch.float32), kpt_q=f(kq, torch.float32), n_q=f(n_q, torch.int32),
+                    desc_r=f(dr, torch.float32), kpt_r=f(kr, torch.float32), n_r=f(n_r, torch.int32),
+                    dem=f(dem, torch.uint8), kpt_format=kpt_format)
+
+    # ------------------------------------------------------------------ hot path
+    def match(self, desc_q, kpt_q, n_q, desc_r, kpt_r, n_r, kpt_format: int = _lib.GN_KPT_XYSA,
+              out: Optional[tuple] = None):
+        """gn_match.  Tensors are device tensors: desc [B,S,128] f32, kpt [B,S,4|6] f32, n [B] i32.
+        Returns (idx [B,kmax,2] i64, score [B,kmax] f32, n_match [B] i32) on the device."""
+        B = desc_q.shape[0]
+        if out is None:
+            idx = torch.empty((B, self.kmax, 2), dtype=torch.int64, device=self.device)
+            score = torch.empty((B, self.kmax), dtype=torch.float32, device=self.device)
+            n_match = torch.empty((B,), dtype=torch.int32, device=self.device)
+        else:
+            idx, score, n_match = out
+        rc = self.lib.gn_match(self.ctx, B, kpt_format, _ptr(desc_q), _ptr(kpt_q), _ptr(n_q), desc_q.shape[1],
+                               _ptr(desc_r), _ptr(kpt_r), _ptr(n_r), desc_r.shape[1],
+                               _ptr(idx), _ptr(score), _ptr(n_match), self._stream())
+        _lib.check(self.ctx, rc, "gn_match")
+        return idx, score, n_match
+
+    def gather_points(self, kpt_q, kpt_r, idx, n_match, dem, kpt_format: int = _lib.GN_KPT_XYSA):
+        B = kpt_q.shape[0]
+        mkp_q = torch.zeros((B, self.kmax, 2), dtype=torch.float32, device=self.device)
+        obj = torch.zeros((B, self.kmax, 3), dtype=torch.float32, device=self.device)
+        H, W = (dem.shape[1], dem.shape[2]) if dem is not None else (0, 0)
+        rc = self.lib.gn_gather_points(self.ctx, B, kpt_format, _ptr(kpt_q), kpt_q.shape[1], _ptr(kpt_r), kpt_r.shape[1],
+                                       _ptr(idx), _ptr(n_match), _ptr(dem), H, W, _ptr(mkp_q), _ptr(obj), self._stream())
+        _lib.check(self.ctx, rc, "gn_gather_points")
+        return mkp_q, obj
+
+    def pnp_ransac(self, obj, img, n_pts, K: np.ndarray, iterations: int = RANSAC_ITERATIONS,
+                   reproj_px: float = RANSAC_REPROJ_PX, confidence: float = RANSAC_CONFIDENCE, min_pts: int = 5):
+        """gn_pnp_ransac.  obj [B,S,3] f32, img [B,S,2] f32, n_pts [B] i32 (device)."""
+        B = obj.shape[0]
+        R = torch.empty((B, 3, 3), dtype=torch.float64, device=self.device)
+        t = torch.empty((B, 3, 1), dtype=torch.float64, device=self.device)
+        n_inl = torch.empty((B,), dtype=torch.int32, device=self.device)
+        ok = torch.empty((B,), dtype=torch.uint8, device=self.device)
+        K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+        rc = self.lib.gn_pnp_ransac(self.ctx, B, _ptr(obj), _ptr(img), _ptr(n_pts), obj.shape[1],
+                                    K9.ctypes.data_as(_lib.c_f64p), iterations, reproj_px, confidence, min_pts,
+                                    _ptr(R), _ptr(t), _ptr(n_inl), _ptr(ok), self._stream())
+        _lib.check(self.ctx, rc, "gn_pnp_ransac")
+        return R, t, n_inl, ok
+
+    def estimate(self, inputs: dict, K: np.ndarray, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
+        """gn_estimate on staged inputs: PoseNode._pose lines 246-308 for the whole batch."""
+        B = inputs["desc_q"].shape[0]
+        if out is None:
+            out = self.alloc_outputs(B)
+        dem = inputs.get("dem")
+        H, W = (dem.shape[1], dem.shape[2]) if dem is not None else (0, 0)
+        K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+        rc = self.lib.gn_estimate(self.ctx, B, inputs["kpt_format"],
+                                  _ptr(inputs["desc_q"]), _ptr(inputs["kpt_q"]), _ptr(inputs["n_q"]), inputs["desc_q"].shape[1],
+                                  _ptr(inputs["desc_r"]), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["desc_r"].shape[1],
+                                  _ptr(dem), H, W, K9.ctypes.data_as(_lib.c_f64p), min_matches,
+                                  _ptr(out["R"]), _ptr(out["t"]), _ptr(out["n_match"]), _ptr(out["n_inliers"]), _ptr(out["ok"]),
+                                  self._stream())
+        _lib.check(self.ctx, rc, "gn_estimate")
+        return out
+
+    def alloc_outputs(self, B: int) -> dict:
+        d = self.device
+        return dict(R=torch.empty((B, 3, 3), dtype=torch.float64, device=d), t=torch.empty((B, 3, 1), dtype=torch.float64, device=d),
+                    n_match=torch.empty((B,), dtype=torch.int32, device=d), n_inliers=torch.empty((B,), dtype=torch.int32, device=d),
+                    ok=torch.empty((B,), dtype=torch.uint8, device=d))
+
+    # ------------------------------------------------------------------ test hooks
+    def debug_read(self, name: str, count: int, dtype=np.float32) -> np.ndarray:
+        buf = np.empty(count, dtype=dtype)
+        n = self.lib.gn_debug_read(self.ctx, name.encode(), buf.ctypes.data_as(C.c_void_p), buf.nbytes, self._stream())
+        _lib.check(self.ctx, int(n), f"gn_debug_read({name})")
+        return buf[: int(n)]
+
+    def set_stage_timing(self, enable: bool) -> None:
+        _lib.check(self.ctx, self.lib.gn_set_stage_timing(self.ctx, int(enable)), "gn_set_stage_timing")
+
+    def stage_ms(self) -> Dict[str, float]:
+        buf = (C.c_float * 16)()
+        n = self.lib.gn_get_stage_ms(self.ctx, buf, 16)
+        _lib.check(self.ctx, n, "gn_get_stage_ms")
+        return {name: float(buf[i]) for i, name in enumerate(_lib.STAGE_NAMES[:n])}
+
+    def debug_gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        M, K = A.shape
+        N = W.shape[0]
+        Y = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        rc = self.lib.gn_debug_gemm(self.ctx, M, N, K, _ptr(A), _ptr(W), _ptr(bias), _ptr(Y), self._stream())
+        _lib.check(self.ctx, rc, "gn_debug_gemm")
+        return Y
+
+    def debug_attention(self, q, k, v, nkv, cross: bool, qscale: float) -> torch.Tensor:
+        """q,k,v [BS, npad, 256] f32 (4 heads x 64 concatenated); nkv [BS] i32."""
+        BS, npad, _ = q.shape
+        out = torch.empty_like(q)
+        rc = self.lib.gn_debug_attention(self.ctx, BS, npad, int(cross), qscale, _ptr(q), 256, _ptr(k), 256, _ptr(v), 256,
+                                         _ptr(nkv), _ptr(out), 256, self._stream())
+        _lib.check(self.ctx, rc, "gn_debug_attention")
+        return out

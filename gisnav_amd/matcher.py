@@ -1,0 +1,76 @@
+"""Seam B1: a drop-in for the matcher object PoseNode builds and calls.
+
+    self._matcher = LightGlueMatcher("sift", params={...}).to(device).eval()   pose_node.py:109-121
+    dists, idx = self._matcher(desc_q, desc_r, lafs_q, lafs_r)                 pose_node.py:285-287
+
+Same constructor arguments, same call signature, same outputs: `dists (K,1)` float tensor and
+`idx (K,2)` int64 tensor on the input device, rows in ascending query index; empty (0,1)/(0,2)
+when either side has fewer than 2 descriptors.  All arithmetic runs in libgisnav_amd.so.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .engine import PoseEngine
+from .weights import N_LAYERS
+
+_DEFAULTS = {"n_layers": N_LAYERS, "filter_threshold": 0.1, "depth_confidence": 0.95, "width_confidence": 0.99}
+
+
+class LightGlueMatcher:
+    def __init__(self, feature_name: str = "sift", params: Optional[Dict] = None, *,
+                 state_dict=None, max_kpts: int = 4096, precision: str = "f32"):
+        if feature_name != "sift":
+            raise NotImplementedError("PoseNode uses LightGlue('sift') only (pose_node.py:110)")
+        p = dict(_DEFAULTS)
+        p.update(params or {})
+        if p["depth_confidence"] > 0 or p["width_confidence"] > 0:
+            # the adaptive depth/width branch is dead code in the reference (torch.device == str is
+            # always False, pose_node.py:88); only the exhaustive configuration is implemented
+            raise NotImplementedError("only depth_confidence = width_confidence = -1 is supported")
+        self.params = p
+        self._state_dict = state_dict
+        self._max_kpts, self._precision = max_kpts, precision
+        self._engine: Optional[PoseEngine] = None
+
+    # torch.nn.Module-shaped conveniences used by the call site
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.GnError("gisnav_amd.LightGlueMatcher runs on an MI355X only (no CPU path)")
+        self._engine = PoseEngine(device.index or 0, max_batch=1, max_kpts=self._max_kpts, precision=self._precision,
+                                  state_dict=self._state_dict, n_layers=self.params["n_layers"],
+                                  filter_threshold=self.params["filter_threshold"])
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd):
+        self._state_dict = sd
+        if self._engine is not None:
+            self._engine.load_state_dict(sd)
+
+    @torch.inference_mode()
+    def __call__(self, desc1: torch.Tensor, desc2: torch.Tensor, lafs1: torch.Tensor, lafs2: torch.Tensor,
+                 hw1=None, hw2=None):
+        if self._engine is None:
+            raise _lib.GnError("call .to(device) first")
+        if hw1 is not None or hw2 is not None:
+            raise NotImplementedError("PoseNode passes hw1 = hw2 = None (pose_node.py:285-287)")
+        dev = self._engine.device
+        if desc1.shape[0] < 2 or desc2.shape[0] < 2:
+            return torch.zeros((0, 1), dtype=desc1.dtype, device=desc1.device), torch.zeros((0, 2), dtype=torch.int64, device=desc1.device)
+        f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        d1, d2 = f(desc1).reshape(1, -1, 128), f(desc2).reshape(1, -1, 128)
+        l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
+        n1 = torch.tensor([d1.shape[1]], dtype=torch.int32, device=dev)
+        n2 = torch.tensor([d2.shape[1]], dtype=torch.int32, device=dev)
+        idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, _lib.GN_KPT_LAF | 0x100)
+        k = int(n_match.item())  # the D2H sync the reference has at pose_node.py:296-297
+        return score[0, :k].reshape(-1, 1), idx[0, :k]
+
+    forward = __call__

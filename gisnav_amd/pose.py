@@ -1,0 +1,49 @@
+"""Seam B2: `compute_pose(camera_info, mkp_qry, mkp_ref, elevation)`.
+
+Mirror of ros/gisnav/gisnav/core/_shared.py:89-125 (also used by TwistNode with a zero DEM,
+core/twist_node.py:289): numpy in, `(R (3,3) f64, t (3,1) f64)` out.  The DEM lookup is the
+reference's own host-side marshalling (`_compute_3d_points`); RANSAC, EPnP, the iterative refinement
+and Rodrigues run in `gn_pnp_ransac` on the GPU.  Returns None where the reference would fail
+(cv2 returning no model).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .engine import PoseEngine, RANSAC_ITERATIONS
+
+_default_engine: Optional[PoseEngine] = None
+
+
+def _engine(max_pts: int) -> PoseEngine:
+    global _default_engine
+    if _default_engine is None or _default_engine.kmax < max_pts:
+        _default_engine = PoseEngine(0, max_batch=1, max_kpts=max(max_pts, 1024))
+    return _default_engine
+
+
+def compute_pose(camera_info, mkp_qry: np.ndarray, mkp_ref: np.ndarray, elevation: Optional[np.ndarray],
+                 engine: Optional[PoseEngine] = None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    def _compute_3d_points(mkp_ref, elevation):
+        if elevation is None:
+            return np.hstack((mkp_ref, np.zeros((len(mkp_ref), 1))))
+        x, y = np.transpose(np.floor(mkp_ref).astype(int))
+        z_values = elevation[y, x].reshape(-1, 1)
+        return np.hstack((mkp_ref, z_values))
+
+    n = len(mkp_qry)
+    if n < 5:
+        return None
+    eng = engine or _engine(n)
+    obj = np.ascontiguousarray(_compute_3d_points(mkp_ref, elevation), dtype=np.float32)[None]
+    img = np.ascontiguousarray(mkp_qry, dtype=np.float32)[None]
+    k_matrix = np.asarray(camera_info.k, dtype=np.float64).reshape((3, 3))
+    dev = eng.device
+    R, t, n_inl, ok = eng.pnp_ransac(torch.from_numpy(obj).to(dev), torch.from_numpy(img).to(dev),
+                                     torch.tensor([n], dtype=torch.int32, device=dev), k_matrix, RANSAC_ITERATIONS)
+    if not bool(ok.cpu()[0]):
+        return None
+    return R[0].cpu().numpy(), t[0].cpu().numpy()

@@ -1,0 +1,75 @@
+"""Seam B3: a ROS-free PoseNode with the reference's message-level behaviour up to the pose.
+
+Reproduces `PoseNode._pose` (ros/gisnav/gisnav/core/pose_node.py:186-308) from the
+OrthoStereoImage payload to `(r, t)`: parse the 532-byte keypoint records, take the mono8
+reference / DEM rasters, (re)compute reference-tile features only when the tile stamp changes
+(cache, pose_node.py:124-126,225-241), match, gate on MIN_MATCHES, solve the pose.  Everything
+after line 308 (debug images, PROJ georeferencing, tf2, message assembly) needs ROS / pyproj and
+is out of scope; an rclpy node would wrap `estimate()` unchanged.
+
+The reference extracts tile features with `cv2.SIFT_create().detectAndCompute`; a GPU SIFT is a
+"next" row, so the extractor is injected: any callable
+`extractor(ref_u8) -> (kp (M,2) f32, desc (M,128) f32, size (M,), angle_deg (M,))`.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import MIN_MATCHES, PoseEngine
+from .wire import CameraInfo, OrthoStereoImage, unpack_keypoints
+
+
+class PoseNode:
+    CONFIDENCE_THRESHOLD = 0.5   # pose_node.py:60
+    MIN_MATCHES = MIN_MATCHES    # pose_node.py:63
+
+    def __init__(self, state_dict, extractor: Callable, device: int = 0, max_kpts: int = 4096, precision: str = "f32"):
+        self._engine = PoseEngine(device, max_batch=1, max_kpts=max_kpts, precision=precision, state_dict=state_dict,
+                                  n_layers=9, filter_threshold=self.CONFIDENCE_THRESHOLD)
+        self._extractor = extractor
+        self._cached_stamp_kps_desc = None
+        self.camera_info: Optional[CameraInfo] = None
+        self.pose_image: Optional[OrthoStereoImage] = None
+        self.last_num_matches = 0
+
+    # `narrow_types` behaviour (gisnav/_decorators.py:117-160): no result until both inputs exist
+    def pose(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        if not isinstance(self.camera_info, CameraInfo) or not isinstance(self.pose_image, OrthoStereoImage):
+            return None
+        return self.estimate(self.camera_info, self.pose_image)
+
+    def estimate(self, camera_info: CameraInfo, msg: OrthoStereoImage) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        eng, dev = self._engine, self._engine.device
+        kp_q, desc_q, size_q, angle_q = unpack_keypoints(msg.query_sift)          # pose_node.py:207-213
+        ref = np.asarray(msg.reference.data)
+        assert ref.ndim == 2 or ref.shape[2] == 1
+        dem = np.asarray(msg.dem.data)
+        stamp = (msg.reference.stamp.sec, msg.reference.stamp.nanosec)
+        if self._cached_stamp_kps_desc is None or self._cached_stamp_kps_desc[0] != stamp:  # pose_node.py:226-241
+            kp_r, desc_r, size_r, angle_r = self._extractor(ref)
+            f = lambda a, w: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(1, -1, w)).to(dev)  # noqa: E731
+            cached = (f(desc_r, 128), f(np.column_stack([kp_r, size_r, angle_r]), 4),
+                      torch.tensor([len(kp_r)], dtype=torch.int32, device=dev))
+            self._cached_stamp_kps_desc = (stamp, cached)
+        desc_r_t, kpt_r_t, n_r_t = self._cached_stamp_kps_desc[1]
+        n = len(kp_q)
+        if n == 0:
+            self.last_num_matches = 0
+            return None
+        f = lambda a, w: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(1, -1, w)).to(dev)  # noqa: E731
+        inputs = dict(desc_q=f(desc_q, 128), kpt_q=f(np.column_stack([kp_q, size_q, angle_q]), 4),
+                      n_q=torch.tensor([n], dtype=torch.int32, device=dev),
+                      desc_r=desc_r_t, kpt_r=kpt_r_t, n_r=n_r_t,
+                      dem=torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev),
+                      kpt_format=_lib.GN_KPT_XYSA)
+        out = eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES)
+        self.last_num_matches = int(out["n_match"].cpu()[0])
+        if self.last_num_matches < self.MIN_MATCHES:        # pose_node.py:299-303
+            return None
+        if not bool(out["ok"].cpu()[0]):                    # pose_node.py:305-307
+            return None
+        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()

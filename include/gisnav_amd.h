@@ -1,0 +1,143 @@
+/*
+ * gisnav_amd.h -- C ABI of the MI355X-native PoseNode hot path (libgisnav_amd.so).
+ *
+ * GISNav has no formal plugin interface; PoseNode hard-codes three seams.
+ * Each entry point below names the reference code it stands in for
+ * (paths relative to the reference tree, ros/gisnav/gisnav/core/):
+ *
+ *   gn_create / gn_load_tensor   LightGlueMatcher("sift", params={n_layers:9, filter_threshold:.5,
+ *                                depth_confidence:-1, width_confidence:-1}).to(device).eval()
+ *                                                                       pose_node.py:109-121
+ *   gn_match                     RootSIFT + self._matcher(desc_q, desc_r, laf_q, laf_r)
+ *                                                                       pose_node.py:278-287
+ *   gn_gather_points             kp[idx] gathers, MIN_MATCHES gate, _compute_3d_points
+ *                                                 pose_node.py:289-303, _shared.py:95-102
+ *   gn_pnp_ransac                cv2.solvePnPRansac(..., iterationsCount=10) + cv2.Rodrigues
+ *                                                                       _shared.py:104-117
+ *   gn_estimate                  the whole of PoseNode._pose lines 246-308 for a batch of pairs
+ *
+ * Conventions: plain C, no torch types.  Every data pointer is a DEVICE pointer unless the
+ * parameter is marked "host".  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  All work is stream-ordered; no entry point synchronises except gn_debug_read.
+ * Return value: 0 on success, negative gn_status on failure; nothing throws.  One context
+ * per GPU; a context is thread-compatible, not thread-safe (PoseNode calls from one executor
+ * thread at a time, gisnav/__init__.py:140-154).
+ */
+#ifndef GISNAV_AMD_H
+#define GISNAV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gn_ctx gn_ctx;
+
+enum gn_status {
+  GN_OK = 0,
+  GN_ERR_ARG = -1,       /* bad argument (NULL, out of range, B > max_batch, n > max_kpts) */
+  GN_ERR_HIP = -2,       /* a HIP runtime call failed; see gn_last_error */
+  GN_ERR_NAME = -3,      /* unknown tensor name */
+  GN_ERR_SHAPE = -4,     /* tensor shape mismatch */
+  GN_ERR_WEIGHTS = -5,   /* forward called before every required tensor was loaded */
+  GN_ERR_ARCH = -6       /* device is not gfx950 */
+};
+
+enum gn_precision {
+  GN_PREC_F32 = 0,       /* every contraction on f32 MFMA (parity mode) */
+  GN_PREC_BF16_ATTN = 1  /* QK^T / PV on bf16 MFMA with f32 softmax+accumulate (what kornia's
+                            Attention does in fp16 on CUDA when flash=True); projections,
+                            FFN and the match head stay f32 */
+};
+
+enum gn_kpt_format {
+  GN_KPT_LAF = 0,        /* 6 floats/keypoint: kornia LAF (2x3 row-major) -- the B1 seam's argument */
+  GN_KPT_XYSA = 1        /* 4 floats/keypoint: x, y, size, angle_deg (cv2.KeyPoint fields,
+                            KEYPOINT_DTYPE in _shared.py:26-35); the LAF of pose_node.py:267-276
+                            is formed in registers */
+};
+/* OR into kpt_format when the descriptors are ALREADY RootSIFT-normalised (the B1 seam: PoseNode
+ * normalises at pose_node.py:278-284 before calling the matcher object); otherwise gn_match applies
+ * RootSIFT itself to raw SIFT descriptors. */
+#define GN_DESC_ROOTSIFT 0x100
+
+/* Library / build info: "gisnav_amd <ver> gfx950". */
+const char* gn_version(void);
+/* Human-readable text for the last failure on this context (or global if ctx is NULL). */
+const char* gn_last_error(const gn_ctx* ctx);
+
+/* Create a context on HIP device `device` sized for batches of up to max_batch pairs with up
+ * to max_kpts keypoints per side (rounded up to a multiple of 128 internally). */
+int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out);
+void gn_destroy(gn_ctx* ctx);
+
+/* Load one tensor of the kornia LightGlue("sift") state dict from HOST
+ * memory, float32, row-major [out,in].  Both spellings `transformers.{i}.self_attn.*` and the
+ * checkpoint's `self_attn.{i}.*` are accepted.  token_confidence.* and confidence_thresholds
+ * are accepted and ignored (dead in PoseNode's live configuration, pose_node.py:113-116). */
+int gn_load_tensor(gn_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* Number of required tensors still missing (0 = ready). */
+int gn_missing_tensors(const gn_ctx* ctx);
+
+/* Matcher options (defaults = PoseNode's: 9 layers, threshold 0.5). */
+int gn_set_num_layers(gn_ctx* ctx, int n_layers);
+int gn_set_filter_threshold(gn_ctx* ctx, float th);
+
+/* Batched LightGlueMatcher.forward on RAW (un-normalised) SIFT descriptors.
+ *   desc_q  [B][stride_q][128] f32     kpt_q [B][stride_q][6 or 4] f32     n_q [B] int32
+ *   desc_r  [B][stride_r][128] f32     kpt_r [B][stride_r][6 or 4] f32     n_r [B] int32
+ * Outputs (device): idx [B][kmax][2] int64 (col0 query index, col1 reference index, rows in
+ * ascending query index), score [B][kmax] f32, n_match [B] int32; kmax = gn_kmax(ctx).
+ * A pair with n_q < 2 or n_r < 2 yields n_match = 0 (kornia's _no_match). */
+int gn_match(gn_ctx* ctx, int B, int kpt_format,
+             const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+             const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+             int64_t* idx, float* score, int32_t* n_match, void* stream);
+int gn_kmax(const gn_ctx* ctx);
+
+/* Gather matched points and lift the reference side to 3-D with the DEM.
+ *   mkp_q [B][kmax][2] f32, obj [B][kmax][3] f32 = (x_r, y_r, dem[floor(y_r)][floor(x_r)])
+ *   dem   [B][H][W] u8 or NULL (z = 0). */
+int gn_gather_points(gn_ctx* ctx, int B, int kpt_format,
+                     const float* kpt_q, int stride_q, const float* kpt_r, int stride_r,
+                     const int64_t* idx, const int32_t* n_match,
+                     const uint8_t* dem, int H, int W,
+                     float* mkp_q, float* obj, void* stream);
+
+/* Batched solvePnPRansac + Rodrigues.
+ *   obj [B][kstride][3] f32, img [B][kstride][2] f32, n_pts [B] int32, K9: HOST 3x3 row-major f64.
+ * Outputs (device): R [B][9] f64 row-major, t [B][3] f64, n_inliers [B] int32,
+ * ok [B] u8 (0 when n_pts < min_pts or RANSAC found no model with > 4 inliers). */
+int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const int32_t* n_pts, int kstride,
+                  const double* K9_host, int iterations_count, float reproj_error_px, double confidence,
+                  int min_pts, double* R, double* t, int32_t* n_inliers, uint8_t* ok, void* stream);
+
+/* PoseNode._pose lines 246-308 for B pairs: match -> gather -> MIN_MATCHES gate -> PnP. */
+int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
+                const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                const uint8_t* dem, int H, int W, const double* K9_host, int min_matches,
+                double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
+
+/* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
+/* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
+ * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"
+ * "colmax" "collog" "m0" "m1" (ints are returned bit-cast in float slots). Returns the element
+ * count copied, or a negative status. */
+int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream);
+/* Stand-alone kernels for unit tests: Y[M,N] = A[M,K] W[N,K]^T + bias (f32 MFMA path). */
+int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float* W, const float* bias,
+                  float* Y, void* stream);
+/* softmax(q k^T * scale) v for [BS][n][heads*64]-strided tensors; nkv [BS] valid key counts. */
+int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale,
+                       const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                       const int32_t* nkv, float* out, int ldo, void* stream);
+/* Milliseconds spent in each stage of the last gn_estimate/gn_match when timing is enabled. */
+int gn_set_stage_timing(gn_ctx* ctx, int enable);
+int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GISNAV_AMD_H */
