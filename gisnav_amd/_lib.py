@@ -41,6 +41,8 @@ SIGNATURES = {
                                      VP, VP, C.c_int, VP]),
     "gn_set_stage_timing": (C.c_int, [VP, C.c_int]),
     "gn_get_stage_ms": (C.c_int, [VP, c_f32p, C.c_int]),
+    "gn_set_kernel_timing": (C.c_int, [VP, C.c_int]),
+    "gn_get_kernel_stats": (C.c_int, [VP, c_f64p]),
 }
 
 STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")

@@ -55,6 +55,11 @@ struct gn_ctx {
   hipEvent_t ev[2 * 128];
   int ev_stage[128]; int n_ev = 0; bool ev_ready = false;
   float stage_ms[ST_COUNT] = {0};
+  // per-launch timing of the dominant kernel (f32 MFMA GEMM) for the roofline report
+  bool ktiming = false;
+  std::vector<hipEvent_t> kev;      // pairs (start, stop)
+  std::vector<double> kflops;       // algorithmic flops of each recorded launch
+  size_t kused = 0;
 };
 
 namespace {
@@ -109,9 +114,20 @@ struct StageTimer {
   }
 };
 
+void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g, int batch, hipStream_t s) {
+  const bool rec = c->ktiming && c->kused < c->kflops.size();
+  if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+  launch_gemm_f32(epi, g, batch, s);
+  if (rec) {
+    hipEventRecord(c->kev[2 * c->kused + 1], s);
+    c->kflops[c->kused] = 2.0 * g.M * (double)g.N * g.K * batch;
+    ++c->kused;
+  }
+}
+
 void gemm(gn_ctx* c, int epi, GemmArgs& g, hipStream_t s) {
   g.strideA = g.strideW = g.strideY = 0;
-  launch_gemm_f32(epi, g, 1, s);
+  timed_gemm(c, epi, g, 1, s);
 }
 
 GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, int M) {
@@ -212,7 +228,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     gs.A = c->md; gs.lda = kDim; gs.K1 = kDim; gs.W = c->md + (size_t)np * kDim; gs.ldw = kDim;
     gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim;
     gs.strideA = gs.strideW = 2LL * np * kDim; gs.strideY = (long long)np * np;
-    launch_gemm_f32(EPI_PLAIN, gs, B, s);
+    timed_gemm(c, EPI_PLAIN, gs, B, s);
     HeadArgs hd;
     hd.sim = c->sim; hd.ls = c->ls; hd.nvalid = c->nvalid; hd.B = B; hd.npad = np; hd.threshold = c->threshold;
     hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
@@ -287,6 +303,7 @@ void gn_destroy(gn_ctx* ctx) {
   hipSetDevice(ctx->device);
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
+  for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   delete ctx;
 }
 
@@ -533,6 +550,33 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
   attention(ctx, a, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_set_kernel_timing(gn_ctx* ctx, int max_launches) {
+  if (!ctx || max_launches < 0) return GN_ERR_ARG;
+  hipSetDevice(ctx->device);
+  while ((int)ctx->kflops.size() < max_launches) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GN_ERR_HIP;
+    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0);
+  }
+  ctx->ktiming = max_launches > 0;
+  ctx->kused = 0;
+  return GN_OK;
+}
+
+int gn_get_kernel_stats(gn_ctx* ctx, double* out3) {
+  if (!ctx || !out3) return GN_ERR_ARG;
+  hipSetDevice(ctx->device);
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < ctx->kused; ++i) {
+    if (hipEventSynchronize(ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ctx->kev[2 * i], ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
+    ms += t; fl += ctx->kflops[i];
+  }
+  out3[0] = (double)ctx->kused; out3[1] = ms; out3[2] = fl;
   return GN_OK;
 }
 

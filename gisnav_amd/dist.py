@@ -1,0 +1,103 @@
+"""One process per GPU; frame<->tile pairs are independent, so the path shards with no data-path
+collective.  The process group (RCCL over xGMI on the GPU box, gloo in the CPU
+tests) is used for exactly three things: one weight broadcast at start-up, barriers around the timed
+region, and a gather of fixed-size per-pair result records.
+
+The reference itself is single-process (one pose per ROS message,
+ros/gisnav/gisnav/core/pose_node.py:178-184,497); batching and sharding are this build's additions.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_F64 = 16  # pair_index, ok, n_match, n_inliers, R (9), t (3)
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend: str) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(total_pairs: int, rank: int, world: int) -> range:
+    """Contiguous shard: pair p -> rank p // ceil(total / world) (the last rank may be short)."""
+    per = -(-total_pairs // world)
+    return range(min(rank * per, total_pairs), min((rank + 1) * per, total_pairs))
+
+
+def _flatten(sd: Dict[str, np.ndarray]):
+    keys = sorted(sd)
+    return keys, np.concatenate([np.asarray(sd[k], np.float32).reshape(-1) for k in keys])
+
+
+def broadcast_state_dict(sd: Dict[str, np.ndarray], device: torch.device, src: int = 0) -> Dict[str, np.ndarray]:
+    """Rank `src` holds the weights (47.5 MB f32); every other rank receives them in ONE broadcast.
+    All ranks must pass a state dict with the same keys/shapes (values are overwritten off-src)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    keys, flat = _flatten(sd)
+    buf = torch.from_numpy(flat).to(device)
+    dist.broadcast(buf, src=src)
+    flat = buf.cpu().numpy()
+    out, off = {}, 0
+    for k in keys:
+        n = int(np.prod(np.shape(sd[k]))) if np.ndim(sd[k]) else 1
+        out[k] = flat[off: off + n].reshape(np.shape(sd[k])).copy()
+        off += n
+    return out
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device: torch.device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def pack_records(first_pair: int, out: dict) -> torch.Tensor:
+    """[B, 16] f64 result records from a PoseEngine.estimate output (stays on the device)."""
+    B = out["R"].shape[0]
+    rec = torch.zeros((B, RECORD_F64), dtype=torch.float64, device=out["R"].device)
+    rec[:, 0] = torch.arange(first_pair, first_pair + B, dtype=torch.float64, device=rec.device)
+    rec[:, 1] = out["ok"].to(torch.float64)
+    rec[:, 2] = out["n_match"].to(torch.float64)
+    rec[:, 3] = out["n_inliers"].to(torch.float64)
+    rec[:, 4:13] = out["R"].reshape(B, 9)
+    rec[:, 13:16] = out["t"].reshape(B, 3)
+    return rec
+
+
+def gather_records(rec: torch.Tensor) -> torch.Tensor:
+    """all_gather of equally-sized per-rank record blocks -> [world * B, 16] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec
+    parts = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, rec.contiguous())
+    return torch.cat(parts, 0)

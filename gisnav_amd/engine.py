@@ -185,6 +185,14 @@ class PoseEngine:
         _lib.check(self.ctx, n, "gn_get_stage_ms")
         return {name: float(buf[i]) for i, name in enumerate(_lib.STAGE_NAMES[:n])}
 
+    def set_kernel_timing(self, max_launches: int) -> None:
+        _lib.check(self.ctx, self.lib.gn_set_kernel_timing(self.ctx, max_launches), "gn_set_kernel_timing")
+
+    def kernel_stats(self) -> Dict[str, float]:
+        buf = (C.c_double * 3)()
+        _lib.check(self.ctx, self.lib.gn_get_kernel_stats(self.ctx, buf), "gn_get_kernel_stats")
+        return {"launches": buf[0], "ms": buf[1], "flops": buf[2]}
+
     def debug_gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         M, K = A.shape
         N = W.shape[0]

@@ -136,6 +136,11 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale,
 /* Milliseconds spent in each stage of the last gn_estimate/gn_match when timing is enabled. */
 int gn_set_stage_timing(gn_ctx* ctx, int enable);
 int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
+/* HIP-event timing of every launch of the dominant kernel (the f32 MFMA GEMM) on the caller's
+ * stream: enable with room for max_launches launches (0 disables), then read
+ * out3 = {launches recorded, total milliseconds, total algorithmic flops (2 M N K)}. */
+int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
+int gn_get_kernel_stats(gn_ctx* ctx, double* out3);
 
 #ifdef __cplusplus
 }

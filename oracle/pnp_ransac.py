@@ -140,7 +140,8 @@ def project_points(obj: np.ndarray, rvec, tvec, A: np.ndarray, jac: bool = False
         R = rodrigues_vec2mat(rvec)
     fx, fy, cx, cy = A[0, 0], A[1, 1], A[0, 2], A[1, 2]
     X = obj @ R.T + t
-    z = np.where(X[:, 2] != 0, 1.0 / X[:, 2], 1.0)
+    with np.errstate(divide="ignore"):
+        z = np.where(X[:, 2] != 0, 1.0 / X[:, 2], 1.0)
     x, y = X[:, 0] * z, X[:, 1] * z
     proj = np.column_stack([x * fx + cx, y * fy + cy])
     if not jac:

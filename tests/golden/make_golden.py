@@ -1,0 +1,78 @@
+"""Generate the golden fixtures of tests/golden/ with the ORACLE (oracle/*.py).
+
+The reference's own path (kornia 0.7.2 + cv2) cannot be imported in the build container and the
+reference holds no golden vectors for it, so these fixtures pin the restatement --
+"parity unpinned" against the real packages.  Run from the repo root:
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gisnav_amd.synthetic import K_MATRIX, make_pair  # noqa: E402
+from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
+from oracle import lightglue_sift as lg  # noqa: E402
+from oracle import pnp_ransac as pr  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def weights_digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    torch.set_num_threads(1)  # fixed reduction order for the committed numbers
+    sd = synthetic_state_dict(0)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    tq = torch.from_numpy
+    for name, (seed, nq, nr) in {"lightglue_seed0_q96_r80": (7, 96, 80), "lightglue_seed0_q200_r256": (8, 200, 256)}.items():
+        p = make_pair(seed, n_q=nq, n_r=nr)
+        taps = {}
+        mq, mr, sc, idx = lg.pose_node_match(tsd, tq(p.kp_q), tq(p.desc_q), tq(p.size_q), tq(p.angle_q),
+                                             tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r), taps=taps)
+        R, t = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
+        layer_sums = np.array([[taps[f"layer{i}_0"].double().sum().item(), taps[f"layer{i}_1"].double().sum().item()] for i in range(9)])
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            kp_q=p.kp_q, desc_q=p.desc_q, size_q=p.size_q, angle_q=p.angle_q,
+            kp_r=p.kp_r, desc_r=p.desc_r, size_r=p.size_r, angle_r=p.angle_r, dem=p.dem,
+            idx=idx.numpy(), scores=sc.numpy(), mkp_q=mq.numpy(), mkp_r=mr.numpy(),
+            layer_sums=layer_sums, x_final_0=taps["layer8_0"][0].numpy(), x_final_1=taps["layer8_1"][0].numpy(),
+            sim=taps["sim"][0].numpy(), R=R, t=t, K=K_MATRIX)
+        print(name, "matches", len(idx))
+    # PnP fixtures with gross outliers, non-planar and planar
+    for name, (seed, flat) in {"pnp_outliers_dem": (21, False), "pnp_outliers_flat": (22, True)}.items():
+        p = make_pair(seed, flat_dem=flat)
+        q = np.nonzero(p.gt_q2r >= 0)[0][:300]
+        mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+        rs = np.random.default_rng(seed)
+        mq[:60] = np.column_stack([rs.uniform(0, 640, 60), rs.uniform(0, 480, 60)]).astype(np.float32)
+        x, y = np.floor(mr).astype(int).T
+        obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32)
+        ok, r, t, inl = pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), obj=obj, img=mq, K=K_MATRIX, rvec=r, tvec=t,
+                            R=pr.rodrigues_vec2mat(r), inliers=inl, R_gt=p.R_gt, t_gt=p.t_gt, dem=p.dem, mkp_r=mr)
+        print(name, "inliers", len(inl))
+    rng = pr.CvRNG()
+    stream = [rng.next() for _ in range(32)]
+    rng = pr.CvRNG()
+    subsets = [pr.get_subset(rng, 100) for _ in range(3)]
+    with open(os.path.join(HERE, "cv_rng.json"), "w") as f:
+        json.dump({"seed": "0xFFFFFFFFFFFFFFFF", "next_u32": stream, "subsets_count100": subsets,
+                   "weights_seed0_sha256": weights_digest(sd)}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,376 @@
+"""Parity tests proper (-m gpu): every check goes through the C ABI of libgisnav_amd.so and compares
+with the oracle on the same seeded inputs, with the committed golden fixtures, or -- at BASELINE.json's
+full size -- through size-independent properties.
+
+Stated tolerances:
+  * correspondence indices: bit-exact (f32 mode, and bf16-attention mode on the seeded fixtures);
+  * match scores: |d| <= 1e-5;  residual stream per layer: max rel 2e-5 (f32), 3e-2 (bf16 attention);
+  * pose (R, t): ||dR||_F <= 1e-6 and ||dt||/||t|| <= 1e-6 when the RANSAC inlier masks coincide
+    (always the case on the fixtures below); <= 2e-3 otherwise (hypotheses from 5 noisy points
+    can classify a handful of borderline points differently between LAPACK and Jacobi eigen-solvers).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_match
+from gisnav_amd.synthetic import K_MATRIX, make_pair
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def eng256(state_dict_np, dev):
+    from gisnav_amd.engine import PoseEngine
+    return PoseEngine(0, max_batch=4, max_kpts=256, precision="f32", state_dict=state_dict_np)
+
+
+@pytest.fixture(scope="module")
+def eng256_bf16(state_dict_np, dev):
+    from gisnav_amd.engine import PoseEngine
+    return PoseEngine(0, max_batch=4, max_kpts=256, precision="bf16_attn", state_dict=state_dict_np)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ------------------------------------------------------------------ kernels in isolation
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 512), (1024, 768, 256), (128, 512, 128)])
+def test_gemm_f32_mfma_against_fp64(eng256, dev, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev); W = torch.randn(N, K, generator=g).to(dev); b = torch.randn(N, generator=g).to(dev)
+    Y = eng256.debug_gemm(A, W, b)
+    ref = (A.double() @ W.double().T + b.double()).cpu().numpy()
+    assert _rel(Y.cpu().numpy(), ref) < 2e-6
+    assert _rel(eng256.debug_gemm(A, W, None).cpu().numpy(), ref - b.double().cpu().numpy()) < 2e-6
+
+
+def test_gemm_layout_is_not_transposed(eng256, dev):
+    A = torch.eye(128, device=dev)
+    W = torch.arange(128 * 128, dtype=torch.float32, device=dev).reshape(128, 128)   # asymmetric
+    assert torch.equal(eng256.debug_gemm(A, W, None), W.T.contiguous())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16_attn"])
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_against_fp64_with_ragged_keys(eng256, eng256_bf16, dev, prec, cross):
+    eng = eng256 if prec == "f32" else eng256_bf16
+    n, BS = 256, 4
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q, k, v = (torch.randn(BS, n, 256, generator=g).to(dev) for _ in range(3))
+    k[1, 7] *= 6.0                                     # one spiked key forces the online-softmax rescale path
+    nkv = torch.tensor([256, 219, 5, 130], dtype=torch.int32, device=dev)
+    out = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+    for bs in range(BS):
+        kvs = bs ^ 1 if cross else bs
+        m = int(nkv[kvs])
+        qq = q[bs].double().cpu().reshape(n, 4, 64).transpose(0, 1) * 0.125
+        kk = k[kvs, :m].double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        vv = v[kvs, :m].double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        o = (torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(n, 256).numpy()
+        assert _rel(out[bs], o) < (3e-6 if prec == "f32" else 2e-2), (bs, prec, cross)
+
+
+# ------------------------------------------------------------------ matcher vs oracle, stage by stage
+def test_matcher_matches_oracle_per_layer_and_bit_exact_indices(eng256, state_dict_t):
+    pairs = [make_pair(40 + i, n_q=256 - 13 * i, n_r=256 - 5 * i) for i in range(3)]
+    inp = eng256.stage_inputs(pairs)
+    taps = []
+    for p in pairs:
+        t = {}
+        t["res"] = oracle_match(state_dict_t, p, taps=t)
+        taps.append(t)
+    T, npad = 4 * 2 * 256, 256
+    for nl in (1, 3, 9):
+        eng256.set_num_layers(nl)
+        idx, score, n_match = eng256.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        torch.cuda.synchronize()
+        x = eng256.debug_read("x", T * 256).reshape(4, 2, npad, 256)
+        for b, p in enumerate(pairs):
+            nq, nr = len(p.kp_q), len(p.kp_r)
+            assert _rel(x[b, 0, :nq], taps[b][f"layer{nl - 1}_0"][0].numpy()) < 2e-5
+            assert _rel(x[b, 1, :nr], taps[b][f"layer{nl - 1}_1"][0].numpy()) < 2e-5
+    desc = eng256.debug_read("desc", T * 128).reshape(4, 2, npad, 128)
+    cos = eng256.debug_read("cos", T * 32).reshape(4, 2, npad, 32)
+    sim = eng256.debug_read("sim", 4 * npad * npad).reshape(4, npad, npad)
+    from oracle import lightglue_sift as lg
+    for b, p in enumerate(pairs):
+        nq, nr = len(p.kp_q), len(p.kp_r)
+        mq, mr, sc, oidx = taps[b]["res"]
+        assert _rel(desc[b, 0, :nq], lg.rootsift(torch.from_numpy(p.desc_q)).numpy()) < 1e-6
+        assert np.abs(cos[b, 1, :nr] - taps[b]["enc1"][0, 0, 0, :, ::2].numpy()).max() < 2e-5
+        assert _rel(sim[b, :nq, :nr], taps[b]["sim"][0].numpy()) < 2e-5
+        k = int(n_match[b])
+        assert k == len(oidx) >= 15
+        assert np.array_equal(idx[b, :k].cpu().numpy(), oidx.numpy())          # bit-exact correspondences
+        assert np.abs(score[b, :k].cpu().numpy() - sc.numpy()[:, 0]).max() < 1e-5
+        assert idx.dtype == torch.int64
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16_attn"])
+@pytest.mark.parametrize("name", ["lightglue_seed0_q96_r80", "lightglue_seed0_q200_r256"])
+def test_golden_fixtures_through_c_abi(eng256, eng256_bf16, dev, prec, name):
+    eng = eng256 if prec == "f32" else eng256_bf16
+    eng.set_num_layers(9)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kq = np.column_stack([g["kp_q"], g["size_q"], g["angle_q"]]).astype(np.float32)[None]
+    kr = np.column_stack([g["kp_r"], g["size_r"], g["angle_r"]]).astype(np.float32)[None]
+    inp = dict(desc_q=f(g["desc_q"][None]), kpt_q=f(kq), n_q=f(np.array([len(g["kp_q"])], np.int32)),
+               desc_r=f(g["desc_r"][None]), kpt_r=f(kr), n_r=f(np.array([len(g["kp_r"])], np.int32)),
+               dem=f(g["dem"][None]), kpt_format=1)
+    idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    k = int(n_match[0])
+    assert np.array_equal(idx[0, :k].cpu().numpy(), g["idx"])
+    assert np.abs(score[0, :k].cpu().numpy() - g["scores"][:, 0]).max() < (1e-5 if prec == "f32" else 5e-3)
+    out = eng.estimate(inp, g["K"])
+    assert int(out["ok"][0]) == 1 and int(out["n_match"][0]) == len(g["idx"])
+    R, t = out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()
+    assert np.linalg.norm(R - g["R"]) < 1e-6 and np.linalg.norm(t - g["t"]) / np.linalg.norm(g["t"]) < 1e-6
+    mkp, obj = eng.gather_points(inp["kpt_q"], inp["kpt_r"], idx, n_match, inp["dem"])
+    assert np.array_equal(mkp[0, :k].cpu().numpy(), g["mkp_q"])
+    x, y = np.floor(g["mkp_r"]).astype(int).T
+    assert np.array_equal(obj[0, :k].cpu().numpy(), np.hstack((g["mkp_r"], g["dem"][y, x].reshape(-1, 1))).astype(np.float32))
+
+
+def test_identity_weights_recover_known_permutation(dev):
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.weights import synthetic_state_dict
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, state_dict=synthetic_state_dict(3, identity_blocks=True))
+    rng = np.random.default_rng(5)
+    n = 96
+    p = make_pair(11, n_q=n, n_r=n)
+    perm = rng.permutation(n)
+    p.desc_q = np.clip(np.rint(p.desc_r[perm] + rng.normal(0, 2.0, (n, 128))), 0, 255).astype(np.float32)
+    inp = eng.stage_inputs([p])
+    idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    assert int(n_match[0]) == n
+    assert idx[0, :n, 0].cpu().tolist() == list(range(n)) and idx[0, :n, 1].cpu().tolist() == perm.tolist()
+
+
+def test_edge_cases_empty_ragged_and_tiny_inputs(eng256, dev):
+    eng256.set_num_layers(9)
+    pairs = [make_pair(60, n_q=256, n_r=256), make_pair(61, n_q=1, n_r=200), make_pair(62, n_q=40, n_r=2), make_pair(63, n_q=129, n_r=128)]
+    inp = eng256.stage_inputs(pairs)
+    inp["n_q"][1] = 0                                   # an empty query cloud
+    idx, score, n_match = eng256.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    nm = n_match.cpu().numpy()
+    assert nm[1] == 0 and nm[0] > 15 and nm[3] > 15    # < 2 descriptors on a side -> no match (kornia _no_match)
+    assert 0 <= nm[2] <= 2
+    out = eng256.estimate(inp, K_MATRIX)
+    ok = out["ok"].cpu().numpy()
+    assert ok[0] == 1 and ok[1] == 0 and ok[2] == 0 and ok[3] == 1          # MIN_MATCHES = 15 gate
+    assert torch.isfinite(out["R"]).all() and torch.isfinite(out["t"]).all()
+    # the other pairs in the batch are unaffected by their neighbours
+    solo = eng256.stage_inputs([pairs[3]])
+    i2, s2, n2 = eng256.match(solo["desc_q"], solo["kpt_q"], solo["n_q"], solo["desc_r"], solo["kpt_r"], solo["n_r"])
+    assert int(n2[0]) == nm[3] and torch.equal(i2[0, : nm[3]], idx[3, : nm[3]])
+
+
+def test_c_abi_rejects_bad_arguments(eng256, dev):
+    from gisnav_amd import _lib
+    from gisnav_amd.engine import PoseEngine
+    pairs = [make_pair(70 + i, n_q=64, n_r=64) for i in range(5)]
+    inp = eng256.stage_inputs(pairs)                     # B = 5 > max_batch = 4
+    with pytest.raises(_lib.GnError):
+        eng256.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    big = eng256.stage_inputs([make_pair(71, n_q=300, n_r=64)])   # stride 300 > max_kpts 256
+    with pytest.raises(_lib.GnError):
+        eng256.match(big["desc_q"], big["kpt_q"], big["n_q"], big["desc_r"], big["kpt_r"], big["n_r"])
+    e = PoseEngine(0, max_batch=1, max_kpts=128)         # no weights loaded
+    one = e.stage_inputs([make_pair(72, n_q=64, n_r=64)])
+    with pytest.raises(_lib.GnError):
+        e.match(one["desc_q"], one["kpt_q"], one["n_q"], one["desc_r"], one["kpt_r"], one["n_r"])
+    with pytest.raises(_lib.GnError):
+        e.load_state_dict({"input_proj.weight": np.zeros((256, 64), np.float32)})
+
+
+# ------------------------------------------------------------------ the three seams
+def test_seam_b1_lightglue_matcher_drop_in(state_dict_np, state_dict_t, dev):
+    from gisnav_amd.matcher import LightGlueMatcher
+    from oracle import lightglue_sift as lg
+    m = LightGlueMatcher("sift", params={"n_layers": 9, "filter_threshold": 0.5, "depth_confidence": -1, "width_confidence": -1},
+                         state_dict=state_dict_np, max_kpts=256).to(dev).eval()
+    p = make_pair(80, n_q=230, n_r=256)
+    tq = torch.from_numpy
+    with torch.inference_mode():   # the calls of pose_node.py:246-287
+        laf_q = lg.laf_from_center_scale_ori(tq(p.kp_q)[None], tq(p.size_q)[None, :, None, None], tq(p.angle_q)[None, :, None])
+        laf_r = lg.laf_from_center_scale_ori(tq(p.kp_r)[None], tq(p.size_r)[None, :, None, None], tq(p.angle_r)[None, :, None])
+        dq, dr = lg.rootsift(tq(p.desc_q)), lg.rootsift(tq(p.desc_r))
+        dists, idx = m(dq.to(dev), dr.to(dev), laf_q.to(dev), laf_r.to(dev))
+        osc, oidx = lg.lightglue_matcher_forward(state_dict_t, dq, dr, laf_q, laf_r)
+    assert dists.shape == (len(oidx), 1) and idx.shape == (len(oidx), 2) and idx.dtype == torch.int64 and idx.device.type == "cuda"
+    assert torch.equal(idx.cpu(), oidx) and (dists.cpu() - osc).abs().max() < 1e-5
+    kp = tq(p.kp_q).to(dev)
+    assert kp[idx[:, 0]].shape == (len(oidx), 2)          # usable as an index, pose_node.py:296
+    e_d, e_i = m(dq[:1].to(dev), dr.to(dev), laf_q[:, :1].to(dev), laf_r.to(dev))
+    assert e_d.shape == (0, 1) and e_i.shape == (0, 2)
+
+
+@pytest.mark.parametrize("name", ["pnp_outliers_dem", "pnp_outliers_flat"])
+def test_seam_b2_compute_pose_on_golden_fixture(name, dev):
+    from gisnav_amd.pose import compute_pose
+    from gisnav_amd.wire import CameraInfo
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    out = compute_pose(CameraInfo(k=g["K"].reshape(-1)), g["img"], g["mkp_r"], g["dem"])
+    assert out is not None
+    R, t = out
+    assert R.shape == (3, 3) and t.shape == (3, 1) and R.dtype == np.float64 and t.dtype == np.float64
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+    assert np.linalg.norm(R - g["R_gt"]) < 3e-3 and np.linalg.norm(t - g["t_gt"]) / np.linalg.norm(g["t_gt"]) < 3e-3
+    assert np.linalg.norm(R - g["R"]) < 2e-3 and np.linalg.norm(t - g["tvec"]) / np.linalg.norm(g["tvec"]) < 2e-3
+    assert compute_pose(CameraInfo(k=g["K"].reshape(-1)), g["img"][:3], g["mkp_r"][:3], g["dem"]) is None
+
+
+def test_pnp_inlier_mask_and_pose_against_oracle(dev, eng256):
+    from oracle import pnp_ransac as pr
+    tight, total = 0, 0
+    for seed in range(90, 98):
+        p = make_pair(seed, n_q=256, n_r=256, flat_dem=(seed % 2 == 0))
+        q = np.nonzero(p.gt_q2r >= 0)[0]
+        mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+        rs = np.random.default_rng(seed)
+        no = len(q) // 6
+        mq[:no] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)
+        x, y = np.floor(mr).astype(int).T
+        obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32)
+        ok, r, t, inl = pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)
+        R, tg, ninl, okg = eng256.pnp_ransac(torch.from_numpy(obj[None]).to(dev), torch.from_numpy(mq[None]).to(dev),
+                                             torch.tensor([len(obj)], dtype=torch.int32, device=dev), K_MATRIX)
+        assert ok and int(okg[0]) == 1
+        dR = np.linalg.norm(R[0].cpu().numpy() - pr.rodrigues_vec2mat(r))
+        dt = np.linalg.norm(tg[0].cpu().numpy() - t) / np.linalg.norm(t)
+        assert dR < 2e-3 and dt < 2e-3, (seed, dR, dt)
+        assert np.linalg.norm(R[0].cpu().numpy() - p.R_gt) < 5e-3
+        total += 1
+        if int(ninl[0]) == len(inl):
+            assert dR < 1e-6 and dt < 1e-6, (seed, dR, dt)          # same inlier set -> same LM optimum
+            tight += 1
+    assert tight >= total // 2
+
+
+def test_seam_b3_pose_node_shim_from_wire_bytes(state_dict_np, state_dict_t, dev):
+    from gisnav_amd import wire
+    from gisnav_amd.pose_node import PoseNode
+    from oracle import pnp_ransac as pr
+    p = make_pair(85, n_q=256, n_r=256)
+    calls = []
+
+    def extractor(ref_u8):   # stands in for cv2.SIFT_create().detectAndCompute(ref, None) (pose_node.py:230)
+        calls.append(ref_u8.shape)
+        return p.kp_r, p.desc_r, p.size_r, p.angle_r
+
+    node = PoseNode(state_dict_np, extractor, max_kpts=256)
+    assert node.pose() is None                                       # narrow_types: inputs not yet received
+    node.camera_info = wire.CameraInfo(k=K_MATRIX.reshape(-1), height=480, width=640)
+    msg = wire.OrthoStereoImage(query_sift=wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q),
+                                reference=wire.ImageMsg(p.ref, wire.Stamp(12, 5)), dem=wire.ImageMsg(p.dem, wire.Stamp(12, 5)))
+    node.pose_image = msg
+    r1 = node.pose()
+    r2 = node.pose()                                                  # same tile stamp -> cached reference features
+    assert len(calls) == 1 and r1 is not None
+    mq, mr, sc, oidx = oracle_match(state_dict_t, p)
+    assert node.last_num_matches == len(oidx)
+    Ro, to = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
+    assert np.linalg.norm(r1[0] - Ro) < 2e-3 and np.linalg.norm(r1[1] - to) / np.linalg.norm(to) < 2e-3
+    assert np.array_equal(r1[0], r2[0])
+    node.pose_image = wire.OrthoStereoImage(query_sift=wire.pack_keypoints(p.kp_q[:10], p.size_q[:10], p.angle_q[:10], p.desc_q[:10]),
+                                            reference=wire.ImageMsg(p.ref, wire.Stamp(13, 0)), dem=wire.ImageMsg(p.dem, wire.Stamp(13, 0)))
+    assert node.pose() is None and len(calls) == 2                   # < MIN_MATCHES -> None; new stamp -> re-extract
+
+
+# ------------------------------------------------------------------ BASELINE.json full size: properties
+@pytest.fixture(scope="module")
+def full_size(state_dict_np, dev):
+    from gisnav_amd.engine import PoseEngine
+    pairs = [make_pair(i) for i in range(32)]
+    res = {}
+    for prec in ("f32", "bf16_attn"):
+        eng = PoseEngine(0, max_batch=32, max_kpts=1024, precision=prec, state_dict=state_dict_np)
+        inp = eng.stage_inputs(pairs)
+        idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        out = eng.estimate(inp, K_MATRIX)
+        torch.cuda.synchronize()
+        res[prec] = (idx.cpu().numpy(), score.cpu().numpy(), n_match.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items()})
+        if prec == "f32":   # permutation equivariance: shuffle the query keypoints of every pair
+            rng = np.random.default_rng(0)
+            perms = [rng.permutation(1024) for _ in pairs]
+            shuffled = []
+            for p, pm in zip(pairs, perms):
+                q = make_pair(0)
+                q.__dict__.update(p.__dict__)
+                q.kp_q, q.desc_q, q.size_q, q.angle_q = p.kp_q[pm], p.desc_q[pm], p.size_q[pm], p.angle_q[pm]
+                shuffled.append(q)
+            inp2 = eng.stage_inputs(shuffled)
+            i2, s2, n2 = eng.match(inp2["desc_q"], inp2["kpt_q"], inp2["n_q"], inp2["desc_r"], inp2["kpt_r"], inp2["n_r"])
+            res["perm"] = (perms, i2.cpu().numpy(), n2.cpu().numpy())
+        del eng
+    return pairs, res
+
+
+def test_full_size_matches_are_mutual_sorted_and_correct(full_size):
+    pairs, res = full_size
+    idx, score, nm, out = res["f32"]
+    for b, p in enumerate(pairs):
+        k = nm[b]
+        ii = idx[b, :k]
+        assert k >= 300
+        assert (np.diff(ii[:, 0]) > 0).all()                          # ascending query index
+        assert len(np.unique(ii[:, 1])) == k                          # one-to-one (mutual nearest neighbours)
+        assert (score[b, :k] > 0.5).all() and (score[b, :k] <= 1.0 + 1e-6).all()
+        gt = p.gt_q2r[ii[:, 0]]
+        assert (gt == ii[:, 1]).mean() > 0.99                         # they are the true correspondences
+        assert k >= 0.97 * (p.gt_q2r >= 0).sum()
+
+
+def test_full_size_pose_close_to_ground_truth(full_size):
+    pairs, res = full_size
+    for prec in ("f32", "bf16_attn"):
+        out = res[prec][3]
+        assert out["ok"].all()
+        for b, p in enumerate(pairs):
+            assert np.linalg.norm(out["R"][b] - p.R_gt) < 5e-3
+            assert np.linalg.norm(out["t"][b] - p.t_gt) / np.linalg.norm(p.t_gt) < 5e-3
+            assert abs(np.linalg.det(out["R"][b]) - 1) < 1e-12
+            assert out["n_inliers"][b] >= 0.9 * out["n_match"][b]
+
+
+def test_full_size_bf16_attention_gives_the_same_correspondences(full_size):
+    _, res = full_size
+    i0, s0, n0, _ = res["f32"]
+    i1, s1, n1, _ = res["bf16_attn"]
+    assert np.array_equal(n0, n1)
+    for b in range(len(n0)):
+        assert np.array_equal(i0[b, : n0[b]], i1[b, : n1[b]])
+        assert np.abs(s0[b, : n0[b]] - s1[b, : n0[b]]).max() < 5e-3
+
+
+def test_full_size_permutation_equivariance(full_size):
+    _, res = full_size
+    idx, _, nm, _ = res["f32"]
+    perms, i2, n2 = res["perm"]
+    for b, pm in enumerate(perms):
+        assert n2[b] == nm[b]
+        a = {(int(q), int(r)) for q, r in idx[b, : nm[b]]}
+        c = {(int(pm[q]), int(r)) for q, r in i2[b, : n2[b]]}        # shuffled index q holds original keypoint pm[q]
+        assert a == c
+
+
+def test_full_size_oracle_spot_check(full_size, state_dict_t):
+    pairs, res = full_size
+    idx, score, nm, out = res["f32"]
+    for b in (0, 17):
+        mq, mr, sc, oidx = oracle_match(state_dict_t, pairs[b])
+        assert np.array_equal(idx[b, : nm[b]], oidx.numpy())
+        assert np.abs(score[b, : nm[b]] - sc.numpy()[:, 0]).max() < 1e-5

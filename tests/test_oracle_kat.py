@@ -1,0 +1,271 @@
+"""Known-answer tests that pin the ORACLE (SURVEY.md 8(c) KATs 1-7) + committed golden fixtures.
+
+The reference holds no golden vector for this path and kornia/cv2 cannot be imported here, so the
+oracle is pinned by (a) analytic known answers, (b) the structurally identical sub-functions of the
+`transformers` LightGlue port where the two coincide, (c) the fixtures under tests/golden/.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_match
+from gisnav_amd.synthetic import K_MATRIX, make_pair
+from gisnav_amd.weights import synthetic_state_dict
+from oracle import lightglue_sift as lg
+from oracle import pnp_ransac as pr
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ KAT 1: match head
+def test_match_head_known_answer():
+    sim = torch.full((1, 4, 5), -20.0)
+    sim[0, 0, 2] = sim[0, 1, 0] = sim[0, 3, 4] = 20.0   # three clean mutual matches
+    sim[0, 2, 1] = 1.0                                  # weak row 2
+    z0 = torch.full((1, 4, 1), 30.0)
+    z1 = torch.full((1, 5, 1), 30.0)
+    scores = lg.sigmoid_log_double_softmax(sim, z0, z1)
+    m0, m1, ms0, ms1 = lg.filter_matches(scores, 0.5)
+    assert m0[0].tolist() == [2, 0, 1, 4]
+    assert m1[0].tolist() == [1, 2, 0, -1, 3]
+    assert (ms0[0] > 0.99).all()
+    assert scores.shape == (1, 5, 6)
+
+
+def test_match_head_threshold_is_strict_and_ties_take_lowest_index():
+    # scores chosen so that exp(max) == 0.5 exactly for row 0: must be rejected ('>' not '>=')
+    P = torch.full((1, 4, 5), -50.0)  # (N+1) x (M+1): last row / column are the dustbins
+    P[0, 0, 1] = math.log(0.5)
+    P[0, 1, 2] = math.log(0.75)
+    P[0, 2, 0] = P[0, 2, 3] = -1.0  # exact tie in row 2 -> index 0; column 0 then prefers row 2
+    m0, m1, ms0, _ = lg.filter_matches(P, 0.5)
+    assert float(ms0[0, 0]) == 0.5
+    assert m0[0].tolist() == [-1, 2, -1]   # row 0 at exactly the threshold, row 2 below it
+    raw0 = P[:, :-1, :-1].max(2).indices[0].tolist()
+    assert raw0[2] == 0                     # first index among exact ties (torch.max semantics)
+    t = torch.tensor([[1.0, 3.0, 3.0], [2.0, 2.0, 1.0]])
+    assert t.max(1).indices.tolist() == [1, 0] and t.max(0).indices.tolist() == [1, 0, 0]
+
+
+# ------------------------------------------------------------------ KAT 2: identity LightGlue == mutual NN
+def test_identity_blocks_reduce_to_mutual_nearest_neighbour():
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(3, identity_blocks=True).items()}
+    rng = np.random.default_rng(5)
+    n = 96
+    p = make_pair(11, n_q=n, n_r=n)
+    perm = rng.permutation(n)
+    desc_q = np.clip(np.rint(p.desc_r[perm] + rng.normal(0, 2.0, (n, 128))), 0, 255).astype(np.float32)
+    tq = torch.from_numpy
+    mq, mr, sc, idx = lg.pose_node_match(sd, tq(p.kp_q), tq(desc_q), tq(p.size_q), tq(p.angle_q),
+                                         tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r))
+    # every block is the identity on the residual stream, so x = input_proj(rootsift) and
+    # sim is a scaled cosine similarity: the recovered permutation is known exactly
+    assert idx[:, 0].tolist() == list(range(n))
+    assert idx[:, 1].tolist() == perm.tolist()
+    a = lg.rootsift(tq(desc_q)); b = lg.rootsift(tq(p.desc_r))
+    nn = (a @ b.T).argmax(1)
+    assert nn.tolist() == perm.tolist()
+
+
+# ------------------------------------------------------------------ KAT 3: seeded golden fixtures
+@pytest.mark.parametrize("name", ["lightglue_seed0_q96_r80", "lightglue_seed0_q200_r256"])
+def test_lightglue_golden(name, state_dict_t):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    tq = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    taps = {}
+    mq, mr, sc, idx = lg.pose_node_match(state_dict_t, tq("kp_q"), tq("desc_q"), tq("size_q"), tq("angle_q"),
+                                         tq("kp_r"), tq("desc_r"), tq("size_r"), tq("angle_r"), taps=taps)
+    assert idx.dtype == torch.int64 and sc.shape == (len(idx), 1)
+    assert np.array_equal(idx.numpy(), g["idx"])                       # bit-exact correspondences
+    assert np.allclose(sc.numpy(), g["scores"], atol=2e-6)
+    assert np.allclose(taps["layer8_0"][0].numpy(), g["x_final_0"], atol=2e-5, rtol=1e-4)
+    sums = np.array([[taps[f"layer{i}_0"].double().sum().item(), taps[f"layer{i}_1"].double().sum().item()] for i in range(9)])
+    assert np.allclose(sums, g["layer_sums"], rtol=1e-4, atol=1e-3)
+    assert (np.diff(idx[:, 0].numpy()) > 0).all()                      # ascending query index
+
+
+def test_weights_generator_is_pinned():
+    import hashlib
+    sd = synthetic_state_dict(0)
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode()); h.update(np.ascontiguousarray(sd[k]).tobytes())
+    ref = json.load(open(os.path.join(GOLD, "cv_rng.json")))["weights_seed0_sha256"]
+    assert h.hexdigest() == ref
+
+
+# ------------------------------------------------------------------ KAT 4: normalisation quirks
+def test_image_size_is_keypoint_extent_and_orientation_wraps():
+    n = 6
+    xy = torch.tensor([[10.0, 5.0], [100.0, 40.0], [50.0, 80.0], [0.0, 0.0], [99.0, 79.0], [3.0, 3.0]])
+    size = torch.tensor([2.0, 4.0, 8.0, 16.0, 3.0, 5.0])
+    ang = torch.tensor([0.0, 90.0, 180.0, 270.0, 359.0, 45.0])
+    laf = lg.laf_from_center_scale_ori(xy[None], size[None, :, None, None], ang[None, :, None])
+    assert laf.shape == (1, n, 2, 3)
+    assert torch.allclose(lg.get_laf_scale(laf).reshape(-1), size, rtol=1e-6)
+    ori = lg.get_laf_orientation(laf).reshape(-1) * math.pi / 180.0
+    ori = torch.where(ori < 0, ori + 2 * math.pi, ori)
+    assert torch.allclose(ori, ang * math.pi / 180.0, atol=1e-5)      # 270 deg, 359 deg wrap into [0, 2 pi)
+    assert (ori >= 0).all() and (ori < 2 * math.pi + 1e-6).all()
+    size_wh = xy.max(0).values[None]                                   # (max_x, max_y), NOT the image shape
+    k = lg.normalize_keypoints(xy[None], size_wh)
+    assert torch.allclose(k[0, 1], torch.tensor([1.0, 0.0]))           # (100-50)/50, (40-40)/50
+    assert torch.allclose(k[0, 3], torch.tensor([-1.0, -0.8]))
+
+
+def test_rootsift_zero_row_and_unit_norm():
+    d = torch.zeros(3, 128); d[1] = torch.arange(128.0); d[2, 5] = 255.0
+    r = lg.rootsift(d)
+    assert torch.equal(r[0], torch.zeros(128))
+    assert abs(float((r[1] ** 2).sum()) - 1.0) < 1e-6 and float(r[2, 5]) == 1.0
+
+
+def test_no_match_for_fewer_than_two_descriptors(state_dict_t):
+    d1 = torch.rand(1, 128); d2 = torch.rand(5, 128)
+    l1 = torch.zeros(1, 1, 2, 3); l2 = torch.zeros(1, 5, 2, 3)
+    sc, idx = lg.lightglue_matcher_forward(state_dict_t, d1, d2, l1, l2)
+    assert sc.shape == (0, 1) and idx.shape == (0, 2) and idx.dtype == torch.int64
+
+
+def test_checkpoint_key_spelling_is_accepted():
+    sd = {"self_attn.3.Wqkv.weight": np.zeros((768, 256), np.float32), "cross_attn.0.to_qk.bias": np.zeros(256, np.float32),
+          "input_proj.weight": np.zeros((256, 128), np.float32)}
+    c = lg.canonical_state_dict(sd)
+    assert set(c) == {"transformers.3.self_attn.Wqkv.weight", "transformers.0.cross_attn.to_qk.bias", "input_proj.weight"}
+
+
+# ------------------------------------------------------------------ cross-checks vs transformers' LightGlue port
+def _hf():
+    return pytest.importorskip("transformers.models.lightglue.modeling_lightglue")
+
+
+def test_double_softmax_and_filter_agree_with_transformers():
+    hf = _hf()
+    torch.manual_seed(0)
+    sim = torch.randn(2, 7, 9) * 3
+    z0, z1 = torch.randn(2, 7, 1), torch.randn(2, 9, 1)
+    a = lg.sigmoid_log_double_softmax(sim, z0, z1)
+    b = hf.sigmoid_log_double_softmax(sim, z0, z1)
+    assert torch.equal(a, b)
+    # the transformers port stacks both directions, so it needs a square problem
+    sim = torch.randn(2, 8, 8) * 4
+    z0, z1 = torch.randn(2, 8, 1) + 2, torch.randn(2, 8, 1) + 2
+    a = lg.sigmoid_log_double_softmax(sim, z0, z1)
+    m0, m1, s0, s1 = lg.filter_matches(a, 0.1)
+    matches, mscores = hf.get_matches_from_scores(a, 0.1)
+    matches, mscores = matches.reshape(2, 2, 8), mscores.reshape(2, 2, 8)
+    assert torch.equal(matches[:, 0], m0) and torch.equal(matches[:, 1], m1)
+    assert torch.equal(mscores[:, 0], s0) and torch.equal(mscores[:, 1], s1)
+    assert (m0 > -1).any()
+
+
+def test_rotary_and_keypoint_normalisation_agree_with_transformers():
+    hf = _hf()
+    torch.manual_seed(1)
+    x = torch.randn(1, 4, 10, 64)
+    assert torch.equal(lg.rotate_half(x), hf.rotate_half(x))
+    proj = torch.randn(1, 10, 32)
+    enc = torch.stack([torch.cos(proj), torch.sin(proj)], 0).unsqueeze(-3).repeat_interleave(2, dim=-1)
+    cos, sin = torch.cos(proj.repeat_interleave(2, -1)), torch.sin(proj.repeat_interleave(2, -1))
+    q_hf, _ = hf.apply_rotary_pos_emb(x, x, cos, sin)
+    assert torch.allclose(lg.apply_cached_rotary_emb(enc, x), q_hf, atol=0, rtol=0)
+    k = torch.rand(1, 10, 2) * 300
+    assert torch.allclose(lg.normalize_keypoints(k, torch.tensor([[640.0, 480.0]])), hf.normalize_keypoints(k, 480, 640))
+
+
+# ------------------------------------------------------------------ KAT 5: PnP analytic
+@pytest.mark.parametrize("flat", [False, True])
+def test_pnp_recovers_known_pose_with_outliers(flat):
+    p = make_pair(31, flat_dem=flat)
+    q = np.nonzero(p.gt_q2r >= 0)[0]
+    mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+    no = len(q) // 5
+    rs = np.random.default_rng(1)
+    mq[:no] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)  # 20 % gross outliers
+    R, t = pr.compute_pose(K_MATRIX.reshape(-1), mq, mr, p.dem)
+    assert R.shape == (3, 3) and t.shape == (3, 1) and R.dtype == np.float64
+    assert np.linalg.norm(R - p.R_gt) < 3e-3 and np.linalg.norm(t - p.t_gt) / np.linalg.norm(p.t_gt) < 3e-3
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["pnp_outliers_dem", "pnp_outliers_flat"])
+def test_pnp_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    ok, r, t, inl = pr.solve_pnp_ransac(g["obj"], g["img"], g["K"], 10)
+    assert ok and np.array_equal(inl, g["inliers"])
+    assert np.allclose(r, g["rvec"], atol=1e-9) and np.allclose(t, g["tvec"], rtol=1e-9)
+    # compute_pose on the same correspondences reproduces the DEM lift + Rodrigues
+    R, t2 = pr.compute_pose(g["K"].reshape(-1), g["img"], g["mkp_r"], g["dem"])
+    assert np.allclose(R, g["R"], atol=1e-9) and np.allclose(t2, g["tvec"], rtol=1e-9)
+
+
+def test_pnp_degenerate_inputs():
+    K = K_MATRIX
+    assert pr.solve_pnp_ransac(np.zeros((4, 3), np.float32), np.zeros((4, 2), np.float32), K)[0] is False  # < 5 points
+    # all-collinear object points: no hypothesis explains random image points
+    rs = np.random.default_rng(0)
+    obj = np.column_stack([np.linspace(0, 600, 40), np.full(40, 100.0), np.zeros(40)]).astype(np.float32)
+    img = rs.uniform(0, 480, (40, 2)).astype(np.float32)
+    ok, *_ = pr.solve_pnp_ransac(obj, img, K)
+    assert ok in (True, False)  # must not raise
+
+
+def test_rodrigues_round_trip_and_jacobian():
+    rs = np.random.default_rng(2)
+    for _ in range(5):
+        r = rs.normal(size=3)
+        r *= rs.uniform(0.1, 3.0) / np.linalg.norm(r)   # |r| < pi: the principal branch
+        R, J = pr.rodrigues_vec2mat(r, True)
+        assert np.allclose(pr.rodrigues_mat2vec(R), r, atol=1e-12)
+        eps = 1e-6
+        Jn = np.array([((pr.rodrigues_vec2mat(r + eps * np.eye(3)[i]) - pr.rodrigues_vec2mat(r - eps * np.eye(3)[i])) / (2 * eps)).reshape(9)
+                       for i in range(3)])
+        assert np.allclose(J, Jn, atol=1e-8)
+    assert np.array_equal(pr.rodrigues_vec2mat(np.zeros(3)), np.eye(3))
+
+
+# ------------------------------------------------------------------ KAT 6: cv::RNG stream
+def test_cv_rng_stream_and_subsets():
+    g = json.load(open(os.path.join(GOLD, "cv_rng.json")))
+    rng = pr.CvRNG()
+    got = [rng.next() for _ in range(32)]
+    assert got == g["next_u32"]
+    assert got[:6] == [130063605, 3133359004, 2578348940, 925327173, 1080261831, 2946015512]
+    rng = pr.CvRNG()
+    assert [rng.uniform(0, 100) for _ in range(6)] == [5, 4, 40, 73, 31, 12]
+    rng = pr.CvRNG()
+    assert [pr.get_subset(rng, 100) for _ in range(3)] == g["subsets_count100"]
+
+
+def test_ransac_update_num_iters():
+    assert pr.ransac_update_num_iters(0.99, 0.0, 5, 10) == 0       # all inliers: loop ends
+    assert pr.ransac_update_num_iters(0.99, 0.3, 5, 10) == 10      # needs 25 > cap
+    assert pr.ransac_update_num_iters(0.99, 0.05, 5, 10) == 3
+    assert pr.ransac_update_num_iters(0.99, 1.0, 5, 10) == 10
+
+
+# ------------------------------------------------------------------ KAT 7: wire format
+def test_keypoint_wire_format_round_trip():
+    from gisnav_amd import wire
+    assert wire.KEYPOINT_DTYPE.itemsize == 532
+    assert [wire.KEYPOINT_DTYPE.fields[k][1] for k in ("x", "y", "z", "size", "angle", "descriptor")] == [0, 4, 8, 12, 16, 20]
+    p = make_pair(2, n_q=17, n_r=9)
+    data = wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q)
+    assert len(data) == 17 * 532
+    kp, desc, size, angle = wire.unpack_keypoints(data)
+    assert np.array_equal(kp, p.kp_q) and np.array_equal(desc, p.desc_q)
+    assert np.array_equal(size, p.size_q) and np.array_equal(angle, p.angle_q)
+    assert np.hstack((p.kp_r, p.dem[:9, :1])).dtype == np.float32      # hstack(f32, u8) stays f32 (_shared.py:102)
+
+
+def test_full_oracle_pipeline_on_synthetic_pair(state_dict_t):
+    p = make_pair(0, n_q=192, n_r=192)
+    mq, mr, sc, idx = oracle_match(state_dict_t, p)
+    gt = p.gt_q2r[idx[:, 0].numpy()]
+    assert len(idx) >= 15 and (gt == idx[:, 1].numpy()).mean() > 0.98
+    R, t = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
+    assert np.linalg.norm(R - p.R_gt) < 5e-3
