@@ -65,6 +65,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: the library and torch have to share ONE HIP runtime instance
+    # (device pointers and streams cross the C ABI), and torch bundles its own libamdhip64.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GnError(f"{LIB_PATH} not found: build it with `python -m gisnav_amd.build` "
                       "(there is no CPU fallback for the product path)")
