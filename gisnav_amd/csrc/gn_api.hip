@@ -553,6 +553,21 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   return GN_OK;
 }
 
+int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
+  if (!ctx) return GN_ERR_ARG;
+  if (which == 0) gn::g_gemm_variant = value;
+  else return GN_ERR_ARG;
+  return GN_OK;
+}
+
+int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream) {
+  if (!ctx || blocks < 1 || iters < 1) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  launch_mfma_probe(ctx->ls, blocks, iters, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
 int gn_set_kernel_timing(gn_ctx* ctx, int max_launches) {
   if (!ctx || max_launches < 0) return GN_ERR_ARG;
   hipSetDevice(ctx->device);

@@ -40,6 +40,8 @@ struct GemmArgs {
   const float* resid; int ldr;     // EPI_RESIDUAL
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
+void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
+extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {

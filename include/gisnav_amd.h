@@ -139,6 +139,10 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
 /* HIP-event timing of every launch of the dominant kernel (the f32 MFMA GEMM) on the caller's
  * stream: enable with room for max_launches launches (0 disables), then read
  * out3 = {launches recorded, total milliseconds, total algorithmic flops (2 M N K)}. */
+/* Developer knobs: select a kernel variant (which = 0: GEMM) for A/B benchmarking; run a pure
+ * v_mfma_f32_32x32x2_f32 issue-rate probe (blocks x 256 threads x iters x 8 MFMAs per wave). */
+int gn_debug_set_variant(gn_ctx* ctx, int which, int value);
+int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream);
 int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
 int gn_get_kernel_stats(gn_ctx* ctx, double* out3);
 

@@ -1,0 +1,53 @@
+"""Developer micro-benchmark: f32 MFMA GEMM variants on the matcher's shapes + pure-MFMA ceiling probe."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gisnav_amd.engine import PoseEngine  # noqa: E402
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n  # ms
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    eng = PoseEngine(0, max_batch=1, max_kpts=128)
+    lib, ctx = eng.lib, eng.ctx
+    for blocks in (256, 512, 1024):
+        iters = 4000
+        ms = timeit(lambda: lib.gn_debug_mfma_probe(ctx, blocks, iters, eng._stream()), n=5, warm=2)
+        fl = blocks * 4 * iters * 8 * 2 * 32 * 32 * 2
+        print(f"mfma probe blocks={blocks}: {fl / ms / 1e9:.1f} TF", flush=True)
+    M = 65536
+    shapes = [(256, 128), (768, 256), (256, 256), (512, 256), (512, 512), (256, 512), (1024, 256)]
+    variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
+    for variant in variants:
+        lib.gn_debug_set_variant(ctx, 0, variant)
+        tot_ms = tot_fl = 0
+        for N, K in shapes:
+            A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+            ms = timeit(lambda: eng.debug_gemm(A, W, b))
+            fl = 2.0 * M * N * K
+            tot_ms += ms; tot_fl += fl
+            print(f"variant {variant} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TF", flush=True)
+        print(f"variant {variant} aggregate {tot_fl / tot_ms / 1e9:.1f} TF", flush=True)
+    A = torch.randn(1024, 512, device=dev); W = torch.randn(384, 512, device=dev); b = torch.randn(384, device=dev)
+    lib.gn_debug_set_variant(ctx, 0, variants[0]); y0 = eng.debug_gemm(A, W, b)
+    lib.gn_debug_set_variant(ctx, 0, variants[-1]); y1 = eng.debug_gemm(A, W, b)
+    print("first vs last variant max abs diff", float((y0 - y1).abs().max()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
