@@ -44,6 +44,8 @@ struct gn_ctx {
   int32_t* nvalid = nullptr;
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *h = nullptr, *md = nullptr, *ls = nullptr;
   float* sim = nullptr;
+  uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
+  int attn_variant = 1;
   float *rowmax = nullptr, *rowlog = nullptr, *colmax = nullptr, *collog = nullptr, *max0 = nullptr;
   int32_t *m0 = nullptr, *m1 = nullptr;
   // pipeline scratch for gn_estimate
@@ -158,6 +160,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
                 const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                 int64_t* idx, float* score, int32_t* n_match, hipStream_t s) {
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
+  const bool bf16v2 = c->precision == GN_PREC_BF16_ATTN && c->attn_variant == 1;
   {
     StageTimer tm(c, s, ST_PREP);
     PrepArgs p;
@@ -176,14 +179,20 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 3 * kDim, T);
         g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
-        gemm(c, EPI_ROTARY, g, s);
+        if (bf16v2) {
+          g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np;
+          gemm(c, EPI_ROTARY_BF16, g, s);
+        } else {
+          gemm(c, EPI_ROTARY, g, s);
+        }
       }
       {
         StageTimer tm(c, s, ST_ATTN);
         AttnArgs a;
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
-        attention(c, a, s);
+        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
+        if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -199,14 +208,20 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 2 * kDim, T);
         g.scale = 0.35355339059327373f;  // (dim_head ** -0.5) ** 0.5 applied to both qk sides
         g.scale_cols = kDim;
-        gemm(c, EPI_SCALE_COLS, g, s);
+        if (bf16v2) {
+          g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np;
+          gemm(c, EPI_SCALE_BF16, g, s);
+        } else {
+          gemm(c, EPI_SCALE_COLS, g, s);
+        }
       }
       {
         StageTimer tm(c, s, ST_ATTN);
         AttnArgs a;
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
-        attention(c, a, s);
+        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
+        if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -276,6 +291,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
   GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
   GN_ALLOC(sim, B * np * np);
+  if (precision == GN_PREC_BF16_ATTN) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
@@ -548,6 +564,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   AttnArgs a;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
+  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0;
   attention(ctx, a, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
   return GN_OK;
@@ -556,6 +573,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
   if (which == 0) gn::g_gemm_variant = value;
+  else if (which == 1) ctx->attn_variant = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -301,6 +301,156 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
       *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// bf16 variant 2: consumes what the projection GEMM's bf16 epilogue already laid out -- Q and K as
+// bf16 rows, V as bf16 V^T per (slot, head) -- so the tile loop does no conversion and no transposition.
+// K / V^T tiles (64 keys) are double-buffered in LDS with register prefetch: tile t+1 is parked in
+// the idle buffer and tile t+2 is fetched while tile t is multiplied; one barrier per tile.
+__global__ __launch_bounds__(256) void k_attn_bf16_v2(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * KT * HLS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, bs = blockIdx.z;
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  bf16x8 qf[4];
+  {
+    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (nkv + KT - 1) / KT;
+  // loader: thread -> row lr (0..63), two 16-byte chunks at halves lc and lc + 32
+  const int lr = tid >> 2, lc = (tid & 3) * 8;
+  const unsigned short* kg = a.kb + ((size_t)kvs * a.npad + lr) * a.ldkb + h * 64 + lc;
+  const unsigned short* vg = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + lr) * a.npad + lc;
+  const size_t kstep = (size_t)KT * a.ldkb;
+  uint4 rk0, rk1, rv0, rv1;
+#define GN_LOAD_KV(t)                                                                 \
+  {                                                                                   \
+    rk0 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep);                  \
+    rk1 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep + 32);             \
+    rv0 = *reinterpret_cast<const uint4*>(vg + (t) * KT);                             \
+    rv1 = *reinterpret_cast<const uint4*>(vg + (t) * KT + 32);                        \
+  }
+#define GN_STORE_KV(buf)                                                              \
+  {                                                                                   \
+    unsigned short* ks_ = smem + (buf) * 2 * KT * HLS + lr * HLS + lc;                \
+    *reinterpret_cast<uint4*>(ks_) = rk0;                                             \
+    *reinterpret_cast<uint4*>(ks_ + 32) = rk1;                                        \
+    *reinterpret_cast<uint4*>(ks_ + KT * HLS) = rv0;                                  \
+    *reinterpret_cast<uint4*>(ks_ + KT * HLS + 32) = rv1;                             \
+  }
+  if (ntiles > 0) {
+    GN_LOAD_KV(0);
+    GN_STORE_KV(0);
+    if (ntiles > 1) GN_LOAD_KV(1);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned short* Ks = smem + (t & 1) * 2 * KT * HLS;
+    const unsigned short* Vt = Ks + KT * HLS;
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + ql) * HLS + 16 * c + 8 * hh]);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[kt], 0, 0, 0);
+      }
+    }
+    // park tile t+1 in the idle buffer and fetch tile t+2 (overlaps the softmax VALU work below)
+    if (t + 1 < ntiles) {
+      GN_STORE_KV((t + 1) & 1);
+      if (t + 2 < ntiles) GN_LOAD_KV(t + 2);
+    }
+    if (t * KT + KT > nkv) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= nkv) st[kt][r] = -INFINITY;
+        }
+    }
+    float mloc = st[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = __expf(st[kt][8 * u + e] - m_new);
+          const unsigned short pb = f2bf(p);
+          pf[kt][u][e] = (short)pb;
+          l_run += __uint_as_float(((unsigned int)pb) << 16);
+        }
+    m_run = m_new;
+
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kb = kt * 32 + 16 * u + 4 * hh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const unsigned short* vp = &Vt[(d * 32 + ql) * HLS + kb];
+          const ushort4 lo = *reinterpret_cast<const ushort4*>(vp);
+          const ushort4 hi = *reinterpret_cast<const ushort4*>(vp + 8);
+          bf16x8 vf;
+          vf[0] = (short)lo.x; vf[1] = (short)lo.y; vf[2] = (short)lo.z; vf[3] = (short)lo.w;
+          vf[4] = (short)hi.x; vf[5] = (short)hi.y; vf[6] = (short)hi.z; vf[7] = (short)hi.w;
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+#undef GN_LOAD_KV
+#undef GN_STORE_KV
+
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
+      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
+    }
+}
 }  // namespace
 
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
@@ -313,4 +463,11 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_attn_bf16, grid, block, 0, s, a);
 }
 
+}  // namespace gn
+
+namespace gn {
+void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
+  dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
+  hipLaunchKernelGGL(k_attn_bf16_v2, grid, block, 0, s, a);
+}
 }  // namespace gn

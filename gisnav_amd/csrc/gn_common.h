@@ -22,7 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- GEMM -----------------------------------------------------------------------------------
-enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4 };
+enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
+               EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6 };
 
 struct GemmArgs {
   const float* A;    int lda;      // A[M][K1] (k < K1)
@@ -38,6 +39,9 @@ struct GemmArgs {
   float scale; int scale_cols;     // EPI_SCALE_COLS: cols < scale_cols multiplied by scale (after bias)
   const float* cos_t; const float* sin_t; int rot_cols;  // EPI_ROTARY: [M][32] tables, cols < rot_cols rotated
   const float* resid; int ldr;     // EPI_RESIDUAL
+  // EPI_*_BF16: columns < vt_start go to Yb (bf16 row-major, q columns < q_cols scaled by qscale),
+  // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))
+  uint16_t* Yb; int ldyb; uint16_t* Vt; int vt_start; int q_cols; float qscale; int npad;
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
@@ -45,6 +49,9 @@ extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B b
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {
+  const uint16_t* qb; int ldqb;   // bf16 variants of q / k (row-major) and V^T ([BS][4][64][npad])
+  const uint16_t* kb; int ldkb;
+  const uint16_t* vt;
   const float* q; int ldq;   // rows = tokens, head h at column offset h*64 from the given pointer
   const float* k; int ldk;
   const float* v; int ldv;
@@ -57,6 +64,7 @@ struct AttnArgs {
 };
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
+void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
 struct PrepArgs {

@@ -20,6 +20,12 @@ namespace gn {
 namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LS = 36;
 
+__device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
+  unsigned int u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
 __device__ __forceinline__ void load_tile(const float* asrc, size_t astr, const float* wsrc, size_t wstr,
                                           f32x4 (&ra)[4], f32x4 (&rb)[4]) {
   ra[0] = *reinterpret_cast<const f32x4*>(asrc);
@@ -443,12 +449,35 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
+  const int colbase = bn + wc * 64;
+  if (kBf16Out && colbase >= a.vt_start) {
+    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad].
+    // lane = feature d; 8 consecutive tokens are packed into one 16-byte store.
+    const int head = (colbase - a.vt_start) >> 6;
+    const int row0 = bm + wr * 64;
+    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
+    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
+    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
+        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
   const int c4 = (lane & 15) * 4;
   const int col = bn + wc * 64 + c4;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-  const bool do_scale = (EPI == EPI_SCALE_COLS) && (col < a.scale_cols);
-  const bool do_rot = (EPI == EPI_ROTARY) && (col < a.rot_cols);
+  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
+  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
   const int f0 = (col & 63) >> 1;
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
@@ -456,9 +485,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
     const int row = bm + wr * 64 + lr_;
     f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lr_ * ES + c4]);
     v += bias4;
-    if (EPI == EPI_SCALE_COLS) {
+    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
       if (do_scale) v *= a.scale;
-    } else if (EPI == EPI_ROTARY) {
+    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
       if (do_rot) {
         const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
         const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
@@ -472,7 +501,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
     } else if (EPI == EPI_RESIDUAL) {
       v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
     }
-    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+    if (kBf16Out) {
+      if (col < a.q_cols) v *= a.qscale;
+      uint2 pk;
+      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
+      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
+    } else {
+      *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+    }
   }
 }
 }  // namespace
@@ -505,12 +542,14 @@ void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
 
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
-  if (g_gemm_variant == 2) {
+  if (g_gemm_variant == 2 || epi >= EPI_ROTARY_BF16) {
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_BIAS>, grid, block, 0, s, a); break;
       case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
       case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_ROTARY>, grid, block, 0, s, a); break;
       case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_RESIDUAL>, grid, block, 0, s, a); break;
+      case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
+      case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
       default: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_PLAIN>, grid, block, 0, s, a); break;
     }
     return;
