@@ -579,7 +579,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
 }
 
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream) {
-  if (!ctx || blocks < 1 || iters < 1) return GN_ERR_ARG;
+  if (!ctx || blocks < 1 || iters == 0) return GN_ERR_ARG;
   GN_HIP(hipSetDevice(ctx->device));
   launch_mfma_probe(ctx->ls, blocks, iters, (hipStream_t)stream);
   GN_HIP(hipGetLastError());

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v1(GemmArgs a) {
 //     MFMA inside chunk 0 instead of forming a block between chunks;
 //   * XCD-aware block order: the 8 XCDs each walk a contiguous range of output tiles so that the
 //     column blocks sharing one A row-panel hit the same L2.
-template <int EPI>
+template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
 
@@ -355,7 +355,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
   acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);         \
   acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);         \
   acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-#define GN_MFMA16(fa, fb) { GN_MFMA4(0, 0, fa, fb) GN_MFMA4(0, 1, fa, fb) GN_MFMA4(1, 0, fa, fb) GN_MFMA4(1, 1, fa, fb) }
+#define GN_MFMA1(i, j, fa, fb, e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].e, fb[j].e, acc[i][j], 0, 0, 0);
+#define GN_MFMAROW(fa, fb, e) GN_MFMA1(0, 0, fa, fb, e) GN_MFMA1(0, 1, fa, fb, e) GN_MFMA1(1, 0, fa, fb, e) GN_MFMA1(1, 1, fa, fb, e)
+#define GN_MFMA16(fa, fb)                                                                         \
+  {                                                                                               \
+    if (VAR & 1) { GN_MFMAROW(fa, fb, x) GN_MFMAROW(fa, fb, y) GN_MFMAROW(fa, fb, z) GN_MFMAROW(fa, fb, w) } \
+    else { GN_MFMA4(0, 0, fa, fb) GN_MFMA4(0, 1, fa, fb) GN_MFMA4(1, 0, fa, fb) GN_MFMA4(1, 1, fa, fb) }      \
+  }
 
   // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
   {
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     GN_FRAG_READ(fa1, fb1, cur, 1);
-    if (t + 1 < nt) {
+    if (!(VAR & 4) && t + 1 < nt) {
       // chunk 0 MFMAs with the staged tile's LDS writes and the next global loads threaded through
       float* d_ = smem + (cur ^ 1) * (BM + BN) * LS + soff;
       const int k2 = (t + 2) * BK;
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
     GN_MFMA16(fa1, fb1)
     GN_FRAG_READ(fa1, fb1, cur, 3);
     GN_MFMA16(fa0, fb0)
-    __syncthreads();
+    if (!(VAR & 2)) __syncthreads();
     if (t + 1 < nt) GN_FRAG_READ(fa0, fb0, cur ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);  // keep the next tile's first fragment reads AHEAD of the chunk-3 MFMAs
     GN_MFMA16(fa1, fb1)
@@ -433,6 +439,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
 #undef GN_FRAG_READ
 #undef GN_MFMA4
 #undef GN_MFMA16
+#undef GN_MFMA1
+#undef GN_MFMAROW
   // (all tile-buffer reads completed before the last barrier: the slabs below may overwrite them)
 
   float* slab = smem + wave * 64 * ES;
@@ -512,9 +520,234 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Variant 3: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction),
+// no VGPR staging and no ds_write pass (ablation: the register-staged copy cost ~20 % of the loop).
+// The LDS-DMA writes lane-linear (base + 16 * lane), so rows are stored unpadded (128 B) and the bank
+// conflicts are removed by an XOR swizzle applied on the SOURCE side: 16-byte chunk c of tile row r
+// lands at chunk position c ^ f(r), f(r) = (r ^ (r >> 3)) & 7, and the fragment reads apply the same
+// involution.  With it every 16-lane ds_read_b128 group touches 16 distinct 16-byte bank slots.
+// Schedule per k-tile: issue the DMA of tile t+1 into the idle buffer, chunks 0-2 with register
+// double-buffered fragments, barrier (its release drains the DMA: tile t+1 has landed), fetch the
+// first fragments of tile t+1, chunk 3.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int EPI, bool PIN = true>
+__global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
+  constexpr int TILE = (BM + BN) * BK;                 // floats per buffer (unpadded rows of 32 floats)
+  constexpr int SLAB = 4 * 64 * ES;
+  __shared__ __attribute__((aligned(16))) float smem[(2 * TILE > SLAB) ? 2 * TILE : SLAB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int bx, by;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * BM, bn = bx * BN;
+  const float* A = a.A + (long long)blockIdx.z * a.strideA;
+  const float* W = a.W + (long long)blockIdx.z * a.strideW;
+  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
+  const float* const A2 = a.A2;
+  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
+
+  // DMA source addressing: wave w stages tile rows [32w, 32w + 32) of A and of B, 8 rows per instruction.
+  // lane -> (row offset lane >> 3, chunk position lane & 7) fetches source chunk pos ^ f(row).
+  const int drow = wave * 32 + (lane >> 3);            // + 8 * j
+  const int dpos = lane & 7;
+  // f(row) for row = drow + 8j: (row ^ (row >> 3)) & 7; row >> 3 = 4 * wave + j
+  const float* asrc[4]; const float* a2src[4]; const float* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = drow + 8 * j;
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    asrc[j] = A + (size_t)(bm + row) * lda + c * 4;
+    a2src[j] = A2 ? A2 + (size_t)(bm + row) * lda2 + c * 4 - K1 : nullptr;
+    wsrc[j] = W + (size_t)(bn + row) * ldw + c * 4;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define GN_DMA_TILE(buf, k0)                                                                      \
+  {                                                                                               \
+    const bool second = (A2 != nullptr) && ((k0) >= K1);                                          \
+    float* la_ = smem + (buf) * TILE + (wave_u * 32) * BK;                                        \
+    float* lb_ = la_ + BM * BK;                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+      const float* ga_ = (second ? a2src[j] : asrc[j]) + (k0);                                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(la_ + j * 8 * BK), 16, 0, 0);       \
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (k0)), (lptr_t)(lb_ + j * 8 * BK), 16, 0, 0); \
+    }                                                                                             \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addressing (floats): row * 32 + 4 * (chunk ^ f(row)), chunk = 2 kc + hh
+  const int hh = lane >> 5;
+  int arow_[2], brow_[2], ga_[2], gb_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra_ = wr * 64 + 32 * i + (lane & 31), rb_ = wc * 64 + 32 * i + (lane & 31);
+    arow_[i] = ra_ * BK; brow_[i] = BM * BK + rb_ * BK;
+    ga_[i] = hh ^ ((ra_ ^ (ra_ >> 3)) & 7); gb_[i] = hh ^ ((rb_ ^ (rb_ >> 3)) & 7);
+  }
+  const int nt = K / BK;
+
+#define GN_FRAG_READ(fa, fb, buf, kc)                                                             \
+  {                                                                                               \
+    const float* b_ = smem + (buf) * TILE;                                                        \
+    fa[0] = *reinterpret_cast<const f32x4*>(b_ + arow_[0] + 4 * (((kc) << 1) ^ ga_[0]));          \
+    fa[1] = *reinterpret_cast<const f32x4*>(b_ + arow_[1] + 4 * (((kc) << 1) ^ ga_[1]));          \
+    fb[0] = *reinterpret_cast<const f32x4*>(b_ + brow_[0] + 4 * (((kc) << 1) ^ gb_[0]));          \
+    fb[1] = *reinterpret_cast<const f32x4*>(b_ + brow_[1] + 4 * (((kc) << 1) ^ gb_[1]));          \
+  }
+#define GN_MFMA4(i, j, fa, fb)                                                                    \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);         \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);         \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);         \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+#define GN_MFMA16(fa, fb) { GN_MFMA4(0, 0, fa, fb) GN_MFMA4(0, 1, fa, fb) GN_MFMA4(1, 0, fa, fb) GN_MFMA4(1, 1, fa, fb) }
+
+  GN_DMA_TILE(0, 0);
+  __syncthreads();
+  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+  GN_FRAG_READ(fa0, fb0, 0, 0);
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    GN_FRAG_READ(fa1, fb1, cur, 1);
+    if (t + 1 < nt) {
+      // chunk 0 with the 8 DMA pieces of tile t+1 threaded between the MFMA groups
+      const int k0 = (t + 1) * BK;
+      const bool second = (A2 != nullptr) && (k0 >= K1);
+      float* la_ = smem + (cur ^ 1) * TILE + (wave_u * 32) * BK;
+      float* lb_ = la_ + BM * BK;
+#define GN_DMA_PAIR(j)                                                                            \
+      __builtin_amdgcn_global_load_lds((gptr_t)((second ? a2src[j] : asrc[j]) + k0), (lptr_t)(la_ + (j) * 8 * BK), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(lb_ + (j) * 8 * BK), 16, 0, 0);
+      GN_MFMA4(0, 0, fa0, fb0)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_DMA_PAIR(0)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_MFMA4(0, 1, fa0, fb0)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_DMA_PAIR(1)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_MFMA4(1, 0, fa0, fb0)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_DMA_PAIR(2)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_MFMA4(1, 1, fa0, fb0)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      GN_DMA_PAIR(3)
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+#undef GN_DMA_PAIR
+    } else {
+      GN_MFMA16(fa0, fb0)
+    }
+    GN_FRAG_READ(fa0, fb0, cur, 2);
+    GN_MFMA16(fa1, fb1)
+    GN_FRAG_READ(fa1, fb1, cur, 3);
+    GN_MFMA16(fa0, fb0)
+    __syncthreads();
+    if (t + 1 < nt) GN_FRAG_READ(fa0, fb0, cur ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    GN_MFMA16(fa1, fb1)
+  }
+#undef GN_DMA_TILE
+#undef GN_FRAG_READ
+#undef GN_MFMA4
+#undef GN_MFMA16
+
+  float* slab = smem + wave * 64 * ES;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[row * ES + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
+  const int colbase = bn + wc * 64;
+  if (kBf16Out && colbase >= a.vt_start) {
+    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad].
+    // lane = feature d; 8 consecutive tokens are packed into one 16-byte store.
+    const int head = (colbase - a.vt_start) >> 6;
+    const int row0 = bm + wr * 64;
+    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
+    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
+    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
+        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
+  const int c4 = (lane & 15) * 4;
+  const int col = bn + wc * 64 + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
+  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
+  const int f0 = (col & 63) >> 1;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int lr_ = it * 4 + (lane >> 4);
+    const int row = bm + wr * 64 + lr_;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lr_ * ES + c4]);
+    v += bias4;
+    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
+      if (do_rot) {
+        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+    }
+    if (kBf16Out) {
+      if (col < a.q_cols) v *= a.qscale;
+      uint2 pk;
+      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
+      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
+    } else {
+      *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+    }
+  }
+}
 }  // namespace
 
-int g_gemm_variant = 2;
+int g_gemm_variant = 3;
 
 // Pure-MFMA ceiling probe: 4 waves per CU-resident block, 8 independent accumulators, no memory traffic.
 __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
@@ -523,10 +756,24 @@ __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
-  for (int it = 0; it < iters; ++it) {
+  // iters > 0: constant operands (lowest switching activity); iters < 0: pseudo-random full-range
+  // operands that differ per lane and per MFMA (what a real GEMM feeds the pipe)
+  const bool rnd = iters < 0;
+  const int n = rnd ? -iters : iters;
+  float av[8], bv[8];
+  unsigned int h = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  for (int i = 0; i < 8; ++i) {
+    h = h * 1664525u + 1013904223u;
+    av[i] = rnd ? ((int)(h >> 8) & 0xffff) * (1.0f / 32768.0f) - 1.0f : threadIdx.x * 1e-3f;
+    h = h * 1664525u + 1013904223u;
+    bv[i] = rnd ? ((int)(h >> 8) & 0xffff) * (1.0f / 32768.0f) - 1.0f : 1.0f + blockIdx.x * 1e-6f;
+  }
+  for (int it = 0; it < n; it += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[(i + j) & 7], acc[i], 0, 0, 0);
   }
   float s = 0.f;
 #pragma unroll
@@ -542,6 +789,32 @@ void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
 
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
+  if (g_gemm_variant >= 20 && epi == EPI_BIAS) {  // ablation builds (timing only; 22+ give wrong numbers)
+    switch (g_gemm_variant) {
+      case 21: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 1>), grid, block, 0, s, a); break;
+      case 22: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 2>), grid, block, 0, s, a); break;
+      case 24: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 4>), grid, block, 0, s, a); break;
+      case 26: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 6>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 0>), grid, block, 0, s, a); break;
+    }
+    return;
+  }
+  if (g_gemm_variant == 4 && epi == EPI_BIAS) {
+    hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);
+    return;
+  }
+  if (g_gemm_variant == 3) {
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_BIAS>, grid, block, 0, s, a); break;
+      case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
+      case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY>, grid, block, 0, s, a); break;
+      case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_RESIDUAL>, grid, block, 0, s, a); break;
+      case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
+      case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_PLAIN>, grid, block, 0, s, a); break;
+    }
+    return;
+  }
   if (g_gemm_variant == 2 || epi >= EPI_ROTARY_BF16) {
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_BIAS>, grid, block, 0, s, a); break;

@@ -25,13 +25,14 @@ def main():
     dev = torch.device("cuda", 0)
     eng = PoseEngine(0, max_batch=1, max_kpts=128)
     lib, ctx = eng.lib, eng.ctx
-    for blocks in (256, 512, 1024):
-        iters = 4000
-        ms = timeit(lambda: lib.gn_debug_mfma_probe(ctx, blocks, iters, eng._stream()), n=5, warm=2)
-        fl = blocks * 4 * iters * 8 * 2 * 32 * 32 * 2
-        print(f"mfma probe blocks={blocks}: {fl / ms / 1e9:.1f} TF", flush=True)
+    for blocks in (512, 1024):
+        for sign, label in ((1, "constant operands"), (-1, "random operands")):
+            iters = 4000
+            ms = timeit(lambda: lib.gn_debug_mfma_probe(ctx, blocks, sign * iters, eng._stream()), n=5, warm=2)
+            fl = blocks * 4 * iters * 8 * 2 * 32 * 32 * 2
+            print(f"mfma probe blocks={blocks} {label}: {fl / ms / 1e9:.1f} TF", flush=True)
     M = 65536
-    shapes = [(256, 128), (768, 256), (256, 256), (512, 256), (512, 512), (256, 512), (1024, 256)]
+    shapes = [(256, 128), (768, 256), (256, 256), (512, 256), (512, 512), (256, 512), (1024, 256), (512, 2048)]
     variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
     for variant in variants:
         lib.gn_debug_set_variant(ctx, 0, variant)
