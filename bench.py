@@ -73,6 +73,18 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
                       f"cpu={platform.processor() or platform.machine()}"}
 
 
+def measured_gemm_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (bench.py cannot run under
+    the profiler itself); None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d["k_gemm_f32_all_variants"]["hbm_bytes_per_launch_corrected"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +142,7 @@ def main() -> None:
         total_pairs = args.batch * world * args.steps
         pairs_per_s = total_pairs / elapsed
         ach = kstats["flops"] / (kstats["ms"] * 1e-3) / 1e12 if kstats["ms"] > 0 else 0.0
+        traffic, traffic_src = measured_gemm_traffic() if (args.batch == 32 and args.kpts == 1024) else (None, None)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
             "value": round(pairs_per_s, 2),
@@ -164,7 +177,8 @@ def main() -> None:
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches_timed": int(kstats["launches"]),
                 "avg_launch_us": round(kstats["ms"] * 1e3 / max(kstats["launches"], 1), 2),
                 "algorithmic_gflop_per_launch": round(kstats["flops"] / max(kstats["launches"], 1) / 1e9, 3),
