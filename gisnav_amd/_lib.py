@@ -43,6 +43,7 @@ SIGNATURES = {
     "gn_get_stage_ms": (C.c_int, [VP, c_f32p, C.c_int]),
     "gn_debug_set_variant": (C.c_int, [VP, C.c_int, C.c_int]),
     "gn_debug_mfma_probe": (C.c_int, [VP, C.c_int, C.c_int, VP]),
+    "gn_debug_epnp": (C.c_int, [VP, C.c_int, VP, VP, VP, VP]),
     "gn_set_kernel_timing": (C.c_int, [VP, C.c_int]),
     "gn_get_kernel_stats": (C.c_int, [VP, c_f64p]),
 }

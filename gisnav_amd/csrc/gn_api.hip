@@ -578,6 +578,14 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   return GN_OK;
 }
 
+int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, double* out, void* stream) {
+  if (!ctx || n < 1 || !pws || !us || !out) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  launch_epnp_debug(pws, us, out, n, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream) {
   if (!ctx || blocks < 1 || iters == 0) return GN_ERR_ARG;
   GN_HIP(hipSetDevice(ctx->device));

@@ -109,6 +109,7 @@ struct PnpArgs {
   uint8_t* mask_ws;          // [B][kstride] scratch for inlier masks (2 per pair)
 };
 void launch_pnp(const PnpArgs& a, hipStream_t s);
+void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s);
 
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);

@@ -340,24 +340,66 @@ __device__ inline void epnp_Ab(const Shared& sh, const double be[4], double A[6]
   }
 }
 
+// min ||A x - b|| for a 6 x K system by Householder QR (no pivoting, like epnp.cpp's qr_solve; the
+// condition number is NOT squared as it would be with normal equations).  A vanishing column norm
+// zeroes that unknown.  Fully unrolled, wave-uniform.
 template <int K>
-__device__ inline void lsq6(const double A[6][K], const double b[6], double x[K]) {
-  double N[K][K], r[K];
+__device__ inline void lsq6(const double Ain[6][K], const double bin[6], double x[K]) {
+  double A[6][K], b[6], rd[K];
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    double v = 0;
+  for (int i = 0; i < 6; ++i) {
+    b[i] = bin[i];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) v += A[m][i] * b[m];
-    r[i] = v;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      double u = 0;
-#pragma unroll
-      for (int m = 0; m < 6; ++m) u += A[m][i] * A[m][j];
-      N[i][j] = u;
-    }
+    for (int j = 0; j < K; ++j) A[i][j] = Ain[i][j];
   }
-  spd_solve<K>(N, r, x);
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) scale = fmax(scale, fabs(A[i][j]));
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double sigma = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i >= k) sigma += A[i][k] * A[i][k];
+    if (!(sigma > 1e-30 * scale * scale)) { rd[k] = 0.0; continue; }
+    const double akk = A[k][k];
+    const double alpha = akk > 0 ? -sqrt(sigma) : sqrt(sigma);
+    const double beta = 1.0 / (sigma - akk * alpha);
+    A[k][k] = akk - alpha;  // v_k; v_i = A[i][k] for i > k
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (j > k) {
+        double sdot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (i >= k) sdot += A[i][k] * A[i][j];
+        sdot *= beta;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (i >= k) A[i][j] -= sdot * A[i][k];
+      }
+    {
+      double sdot = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (i >= k) sdot += A[i][k] * b[i];
+      sdot *= beta;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (i >= k) b[i] -= sdot * A[i][k];
+    }
+    rd[k] = alpha;
+  }
+#pragma unroll
+  for (int k = K - 1; k >= 0; --k) {
+    double v = b[k];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (j > k) v -= A[k][j] * x[j];
+    x[k] = (rd[k] != 0.0) ? v / rd[k] : 0.0;
+  }
 }
 
 __device__ inline double epnp_Rt(const Shared& sh, const double be[4], double R[3][3], double t[3]) {
@@ -421,7 +463,7 @@ __device__ inline double epnp_Rt(const Shared& sh, const double be[4], double R[
   return err * 0.2;
 }
 
-__device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3]) {
+__device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], double* dbg = nullptr) {
   // control points: centroid + PCA axes
   double c0[3] = {0, 0, 0};
 #pragma unroll
@@ -442,6 +484,14 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3]) {
     }
   double dc[3], uc[3][3];
   eig3(S, dc, uc);
+  // canonical axis signs (same rule as the oracle's canonical_axis_signs): the largest-magnitude
+  // component of every principal axis is made positive, first such component on ties
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a0 = fabs(uc[0][i]), a1 = fabs(uc[1][i]), a2 = fabs(uc[2][i]);
+    const double lead = (a0 >= a1 && a0 >= a2) ? uc[0][i] : ((a1 >= a2) ? uc[1][i] : uc[2][i]);
+    if (lead < 0) { uc[0][i] = -uc[0][i]; uc[1][i] = -uc[1][i]; uc[2][i] = -uc[2][i]; }
+  }
   double kk[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) kk[i] = sqrt(fmax(dc[i], 0.0) / 5.0);
@@ -487,6 +537,29 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3]) {
   }
   __syncthreads();
   sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+  // M is 10 x 12, so the two smallest eigenvectors span an exactly 2-D null space whose basis is an
+  // artefact of the eigen-solver.  Fix it deterministically (same rule as the oracle's
+  // canonical_nullspace): v0 = normalised projection of e_11 onto the null space, v1 = its in-plane
+  // complement with component 10 >= 0.
+  {
+    const int c0 = sh.ord[0], c1 = sh.ord[1];
+    const double na = sh.V[11 * 12 + c0], nb = sh.V[11 * 12 + c1];
+    const double nrm = sqrt(na * na + nb * nb);
+    double w0 = 0, w1 = 0, w1_10 = 0;
+    if (nrm >= 1e-12) {
+      const double p0 = sh.V[10 * 12 + c0], p1 = sh.V[10 * 12 + c1];
+      w1_10 = (-nb * p0 + na * p1) / nrm;
+      if (lane < 12) {
+        const double x0 = sh.V[lane * 12 + c0], x1 = sh.V[lane * 12 + c1];
+        w0 = (na * x0 + nb * x1) / nrm;
+        w1 = (-nb * x0 + na * x1) / nrm;
+        if (w1_10 < 0) w1 = -w1;
+      }
+    }
+    __syncthreads();
+    if (nrm >= 1e-12 && lane < 12) { sh.V[lane * 12 + c0] = w0; sh.V[lane * 12 + c1] = w1; }
+    __syncthreads();
+  }
   // L (6 x 10) and rho
   if (lane < 60) {
     const int j = lane / 10, m = lane % 10;
@@ -557,6 +630,11 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3]) {
     }
     double R[3][3], t[3];
     const double err = epnp_Rt(sh, be, R, t);
+    if (dbg && lane == 0) {
+      dbg[12 + cand] = err;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dbg[15 + 4 * cand + k] = be[k];
+    }
     if (err == err && (!have || err < best_err)) {
       have = true; best_err = err;
 #pragma unroll
@@ -1007,6 +1085,34 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
   }
 }
 }  // namespace
+
+// test hook: EPnP on n independent 5-point sets (world points f64 [n][5][3], normalised image points
+// f64 [n][5][2]); out [n][64]: R (9), t (3), candidate errors (3), candidate betas (12), eigenvalues (12), rho(6), L row 0 (10)
+__global__ __launch_bounds__(64) void k_epnp_debug(const double* pws, const double* us, double* out) {
+  __shared__ Shared sh;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (lane < 15) sh.pws[lane] = pws[b * 15 + lane];
+  if (lane < 10) sh.us[lane] = us[b * 10 + lane];
+  __syncthreads();
+  double R[3][3], t[3];
+  double* o = out + (size_t)b * 64;
+  const bool ok = epnp5(sh, lane, R, t, o);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[9 + i] = t[i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o[3 * i + j] = R[i][j]; }
+    for (int k = 0; k < 12; ++k) o[27 + k] = sh.A[sh.ord[k] * 12 + sh.ord[k]];
+    for (int k = 0; k < 6; ++k) o[39 + k] = sh.rho[k];
+    for (int k = 0; k < 10; ++k) o[45 + k] = sh.L[k];
+    o[55] = ok ? 1.0 : 0.0;
+  }
+}
+
+void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_epnp_debug, dim3(n), dim3(64), 0, s, pws, us, out);
+}
 
 void launch_pnp(const PnpArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_pnp_ransac, dim3(a.B), dim3(64), 0, s, a);

@@ -143,6 +143,9 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * v_mfma_f32_32x32x2_f32 issue-rate probe (blocks x 256 threads x iters x 8 MFMAs per wave). */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream);
+/* EPnP minimal solver on n 5-point sets: pws [n][5][3] f64, us [n][5][2] f64 (normalised image
+ * coordinates), out [n][64] f64 = R(9) t(3) candidate errors(3) candidate betas(12) eigenvalues(12) rho(6) L row0(10) ok(1). */
+int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, double* out, void* stream);
 int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
 int gn_get_kernel_stats(gn_ctx* ctx, double* out3);
 

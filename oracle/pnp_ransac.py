@@ -17,8 +17,9 @@ CPU (numpy float64) restatement of the pose-solver half of GISNav's PoseNode hot
 PARITY UNPINNED: cv2 is absent from this container and the reference's tests hold no
 golden vector for this call.  The restatement follows the published OpenCV algorithm
 (SURVEY.md Appendix B); linear algebra uses LAPACK via numpy where OpenCV uses its own
-Jacobi SVD / eigen, so sub-results that OpenCV itself leaves implementation-defined (the
-basis of the 2-D null space of EPnP's M^T M for 5 points) are not bit-reproducible.
+Jacobi SVD / eigen.  Where OpenCV's own result is implementation-defined the restatement picks a
+deterministic representative and says so at the spot: the basis of the exactly 2-D null space of EPnP's
+M^T M for 5 points (`canonical_nullspace`) and the third singular pair of a rank-deficient 3x3 alignment.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may
 import this module.
@@ -165,11 +166,45 @@ def project_points(obj: np.ndarray, rvec, tvec, A: np.ndarray, jac: bool = False
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
 
 
+def canonical_nullspace(v0: np.ndarray, v1: np.ndarray):
+    """With 5 points M is 10 x 12, so the two smallest right-singular vectors span an exactly
+    2-dimensional null space and their individual directions are an artefact of the SVD code path
+    (OpenCV: the sweep order of its one-sided Jacobi).  EPnP's approx_1 / approx_3 initialisations
+    depend on that artefact, so the restatement fixes the basis deterministically: v0 is the normalised
+    projection of the coordinate axis e_11 onto the null space, v1 its in-plane orthogonal complement
+    (sign: component 10 non-negative).  Any orthonormal basis is an equally valid stand-in for OpenCV's."""
+    a, b = v0[11], v1[11]
+    nrm = math.hypot(a, b)
+    if nrm < 1e-12:
+        return v0, v1
+    w0 = (a * v0 + b * v1) / nrm
+    w1 = (-b * v0 + a * v1) / nrm
+    if w1[10] < 0:
+        w1 = -w1
+    return w0, w1
+
+
+_NULLSPACE_BASIS = canonical_nullspace
+
+
+def canonical_axis_signs(u: np.ndarray) -> np.ndarray:
+    """The sign of each principal axis returned by an SVD is implementation-defined, and it changes
+    where EPnP puts its control points (c_i = c_0 +- k_i u_i), i.e. the parametrisation in which the
+    basis-dependent beta initialisations are computed.  Fix it: every axis (column) gets the sign that
+    makes its largest-magnitude component positive (first such component on ties)."""
+    u = u.copy()
+    for i in range(u.shape[1]):
+        k = int(np.argmax(np.abs(u[:, i])))
+        if u[k, i] < 0:
+            u[:, i] = -u[:, i]
+    return u
+
+
 def _lstsq(A, b):
     return np.linalg.lstsq(A, b, rcond=None)[0]
 
 
-def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0) -> Tuple[np.ndarray, np.ndarray]:
+def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray]:
     """EPnP (Lepetit et al.) as in OpenCV's epnp.cpp.  pws (n,3), us (n,2) -> R (3,3), t (3,)."""
     n = pws.shape[0]
     # choose_control_points
@@ -177,6 +212,7 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0) -> Tup
     cws[0] = pws.mean(axis=0)
     pw0 = pws - cws[0]
     u_, dc, _ = np.linalg.svd(pw0.T @ pw0)
+    u_ = canonical_axis_signs(u_)
     for i in range(3):
         cws[i + 1] = cws[0] + math.sqrt(dc[i] / n) * u_[:, i]
     # barycentric coordinates
@@ -193,6 +229,8 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0) -> Tup
         M[1::2, 3 * j + 2] = alphas[:, j] * (vc - us[:, 1])
     _, _, ut = np.linalg.svd(M.T @ M)  # rows of ut: right singular vectors, descending
     v = [ut[11 - k] for k in range(4)]
+    if n == 5 and _NULLSPACE_BASIS is not None:
+        v[0], v[1] = _NULLSPACE_BASIS(v[0], v[1])
     # L (6x10) and rho
     dv = np.array([[v[i][3 * a:3 * a + 3] - v[i][3 * b:3 * b + 3] for (a, b) in _PAIRS] for i in range(4)])
     L = np.empty((6, 10))
@@ -258,7 +296,12 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0) -> Tup
             ccs, pcs = -ccs, -pcs
         pc0, pw0_ = pcs.mean(axis=0), pws.mean(axis=0)
         abt = (pcs - pc0).T @ (pws - pw0_)
-        U, _, Vt = np.linalg.svd(abt)
+        U, sv, Vt = np.linalg.svd(abt)
+        if sv[2] <= 1e-9 * sv[0]:
+            # rank-deficient alignment (coplanar world points): OpenCV fills the third singular pair from
+            # a seeded random vector; the restatement completes it as u0 x u1, v0 x v1 (proper rotation)
+            U = np.column_stack([U[:, 0], U[:, 1], np.cross(U[:, 0], U[:, 1])])
+            Vt = np.vstack([Vt[0], Vt[1], np.cross(Vt[0], Vt[1])])
         R = U @ Vt
         if np.linalg.det(R) < 0:
             R[2] = -R[2]
@@ -269,10 +312,16 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0) -> Tup
         err = np.sqrt((us[:, 0] - ue) ** 2 + (us[:, 1] - ve) ** 2).sum() / n
         return err, R, t
 
+    if dbg is not None:
+        dbg.update(L=L, rho=rho, v=v, alphas=alphas, cws=cws, cands=[])
     best = None
     for f in (approx1, approx2, approx3):
         with np.errstate(all="ignore"):
-            cand = r_and_t(gauss_newton(f()))
+            b_init = f()
+            b_fin = gauss_newton(b_init)
+            cand = r_and_t(b_fin)
+        if dbg is not None:
+            dbg["cands"].append((b_init, b_fin, cand[0]))
         if best is None or cand[0] < best[0]:  # strict '<': first wins ties (epnp.cpp compute_pose)
             best = cand
     return best[1], best[2]

@@ -5,9 +5,12 @@ full size -- through size-independent properties.
 Stated tolerances:
   * correspondence indices: bit-exact (f32 mode, and bf16-attention mode on the seeded fixtures);
   * match scores: |d| <= 1e-5;  residual stream per layer: max rel 2e-5 (f32), 3e-2 (bf16 attention);
-  * pose (R, t): ||dR||_F <= 1e-6 and ||dt||/||t|| <= 1e-6 when the RANSAC inlier masks coincide
-    (always the case on the fixtures below); <= 2e-3 otherwise (hypotheses from 5 noisy points
-    can classify a handful of borderline points differently between LAPACK and Jacobi eigen-solvers).
+  * EPnP minimal solver, per RANSAC hypothesis: ||dR||_F, ||dt|| <= 1e-8 (measured ~1e-12);
+  * pose (R, t) on non-planar scenes: RANSAC inlier COUNT identical, ||dR||_F <= 1e-8 and
+    ||dt||/||t|| <= 1e-8 (measured ~1e-16: both sides run the LM refinement to the same fixed point);
+  * planar scenes (flat DEM): <= 2e-3 -- EPnP with 4 control points is degenerate on coplanar points
+    (the null space of M^T M has dimension >= 5), so hypotheses are implementation-defined there, in
+    OpenCV as well; only the refined pose is comparable, and only when the inlier sets happen to agree.
 """
 import os
 
@@ -137,7 +140,7 @@ def test_golden_fixtures_through_c_abi(eng256, eng256_bf16, dev, prec, name):
     out = eng.estimate(inp, g["K"])
     assert int(out["ok"][0]) == 1 and int(out["n_match"][0]) == len(g["idx"])
     R, t = out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()
-    assert np.linalg.norm(R - g["R"]) < 1e-6 and np.linalg.norm(t - g["t"]) / np.linalg.norm(g["t"]) < 1e-6
+    assert np.linalg.norm(R - g["R"]) < 1e-8 and np.linalg.norm(t - g["t"]) / np.linalg.norm(g["t"]) < 1e-8
     mkp, obj = eng.gather_points(inp["kpt_q"], inp["kpt_r"], idx, n_match, inp["dem"])
     assert np.array_equal(mkp[0, :k].cpu().numpy(), g["mkp_q"])
     x, y = np.floor(g["mkp_r"]).astype(int).T
@@ -229,20 +232,46 @@ def test_seam_b2_compute_pose_on_golden_fixture(name, dev):
     assert R.shape == (3, 3) and t.shape == (3, 1) and R.dtype == np.float64 and t.dtype == np.float64
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
     assert np.linalg.norm(R - g["R_gt"]) < 3e-3 and np.linalg.norm(t - g["t_gt"]) / np.linalg.norm(g["t_gt"]) < 3e-3
-    assert np.linalg.norm(R - g["R"]) < 2e-3 and np.linalg.norm(t - g["tvec"]) / np.linalg.norm(g["tvec"]) < 2e-3
+    tol = 2e-3 if name.endswith("flat") else 1e-8
+    assert np.linalg.norm(R - g["R"]) < tol and np.linalg.norm(t - g["tvec"]) / np.linalg.norm(g["tvec"]) < tol
     assert compute_pose(CameraInfo(k=g["K"].reshape(-1)), g["img"][:3], g["mkp_r"][:3], g["dem"]) is None
 
 
-def test_pnp_inlier_mask_and_pose_against_oracle(dev, eng256):
+def test_epnp_minimal_solver_per_hypothesis(dev, eng256):
+    import ctypes as C
     from oracle import pnp_ransac as pr
-    tight, total = 0, 0
-    for seed in range(90, 98):
-        p = make_pair(seed, n_q=256, n_r=256, flat_dem=(seed % 2 == 0))
+    p = make_pair(20)
+    q = np.nonzero(p.gt_q2r >= 0)[0]
+    mq, mr = p.kp_q[q], p.kp_r[p.gt_q2r[q]]
+    x, y = np.floor(mr).astype(int).T
+    obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32).astype(np.float64)
+    und = np.column_stack([(mq[:, 0].astype(np.float64) - K_MATRIX[0, 2]) / K_MATRIX[0, 0],
+                           (mq[:, 1].astype(np.float64) - K_MATRIX[1, 2]) / K_MATRIX[1, 1]])
+    rng = pr.CvRNG()
+    subsets = [pr.get_subset(rng, len(obj), 5) for _ in range(10)]      # the subsets solvePnPRansac would draw
+    pws = np.stack([obj[s] for s in subsets]); us = np.stack([und[s] for s in subsets])
+    tp, tu = torch.from_numpy(pws).to(dev), torch.from_numpy(us).to(dev)
+    out = torch.zeros((10, 64), dtype=torch.float64, device=dev)
+    rc = eng256.lib.gn_debug_epnp(eng256.ctx, 10, C.c_void_p(tp.data_ptr()), C.c_void_p(tu.data_ptr()),
+                                  C.c_void_p(out.data_ptr()), eng256._stream())
+    assert rc == 0
+    o = out.cpu().numpy()
+    for k in range(10):
+        R, t = pr.epnp(pws[k], us[k])
+        assert np.linalg.norm(o[k, :9].reshape(3, 3) - R) < 1e-8 and np.linalg.norm(o[k, 9:12] - t) < 1e-8, k
+        assert abs(o[k, 27]) < 1e-12 and abs(o[k, 28]) < 1e-12 and o[k, 29] > 1e-4   # exactly 2-D null space of M^T M
+
+
+def test_pnp_inlier_count_and_pose_against_oracle(dev, eng256):
+    from oracle import pnp_ransac as pr
+    for seed in range(90, 102):
+        flat = seed % 4 == 0
+        p = make_pair(seed, n_q=256, n_r=256, flat_dem=flat)
         q = np.nonzero(p.gt_q2r >= 0)[0]
         mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
         rs = np.random.default_rng(seed)
         no = len(q) // 6
-        mq[:no] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)
+        mq[:no] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)   # gross outliers
         x, y = np.floor(mr).astype(int).T
         obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32)
         ok, r, t, inl = pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)
@@ -251,13 +280,12 @@ def test_pnp_inlier_mask_and_pose_against_oracle(dev, eng256):
         assert ok and int(okg[0]) == 1
         dR = np.linalg.norm(R[0].cpu().numpy() - pr.rodrigues_vec2mat(r))
         dt = np.linalg.norm(tg[0].cpu().numpy() - t) / np.linalg.norm(t)
-        assert dR < 2e-3 and dt < 2e-3, (seed, dR, dt)
         assert np.linalg.norm(R[0].cpu().numpy() - p.R_gt) < 5e-3
-        total += 1
-        if int(ninl[0]) == len(inl):
-            assert dR < 1e-6 and dt < 1e-6, (seed, dR, dt)          # same inlier set -> same LM optimum
-            tight += 1
-    assert tight >= total // 2
+        if flat:
+            assert dR < 2e-3 and dt < 2e-3, (seed, dR, dt)
+        else:
+            assert int(ninl[0]) == len(inl), (seed, int(ninl[0]), len(inl))
+            assert dR < 1e-8 and dt < 1e-8, (seed, dR, dt)
 
 
 def test_seam_b3_pose_node_shim_from_wire_bytes(state_dict_np, state_dict_t, dev):
@@ -283,7 +311,7 @@ def test_seam_b3_pose_node_shim_from_wire_bytes(state_dict_np, state_dict_t, dev
     mq, mr, sc, oidx = oracle_match(state_dict_t, p)
     assert node.last_num_matches == len(oidx)
     Ro, to = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
-    assert np.linalg.norm(r1[0] - Ro) < 2e-3 and np.linalg.norm(r1[1] - to) / np.linalg.norm(to) < 2e-3
+    assert np.linalg.norm(r1[0] - Ro) < 1e-8 and np.linalg.norm(r1[1] - to) / np.linalg.norm(to) < 1e-8
     assert np.array_equal(r1[0], r2[0])
     node.pose_image = wire.OrthoStereoImage(query_sift=wire.pack_keypoints(p.kp_q[:10], p.size_q[:10], p.angle_q[:10], p.desc_q[:10]),
                                             reference=wire.ImageMsg(p.ref, wire.Stamp(13, 0)), dem=wire.ImageMsg(p.dem, wire.Stamp(13, 0)))
@@ -368,9 +396,14 @@ def test_full_size_permutation_equivariance(full_size):
 
 
 def test_full_size_oracle_spot_check(full_size, state_dict_t):
+    from oracle import pnp_ransac as pr
     pairs, res = full_size
     idx, score, nm, out = res["f32"]
-    for b in (0, 17):
+    for b in (0, 12, 17, 25):
         mq, mr, sc, oidx = oracle_match(state_dict_t, pairs[b])
         assert np.array_equal(idx[b, : nm[b]], oidx.numpy())
         assert np.abs(score[b, : nm[b]] - sc.numpy()[:, 0]).max() < 1e-5
+        Ro, to = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), pairs[b].dem)
+        for prec in ("f32", "bf16_attn"):      # identical correspondences -> identical pose problem
+            o = res[prec][3]
+            assert np.linalg.norm(o["R"][b] - Ro) < 1e-8 and np.linalg.norm(o["t"][b] - to) / np.linalg.norm(to) < 1e-8
