@@ -94,9 +94,13 @@ def main() -> None:
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--precision", default="bf16_attn", choices=["f32", "bf16_attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
-    rank, local_rank, world = gdist.init("nccl")
+    rank, local_rank, world = gdist.init(args.backend)
+    if args.share_gpu:
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)

@@ -38,6 +38,11 @@ def shard_range(total_pairs: int, rank: int, world: int) -> range:
     return range(min(rank * per, total_pairs), min((rank + 1) * per, total_pairs))
 
 
+def _comm_device(device: torch.device) -> torch.device:
+    """gloo moves host tensors; nccl (RCCL) moves device tensors."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def _flatten(sd: Dict[str, np.ndarray]):
     keys = sorted(sd)
     return keys, np.concatenate([np.asarray(sd[k], np.float32).reshape(-1) for k in keys])
@@ -49,7 +54,7 @@ def broadcast_state_dict(sd: Dict[str, np.ndarray], device: torch.device, src: i
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sd
     keys, flat = _flatten(sd)
-    buf = torch.from_numpy(flat).to(device)
+    buf = torch.from_numpy(flat).to(_comm_device(device))
     dist.broadcast(buf, src=src)
     flat = buf.cpu().numpy()
     out, off = {}, 0
@@ -68,7 +73,7 @@ def barrier() -> None:
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -76,7 +81,7 @@ def max_over_ranks(value: float, device: torch.device) -> float:
 def sum_over_ranks(value: float, device: torch.device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -98,6 +103,7 @@ def gather_records(rec: torch.Tensor) -> torch.Tensor:
     """all_gather of equally-sized per-rank record blocks -> [world * B, 16] on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rec
-    parts = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, rec.contiguous())
-    return torch.cat(parts, 0)
+    src = rec.contiguous().to(_comm_device(rec.device))
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src)
+    return torch.cat(parts, 0).to(rec.device)
