@@ -51,6 +51,7 @@ struct gn_ctx {
   // pipeline scratch for gn_estimate
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
   uint8_t* mask_ws = nullptr;
+  gn::HypResult* hyp_ws = nullptr;
   std::vector<void*> allocs;
   // stage timing
   bool timing = false;
@@ -295,7 +296,8 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
-  GN_ALLOC(mask_ws, B * np * 2);
+  GN_ALLOC(mask_ws, B * np * 16);
+  GN_ALLOC(hyp_ws, B * 16);
 #undef GN_ALLOC
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
@@ -485,12 +487,13 @@ int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const 
   if (!ctx || !obj || !img || !n_pts || !K9 || !R || !t || !n_inliers || !ok || B < 1 || B > ctx->max_batch)
     return fail(ctx, GN_ERR_ARG, "bad gn_pnp_ransac argument");
   if (kstride < 1 || kstride > ctx->npad) return fail(ctx, GN_ERR_ARG, "kstride exceeds max_kpts of this context");
+  if (iterations_count < 1 || iterations_count > 16) return fail(ctx, GN_ERR_ARG, "iterations_count must be in 1..16 (PoseNode uses 10)");
   GN_HIP(hipSetDevice(ctx->device));
   PnpArgs a;
   a.obj = obj; a.img = img; a.n_pts = n_pts; a.kstride = kstride; a.B = B;
   a.fx = K9[0]; a.fy = K9[4]; a.cx = K9[2]; a.cy = K9[5];
   a.iterations = iterations_count; a.reproj = reproj_error_px; a.confidence = confidence; a.min_pts = min_pts;
-  a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws;
+  a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws; a.hyp = ctx->hyp_ws;
   StageTimer tm(ctx, (hipStream_t)stream, ST_PNP);
   launch_pnp(a, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
@@ -525,7 +528,8 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"rowmax", ctx->rowmax, B * np}, {"rowlog", ctx->rowlog, B * np}, {"colmax", ctx->colmax, B * np},
       {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
-      {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np}};
+      {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
+      {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)}};
   for (const Ent& e : tab)
     if (strcmp(e.n, name) == 0) {
       size_t count = e.count;

@@ -101,12 +101,15 @@ struct GatherArgs {
 };
 void launch_gather(const GatherArgs& a, hipStream_t s);
 
+struct HypResult { double R[9]; double t[3]; int good; int valid; };   // one RANSAC hypothesis
+
 struct PnpArgs {
   const float* obj; const float* img; const int32_t* n_pts; int kstride; int B;
   double fx, fy, cx, cy;
   int iterations; float reproj; double confidence; int min_pts;
   double* R; double* t; int32_t* n_inliers; uint8_t* ok;
-  uint8_t* mask_ws;          // [B][kstride] scratch for inlier masks (2 per pair)
+  uint8_t* mask_ws;          // [B][16][kstride] scratch: one inlier mask per concurrent hypothesis
+  HypResult* hyp;            // [B][16]
 };
 void launch_pnp(const PnpArgs& a, hipStream_t s);
 void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s);

@@ -36,6 +36,10 @@ __device__ inline double wsum(double v) {
   return v;
 }
 
+// Every PnP kernel runs single-wave workgroups, so a workgroup barrier is a wave barrier: it orders the
+// LDS traffic exchanged between lanes and costs next to nothing.
+__device__ inline void wave_sync() { __syncthreads(); }
+
 struct Shared {
   double A[144];
   double V[144];
@@ -277,7 +281,7 @@ __device__ inline void spd_solve(const double N[K][K], const double b[K], double
 // column indices by ASCENDING eigenvalue.  Called by the whole (single-wave) block.
 __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
   for (int idx = lane; idx < n * n; idx += 64) V[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
-  __syncthreads();
+  wave_sync();
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0, dg = 0.0;
     for (int idx = lane; idx < n * n; idx += 64) {
@@ -294,7 +298,7 @@ __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
         const double tau = (aqq - app) / (2.0 * apq);
         const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
         const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-        __syncthreads();
+        wave_sync();
         if (lane < n) {
           const int k = lane;
           const double akp = A[k * n + p], akq = A[k * n + q];
@@ -302,13 +306,13 @@ __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
           const double vkp = V[k * n + p], vkq = V[k * n + q];
           V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
         }
-        __syncthreads();
+        wave_sync();
         if (lane < n) {
           const int k = lane;
           const double apk = A[p * n + k], aqk = A[q * n + k];
           A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
         }
-        __syncthreads();
+        wave_sync();
       }
   }
   if (lane == 0) {
@@ -321,7 +325,7 @@ __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
       ord[j + 1] = oi;
     }
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -495,7 +499,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
   double kk[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) kk[i] = sqrt(fmax(dc[i], 0.0) / 5.0);
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) sh.cws[k] = c0[k];
@@ -519,7 +523,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
       sh.alphas[p * 4] = 1.0 - a123;
     }
   }
-  __syncthreads();
+  wave_sync();
   // M^T M (12 x 12), M is 10 x 12 with fu = fv = 1, uc = vc = 0
   for (int idx = lane; idx < 144; idx += 64) {
     const int r = idx / 12, c = idx % 12;
@@ -535,7 +539,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
     }
     sh.A[idx] = v;
   }
-  __syncthreads();
+  wave_sync();
   sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
   // M is 10 x 12, so the two smallest eigenvectors span an exactly 2-D null space whose basis is an
   // artefact of the eigen-solver.  Fix it deterministically (same rule as the oracle's
@@ -556,9 +560,9 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
         if (w1_10 < 0) w1 = -w1;
       }
     }
-    __syncthreads();
+    wave_sync();
     if (nrm >= 1e-12 && lane < 12) { sh.V[lane * 12 + c0] = w0; sh.V[lane * 12 + c1] = w1; }
-    __syncthreads();
+    wave_sync();
   }
   // L (6 x 10) and rho
   if (lane < 60) {
@@ -584,7 +588,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
       sh.rho[j] = rr;
     }
   }
-  __syncthreads();
+  wave_sync();
 
   double best_err = 0; bool have = false;
   double rho[6];
@@ -770,114 +774,12 @@ __device__ inline unsigned rng_next(unsigned long long& st) {
   return (unsigned)st;
 }
 
-__global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
-  __shared__ Shared sh;
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int n = a.n_pts[b];
-  const float* obj = a.obj + (size_t)b * a.kstride * 3;
-  const float* img = a.img + (size_t)b * a.kstride * 2;
-  uint8_t* mask_cur = a.mask_ws + (size_t)b * 2 * a.kstride;
-  uint8_t* mask_best = mask_cur + a.kstride;
-  double* Rout = a.R + (size_t)b * 9;
-  double* tout = a.t + (size_t)b * 3;
-  const Cam cam = {a.fx, a.fy, a.cx, a.cy};
+constexpr int kMaxHyp = 16;   // RANSAC hypotheses evaluated concurrently, one wavefront each
 
-  auto fail = [&]() {
-    if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
-    if (lane < 3) tout[lane] = 0.0;
-    if (lane == 0) { a.ok[b] = 0; a.n_inliers[b] = 0; }
-  };
-  if (n < a.min_pts || n < 5) { fail(); return; }
 
-  // ---- RANSAC ---------------------------------------------------------------------------------
-  unsigned long long rng = 0xFFFFFFFFFFFFFFFFull;
-  int niters = a.iterations, max_good = 0;
-  double bestR[3][3], bestT[3];
-  const float thr = a.reproj * a.reproj;
-  for (int it = 0; it < niters; ++it) {
-    int idx[5];
-    if (n > 5) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        for (;;) {
-          const int v = (int)(rng_next(rng) % (unsigned)n);
-          bool dup = false;
-#pragma unroll
-          for (int j = 0; j < 5; ++j) if (j < i && idx[j] == v) dup = true;
-          if (!dup) { idx[i] = v; break; }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) idx[i] = i;
-    }
-    __syncthreads();
-    if (lane < 5) {
-      int id = 0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) if (i == lane) id = idx[i];
-      sh.pws[lane * 3 + 0] = obj[3 * id]; sh.pws[lane * 3 + 1] = obj[3 * id + 1]; sh.pws[lane * 3 + 2] = obj[3 * id + 2];
-      sh.us[2 * lane] = ((double)img[2 * id] - cam.cx) / cam.fx;
-      sh.us[2 * lane + 1] = ((double)img[2 * id + 1] - cam.cy) / cam.fy;
-    }
-    __syncthreads();
-    double R[3][3], t[3];
-    if (!epnp5(sh, lane, R, t)) continue;
-    // hypothesis scoring: float32 squared reprojection error <= thr
-    int good = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      bool inl = false;
-      if (i < n) {
-        const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
-        const double X = R[0][0] * M0 + R[0][1] * M1 + R[0][2] * M2 + t[0];
-        const double Y = R[1][0] * M0 + R[1][1] * M1 + R[1][2] * M2 + t[1];
-        const double Z = R[2][0] * M0 + R[2][1] * M1 + R[2][2] * M2 + t[2];
-        const double z = Z != 0 ? 1.0 / Z : 1.0;
-        const float pu = (float)(X * z * cam.fx + cam.cx), pv = (float)(Y * z * cam.fy + cam.cy);
-        const float dx = img[2 * i] - pu, dy = img[2 * i + 1] - pv;
-        const float e = dx * dx + dy * dy;
-        inl = e <= thr;
-        mask_cur[i] = inl ? 1 : 0;
-      }
-      good += __popcll(__ballot(inl));
-    }
-    if (good > (max_good > 4 ? max_good : 4)) {
-      uint8_t* tmp = mask_cur; mask_cur = mask_best; mask_best = tmp;
-      max_good = good;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { bestT[i] = t[i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) bestR[i][j] = R[i][j]; }
-      niters = ransac_update_iters(a.confidence, (double)(n - good) / n, 5, niters);
-    }
-  }
-  if (max_good == 0) { fail(); return; }
-  __syncthreads();  // mask_best writes visible to the whole wave (global memory, same wave: ordered)
-
-  // ---- solvePnP(SOLVEPNP_ITERATIVE) on the inliers ---------------------------------------------
-  const uint8_t* mask = mask_best;
-  const int ninl = max_good;
-  double p[6];
-  // PCA of the inlier object points
-  double mc[3] = {0, 0, 0};
-  for (int i = lane; i < n; i += 64)
-    if (mask[i]) { mc[0] += obj[3 * i]; mc[1] += obj[3 * i + 1]; mc[2] += obj[3 * i + 2]; }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) mc[k] = wsum(mc[k]) / ninl;
-  double mm[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = lane; i < n; i += 64)
-    if (mask[i]) {
-      const double d0 = obj[3 * i] - mc[0], d1 = obj[3 * i + 1] - mc[1], d2 = obj[3 * i + 2] - mc[2];
-      mm[0] += d0 * d0; mm[1] += d0 * d1; mm[2] += d0 * d2; mm[3] += d1 * d1; mm[4] += d1 * d2; mm[5] += d2 * d2;
-    }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) mm[k] = wsum(mm[k]);
-  double MM[3][3] = {{mm[0], mm[1], mm[2]}, {mm[1], mm[3], mm[4]}, {mm[2], mm[4], mm[5]}};
-  double W[3], Vc[3][3];
-  eig3(MM, W, Vc);
+// planar-structure initial guess of cvFindExtrinsicCameraParams2 (homography from the model plane)
+__device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const float* img, const uint8_t* mask, int n, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
   bool init_ok = true;
-  if (W[2] / W[1] < 1e-3) {
     // planar structure: homography from the model plane to the normalised image
     double Rt[3][3];  // rows = principal axes (V^T)
 #pragma unroll
@@ -937,7 +839,7 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
         }
 #pragma unroll
       for (int k = 0; k < 24; ++k) q24[k] = wsum(q24[k]);
-      __syncthreads();
+      wave_sync();
       for (int idx = lane; idx < 81; idx += 64) {
         const int r = idx / 9, c = idx % 9, br = r / 3, bc = c / 3, ir = r % 3, ic = c % 3;
         const int lo = ir < ic ? ir : ic, hi = ir < ic ? ic : ir;
@@ -949,7 +851,7 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
         else if ((br == 1 && bc == 2) || (br == 2 && bc == 1)) v = -q24[12 + sidx];
         sh.A[idx] = v;
       }
-      __syncthreads();
+      wave_sync();
       sym_eig_lds(sh.A, sh.V, sh.ord, 9, lane);
       double H0[3][3];
       const int c0 = sh.ord[0];
@@ -997,7 +899,11 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
       }
     }
     if (!init_ok) { p[0] = p[1] = p[2] = p[3] = p[4] = p[5] = 0.0; init_ok = true; }
-  } else if (ninl >= 6) {
+  return init_ok;
+}
+
+// non-planar initial guess of cvFindExtrinsicCameraParams2 (12 x 12 DLT)
+__device__ __noinline__ bool pnp_init_dlt(Shared& sh, const float* obj, const float* img, const uint8_t* mask, int n, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
     // DLT: L^T L from 4 weighted sums of P P^T, P = [X Y Z 1]
     double s40[40];
 #pragma unroll
@@ -1013,7 +919,7 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
       }
 #pragma unroll
     for (int k = 0; k < 40; ++k) s40[k] = wsum(s40[k]);
-    __syncthreads();
+    wave_sync();
     for (int idx = lane; idx < 144; idx += 64) {
       const int r = idx / 12, c = idx % 12, br = r / 4, bc = c / 4, ir = r % 4, ic = c % 4;
       const int lo = ir < ic ? ir : ic, hi = ir < ic ? ic : ir;
@@ -1025,7 +931,7 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
       else if ((br == 1 && bc == 2) || (br == 2 && bc == 1)) v = s40[20 + sidx];
       sh.A[idx] = v;
     }
-    __syncthreads();
+    wave_sync();
     sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
     const int c0 = sh.ord[0];
     double RR[3][3], tt[3];
@@ -1057,6 +963,153 @@ __global__ __launch_bounds__(64) void k_pnp_ransac(PnpArgs a) {
     rn = sqrt(rn);
     rodrigues_m2v(Rq, p);
     p[3] = tt[0] * (rn / sc); p[4] = tt[1] * (rn / sc); p[5] = tt[2] * (rn / sc);
+  return true;
+}
+
+// Two launches per batch.  k_pnp_hyp: one single-wave workgroup per (pair, RANSAC hypothesis) -- the
+// RNG stream and therefore the subsets do not depend on the models, so workgroup h replays cv::RNG to its
+// own subset, runs EPnP and scores it with the full 512-register budget of a lone wave.  k_pnp_refine:
+// one wave per pair replays the sequential `good > max(maxGood, 4)` / RANSACUpdateNumIters logic over
+// the results in hypothesis order (hypotheses past the adapted iteration count are ignored, exactly as
+// the sequential loop would never have computed them) and refines the winner.
+__global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
+  __shared__ Shared sh;
+  const int b = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x;
+  const int n = a.n_pts[b];
+  const float* obj = a.obj + (size_t)b * a.kstride * 3;
+  const float* img = a.img + (size_t)b * a.kstride * 2;
+  uint8_t* mask_w = a.mask_ws + ((size_t)b * kMaxHyp + wave) * a.kstride;
+  HypResult* hyp = a.hyp + (size_t)b * kMaxHyp;
+  const Cam cam = {a.fx, a.fy, a.cx, a.cy};
+  if (n < a.min_pts || n < 5) return;
+  {
+    unsigned long long rng = 0xFFFFFFFFFFFFFFFFull;
+    int idx[5] = {0, 1, 2, 3, 4};
+    if (n > 5) {
+      for (int h = 0; h <= wave; ++h) {   // replay the stream up to this wave's subset
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          for (;;) {
+            const int v = (int)(rng_next(rng) % (unsigned)n);
+            bool dup = false;
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) if (jj < i && idx[jj] == v) dup = true;
+            if (!dup) { idx[i] = v; break; }
+          }
+        }
+      }
+    }
+    if (lane < 5) {
+      int id = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) if (i == lane) id = idx[i];
+      sh.pws[lane * 3 + 0] = obj[3 * id]; sh.pws[lane * 3 + 1] = obj[3 * id + 1]; sh.pws[lane * 3 + 2] = obj[3 * id + 2];
+      sh.us[2 * lane] = ((double)img[2 * id] - cam.cx) / cam.fx;
+      sh.us[2 * lane + 1] = ((double)img[2 * id + 1] - cam.cy) / cam.fy;
+    }
+    wave_sync();
+    double R[3][3], t[3];
+    const bool okm = epnp5(sh, lane, R, t);
+    int good = 0;
+    if (okm) {
+      const float thr = a.reproj * a.reproj;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool inl = false;
+        if (i < n) {
+          const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
+          const double X = R[0][0] * M0 + R[0][1] * M1 + R[0][2] * M2 + t[0];
+          const double Y = R[1][0] * M0 + R[1][1] * M1 + R[1][2] * M2 + t[1];
+          const double Z = R[2][0] * M0 + R[2][1] * M1 + R[2][2] * M2 + t[2];
+          const double z = Z != 0 ? 1.0 / Z : 1.0;
+          const float pu = (float)(X * z * cam.fx + cam.cx), pv = (float)(Y * z * cam.fy + cam.cy);
+          const float dx = img[2 * i] - pu, dy = img[2 * i + 1] - pv;
+          const float e = dx * dx + dy * dy;   // float32 squared reprojection error, tested <= thr
+          inl = e <= thr;
+          mask_w[i] = inl ? 1 : 0;
+        }
+        good += __popcll(__ballot(inl));
+      }
+    }
+    if (lane == 0) {
+      HypResult& hr = hyp[wave];
+      hr.good = good; hr.valid = okm ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { hr.t[i] = t[i];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) hr.R[3 * i + jj] = R[i][jj]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
+  __shared__ Shared sh;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nhyp = a.iterations;
+  const int n = a.n_pts[b];
+  const float* obj = a.obj + (size_t)b * a.kstride * 3;
+  const float* img = a.img + (size_t)b * a.kstride * 2;
+  const HypResult* hyp = a.hyp + (size_t)b * kMaxHyp;
+  double* Rout = a.R + (size_t)b * 9;
+  double* tout = a.t + (size_t)b * 3;
+  const Cam cam = {a.fx, a.fy, a.cx, a.cy};
+  if (n < a.min_pts || n < 5) {
+    if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
+    if (lane < 3) tout[lane] = 0.0;
+    if (lane == 0) { a.ok[b] = 0; a.n_inliers[b] = 0; }
+    return;
+  }
+
+  // ---- sequential selection over the hypotheses ----------------------------------------------------
+  int niters = nhyp, max_good = 0, best = -1;
+  for (int it = 0; it < nhyp; ++it) {
+    if (it >= niters) break;
+    if (!hyp[it].valid) continue;
+    const int good = hyp[it].good;
+    if (good > (max_good > 4 ? max_good : 4)) {
+      best = it; max_good = good;
+      niters = ransac_update_iters(a.confidence, (double)(n - good) / n, 5, niters);
+    }
+  }
+  if (best < 0) {
+    if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
+    if (lane < 3) tout[lane] = 0.0;
+    if (lane == 0) { a.ok[b] = 0; a.n_inliers[b] = 0; }
+    return;
+  }
+  double bestR[3][3], bestT[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { bestT[i] = hyp[best].t[i];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) bestR[i][jj] = hyp[best].R[3 * i + jj]; }
+  const uint8_t* mask_best = a.mask_ws + ((size_t)b * kMaxHyp + best) * a.kstride;
+
+  // ---- solvePnP(SOLVEPNP_ITERATIVE) on the inliers ---------------------------------------------
+  const uint8_t* mask = mask_best;
+  const int ninl = max_good;
+  double p[6];
+  // PCA of the inlier object points
+  double mc[3] = {0, 0, 0};
+  for (int i = lane; i < n; i += 64)
+    if (mask[i]) { mc[0] += obj[3 * i]; mc[1] += obj[3 * i + 1]; mc[2] += obj[3 * i + 2]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mc[k] = wsum(mc[k]) / ninl;
+  double mm[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < n; i += 64)
+    if (mask[i]) {
+      const double d0 = obj[3 * i] - mc[0], d1 = obj[3 * i + 1] - mc[1], d2 = obj[3 * i + 2] - mc[2];
+      mm[0] += d0 * d0; mm[1] += d0 * d1; mm[2] += d0 * d2; mm[3] += d1 * d1; mm[4] += d1 * d2; mm[5] += d2 * d2;
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mm[k] = wsum(mm[k]);
+  double MM[3][3] = {{mm[0], mm[1], mm[2]}, {mm[1], mm[3], mm[4]}, {mm[2], mm[4], mm[5]}};
+  double W[3], Vc[3][3];
+  eig3(MM, W, Vc);
+  bool init_ok = true;
+  if (W[2] / W[1] < 1e-3) {
+    init_ok = pnp_init_planar(sh, obj, img, mask, n, ninl, lane, cam, mc, Vc, p);
+  } else if (ninl >= 6) {
+    init_ok = pnp_init_dlt(sh, obj, img, mask, n, ninl, lane, cam, mc, Vc, p);
   } else {
     init_ok = false;  // < 6 non-planar inliers: OpenCV >= 4.5 falls back to the RANSAC model
   }
@@ -1115,7 +1168,9 @@ void launch_epnp_debug(const double* pws, const double* us, double* out, int n, 
 }
 
 void launch_pnp(const PnpArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_pnp_ransac, dim3(a.B), dim3(64), 0, s, a);
+  const int nh = a.iterations < 1 ? 1 : (a.iterations > kMaxHyp ? kMaxHyp : a.iterations);
+  hipLaunchKernelGGL(k_pnp_hyp, dim3(nh, a.B), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_pnp_refine, dim3(a.B), dim3(64), 0, s, a);
 }
 
 }  // namespace gn

@@ -6,11 +6,9 @@ Stated tolerances:
   * correspondence indices: bit-exact (f32 mode, and bf16-attention mode on the seeded fixtures);
   * match scores: |d| <= 1e-5;  residual stream per layer: max rel 2e-5 (f32), 3e-2 (bf16 attention);
   * EPnP minimal solver, per RANSAC hypothesis: ||dR||_F, ||dt|| <= 1e-8 (measured ~1e-12);
-  * pose (R, t) on non-planar scenes: RANSAC inlier COUNT identical, ||dR||_F <= 1e-8 and
-    ||dt||/||t|| <= 1e-8 (measured ~1e-16: both sides run the LM refinement to the same fixed point);
-  * planar scenes (flat DEM): <= 2e-3 -- EPnP with 4 control points is degenerate on coplanar points
-    (the null space of M^T M has dimension >= 5), so hypotheses are implementation-defined there, in
-    OpenCV as well; only the refined pose is comparable, and only when the inlier sets happen to agree.
+  * pose (R, t), planar (flat DEM) and non-planar scenes alike: RANSAC inlier COUNT identical,
+    ||dR||_F <= 1e-8 and ||dt||/||t|| <= 1e-8 (measured 1e-13..1e-16: both sides run the LM refinement
+    to the same fixed point).
 """
 import os
 
@@ -232,8 +230,7 @@ def test_seam_b2_compute_pose_on_golden_fixture(name, dev):
     assert R.shape == (3, 3) and t.shape == (3, 1) and R.dtype == np.float64 and t.dtype == np.float64
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
     assert np.linalg.norm(R - g["R_gt"]) < 3e-3 and np.linalg.norm(t - g["t_gt"]) / np.linalg.norm(g["t_gt"]) < 3e-3
-    tol = 2e-3 if name.endswith("flat") else 1e-8
-    assert np.linalg.norm(R - g["R"]) < tol and np.linalg.norm(t - g["tvec"]) / np.linalg.norm(g["tvec"]) < tol
+    assert np.linalg.norm(R - g["R"]) < 1e-8 and np.linalg.norm(t - g["tvec"]) / np.linalg.norm(g["tvec"]) < 1e-8
     assert compute_pose(CameraInfo(k=g["K"].reshape(-1)), g["img"][:3], g["mkp_r"][:3], g["dem"]) is None
 
 
@@ -281,11 +278,8 @@ def test_pnp_inlier_count_and_pose_against_oracle(dev, eng256):
         dR = np.linalg.norm(R[0].cpu().numpy() - pr.rodrigues_vec2mat(r))
         dt = np.linalg.norm(tg[0].cpu().numpy() - t) / np.linalg.norm(t)
         assert np.linalg.norm(R[0].cpu().numpy() - p.R_gt) < 5e-3
-        if flat:
-            assert dR < 2e-3 and dt < 2e-3, (seed, dR, dt)
-        else:
-            assert int(ninl[0]) == len(inl), (seed, int(ninl[0]), len(inl))
-            assert dR < 1e-8 and dt < 1e-8, (seed, dR, dt)
+        assert int(ninl[0]) == len(inl), (seed, flat, int(ninl[0]), len(inl))
+        assert dR < 1e-8 and dt < 1e-8, (seed, flat, dR, dt)
 
 
 def test_seam_b3_pose_node_shim_from_wire_bytes(state_dict_np, state_dict_t, dev):

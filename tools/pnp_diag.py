@@ -31,7 +31,8 @@ def main():
     dev = torch.device("cuda", 0)
     eng = PoseEngine(0, max_batch=1, max_kpts=1024)
     for pi in [int(a) for a in sys.argv[1:]] or [12, 13]:
-        p = make_pair(pi)
+        flat = pi >= 1000
+        p = make_pair(pi % 1000, flat_dem=flat)
         q = np.nonzero(p.gt_q2r >= 0)[0]
         mq, mr = p.kp_q[q], p.kp_r[p.gt_q2r[q]]
         x, y = np.floor(mr).astype(int).T
@@ -56,6 +57,10 @@ def main():
                 niters = pr.ransac_update_num_iters(0.99, (len(obj) - g) / len(obj), 5, niters)
             ol.append(best)
         print("   oracle best-so-far               :", ol)
+        R, t, ninl, ok = eng.pnp_ransac(to, tg, n, K_MATRIX, iterations=10)
+        oko, ro, t_o, inl = pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)
+        print("   final: gpu |R-Rgt|", float(np.linalg.norm(R[0].cpu().numpy() - p.R_gt)), "oracle |R-Rgt|",
+              float(np.linalg.norm(pr.rodrigues_vec2mat(ro) - p.R_gt)), "gpu ninl", int(ninl[0]), "oracle ninl", len(inl))
 
 
 if __name__ == "__main__":
