@@ -33,6 +33,7 @@ from gisnav_amd.synthetic import K_MATRIX, make_pair  # noqa: E402
 from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (the 2:1-sparsity figure is never used)
 GEMM_LAUNCHES_PER_STEP = 1 + 9 * 8 + 2  # input_proj + 9 x (4 proj + 2 x 2 ffn) + final_proj + sim
 
 
@@ -73,10 +74,10 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
                       f"cpu={platform.processor() or platform.machine()}"}
 
 
-def measured_gemm_traffic():
+def measured_gemm_traffic(x3: bool):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (bench.py cannot run under
     the profiler itself); None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_f32x3.json" if x3 else "r01_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -92,7 +93,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16_attn", choices=["f32", "bf16_attn"])
+    ap.add_argument("--precision", default="f32x3_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
@@ -146,7 +147,9 @@ def main() -> None:
         total_pairs = args.batch * world * args.steps
         pairs_per_s = total_pairs / elapsed
         ach = kstats["flops"] / (kstats["ms"] * 1e-3) / 1e12 if kstats["ms"] > 0 else 0.0
-        traffic, traffic_src = measured_gemm_traffic() if (args.batch == 32 and args.kpts == 1024) else (None, None)
+        x3 = args.precision == "f32x3_bf16_attn"
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = measured_gemm_traffic(x3) if (args.batch == 32 and args.kpts == 1024) else (None, None)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
             "value": round(pairs_per_s, 2),
@@ -158,7 +161,10 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 projections/FFN/match-head + bf16 MFMA attention (f32 accumulate)",
+            "dtype": {"f32": "f32",
+                      "bf16_attn": "f32 projections/FFN/match-head + bf16 MFMA attention (f32 accumulate)",
+                      "f32x3_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split exactly into 3 bf16 terms, "
+                                         "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[2]/[3]: batch-{args.batch} 640x480 pairs per GPU, {args.kpts} SIFT kpts/side, "
@@ -175,12 +181,17 @@ def main() -> None:
             "mean_matches_per_pair": round(n_match_mean, 1),
             "result_records_gathered": int(rec.shape[0]),
             "roofline": {
-                "kernel": "k_gemm_f32 (f32 MFMA 32x32x2 projection/FFN/similarity GEMM)",
+                "kernel": ("k_gemm_f32x3 (projection/FFN/similarity GEMM: 3 x bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)"
+                           if x3 else "k_gemm_f32_v3 (projection/FFN/similarity GEMM on v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": round(ach, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": round(peak, 1),
                 "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac": round(ach / peak, 4),
+                "note": ("achieved = algorithmic 2*M*N*K flops / HIP-event time; the kernel issues 6 bf16 MFMA flops per algorithmic "
+                         "flop, so peak = 2500 TF bf16 dense / 6 and frac is the fraction of the bf16 matrix-pipe roofline actually used"
+                         if x3 else "achieved = algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak"),
+                "executed_mfma_tflops": round(ach * (6 if x3 else 1), 1),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "launches_timed": int(kstats["launches"]),

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gn_debug_set_variant": (C.c_int, [VP, C.c_int, C.c_int]),
     "gn_debug_mfma_probe": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "gn_debug_epnp": (C.c_int, [VP, C.c_int, VP, VP, VP, VP]),
+    "gn_debug_lds_dma_probe": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
     "gn_set_kernel_timing": (C.c_int, [VP, C.c_int]),
     "gn_get_kernel_stats": (C.c_int, [VP, c_f64p]),
 }
@@ -52,6 +53,7 @@ STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")
 
 GN_PREC_F32 = 0
 GN_PREC_BF16_ATTN = 1
+GN_PREC_F32X3_BF16_ATTN = 2
 GN_KPT_LAF = 0
 GN_KPT_XYSA = 1
 

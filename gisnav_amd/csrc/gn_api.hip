@@ -13,7 +13,7 @@ namespace {
 
 thread_local std::string g_err;
 
-struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; };  // wp: [3][out][in] bf16 planes
 
 struct Block {       // one SelfBlock or CrossBlock
   Linear proj_in;    // self: Wqkv re-ordered to [q|k|v][head][d] (768x256); cross: [to_qk ; to_v] (512x256)
@@ -46,6 +46,12 @@ struct gn_ctx {
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
   int attn_variant = 1;
+  int stop_after = 0;      // developer knob: return from run_matcher after this many GEMM/attention launches
+  int launch_count = 0;
+  int no_planes = 0;       // developer knob: ignore the pre-split weight planes (f32x3 splits B on the fly)
+  int dbg_planes = 0;      // gn_debug_gemm: pre-split W into bf16 planes first (exercises the WP path)
+  uint16_t* dbg_wp = nullptr; size_t dbg_wp_n = 0;
+  int gemm_variant = -1;   // -1: library default (f32 MFMA, LDS-DMA); 5: f32x3 (GN_PREC_F32X3_BF16_ATTN)
   float *rowmax = nullptr, *rowlog = nullptr, *colmax = nullptr, *collog = nullptr, *max0 = nullptr;
   int32_t *m0 = nullptr, *m1 = nullptr;
   // pipeline scratch for gn_estimate
@@ -117,7 +123,12 @@ struct StageTimer {
   }
 };
 
-void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g, int batch, hipStream_t s) {
+void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t s) {
+  if (c->gemm_variant >= 0) gn::g_gemm_variant = c->gemm_variant;
+  GemmArgs g = g_in;
+  if (c->no_planes) g.Wp = nullptr;
+  ++c->launch_count;
+  if (c->stop_after && c->launch_count > c->stop_after) return;
   const bool rec = c->ktiming && c->kused < c->kflops.size();
   if (rec) hipEventRecord(c->kev[2 * c->kused], s);
   launch_gemm_f32(epi, g, batch, s);
@@ -133,16 +144,27 @@ void gemm(gn_ctx* c, int epi, GemmArgs& g, hipStream_t s) {
   timed_gemm(c, epi, g, 1, s);
 }
 
+// (re)build the three bf16 planes of a weight matrix (w = wh + wm + wl exactly) for the f32x3 GEMM
+int build_planes(gn_ctx* ctx, Linear& L) {
+  if (!L.w || L.out <= 0 || L.in <= 0) return GN_OK;
+  const size_t n = (size_t)L.out * L.in;
+  if (!L.wp) { int rc = dalloc(ctx, &L.wp, 3 * n); if (rc != GN_OK) return rc; }
+  launch_split3_bf16(L.w, L.wp, (long long)n, 0);
+  GN_HIP(hipStreamSynchronize(0));
+  return GN_OK;
+}
+
 GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, int M) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.Wp = L.wp; g.wp_plane = (long long)L.out * L.in;
   g.A = A; g.lda = lda; g.A2 = nullptr; g.lda2 = 0; g.K1 = L.in;
   g.W = L.w; g.ldw = L.in; g.bias = L.b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = L.out; g.K = L.in;
   return g;
 }
 
 void attention(gn_ctx* c, const AttnArgs& a, hipStream_t s) {
-  if (c->precision == GN_PREC_BF16_ATTN) launch_attention_bf16(a, s); else launch_attention_f32(a, s);
+  if (c->precision != GN_PREC_F32) launch_attention_bf16(a, s); else launch_attention_f32(a, s);
 }
 
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
@@ -161,7 +183,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
                 const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                 int64_t* idx, float* score, int32_t* n_match, hipStream_t s) {
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
-  const bool bf16v2 = c->precision == GN_PREC_BF16_ATTN && c->attn_variant == 1;
+  const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant == 1;
+  c->launch_count = 0;
   {
     StageTimer tm(c, s, ST_PREP);
     PrepArgs p;
@@ -193,7 +216,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
         a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
-        if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s);
+        ++c->launch_count;
+        if (!(c->stop_after && c->launch_count > c->stop_after)) { if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s); }
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -222,7 +246,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
         a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
-        if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s);
+        ++c->launch_count;
+        if (!(c->stop_after && c->launch_count > c->stop_after)) { if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s); }
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -275,7 +300,8 @@ const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out) {
   gn_ctx* ctx = nullptr;
   if (!out || max_batch < 1 || max_kpts < 2) return fail(nullptr, GN_ERR_ARG, "bad gn_create argument");
-  if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN) return fail(nullptr, GN_ERR_ARG, "bad precision");
+  if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN && precision != GN_PREC_F32X3_BF16_ATTN)
+    return fail(nullptr, GN_ERR_ARG, "bad precision");
   GN_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   GN_HIP(hipGetDeviceProperties(&prop, device));
@@ -283,6 +309,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
     return fail(nullptr, GN_ERR_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   ctx = new gn_ctx();
   ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision;
+  ctx->gemm_variant = precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   ctx->npad = ((max_kpts + 127) / 128) * 128;
   const size_t np = ctx->npad, T = (size_t)max_batch * 2 * np, B = max_batch;
 #define GN_ALLOC(field, count)                                     \
@@ -292,7 +319,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
   GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
   GN_ALLOC(sim, B * np * np);
-  if (precision == GN_PREC_BF16_ATTN) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
+  if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
@@ -380,6 +407,8 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
       if (ndim != 2 || d0 != out || d1 != in) return shape_err();
       if (!L.w) { int rc = dalloc(ctx, &L.w, (size_t)rows_total * in); if (rc != GN_OK) return rc; }
       GN_HIP(hipMemcpy(L.w + (size_t)row_off * in, host, (size_t)out * in * sizeof(float), hipMemcpyHostToDevice));
+      L.out = rows_total; L.in = in;
+      { int rcp = build_planes(ctx, L); if (rcp != GN_OK) return rcp; }
     } else {
       if (d0 != out || d1 != 1) return shape_err();
       if (!L.b) { int rc = dalloc(ctx, &L.b, (size_t)rows_total); if (rc != GN_OK) return rc; }
@@ -421,6 +450,7 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
       Linear& L = blk.proj_in;
       if (is_w) { rc = upload(&L.w, tmp.data(), tmp.size()); } else { rc = upload(&L.b, tmp.data(), tmp.size()); }
       L.out = 3 * kDim; L.in = kDim;
+      if (is_w && rc == GN_OK) rc = build_planes(ctx, L);
     } else if (self && leaf == "out_proj") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
     else if (cross && leaf == "to_qk") rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim);
     else if (cross && leaf == "to_v") rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim);
@@ -529,7 +559,8 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
       {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
-      {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)}};
+      {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)},
+      {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
   for (const Ent& e : tab)
     if (strcmp(e.n, name) == 0) {
       size_t count = e.count;
@@ -555,6 +586,12 @@ int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float*
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = K; g.K1 = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = K;
+  if (ctx->dbg_planes) {
+    const size_t n = (size_t)N * K;
+    if (ctx->dbg_wp_n < n) { ctx->dbg_wp = nullptr; int rc = dalloc(ctx, &ctx->dbg_wp, 3 * n); if (rc != GN_OK) return rc; ctx->dbg_wp_n = n; }
+    launch_split3_bf16(W, ctx->dbg_wp, (long long)n, (hipStream_t)stream);
+    g.Wp = ctx->dbg_wp; g.wp_plane = (long long)n;
+  }
   launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
   return GN_OK;
@@ -576,8 +613,11 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
 
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
-  if (which == 0) gn::g_gemm_variant = value;
+  if (which == 0) { gn::g_gemm_variant = value; ctx->gemm_variant = value; }
   else if (which == 1) ctx->attn_variant = value;
+  else if (which == 2) ctx->dbg_planes = value;
+  else if (which == 3) ctx->no_planes = value;
+  else if (which == 4) ctx->stop_after = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }
@@ -586,6 +626,14 @@ int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, doubl
   if (!ctx || n < 1 || !pws || !us || !out) return GN_ERR_ARG;
   GN_HIP(hipSetDevice(ctx->device));
   launch_epnp_debug(pws, us, out, n, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_debug_lds_dma_probe(gn_ctx* ctx, const float* pattern, unsigned int* out, int blocks, int spin, void* stream) {
+  if (!ctx || !pattern || !out || blocks < 1) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  launch_lds_dma_probe(pattern, out, blocks, spin, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
   return GN_OK;
 }

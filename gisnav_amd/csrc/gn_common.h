@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* A2;   int lda2;     // optional second source for k >= K1 (concat), else nullptr
   int K1;
   const float* W;    int ldw;      // W[N][K]
+  const uint16_t* Wp; long long wp_plane;  // optional pre-split weights: three bf16 planes [3][N][K], plane stride in elements
   const float* bias;               // [N] or nullptr
   float* Y;          int ldy;      // Y[M][N]
   int M, N, K;
@@ -45,6 +46,7 @@ struct GemmArgs {
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
+void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s);
 extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking
 
 // ---- attention --------------------------------------------------------------------------------
@@ -116,5 +118,6 @@ void launch_epnp_debug(const double* pws, const double* us, double* out, int n, 
 
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
+void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]
 
 }  // namespace gn

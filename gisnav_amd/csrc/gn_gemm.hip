@@ -264,11 +264,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v1(GemmArgs a) {
   const bool do_scale = (EPI == EPI_SCALE_COLS) && (col < a.scale_cols);
   const bool do_rot = (EPI == EPI_ROTARY) && (col < a.rot_cols);
   const int f0 = (col & 63) >> 1;
-#pragma unroll 4
+  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
+  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
+  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
+  // of a 16-lane group replaced by the next row's raw accumulator).
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int lr_ = it * 4 + (lane >> 4);
     const int row = bm + wr * 64 + lr_;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lr_ * ES + c4]);
+    f32x4 v = vals[it];
     v += bias4;
     if (EPI == EPI_SCALE_COLS) {
       if (do_scale) v *= a.scale;
@@ -487,11 +494,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
   const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
   const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
   const int f0 = (col & 63) >> 1;
-#pragma unroll 4
+  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
+  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
+  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
+  // of a 16-lane group replaced by the next row's raw accumulator).
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int lr_ = it * 4 + (lane >> 4);
     const int row = bm + wr * 64 + lr_;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lr_ * ES + c4]);
+    f32x4 v = vals[it];
     v += bias4;
     if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
       if (do_scale) v *= a.scale;
@@ -531,6 +545,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
 // Schedule per k-tile: issue the DMA of tile t+1 into the idle buffer, chunks 0-2 with register
 // double-buffered fragments, barrier (its release drains the DMA: tile t+1 has landed), fetch the
 // first fragments of tile t+1, chunk 3.
+#ifndef GN_V3_LDS_PAD
+#define GN_V3_LDS_PAD 0
+#endif
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -538,7 +555,7 @@ template <int EPI, bool PIN = true>
 __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
   constexpr int TILE = (BM + BN) * BK;                 // floats per buffer (unpadded rows of 32 floats)
   constexpr int SLAB = 4 * 64 * ES;
-  __shared__ __attribute__((aligned(16))) float smem[(2 * TILE > SLAB) ? 2 * TILE : SLAB];
+  __shared__ __attribute__((aligned(16))) float smem[((2 * TILE > SLAB) ? 2 * TILE : SLAB) + GN_V3_LDS_PAD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -712,11 +729,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
   const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
   const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
   const int f0 = (col & 63) >> 1;
-#pragma unroll 4
+  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
+  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
+  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
+  // of a 16-lane group replaced by the next row's raw accumulator).
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int lr_ = it * 4 + (lane >> 4);
     const int row = bm + wr * 64 + lr_;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lr_ * ES + c4]);
+    f32x4 v = vals[it];
     v += bias4;
     if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
       if (do_scale) v *= a.scale;
@@ -742,6 +766,305 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
       *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
     } else {
       *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32x3: f32-accurate GEMM on the bf16 matrix pipe.  Every f32 operand is split exactly into three
+// bf16 terms (x = xh + xm + xl, 8 + 8 + 8 mantissa bits) while its fragment sits in registers, and each
+// 32x32x16 block is accumulated from the six products whose magnitude exceeds 2^-24 of the leading one
+// (hh, hm, mh, hl, lh, mm) in f32.  Measured error vs fp64 is at or below that of the exact-f32 MFMA path
+// (tests/test_gpu_parity.py) at 6 x 32 = 192 matrix-pipe cycles per 32x32x16 instead of 8 x 64 = 512.
+// Tiles travel exactly as in variant 3 (f32 in HBM/LDS, LDS-DMA, XOR swizzle); the split is VALU work
+// that overlaps the MFMAs of the previous k-step.
+#ifndef GN_X3_LDS_PAD
+#define GN_X3_LDS_PAD 0
+#endif
+// Exact 3-way split by TRUNCATION, integer ops only (no dependence on the SLP vectoriser): hi = top 16 bits
+// of x, r = x - hi (exact), mid = top 16 bits of r, lo = top 16 bits of r - mid.  x has 24 significant bits,
+// hi keeps 8, r at most 16, mid 8 of those, so lo (<= 8 bits) is exact too: x == hi + mid + lo.
+// v_perm_b32 packs the upper halves of two dwords into one bf16 pair.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned int& h, unsigned int& m, unsigned int& l) {
+  const unsigned int u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+  const unsigned int v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& m, bf16x8& l) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  unsigned int h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+  split2(a.x, a.y, h0, m0, l0);
+  split2(a.z, a.w, h1, m1, l1);
+  split2(b.x, b.y, h2, m2, l2);
+  split2(b.z, b.w, h3, m3, l3);
+  const u32x4 hv = {h0, h1, h2, h3}, mv = {m0, m1, m2, m3}, lv = {l0, l1, l2, l3};
+  h = __builtin_bit_cast(bf16x8, hv); m = __builtin_bit_cast(bf16x8, mv); l = __builtin_bit_cast(bf16x8, lv);
+}
+
+// WP = true: the B operand (weights) arrives PRE-SPLIT as three bf16 planes [3][N][K] (made once at load time),
+// so only the A fragments are split in registers.  B plane tiles are [plane][128 rows][32 k] bf16 (64-byte
+// rows); 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3), which makes every ds_read_b128 lane
+// group hit 16 distinct bank slots.
+template <int EPI, bool WP>
+__global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
+  constexpr int TILE = WP ? (BM * BK + 3 * BN * BK / 2) : (BM + BN) * BK;  // floats per buffer: f32 A tile + (f32 | 3 bf16-plane) B tile
+  constexpr int SLAB = 4 * 64 * ES;
+  __shared__ __attribute__((aligned(16))) float smem[((2 * TILE > SLAB) ? 2 * TILE : SLAB) + GN_X3_LDS_PAD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int bx, by;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * BM, bn = bx * BN;
+  const float* A = a.A + (long long)blockIdx.z * a.strideA;
+  const float* W = a.W + (long long)blockIdx.z * a.strideW;
+  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
+  const float* const A2 = a.A2;
+  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
+
+  // DMA source addressing: wave w stages tile rows [32w, 32w + 32) of A and of B, 8 rows per instruction.
+  // lane -> (row offset lane >> 3, chunk position lane & 7) fetches source chunk pos ^ f(row).
+  const int drow = wave * 32 + (lane >> 3);            // + 8 * j
+  const int dpos = lane & 7;
+  // f(row) for row = drow + 8j: (row ^ (row >> 3)) & 7; row >> 3 = 4 * wave + j
+  const float* asrc[4]; const float* a2src[4]; const float* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = drow + 8 * j;
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    asrc[j] = A + (size_t)(bm + row) * lda + c * 4;
+    a2src[j] = A2 ? A2 + (size_t)(bm + row) * lda2 + c * 4 - K1 : nullptr;
+    wsrc[j] = W + (size_t)(bn + row) * ldw + c * 4;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // pre-split weight planes: piece = 16 rows x 64 B; lane -> (row lane >> 2, position lane & 3) fetches chunk pos ^ g(row)
+  const unsigned short* wpsrc[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int piece = wave_u * 6 + q, plane = piece >> 3, row = (piece & 7) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    wpsrc[q] = WP ? a.Wp + (size_t)plane * a.wp_plane + (size_t)(bn + row) * ldw + c * 8 : nullptr;
+  }
+#define GN_DMA_TILE(buf, k0)                                                                      \
+  {                                                                                               \
+    const bool second = (A2 != nullptr) && ((k0) >= K1);                                          \
+    float* la_ = smem + (buf) * TILE + (wave_u * 32) * BK;                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+      const float* ga_ = (second ? a2src[j] : asrc[j]) + (k0);                                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(la_ + j * 8 * BK), 16, 0, 0);       \
+    }                                                                                             \
+    if (WP) {                                                                                     \
+      unsigned short* lb_ = reinterpret_cast<unsigned short*>(smem + (buf) * TILE + BM * BK);    \
+      _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                             \
+        const int piece = wave_u * 6 + q;                    /* 24 pieces: plane = piece / 8 */   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wpsrc[q] + (k0)), (lptr_t)(lb_ + piece * 512), 16, 0, 0); \
+      }                                                                                           \
+    } else {                                                                                      \
+      float* lb_ = smem + (buf) * TILE + BM * BK + (wave_u * 32) * BK;                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (k0)), (lptr_t)(lb_ + j * 8 * BK), 16, 0, 0); \
+    }                                                                                             \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addressing (floats): row * 32 + 4 * (chunk ^ f(row)), chunk = 2 kc + hh
+  const int hh = lane >> 5;
+  int arow_[2], brow_[2], ga_[2], gb_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra_ = wr * 64 + 32 * i + (lane & 31), rb_ = wc * 64 + 32 * i + (lane & 31);
+    arow_[i] = ra_ * BK; brow_[i] = BM * BK + rb_ * BK;
+    ga_[i] = hh ^ ((ra_ ^ (ra_ >> 3)) & 7); gb_[i] = hh ^ ((rb_ ^ (rb_ >> 3)) & 7);
+  }
+  const int nt = K / BK;
+
+// raw f32 fragments of k-step s (16 k values): lane (row, hh) holds k = 16 s + 8 hh + 0..7 = two 16-byte chunks
+#define GN_RAW_READ(ra_, rb_, buf, s_)                                                            \
+  {                                                                                               \
+    const float* b_ = smem + (buf) * TILE;                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+      ra_[i][0] = *reinterpret_cast<const f32x4*>(b_ + arow_[i] + 4 * ((4 * (s_) + 0) ^ ga2_[i])); \
+      ra_[i][1] = *reinterpret_cast<const f32x4*>(b_ + arow_[i] + 4 * ((4 * (s_) + 1) ^ ga2_[i])); \
+      if (!WP) {                                                                                  \
+        rb_[i][0] = *reinterpret_cast<const f32x4*>(b_ + brow_[i] + 4 * ((4 * (s_) + 0) ^ gb2_[i])); \
+        rb_[i][1] = *reinterpret_cast<const f32x4*>(b_ + brow_[i] + 4 * ((4 * (s_) + 1) ^ gb2_[i])); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#define GN_SPLIT(ra_, rb_, A_, B_)                                                                \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+      split8(ra_[i][0], ra_[i][1], A_[i][0], A_[i][1], A_[i][2]);                                 \
+      if (!WP) split8(rb_[i][0], rb_[i][1], B_[i][0], B_[i][1], B_[i][2]);                        \
+    }                                                                                             \
+  }
+// pre-split B fragments straight from the plane tiles (no VALU): lane (col, hh), k-step s -> chunk 2 s + hh
+#define GN_BPLANE_READ(B_, buf, s_)                                                               \
+  {                                                                                               \
+    const unsigned short* pb_ = reinterpret_cast<const unsigned short*>(smem + (buf) * TILE + BM * BK); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                            \
+        B_[i][pl] = *reinterpret_cast<const bf16x8*>(pb_ + pl * (BN * BK) + bprow_[i] + 8 * ((2 * (s_)) ^ gbp_[i])); \
+  }
+// x y = (xh + xm + xl)(yh + ym + yl) ~ xh yh + xh ym + xm yh + xh yl + xl yh + xm ym, smallest terms first
+// x y = (xh + xm + xl)(yh + ym + yl) ~ xh yh + xh ym + xm yh + xh yl + xl yh + xm ym (smallest terms first).
+// The four accumulators are visited round-robin inside every product so that consecutive MFMAs are independent.
+#define GN_MFMA_P(pa, pb, A_, B_)                                                                  \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0][pa], B_[0][pb], acc[0][0], 0, 0, 0);  \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0][pa], B_[1][pb], acc[0][1], 0, 0, 0);  \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1][pa], B_[0][pb], acc[1][0], 0, 0, 0);  \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1][pa], B_[1][pb], acc[1][1], 0, 0, 0);
+#define GN_MFMA24(A_, B_) { GN_MFMA_P(1, 1, A_, B_) GN_MFMA_P(2, 0, A_, B_) GN_MFMA_P(0, 2, A_, B_) GN_MFMA_P(1, 0, A_, B_) GN_MFMA_P(0, 1, A_, B_) GN_MFMA_P(0, 0, A_, B_) }
+
+  // chunk index for k-step s and half hh is 4 s + 2 hh + {0, 1}: fold hh and f(row) into one xor mask
+  int ga2_[2], gb2_[2], bprow_[2], gbp_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ga2_[i] = (2 * hh) ^ (ga_[i] ^ hh); gb2_[i] = (2 * hh) ^ (gb_[i] ^ hh);
+    const int rb_ = wc * 64 + 32 * i + (lane & 31);
+    bprow_[i] = rb_ * BK;                       // halves: 32 bf16 per row
+    gbp_[i] = hh ^ ((rb_ >> 2) & 3);            // chunk 2 s + hh at position (2 s) ^ hh ^ g(row)
+  }
+
+  GN_DMA_TILE(0, 0);
+  __syncthreads();
+  f32x4 rawa[2][2], rawb[2][2];
+  bf16x8 A0[2][3], B0[2][3], A1[2][3], B1[2][3];
+  GN_RAW_READ(rawa, rawb, 0, 0);
+  if (WP) GN_BPLANE_READ(B0, 0, 0);
+  GN_SPLIT(rawa, rawb, A0, B0);
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) GN_DMA_TILE(cur ^ 1, (t + 1) * BK);
+    GN_RAW_READ(rawa, rawb, cur, 1);
+    if (WP) GN_BPLANE_READ(B1, cur, 1);
+    GN_MFMA24(A0, B0)
+    GN_SPLIT(rawa, rawb, A1, B1);
+    __syncthreads();
+    if (t + 1 < nt) {
+      GN_RAW_READ(rawa, rawb, cur ^ 1, 0);
+      if (WP) GN_BPLANE_READ(B0, cur ^ 1, 0);
+    }
+    GN_MFMA24(A1, B1)
+    if (t + 1 < nt) GN_SPLIT(rawa, rawb, A0, B0);
+  }
+#undef GN_DMA_TILE
+#undef GN_RAW_READ
+#undef GN_SPLIT
+#undef GN_BPLANE_READ
+#undef GN_MFMA_P
+#undef GN_MFMA24
+
+  float* slab = smem + wave * 64 * ES;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[row * ES + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
+  const int colbase = bn + wc * 64;
+  if (kBf16Out && colbase >= a.vt_start) {
+    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad].
+    // lane = feature d; 8 consecutive tokens are packed into one 16-byte store.
+    const int head = (colbase - a.vt_start) >> 6;
+    const int row0 = bm + wr * 64;
+    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
+    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
+    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
+        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
+  const int c4 = (lane & 15) * 4;
+  const int col = bn + wc * 64 + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
+  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
+  const int f0 = (col & 63) >> 1;
+  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
+  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
+  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
+  // of a 16-lane group replaced by the next row's raw accumulator).
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int lr_ = it * 4 + (lane >> 4);
+    const int row = bm + wr * 64 + lr_;
+    f32x4 v = vals[it];
+    v += bias4;
+    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
+      if (do_rot) {
+        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+    }
+    if (kBf16Out) {
+      if (col < a.q_cols) v *= a.qscale;
+      uint2 pk;
+      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
+      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
+    } else {
+      vals[it] = v;
+    }
+  }
+  // stores go last, from registers nothing writes any more
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = bm + wr * 64 + it * 4 + (lane >> 4);
+    if (kBf16Out) {
+      uint2 pk; pk.x = __float_as_uint(vals[it].x); pk.y = __float_as_uint(vals[it].y);
+      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
+    } else {
+      *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = vals[it];
     }
   }
 }
@@ -783,6 +1106,36 @@ __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
   if (s == 123.456f) out[0] = s;
 }
 
+// LDS-DMA addressing probe: every block fills 80 KB of LDS with 1 KB DMA pieces from a pattern buffer and
+// verifies each piece with plain ds_reads; mismatching words are counted per piece in out[0..79], and
+// out[80] counts blocks that ran.  spin > 0 keeps blocks resident longer so two blocks share a CU.
+__global__ __launch_bounds__(256) void k_lds_dma_probe(const float* pattern, unsigned int* out, int spin) {
+  __shared__ __attribute__((aligned(16))) float smem[20480];   // 80 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int rep = 0; rep < (spin > 0 ? spin : 1); ++rep) {
+    for (int q = 0; q < 20; ++q) {
+      const int piece = wave * 20 + q;                       // 80 pieces of 1 KB
+      const float* src = pattern + ((size_t)(blockIdx.x & 7) * 80 + piece) * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + piece * 256), 16, 0, 0);
+    }
+    __syncthreads();
+    for (int piece = 0; piece < 80; ++piece) {
+      const float got = smem[piece * 256 + tid];
+      const float want = pattern[((size_t)(blockIdx.x & 7) * 80 + piece) * 256 + tid];
+      if (got != want) atomicAdd(&out[piece], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 20480; i += 256) smem[i] = -1.0f;   // poison before the next repetition
+    __syncthreads();
+  }
+  if (tid == 0) atomicAdd(&out[80], 1u);
+}
+
+void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s) {
+  hipLaunchKernelGGL(k_lds_dma_probe, dim3(blocks), dim3(256), 0, s, pattern, out, spin);
+}
+
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
   hipLaunchKernelGGL(k_mfma_probe, dim3(blocks), dim3(256), 0, s, out, iters);
 }
@@ -801,6 +1154,22 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   }
   if (g_gemm_variant == 4 && epi == EPI_BIAS) {
     hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);
+    return;
+  }
+  if (g_gemm_variant == 5) {
+#define GN_X3(E)                                                                                   \
+  if (a.Wp) hipLaunchKernelGGL((k_gemm_f32x3<E, true>), grid, block, 0, s, a);                     \
+  else hipLaunchKernelGGL((k_gemm_f32x3<E, false>), grid, block, 0, s, a);
+    switch (epi) {
+      case EPI_BIAS: GN_X3(EPI_BIAS) break;
+      case EPI_SCALE_COLS: GN_X3(EPI_SCALE_COLS) break;
+      case EPI_ROTARY: GN_X3(EPI_ROTARY) break;
+      case EPI_RESIDUAL: GN_X3(EPI_RESIDUAL) break;
+      case EPI_ROTARY_BF16: GN_X3(EPI_ROTARY_BF16) break;
+      case EPI_SCALE_BF16: GN_X3(EPI_SCALE_BF16) break;
+      default: GN_X3(EPI_PLAIN) break;
+    }
+#undef GN_X3
     return;
   }
   if (g_gemm_variant == 3) {

@@ -156,7 +156,26 @@ __global__ void k_cast_bf16(const float* in, uint16_t* out, long long n) {
     out[i] = (uint16_t)(u >> 16);
   }
 }
+// x = h + m + l exactly, each term bf16 (8 + 8 + 8 mantissa bits); used once per weight matrix at load time
+__global__ void k_split3_bf16(const float* in, uint16_t* planes, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float x = in[i];
+    const unsigned int u = __float_as_uint(x);
+    const float r = x - __uint_as_float(u & 0xFFFF0000u);      // truncation split, same rule as split8 in gn_gemm.hip
+    const unsigned int v = __float_as_uint(r);
+    const float r2 = r - __uint_as_float(v & 0xFFFF0000u);
+    planes[i] = (uint16_t)(u >> 16);
+    planes[n + i] = (uint16_t)(v >> 16);
+    planes[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
 }  // namespace
+
+void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_split3_bf16, dim3(512), dim3(256), 0, s, in, planes, n);
+}
 
 void launch_prep(const PrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_extent, dim3(a.B * 2), dim3(256), 0, s, a);

@@ -46,9 +46,13 @@ enum gn_status {
 
 enum gn_precision {
   GN_PREC_F32 = 0,       /* every contraction on f32 MFMA (parity mode) */
-  GN_PREC_BF16_ATTN = 1  /* QK^T / PV on bf16 MFMA with f32 softmax+accumulate (what kornia's
+  GN_PREC_BF16_ATTN = 1, /* QK^T / PV on bf16 MFMA with f32 softmax+accumulate (what kornia's
                             Attention does in fp16 on CUDA when flash=True); projections,
-                            FFN and the match head stay f32 */
+                            FFN and the match head stay on the exact-f32 MFMA */
+  GN_PREC_F32X3_BF16_ATTN = 2 /* as 1, but projections / FFN / match-head GEMMs run f32-ACCURATE on the bf16
+                            matrix pipe: every f32 operand is split exactly into three bf16 terms and six
+                            partial products are accumulated in f32 (error vs fp64 at or below the exact-f32
+                            MFMA path's; see tests) */
 };
 
 enum gn_kpt_format {
@@ -143,6 +147,9 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * v_mfma_f32_32x32x2_f32 issue-rate probe (blocks x 256 threads x iters x 8 MFMAs per wave). */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream);
+/* LDS-DMA addressing probe (80 KB of LDS per block filled by global_load_lds, verified by ds_read):
+ * pattern [8][80][256] f32, out [81] u32 = mismatching words per 1 KB piece + number of blocks run. */
+int gn_debug_lds_dma_probe(gn_ctx* ctx, const float* pattern, unsigned int* out, int blocks, int spin, void* stream);
 /* EPnP minimal solver on n 5-point sets: pws [n][5][3] f64, us [n][5][2] f64 (normalised image
  * coordinates), out [n][64] f64 = R(9) t(3) candidate errors(3) candidate betas(12) eigenvalues(12) rho(6) L row0(10) ok(1). */
 int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, double* out, void* stream);

@@ -44,10 +44,18 @@ def main():
             tot_ms += ms; tot_fl += fl
             print(f"variant {variant} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TF", flush=True)
         print(f"variant {variant} aggregate {tot_fl / tot_ms / 1e9:.1f} TF", flush=True)
-    A = torch.randn(1024, 512, device=dev); W = torch.randn(384, 512, device=dev); b = torch.randn(384, device=dev)
-    lib.gn_debug_set_variant(ctx, 0, variants[0]); y0 = eng.debug_gemm(A, W, b)
-    lib.gn_debug_set_variant(ctx, 0, variants[-1]); y1 = eng.debug_gemm(A, W, b)
-    print("first vs last variant max abs diff", float((y0 - y1).abs().max()), flush=True)
+    for (M_, N_, K_) in ((1024, 384, 512), (65536, 512, 512), (65536, 256, 256)):
+        A = torch.randn(M_, K_, device=dev); W = torch.randn(N_, K_, device=dev) * 0.05; b = torch.randn(N_, device=dev)
+        ref = A.double() @ W.double().T + b.double()
+        for v in sorted(set(variants)):
+            for planes in ((0, 1) if v == 5 else (0,)):
+                lib.gn_debug_set_variant(ctx, 0, v); lib.gn_debug_set_variant(ctx, 2, planes)
+                errs = []
+                for rep in range(3):
+                    y = eng.debug_gemm(A, W, b)
+                    errs.append(float((y.double() - ref).abs().max() / ref.abs().max()))
+                print(f"variant {v} planes={planes} M={M_} N={N_} K={K_}: max abs err vs fp64 / max|ref| = {errs}", flush=True)
+        lib.gn_debug_set_variant(ctx, 2, 0)
 
 
 if __name__ == "__main__":
