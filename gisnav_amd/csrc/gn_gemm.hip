@@ -809,7 +809,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 // so only the A fragments are split in registers.  B plane tiles are [plane][128 rows][32 k] bf16 (64-byte
 // rows); 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3), which makes every ds_read_b128 lane
 // group hit 16 distinct bank slots.
-template <int EPI, bool WP>
+template <int EPI, bool WP, int ABL = 0>   // ABL: timing-only ablations (1: no operand split, 2: no DMA in the loop, 4: no barrier)
 __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
   constexpr int TILE = WP ? (BM * BK + 3 * BN * BK / 2) : (BM + BN) * BK;  // floats per buffer: f32 A tile + (f32 | 3 bf16-plane) B tile
   constexpr int SLAB = 4 * 64 * ES;
@@ -911,7 +911,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
 #define GN_SPLIT(ra_, rb_, A_, B_)                                                                \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
-      split8(ra_[i][0], ra_[i][1], A_[i][0], A_[i][1], A_[i][2]);                                 \
+      if (ABL & 1) { A_[i][0] = __builtin_bit_cast(bf16x8, ra_[i][0]); A_[i][1] = __builtin_bit_cast(bf16x8, ra_[i][1]); A_[i][2] = A_[i][0]; } \
+      else split8(ra_[i][0], ra_[i][1], A_[i][0], A_[i][1], A_[i][2]);                            \
       if (!WP) split8(rb_[i][0], rb_[i][1], B_[i][0], B_[i][1], B_[i][2]);                        \
     }                                                                                             \
   }
@@ -945,20 +946,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
 
   GN_DMA_TILE(0, 0);
   __syncthreads();
+  if (nt > 1) GN_DMA_TILE(1, BK);
   f32x4 rawa[2][2], rawb[2][2];
   bf16x8 A0[2][3], B0[2][3], A1[2][3], B1[2][3];
   GN_RAW_READ(rawa, rawb, 0, 0);
   if (WP) GN_BPLANE_READ(B0, 0, 0);
   GN_SPLIT(rawa, rawb, A0, B0);
 
+  // One barrier per k-tile.  Its release drains the DMA of tile t+1 (issued a FULL k-tile earlier, right after
+  // the previous barrier); at that point every wave has also finished reading buffer `cur`, so the DMA of
+  // tile t+2 into `cur` is issued immediately -- the longest prefetch distance two LDS buffers allow.
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) GN_DMA_TILE(cur ^ 1, (t + 1) * BK);
     GN_RAW_READ(rawa, rawb, cur, 1);
     if (WP) GN_BPLANE_READ(B1, cur, 1);
     GN_MFMA24(A0, B0)
     GN_SPLIT(rawa, rawb, A1, B1);
-    __syncthreads();
+    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 2) && t + 2 < nt) GN_DMA_TILE(cur, (t + 2) * BK);
     if (t + 1 < nt) {
       GN_RAW_READ(rawa, rawb, cur ^ 1, 0);
       if (WP) GN_BPLANE_READ(B0, cur ^ 1, 0);
@@ -1142,7 +1147,7 @@ void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
 
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
-  if (g_gemm_variant >= 20 && epi == EPI_BIAS) {  // ablation builds (timing only; 22+ give wrong numbers)
+  if (g_gemm_variant >= 20 && g_gemm_variant < 50 && epi == EPI_BIAS) {  // ablation builds (timing only; 22+ give wrong numbers)
     switch (g_gemm_variant) {
       case 21: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 1>), grid, block, 0, s, a); break;
       case 22: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 2>), grid, block, 0, s, a); break;
@@ -1154,6 +1159,17 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   }
   if (g_gemm_variant == 4 && epi == EPI_BIAS) {
     hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);
+    return;
+  }
+  if (g_gemm_variant >= 50 && epi == EPI_BIAS && a.Wp) {   // ablation builds (timing only, wrong numbers)
+    switch (g_gemm_variant) {
+      case 51: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 1>), grid, block, 0, s, a); break;
+      case 52: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 2>), grid, block, 0, s, a); break;
+      case 53: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 3>), grid, block, 0, s, a); break;
+      case 54: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 4>), grid, block, 0, s, a); break;
+      case 57: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 7>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 0>), grid, block, 0, s, a); break;
+    }
     return;
   }
   if (g_gemm_variant == 5) {

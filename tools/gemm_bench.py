@@ -36,6 +36,7 @@ def main():
     variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
     for variant in variants:
         lib.gn_debug_set_variant(ctx, 0, variant)
+        lib.gn_debug_set_variant(ctx, 2, 1 if variant >= 5 else 0)
         tot_ms = tot_fl = 0
         for N, K in shapes:
             A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
