@@ -35,6 +35,7 @@ from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (the 2:1-sparsity figure is never used)
 GEMM_LAUNCHES_PER_STEP = 1 + 9 * 8 + 2  # input_proj + 9 x (4 proj + 2 x 2 ffn) + final_proj + sim
+ATTN_LAUNCHES_PER_STEP = 9 * 2           # one self + one (two-sided) cross attention launch per layer
 
 
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
@@ -125,7 +126,7 @@ def main() -> None:
 
     for _ in range(args.warmup):
         eng.estimate(inp, K_MATRIX, out=out)
-    eng.set_kernel_timing(GEMM_LAUNCHES_PER_STEP * args.steps)
+    eng.set_kernel_timing((GEMM_LAUNCHES_PER_STEP + ATTN_LAUNCHES_PER_STEP) * args.steps)
     gdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -135,7 +136,8 @@ def main() -> None:
     gdist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = gdist.max_over_ranks(elapsed, dev)
-    kstats = eng.kernel_stats()
+    kstats = eng.kernel_stats(0)
+    astats = eng.kernel_stats(1)
     eng.set_kernel_timing(0)
 
     n_ok = float(out["ok"].sum().item())
@@ -167,7 +169,8 @@ def main() -> None:
                                          "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]/[3]: batch-{args.batch} 640x480 pairs per GPU, {args.kpts} SIFT kpts/side, "
+                "workload": f"BASELINE {'configs[1] (batch-1' if args.batch == 1 else 'configs[2]/[3] (batch-' + str(args.batch)} per GPU): "
+                            f"640x480 pairs, {args.kpts} SIFT kpts/side, "
                             f"LightGlue-sift 9 layers + dual-softmax head + GPU PnP-RANSAC(10 it, 8 px) + LM refine",
                 "pairs_per_gpu_per_step": args.batch,
                 "global_pairs_per_step": args.batch * world,
@@ -198,6 +201,15 @@ def main() -> None:
                 "avg_launch_us": round(kstats["ms"] * 1e3 / max(kstats["launches"], 1), 2),
                 "algorithmic_gflop_per_launch": round(kstats["flops"] / max(kstats["launches"], 1) / 1e9, 3),
             },
+        }
+        a_ach = astats["flops"] / (astats["ms"] * 1e-3) / 1e12 if astats["ms"] > 0 else 0.0
+        a_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+        line["roofline_attention"] = {   # second-largest kernel; the QK^T / PV contractions north_star singles out
+            "kernel": "k_attn_f32" if args.precision == "f32" else "k_attn_bf16_v2",
+            "bound": "mfma", "achieved": round(a_ach, 2), "peak": a_peak, "unit": "TFLOP/s", "frac": round(a_ach / a_peak, 4),
+            "launches_timed": int(astats["launches"]),
+            "avg_launch_us": round(astats["ms"] * 1e3 / max(astats["launches"], 1), 2),
+            "algorithmic_gflop_per_launch": round(astats["flops"] / max(astats["launches"], 1) / 1e9, 3),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, args.kpts)

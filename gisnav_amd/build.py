@@ -20,6 +20,9 @@ SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_attention.hip", "gn_prep.hip", "gn_m
 # two waves share a SIMD (one float4 component of a 16-lane group, a few elements per 10^7; found with a
 # run-to-run bitwise determinism check).  Without SLP packing every kernel is bitwise repeatable.
 FLAGS = ["--offload-arch=gfx950", "-fno-slp-vectorize", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
+# attention: keep the MFMA accumulators in VGPRs (the softmax reads the scores and rescales the output every tile;
+# with the default AGPR form each tile paid ~255 v_accvgpr_read/write moves on the VALU, the kernel's bottleneck)
+EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -45,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [_hipcc(), *FLAGS, "-c", s, "-o", o]
+            cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

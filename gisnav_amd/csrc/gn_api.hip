@@ -45,7 +45,7 @@ struct gn_ctx {
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *h = nullptr, *md = nullptr, *ls = nullptr;
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
-  int attn_variant = 1;
+  int attn_variant = 3;    // 0: k_attn_bf16 (in-kernel conversion), 1: k_attn_bf16_v2, 2: k_attn_bf16_v3, 3: k_attn_bf16_v4
   int stop_after = 0;      // developer knob: return from run_matcher after this many GEMM/attention launches
   int launch_count = 0;
   int no_planes = 0;       // developer knob: ignore the pre-split weight planes (f32x3 splits B on the fly)
@@ -68,6 +68,7 @@ struct gn_ctx {
   bool ktiming = false;
   std::vector<hipEvent_t> kev;      // pairs (start, stop)
   std::vector<double> kflops;       // algorithmic flops of each recorded launch
+  std::vector<int> kclass;          // 0 = projection/FFN/similarity GEMM, 1 = attention
   size_t kused = 0;
 };
 
@@ -135,6 +136,7 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
   if (rec) {
     hipEventRecord(c->kev[2 * c->kused + 1], s);
     c->kflops[c->kused] = 2.0 * g.M * (double)g.N * g.K * batch;
+    c->kclass[c->kused] = 0;
     ++c->kused;
   }
 }
@@ -167,6 +169,22 @@ void attention(gn_ctx* c, const AttnArgs& a, hipStream_t s) {
   if (c->precision != GN_PREC_F32) launch_attention_bf16(a, s); else launch_attention_f32(a, s);
 }
 
+// one attention launch of the matcher schedule, optionally bracketed by HIP events (kernel class 1);
+// flops = QK^T + PV over full npad x npad score panels (the bench fills every slot)
+void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
+  ++c->launch_count;
+  if (c->stop_after && c->launch_count > c->stop_after) return;
+  const bool rec = c->ktiming && c->kused < c->kflops.size();
+  if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+  if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s);
+  if (rec) {
+    hipEventRecord(c->kev[2 * c->kused + 1], s);
+    c->kflops[c->kused] = 4.0 * a.BS * kHeads * (double)a.npad * a.npad * kHeadDim;
+    c->kclass[c->kused] = 1;
+    ++c->kused;
+  }
+}
+
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
@@ -183,7 +201,9 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
                 const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                 int64_t* idx, float* score, int32_t* n_match, hipStream_t s) {
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
-  const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant == 1;
+  const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
+  gn::g_attn_variant = c->attn_variant;
+  const int vt_perm = (c->attn_variant == 3 || c->attn_variant >= 30) ? 1 : 0;   // k_attn_bf16_v4 reads permuted V^T
   c->launch_count = 0;
   {
     StageTimer tm(c, s, ST_PREP);
@@ -204,7 +224,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 3 * kDim, T);
         g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
         if (bf16v2) {
-          g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np;
+          g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np; g.vt_perm = vt_perm;
           gemm(c, EPI_ROTARY_BF16, g, s);
         } else {
           gemm(c, EPI_ROTARY, g, s);
@@ -216,8 +236,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
         a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
-        ++c->launch_count;
-        if (!(c->stop_after && c->launch_count > c->stop_after)) { if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s); }
+        timed_attention(c, a, bf16v2, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -234,7 +253,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         g.scale = 0.35355339059327373f;  // (dim_head ** -0.5) ** 0.5 applied to both qk sides
         g.scale_cols = kDim;
         if (bf16v2) {
-          g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np;
+          g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np; g.vt_perm = vt_perm;
           gemm(c, EPI_SCALE_BF16, g, s);
         } else {
           gemm(c, EPI_SCALE_COLS, g, s);
@@ -246,8 +265,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
         a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
-        ++c->launch_count;
-        if (!(c->stop_after && c->launch_count > c->stop_after)) { if (bf16v2) launch_attention_bf16_v2(a, s); else attention(c, a, s); }
+        timed_attention(c, a, bf16v2, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -652,24 +670,25 @@ int gn_set_kernel_timing(gn_ctx* ctx, int max_launches) {
   while ((int)ctx->kflops.size() < max_launches) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GN_ERR_HIP;
-    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0);
+    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0); ctx->kclass.push_back(0);
   }
   ctx->ktiming = max_launches > 0;
   ctx->kused = 0;
   return GN_OK;
 }
 
-int gn_get_kernel_stats(gn_ctx* ctx, double* out3) {
-  if (!ctx || !out3) return GN_ERR_ARG;
+int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3) {
+  if (!ctx || !out3 || kernel_class < 0 || kernel_class > 1) return GN_ERR_ARG;
   hipSetDevice(ctx->device);
-  double ms = 0.0, fl = 0.0;
+  double ms = 0.0, fl = 0.0, n = 0.0;
   for (size_t i = 0; i < ctx->kused; ++i) {
     if (hipEventSynchronize(ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
     float t = 0.f;
     if (hipEventElapsedTime(&t, ctx->kev[2 * i], ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
-    ms += t; fl += ctx->kflops[i];
+    if (ctx->kclass[i] != kernel_class) continue;
+    ms += t; fl += ctx->kflops[i]; n += 1.0;
   }
-  out3[0] = (double)ctx->kused; out3[1] = ms; out3[2] = fl;
+  out3[0] = n; out3[1] = ms; out3[2] = fl;
   return GN_OK;
 }
 

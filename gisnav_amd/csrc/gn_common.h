@@ -43,6 +43,7 @@ struct GemmArgs {
   // EPI_*_BF16: columns < vt_start go to Yb (bf16 row-major, q columns < q_cols scaled by qscale),
   // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))
   uint16_t* Yb; int ldyb; uint16_t* Vt; int vt_start; int q_cols; float qscale; int npad;
+  int vt_perm;                     // 1: V^T tokens permuted within 16-groups for k_attn_bf16_v4 (see the epilogue)
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
@@ -67,6 +68,7 @@ struct AttnArgs {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
+extern int g_attn_variant;  // developer knob: 1 = k_attn_bf16_v2, 2 = k_attn_bf16_v3 (default), 2x = v3 timing ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
 struct PrepArgs {

@@ -479,8 +479,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
       unsigned int w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
-        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        // vt_perm: within each 16-token group, 16-byte chunk hh holds tokens 4hh + {0..3, 8..11} -- the key order
+        // one lane of the attention kernel's P^T operand carries, so its V^T fragment is one ds_read_b128
+        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
+        const float lo = slab[t0 * ES + lane] + bias;
+        const float hi = slab[(t0 + 1) * ES + lane] + bias;
         w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -714,8 +717,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
       unsigned int w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
-        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        // vt_perm: within each 16-token group, 16-byte chunk hh holds tokens 4hh + {0..3, 8..11} -- the key order
+        // one lane of the attention kernel's P^T operand carries, so its V^T fragment is one ds_read_b128
+        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
+        const float lo = slab[t0 * ES + lane] + bias;
+        const float hi = slab[(t0 + 1) * ES + lane] + bias;
         w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -1006,8 +1012,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
       unsigned int w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = slab[(8 * c + 2 * e) * ES + lane] + bias;
-        const float hi = slab[(8 * c + 2 * e + 1) * ES + lane] + bias;
+        // vt_perm: within each 16-token group, 16-byte chunk hh holds tokens 4hh + {0..3, 8..11} -- the key order
+        // one lane of the attention kernel's P^T operand carries, so its V^T fragment is one ds_read_b128
+        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
+        const float lo = slab[t0 * ES + lane] + bias;
+        const float hi = slab[(t0 + 1) * ES + lane] + bias;
         w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);

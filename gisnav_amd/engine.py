@@ -188,9 +188,10 @@ class PoseEngine:
     def set_kernel_timing(self, max_launches: int) -> None:
         _lib.check(self.ctx, self.lib.gn_set_kernel_timing(self.ctx, max_launches), "gn_set_kernel_timing")
 
-    def kernel_stats(self) -> Dict[str, float]:
+    def kernel_stats(self, kernel_class: int = 0) -> Dict[str, float]:
+        """HIP-event totals of the recorded launches; kernel_class 0 = GEMMs, 1 = attention."""
         buf = (C.c_double * 3)()
-        _lib.check(self.ctx, self.lib.gn_get_kernel_stats(self.ctx, buf), "gn_get_kernel_stats")
+        _lib.check(self.ctx, self.lib.gn_get_kernel_stats(self.ctx, kernel_class, buf), "gn_get_kernel_stats")
         return {"launches": buf[0], "ms": buf[1], "flops": buf[2]}
 
     def debug_gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:

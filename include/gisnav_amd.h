@@ -153,8 +153,11 @@ int gn_debug_lds_dma_probe(gn_ctx* ctx, const float* pattern, unsigned int* out,
 /* EPnP minimal solver on n 5-point sets: pws [n][5][3] f64, us [n][5][2] f64 (normalised image
  * coordinates), out [n][64] f64 = R(9) t(3) candidate errors(3) candidate betas(12) eigenvalues(12) rho(6) L row0(10) ok(1). */
 int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, double* out, void* stream);
+/* HIP-event timing of individual launches inside gn_match / gn_estimate (on the caller's stream):
+ * record up to max_launches launches (0 = off, resets the log); kernel_class 0 = projection / FFN /
+ * similarity GEMMs, 1 = attention; out3 = {launches, summed ms, summed algorithmic flops}. */
 int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
-int gn_get_kernel_stats(gn_ctx* ctx, double* out3);
+int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3);
 
 #ifdef __cplusplus
 }
