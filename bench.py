@@ -75,10 +75,12 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
                       f"cpu={platform.processor() or platform.machine()}"}
 
 
-def measured_gemm_traffic(x3: bool):
+def measured_gemm_traffic(precision: str):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (bench.py cannot run under
     the profiler itself); None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_f32x3.json" if x3 else "r01_pmc_hbm_traffic.json")
+    name = {"f32x3_bf16_attn": "r01_pmc_hbm_traffic_f32x3.json", "f16x2_bf16_attn": "r01_pmc_hbm_traffic_f16x2.json"}.get(
+        precision, "r01_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -94,7 +96,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--precision", default="f32x3_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn"])
+    ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
@@ -150,8 +152,10 @@ def main() -> None:
         pairs_per_s = total_pairs / elapsed
         ach = kstats["flops"] / (kstats["ms"] * 1e-3) / 1e12 if kstats["ms"] > 0 else 0.0
         x3 = args.precision == "f32x3_bf16_attn"
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = measured_gemm_traffic(x3) if (args.batch == 32 and args.kpts == 1024) else (None, None)
+        h2 = args.precision == "f16x2_bf16_attn"
+        mult = 6 if x3 else 3 if h2 else 1      # matrix-pipe flops issued per algorithmic flop
+        peak = PEAK_BF16_MFMA_TFLOPS / mult if (x3 or h2) else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = measured_gemm_traffic(args.precision) if (args.batch == 32 and args.kpts == 1024) else (None, None)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
             "value": round(pairs_per_s, 2),
@@ -166,7 +170,10 @@ def main() -> None:
             "dtype": {"f32": "f32",
                       "bf16_attn": "f32 projections/FFN/match-head + bf16 MFMA attention (f32 accumulate)",
                       "f32x3_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split exactly into 3 bf16 terms, "
-                                         "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
+                                         "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)",
+                      "f16x2_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
+                                         "significant bits, 3 fp16 MFMA partial products, f32 accumulate; error vs fp64 <= the f32 "
+                                         "MFMA path's) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE {'configs[1] (batch-1' if args.batch == 1 else 'configs[2]/[3] (batch-' + str(args.batch)} per GPU): "
@@ -185,16 +192,17 @@ def main() -> None:
             "result_records_gathered": int(rec.shape[0]),
             "roofline": {
                 "kernel": ("k_gemm_f32x3 (projection/FFN/similarity GEMM: 3 x bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)"
-                           if x3 else "k_gemm_f32_v3 (projection/FFN/similarity GEMM on v_mfma_f32_32x32x2_f32)"),
+                           if x3 else "k_gemm_f16x2 (projection/FFN/similarity GEMM: 2 x fp16 split, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block)"
+                           if h2 else "k_gemm_f32_v3 (projection/FFN/similarity GEMM on v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": round(ach, 2),
                 "peak": round(peak, 1),
                 "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "note": ("achieved = algorithmic 2*M*N*K flops / HIP-event time; the kernel issues 6 bf16 MFMA flops per algorithmic "
-                         "flop, so peak = 2500 TF bf16 dense / 6 and frac is the fraction of the bf16 matrix-pipe roofline actually used"
-                         if x3 else "achieved = algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak"),
-                "executed_mfma_tflops": round(ach * (6 if x3 else 1), 1),
+                "note": (f"achieved = algorithmic 2*M*N*K flops / HIP-event time; the kernel issues {mult} 16-bit MFMA flops per algorithmic "
+                         f"flop, so peak = 2500 TF dense / {mult} and frac is the fraction of the 16-bit matrix-pipe roofline actually used"
+                         if (x3 or h2) else "achieved = algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak"),
+                "executed_mfma_tflops": round(ach * mult, 1),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "launches_timed": int(kstats["launches"]),
@@ -205,7 +213,7 @@ def main() -> None:
         a_ach = astats["flops"] / (astats["ms"] * 1e-3) / 1e12 if astats["ms"] > 0 else 0.0
         a_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
         line["roofline_attention"] = {   # second-largest kernel; the QK^T / PV contractions north_star singles out
-            "kernel": "k_attn_f32" if args.precision == "f32" else "k_attn_bf16_v2",
+            "kernel": "k_attn_f32" if args.precision == "f32" else "k_attn_bf16_v5",
             "bound": "mfma", "achieved": round(a_ach, 2), "peak": a_peak, "unit": "TFLOP/s", "frac": round(a_ach / a_peak, 4),
             "launches_timed": int(astats["launches"]),
             "avg_launch_us": round(astats["ms"] * 1e3 / max(astats["launches"], 1), 2),

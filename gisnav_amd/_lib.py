@@ -54,6 +54,7 @@ STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")
 GN_PREC_F32 = 0
 GN_PREC_BF16_ATTN = 1
 GN_PREC_F32X3_BF16_ATTN = 2
+GN_PREC_F16X2_BF16_ATTN = 3
 GN_KPT_LAF = 0
 GN_KPT_XYSA = 1
 

@@ -13,7 +13,8 @@ namespace {
 
 thread_local std::string g_err;
 
-struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; };  // wp: [3][out][in] bf16 planes
+struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; float acc_scale = 1.f; };
+// wp: pre-split planes, [3][out][in] bf16 (f32x3) or [2][out][in] fp16 of w / acc_scale (f16x2; acc_scale a power of two)
 
 struct Block {       // one SelfBlock or CrossBlock
   Linear proj_in;    // self: Wqkv re-ordered to [q|k|v][head][d] (768x256); cross: [to_qk ; to_v] (512x256)
@@ -45,7 +46,7 @@ struct gn_ctx {
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *h = nullptr, *md = nullptr, *ls = nullptr;
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
-  int attn_variant = 3;    // 0: k_attn_bf16 (in-kernel conversion), 1: k_attn_bf16_v2, 2: k_attn_bf16_v3, 3: k_attn_bf16_v4
+  int attn_variant = 4;    // 0: k_attn_bf16 (in-kernel conversion), 1: k_attn_bf16_v2, 2: k_attn_bf16_v3, 3: k_attn_bf16_v4, 4: k_attn_bf16_v5
   int stop_after = 0;      // developer knob: return from run_matcher after this many GEMM/attention launches
   int launch_count = 0;
   int no_planes = 0;       // developer knob: ignore the pre-split weight planes (f32x3 splits B on the fly)
@@ -151,7 +152,24 @@ int build_planes(gn_ctx* ctx, Linear& L) {
   if (!L.w || L.out <= 0 || L.in <= 0) return GN_OK;
   const size_t n = (size_t)L.out * L.in;
   if (!L.wp) { int rc = dalloc(ctx, &L.wp, 3 * n); if (rc != GN_OK) return rc; }
-  launch_split3_bf16(L.w, L.wp, (long long)n, 0);
+  if (ctx->precision == GN_PREC_F16X2_BF16_ATTN) {
+    // power-of-two scale that puts max |w| in [2^12, 2^13): both fp16 planes stay normal for every weight within
+    // 2^-15 of the largest, and there is headroom to fp16's 65504
+    std::vector<float> host(n);
+    GN_HIP(hipMemcpy(host.data(), L.w, n * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (float v : host) { const float av = fabsf(v); if (av > mx) mx = av; }
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) { frexpf(mx, &e); e = 13 - e; }   // mx = f * 2^(13 - e'), f in [0.5, 1)
+    if (e > 60) e = 60;
+    if (e < -60) e = -60;
+    const float scale = ldexpf(1.0f, e);
+    L.acc_scale = ldexpf(1.0f, -e);
+    launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);
+  } else {
+    L.acc_scale = 1.f;
+    launch_split3_bf16(L.w, L.wp, (long long)n, 0);
+  }
   GN_HIP(hipStreamSynchronize(0));
   return GN_OK;
 }
@@ -159,7 +177,7 @@ int build_planes(gn_ctx* ctx, Linear& L) {
 GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, int M) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
-  g.Wp = L.wp; g.wp_plane = (long long)L.out * L.in;
+  g.Wp = L.wp; g.wp_plane = (long long)L.out * L.in; g.acc_scale = L.acc_scale;
   g.A = A; g.lda = lda; g.A2 = nullptr; g.lda2 = 0; g.K1 = L.in;
   g.W = L.w; g.ldw = L.in; g.bias = L.b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = L.out; g.K = L.in;
   return g;
@@ -203,7 +221,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
-  const int vt_perm = (c->attn_variant == 3 || c->attn_variant >= 30) ? 1 : 0;   // k_attn_bf16_v4 reads permuted V^T
+  const int vt_perm = (c->attn_variant == 3 || c->attn_variant == 4 || c->attn_variant >= 30) ? 1 : 0;   // k_attn_bf16_v4 reads permuted V^T
   c->launch_count = 0;
   {
     StageTimer tm(c, s, ST_PREP);
@@ -285,7 +303,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     GemmArgs gs;
     memset(&gs, 0, sizeof gs);
     gs.A = c->md; gs.lda = kDim; gs.K1 = kDim; gs.W = c->md + (size_t)np * kDim; gs.ldw = kDim;
-    gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim;
+    gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim; gs.acc_scale = 1.f;
     gs.strideA = gs.strideW = 2LL * np * kDim; gs.strideY = (long long)np * np;
     timed_gemm(c, EPI_PLAIN, gs, B, s);
     HeadArgs hd;
@@ -318,7 +336,8 @@ const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out) {
   gn_ctx* ctx = nullptr;
   if (!out || max_batch < 1 || max_kpts < 2) return fail(nullptr, GN_ERR_ARG, "bad gn_create argument");
-  if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN && precision != GN_PREC_F32X3_BF16_ATTN)
+  if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN && precision != GN_PREC_F32X3_BF16_ATTN &&
+      precision != GN_PREC_F16X2_BF16_ATTN)
     return fail(nullptr, GN_ERR_ARG, "bad precision");
   GN_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -327,7 +346,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
     return fail(nullptr, GN_ERR_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   ctx = new gn_ctx();
   ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision;
-  ctx->gemm_variant = precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
+  ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   ctx->npad = ((max_kpts + 127) / 128) * 128;
   const size_t np = ctx->npad, T = (size_t)max_batch * 2 * np, B = max_batch;
 #define GN_ALLOC(field, count)                                     \
@@ -604,10 +623,16 @@ int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float*
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = K; g.K1 = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = K;
+  g.acc_scale = 1.f;
   if (ctx->dbg_planes) {
     const size_t n = (size_t)N * K;
     if (ctx->dbg_wp_n < n) { ctx->dbg_wp = nullptr; int rc = dalloc(ctx, &ctx->dbg_wp, 3 * n); if (rc != GN_OK) return rc; ctx->dbg_wp_n = n; }
-    launch_split3_bf16(W, ctx->dbg_wp, (long long)n, (hipStream_t)stream);
+    if (ctx->gemm_variant == 6) {   // fp16 planes of W * 2^(dbg_planes - 1)
+      launch_split2_f16(W, ctx->dbg_wp, (long long)n, ldexpf(1.0f, ctx->dbg_planes - 1), (hipStream_t)stream);
+      g.acc_scale = ldexpf(1.0f, 1 - ctx->dbg_planes);
+    } else {
+      launch_split3_bf16(W, ctx->dbg_wp, (long long)n, (hipStream_t)stream);
+    }
     g.Wp = ctx->dbg_wp; g.wp_plane = (long long)n;
   }
   launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, (hipStream_t)stream);

@@ -159,6 +159,7 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kRing = 64 * 64;         // k_attn_bf16_v5: shorts per ring stage (one 64 x 64 bf16 tile)
 constexpr int kStage = 2 * 64 * 64;   // k_attn_bf16_v4: shorts per LDS stage (K tile + V^T tile, 64 x 64 bf16 each)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -832,6 +833,196 @@ __global__ __launch_bounds__(256) void k_attn_bf16_v4(AttnArgs a) {
       *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// bf16 variant 5: software-pipelined across key tiles.  Measured on gfx950 (tools/probes/overlap.hip): VALU work
+// overlaps MFMA execution only when both sit in the SAME wave's instruction stream; a softmax-phase wave and an
+// MFMA-phase wave sharing a SIMD do not overlap.  So each iteration issues the QK^T MFMAs of tile t+1 inside the
+// exp / convert work of tile t.  K runs one tile ahead of V^T in two 3-deep LDS-DMA rings (prefetch distance two
+// tiles for both), one barrier per tile.  The running maximum is updated lazily: the output is rescaled only when
+// some query's maximum grew by more than 2^8 (probabilities then stay <= 256, exact in f32 / harmless in bf16),
+// which removes the per-tile rescale after the first tiles.
+template <int ABL>
+__global__ __launch_bounds__(256) void k_attn_bf16_v5(AttnArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[6 * kRing];   // K ring [3][64 keys][64], V^T ring [3][64 dims][64 keys]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, ql = lane & 31;
+  int qblk, h, bs;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    qblk = v % gx;
+    const int g = v / gx;
+    h = g % kHeads; bs = g / kHeads;
+  }
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = qblk * QB + wave * 32;
+  const int ntiles = (nkv + KT - 1) / KT;
+
+  bf16x8 qf[4];
+  {
+    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+  }
+
+  f32x16 o[2], ol;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+  float m_run = -INFINITY;
+
+  // LDS-DMA addressing as in variant 4 (source-side swizzle f(row) = (row >> 1) & 7)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned short* ksrc[2]; const unsigned short* vsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (2 * wave + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    ksrc[j] = a.kb + ((size_t)kvs * a.npad + r) * a.ldkb + h * 64 + c * 8;
+    vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + c * 8;
+    if (ABL & 2) {   // timing probe: the same bytes fetched as contiguous 8 KB tiles (wrong data)
+      ksrc[j] = a.kb + ((size_t)kvs * kHeads + h) * a.npad * 64 + (2 * wave + j) * 512 + lane * 8;
+      vsrc[j] = a.vt + ((size_t)kvs * kHeads + h) * a.npad * 64 + (2 * wave + j) * 512 + lane * 8;
+    }
+  }
+  const size_t kstep = (ABL & 2) ? (size_t)KT * 64 : (size_t)KT * a.ldkb;
+  const int vstep = (ABL & 2) ? KT * 64 : KT;
+#define GN_DMA_K(stage, t)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)(t) * kstep),                                           \
+                                     (lptr_t)(smem + (stage) * kRing + (2 * wave_u + j) * 512), 16, 0, 0);
+#define GN_DMA_V(stage, t)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                         \
+    __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (t) * vstep),                                                   \
+                                     (lptr_t)(smem + (3 + (stage)) * kRing + (2 * wave_u + j) * 512), 16, 0, 0);
+  int ro[2], fsw[2];     // fragment row offsets (shorts) and swizzle of rows ql, 32 + ql
+#pragma unroll
+  for (int i2 = 0; i2 < 2; ++i2) {
+    const int row = i2 * 32 + ql;
+    fsw[i2] = (row >> 1) & 7;
+    ro[i2] = row * 64;
+  }
+
+  auto qk_tile = [&](f32x16 (&S)[2], int stage) __attribute__((always_inline)) {
+    const unsigned short* Ks = smem + stage * kRing;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[ro[kt] + (((2 * c + hh) ^ fsw[kt]) << 3)]);
+        S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], S[kt], 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 sa[2], sb[2];
+  int s0 = 0, s1 = 1, s2 = 2;          // ring stages of tiles t, t+1, t+2 (mod 3)
+  if (ntiles > 0) {
+    GN_DMA_K(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ntiles > 1) GN_DMA_K(1, 1);
+    GN_DMA_V(0, 0);
+    if (ntiles > 2) GN_DMA_K(2, 2);
+    if (ntiles > 1) GN_DMA_V(1, 1);
+    qk_tile(sa, 0);
+  }
+
+  auto tile = [&](f32x16 (&ST)[2], f32x16 (&SN)[2], int t) __attribute__((always_inline)) {
+    // K(t+1) and V^T(t) have landed once everything but the newest DMA group {K(t+2), V^T(t+1)} is complete;
+    // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
+    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!(ABL & 1)) {
+      if (t + 3 < ntiles) GN_DMA_K(s0, t + 3);
+      if (t + 2 < ntiles) GN_DMA_V(s2, t + 2);
+    }
+    if (t * KT + KT > nkv) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= nkv) ST[kt][r] = -INFINITY;
+        }
+    }
+    float mloc = fmaxf(ST[0][0], ST[1][0]);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, ST[kt][r]), ST[kt][(r + 1) & 15]);   // v_max3_f32
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8
+    if (__builtin_amdgcn_ballot_w64((mloc - m_run) * kLog2e > 8.0f) != 0) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
+      m_run = m_new;
+    }
+    const float mneg = -m_run * kLog2e;
+
+    // scores of the next tile on the matrix pipe while this tile's probabilities are computed on the VALU
+    qk_tile(SN, s1);
+
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x2 p;
+          p[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[kt][8 * u + 2 * e], kLog2e, mneg));
+          p[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[kt][8 * u + 2 * e + 1], kLog2e, mneg));
+          pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
+        }
+        pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
+      }
+    const unsigned short* Vs = smem + (3 + s0) * kRing;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][u], ol, 0, 0, 0);   // softmax denominator (rounded p)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[ro[d] + (((4 * kt + 2 * u + hh) ^ fsw[d]) << 3)]);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
+        }
+      }
+    const int s_ = s0; s0 = s1; s1 = s2; s2 = s_;
+  };
+
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(sa, sb, t);
+    if (t + 1 < ntiles) tile(sb, sa, t + 1);
+  }
+#undef GN_DMA_K
+#undef GN_DMA_V
+
+  const float l = ol[0];
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w;
+      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
+      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
+    }
+}
 }  // namespace
 
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
@@ -847,7 +1038,7 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 }  // namespace gn
 
 namespace gn {
-int g_attn_variant = 3;  // developer knob: 1 = k_attn_bf16_v2, 2 = k_attn_bf16_v3, 3 = k_attn_bf16_v4 (default)
+int g_attn_variant = 4;  // developer knob: 1 = k_attn_bf16_v2, 2 = k_attn_bf16_v3, 3 = k_attn_bf16_v4, 4 = k_attn_bf16_v5 (default)
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
   switch (g_attn_variant) {
@@ -859,6 +1050,9 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 24: hipLaunchKernelGGL(k_attn_bf16_v3<4>, grid, block, 0, s, a); break;
     case 27: hipLaunchKernelGGL(k_attn_bf16_v3<7>, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(k_attn_bf16_v3<0>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_attn_bf16_v5<0>, grid, block, 0, s, a); break;
+    case 41: hipLaunchKernelGGL(k_attn_bf16_v5<1>, grid, block, 0, s, a); break;
+    case 42: hipLaunchKernelGGL(k_attn_bf16_v5<2>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(k_attn_bf16_v4<0>, grid, block, 0, s, a); break;
   }
 }

@@ -30,7 +30,8 @@ struct GemmArgs {
   const float* A2;   int lda2;     // optional second source for k >= K1 (concat), else nullptr
   int K1;
   const float* W;    int ldw;      // W[N][K]
-  const uint16_t* Wp; long long wp_plane;  // optional pre-split weights: three bf16 planes [3][N][K], plane stride in elements
+  const uint16_t* Wp; long long wp_plane;  // optional pre-split weights: bf16 planes [3][N][K] (f32x3) or scaled fp16 planes [2][N][K] (f16x2)
+  float acc_scale;                 // f16x2: exact inverse of the power-of-two weight-plane scale (1 if none)
   const float* bias;               // [N] or nullptr
   float* Y;          int ldy;      // Y[M][N]
   int M, N, K;
@@ -121,5 +122,6 @@ void launch_epnp_debug(const double* pws, const double* us, double* out, int n, 
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]
+void launch_split2_f16(const float* in, uint16_t* planes, long long n, float scale, hipStream_t s);  // planes[2][n] = fp16 split of in * scale
 
 }  // namespace gn

@@ -1082,6 +1082,306 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
     }
   }
 }
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// two-term fp16 split with round-to-nearest: h = fp16(x), m = fp16(x - h)   (v_cvt_pk_f16_f32, v_cvt_f32_f16, v_sub)
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned int& h, unsigned int& m) {
+  f32x2v x = {x0, x1};
+  const f16x2v hv = __builtin_convertvector(x, f16x2v);
+  f32x2v r = {x0 - (float)hv[0], x1 - (float)hv[1]};
+  const f16x2v mv = __builtin_convertvector(r, f16x2v);
+  h = __builtin_bit_cast(unsigned int, hv);
+  m = __builtin_bit_cast(unsigned int, mv);
+}
+__device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, f16x8& h, f16x8& m) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  unsigned int h0, h1, h2, h3, m0, m1, m2, m3;
+  split2h(a.x, a.y, h0, m0);
+  split2h(a.z, a.w, h1, m1);
+  split2h(b.x, b.y, h2, m2);
+  split2h(b.z, b.w, h3, m3);
+  const u32x4 hv = {h0, h1, h2, h3}, mv = {m0, m1, m2, m3};
+  h = __builtin_bit_cast(f16x8, hv); m = __builtin_bit_cast(f16x8, mv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f16x2: f32-class GEMM on the fp16 matrix pipe at HALF the MFMA work of f32x3.  Every f32 operand is split into
+// two fp16 terms with round-to-nearest (x = xh + xm + e, |e| <= max(2^-22 |x|, 2^-25): the fp16 matrix pipe of
+// gfx950 honours subnormal inputs, checked by tools/probes/f16_denorm.hip) and each 32x32x16 block is
+// accumulated in f32 from three products (xm yh, xh ym, xh yh); the dropped terms are <= 3 * 2^-22 |x y|,
+// below the rounding noise of an f32 accumulation over K >= 128.  Weights arrive PRE-SPLIT as two fp16 planes
+// [2][N][K], scaled by a power of two so that max |w| sits near 2^13 (keeps both planes far from the
+// subnormal range; the epilogue multiplies the accumulator by the exact inverse, GemmArgs::acc_scale).
+// Domain: |activation| < 65504 (fp16 range) -- LightGlue's activations are O(1..100).
+// Tiles, DMA, swizzles and epilogues are those of k_gemm_f32x3.
+template <int EPI, bool WP, int ABL = 0>   // ABL: timing-only ablations (1: no operand split, 2: no DMA in the loop, 4: no barrier)
+__global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
+  constexpr int TILE = (BM + BN) * BK;  // floats per buffer: f32 A tile + (f32 | 2 fp16-plane) B tile, 16 KB each
+  constexpr int SLAB = 4 * 64 * ES;
+  __shared__ __attribute__((aligned(16))) float smem[((2 * TILE > SLAB) ? 2 * TILE : SLAB) + GN_X3_LDS_PAD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int bx, by;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * BM, bn = bx * BN;
+  const float* A = a.A + (long long)blockIdx.z * a.strideA;
+  const float* W = a.W + (long long)blockIdx.z * a.strideW;
+  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
+  const float* const A2 = a.A2;
+  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
+
+  // DMA source addressing: wave w stages tile rows [32w, 32w + 32) of A and of B, 8 rows per instruction.
+  // lane -> (row offset lane >> 3, chunk position lane & 7) fetches source chunk pos ^ f(row).
+  const int drow = wave * 32 + (lane >> 3);            // + 8 * j
+  const int dpos = lane & 7;
+  // f(row) for row = drow + 8j: (row ^ (row >> 3)) & 7; row >> 3 = 4 * wave + j
+  const float* asrc[4]; const float* a2src[4]; const float* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = drow + 8 * j;
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    asrc[j] = A + (size_t)(bm + row) * lda + c * 4;
+    a2src[j] = A2 ? A2 + (size_t)(bm + row) * lda2 + c * 4 - K1 : nullptr;
+    wsrc[j] = W + (size_t)(bn + row) * ldw + c * 4;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // pre-split weight planes: piece = 16 rows x 64 B; lane -> (row lane >> 2, position lane & 3) fetches chunk pos ^ g(row)
+  const unsigned short* wpsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int piece = wave_u * 4 + q, plane = piece >> 3, row = (piece & 7) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    wpsrc[q] = WP ? a.Wp + (size_t)plane * a.wp_plane + (size_t)(bn + row) * ldw + c * 8 : nullptr;
+  }
+#define GN_DMA_TILE(buf, k0)                                                                      \
+  {                                                                                               \
+    const bool second = (A2 != nullptr) && ((k0) >= K1);                                          \
+    float* la_ = smem + (buf) * TILE + (wave_u * 32) * BK;                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+      const float* ga_ = (second ? a2src[j] : asrc[j]) + (k0);                                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)ga_, (lptr_t)(la_ + j * 8 * BK), 16, 0, 0);       \
+    }                                                                                             \
+    if (WP) {                                                                                     \
+      unsigned short* lb_ = reinterpret_cast<unsigned short*>(smem + (buf) * TILE + BM * BK);    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        const int piece = wave_u * 4 + q;                    /* 16 pieces: plane = piece / 8 */   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wpsrc[q] + (k0)), (lptr_t)(lb_ + piece * 512), 16, 0, 0); \
+      }                                                                                           \
+    } else {                                                                                      \
+      float* lb_ = smem + (buf) * TILE + BM * BK + (wave_u * 32) * BK;                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (k0)), (lptr_t)(lb_ + j * 8 * BK), 16, 0, 0); \
+    }                                                                                             \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addressing (floats): row * 32 + 4 * (chunk ^ f(row)), chunk = 2 kc + hh
+  const int hh = lane >> 5;
+  int arow_[2], brow_[2], ga_[2], gb_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra_ = wr * 64 + 32 * i + (lane & 31), rb_ = wc * 64 + 32 * i + (lane & 31);
+    arow_[i] = ra_ * BK; brow_[i] = BM * BK + rb_ * BK;
+    ga_[i] = hh ^ ((ra_ ^ (ra_ >> 3)) & 7); gb_[i] = hh ^ ((rb_ ^ (rb_ >> 3)) & 7);
+  }
+  const int nt = K / BK;
+
+// raw f32 fragments of k-step s (16 k values): lane (row, hh) holds k = 16 s + 8 hh + 0..7 = two 16-byte chunks
+#define GN_RAW_READ(ra_, rb_, buf, s_)                                                            \
+  {                                                                                               \
+    const float* b_ = smem + (buf) * TILE;                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+      ra_[i][0] = *reinterpret_cast<const f32x4*>(b_ + arow_[i] + 4 * ((4 * (s_) + 0) ^ ga2_[i])); \
+      ra_[i][1] = *reinterpret_cast<const f32x4*>(b_ + arow_[i] + 4 * ((4 * (s_) + 1) ^ ga2_[i])); \
+      if (!WP) {                                                                                  \
+        rb_[i][0] = *reinterpret_cast<const f32x4*>(b_ + brow_[i] + 4 * ((4 * (s_) + 0) ^ gb2_[i])); \
+        rb_[i][1] = *reinterpret_cast<const f32x4*>(b_ + brow_[i] + 4 * ((4 * (s_) + 1) ^ gb2_[i])); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#define GN_SPLIT(ra_, rb_, A_, B_)                                                                \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+      if (ABL & 1) { A_[i][0] = __builtin_bit_cast(f16x8, ra_[i][0]); A_[i][1] = __builtin_bit_cast(f16x8, ra_[i][1]); } \
+      else split8h(ra_[i][0], ra_[i][1], A_[i][0], A_[i][1]);                                     \
+      if (!WP) split8h(rb_[i][0], rb_[i][1], B_[i][0], B_[i][1]);                                 \
+    }                                                                                             \
+  }
+// pre-split B fragments straight from the plane tiles (no VALU): lane (col, hh), k-step s -> chunk 2 s + hh
+#define GN_BPLANE_READ(B_, buf, s_)                                                               \
+  {                                                                                               \
+    const unsigned short* pb_ = reinterpret_cast<const unsigned short*>(smem + (buf) * TILE + BM * BK); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                            \
+        B_[i][pl] = *reinterpret_cast<const f16x8*>(pb_ + pl * (BN * BK) + bprow_[i] + 8 * ((2 * (s_)) ^ gbp_[i])); \
+  }
+// x y = (xh + xm)(yh + ym) ~ xm yh + xh ym + xh yh (small terms first).
+// The four accumulators are visited round-robin inside every product so that consecutive MFMAs are independent.
+#define GN_MFMA_P(pa, pb, A_, B_)                                                                  \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[0][pa], B_[0][pb], acc[0][0], 0, 0, 0);  \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[0][pa], B_[1][pb], acc[0][1], 0, 0, 0);  \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[1][pa], B_[0][pb], acc[1][0], 0, 0, 0);  \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[1][pa], B_[1][pb], acc[1][1], 0, 0, 0);
+#define GN_MFMA24(A_, B_) { GN_MFMA_P(1, 0, A_, B_) GN_MFMA_P(0, 1, A_, B_) GN_MFMA_P(0, 0, A_, B_) }
+
+  // chunk index for k-step s and half hh is 4 s + 2 hh + {0, 1}: fold hh and f(row) into one xor mask
+  int ga2_[2], gb2_[2], bprow_[2], gbp_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ga2_[i] = (2 * hh) ^ (ga_[i] ^ hh); gb2_[i] = (2 * hh) ^ (gb_[i] ^ hh);
+    const int rb_ = wc * 64 + 32 * i + (lane & 31);
+    bprow_[i] = rb_ * BK;                       // halves: 32 bf16 per row
+    gbp_[i] = hh ^ ((rb_ >> 2) & 3);            // chunk 2 s + hh at position (2 s) ^ hh ^ g(row)
+  }
+
+  GN_DMA_TILE(0, 0);
+  __syncthreads();
+  if (nt > 1) GN_DMA_TILE(1, BK);
+  f32x4 rawa[2][2], rawb[2][2];
+  f16x8 A0[2][2], B0[2][2], A1[2][2], B1[2][2];
+  GN_RAW_READ(rawa, rawb, 0, 0);
+  if (WP) GN_BPLANE_READ(B0, 0, 0);
+  GN_SPLIT(rawa, rawb, A0, B0);
+
+  // One barrier per k-tile.  Its release drains the DMA of tile t+1 (issued a FULL k-tile earlier, right after
+  // the previous barrier); at that point every wave has also finished reading buffer `cur`, so the DMA of
+  // tile t+2 into `cur` is issued immediately -- the longest prefetch distance two LDS buffers allow.
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    GN_RAW_READ(rawa, rawb, cur, 1);
+    if (WP) GN_BPLANE_READ(B1, cur, 1);
+    GN_MFMA24(A0, B0)
+    GN_SPLIT(rawa, rawb, A1, B1);
+    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 2) && t + 2 < nt) GN_DMA_TILE(cur, (t + 2) * BK);
+    if (t + 1 < nt) {
+      GN_RAW_READ(rawa, rawb, cur ^ 1, 0);
+      if (WP) GN_BPLANE_READ(B0, cur ^ 1, 0);
+    }
+    GN_MFMA24(A1, B1)
+    if (t + 1 < nt) GN_SPLIT(rawa, rawb, A0, B0);
+  }
+#undef GN_DMA_TILE
+#undef GN_RAW_READ
+#undef GN_SPLIT
+#undef GN_BPLANE_READ
+#undef GN_MFMA_P
+#undef GN_MFMA24
+
+  float* slab = smem + wave * 64 * ES;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[row * ES + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
+  const int colbase = bn + wc * 64;
+  if (kBf16Out && colbase >= a.vt_start) {
+    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad].
+    // lane = feature d; 8 consecutive tokens are packed into one 16-byte store.
+    const int head = (colbase - a.vt_start) >> 6;
+    const int row0 = bm + wr * 64;
+    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
+    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
+    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // vt_perm: within each 16-token group, 16-byte chunk hh holds tokens 4hh + {0..3, 8..11} -- the key order
+        // one lane of the attention kernel's P^T operand carries, so its V^T fragment is one ds_read_b128
+        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
+        const float lo = slab[t0 * ES + lane] * a.acc_scale + bias;
+        const float hi = slab[(t0 + 1) * ES + lane] * a.acc_scale + bias;
+        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
+  const int c4 = (lane & 15) * 4;
+  const int col = bn + wc * 64 + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
+  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
+  const int f0 = (col & 63) >> 1;
+  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
+  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
+  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
+  // of a 16-lane group replaced by the next row's raw accumulator).
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int lr_ = it * 4 + (lane >> 4);
+    const int row = bm + wr * 64 + lr_;
+    f32x4 v = vals[it] * a.acc_scale;
+    v += bias4;
+    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
+      if (do_rot) {
+        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+    }
+    if (kBf16Out) {
+      if (col < a.q_cols) v *= a.qscale;
+      uint2 pk;
+      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
+      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
+    } else {
+      vals[it] = v;
+    }
+  }
+  // stores go last, from registers nothing writes any more
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = bm + wr * 64 + it * 4 + (lane >> 4);
+    if (kBf16Out) {
+      uint2 pk; pk.x = __float_as_uint(vals[it].x); pk.y = __float_as_uint(vals[it].y);
+      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
+    } else {
+      *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = vals[it];
+    }
+  }
+}
 }  // namespace
 
 int g_gemm_variant = 3;
@@ -1179,6 +1479,22 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
       case 57: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 7>), grid, block, 0, s, a); break;
       default: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 0>), grid, block, 0, s, a); break;
     }
+    return;
+  }
+  if (g_gemm_variant == 6) {
+#define GN_H2(E)                                                                                   \
+  if (a.Wp) hipLaunchKernelGGL((k_gemm_f16x2<E, true>), grid, block, 0, s, a);                     \
+  else hipLaunchKernelGGL((k_gemm_f16x2<E, false>), grid, block, 0, s, a);
+    switch (epi) {
+      case EPI_BIAS: GN_H2(EPI_BIAS) break;
+      case EPI_SCALE_COLS: GN_H2(EPI_SCALE_COLS) break;
+      case EPI_ROTARY: GN_H2(EPI_ROTARY) break;
+      case EPI_RESIDUAL: GN_H2(EPI_RESIDUAL) break;
+      case EPI_ROTARY_BF16: GN_H2(EPI_ROTARY_BF16) break;
+      case EPI_SCALE_BF16: GN_H2(EPI_SCALE_BF16) break;
+      default: GN_H2(EPI_PLAIN) break;
+    }
+#undef GN_H2
     return;
   }
   if (g_gemm_variant == 5) {

@@ -171,7 +171,23 @@ __global__ void k_split3_bf16(const float* in, uint16_t* planes, long long n) {
     planes[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
   }
 }
+// x * scale = h + m + e with h, m fp16 (round to nearest), |e| <= 2^-22 |x * scale|; planes of the f16x2 GEMM
+__global__ void k_split2_f16(const float* in, uint16_t* planes, long long n, float scale) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float x = in[i] * scale;
+    const _Float16 h = (_Float16)x;
+    const _Float16 m = (_Float16)(x - (float)h);
+    planes[i] = __builtin_bit_cast(uint16_t, h);
+    planes[n + i] = __builtin_bit_cast(uint16_t, m);
+  }
+}
 }  // namespace
+
+void launch_split2_f16(const float* in, uint16_t* planes, long long n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_split2_f16, dim3(512), dim3(256), 0, s, in, planes, n, scale);
+}
 
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_split3_bf16, dim3(512), dim3(256), 0, s, in, planes, n);

@@ -24,7 +24,8 @@ RANSAC_ITERATIONS = 10    # _shared.py:115
 RANSAC_REPROJ_PX = 8.0    # cv2.solvePnPRansac default
 RANSAC_CONFIDENCE = 0.99  # cv2.solvePnPRansac default
 
-_PRECISIONS = {"f32": _lib.GN_PREC_F32, "bf16_attn": _lib.GN_PREC_BF16_ATTN, "f32x3_bf16_attn": _lib.GN_PREC_F32X3_BF16_ATTN}
+_PRECISIONS = {"f32": _lib.GN_PREC_F32, "bf16_attn": _lib.GN_PREC_BF16_ATTN, "f32x3_bf16_attn": _lib.GN_PREC_F32X3_BF16_ATTN,
+               "f16x2_bf16_attn": _lib.GN_PREC_F16X2_BF16_ATTN}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:

@@ -49,10 +49,15 @@ enum gn_precision {
   GN_PREC_BF16_ATTN = 1, /* QK^T / PV on bf16 MFMA with f32 softmax+accumulate (what kornia's
                             Attention does in fp16 on CUDA when flash=True); projections,
                             FFN and the match head stay on the exact-f32 MFMA */
-  GN_PREC_F32X3_BF16_ATTN = 2 /* as 1, but projections / FFN / match-head GEMMs run f32-ACCURATE on the bf16
+  GN_PREC_F32X3_BF16_ATTN = 2, /* as 1, but projections / FFN / match-head GEMMs run f32-ACCURATE on the bf16
                             matrix pipe: every f32 operand is split exactly into three bf16 terms and six
                             partial products are accumulated in f32 (error vs fp64 at or below the exact-f32
                             MFMA path's; see tests) */
+  GN_PREC_F16X2_BF16_ATTN = 3 /* as 2 at half the matrix-pipe work: every f32 operand is split into two fp16
+                            terms (round to nearest, 22 significant bits, subnormals honoured by the gfx950
+                            matrix pipe) and three partial products are accumulated in f32; weight planes are
+                            pre-scaled by a power of two.  Requires |activation| < 65504.  Error vs fp64 at the
+                            level of an f32 accumulation (see tests) */
 };
 
 enum gn_kpt_format {

@@ -47,6 +47,12 @@ def eng256_x3(state_dict_np, dev):
     return PoseEngine(0, max_batch=4, max_kpts=256, precision="f32x3_bf16_attn", state_dict=state_dict_np)
 
 
+@pytest.fixture(scope="module")
+def eng256_h2(state_dict_np, dev):
+    from gisnav_amd.engine import PoseEngine
+    return PoseEngine(0, max_batch=4, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
@@ -78,6 +84,26 @@ def test_gemm_f32x3_split_is_f32_accurate(eng256_x3, eng256, dev, M, N, K, plane
     eng256_x3.lib.gn_debug_set_variant(eng256_x3.ctx, 2, 0)
     ex3 = _rel(y.cpu().numpy(), ref)
     assert ex3 < 2e-6 and ex3 < 2 * e32 + 1e-7, (ex3, e32)
+    assert torch.equal(y, y2)                                  # bitwise repeatable
+
+
+@pytest.mark.parametrize("planes,wstd,astd", [(0, 0.05, 1.0), (1, 0.05, 1.0), (14, 0.05, 1.0), (19, 1e-3, 1.0), (14, 0.05, 30.0), (1, 0.05, 1e-2)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1024, 768, 256), (4096, 512, 512)])
+def test_gemm_f16x2_split_is_f32_accurate(eng256_h2, eng256, dev, M, N, K, planes, wstd, astd):
+    """The 2 x fp16 split GEMM (3 partial products, f32 accumulate) against fp64, next to the exact-f32 MFMA GEMM:
+    weights split on the fly (planes=0), pre-split unscaled (1) or pre-split with a 2^(planes-1) scale as the
+    library does at load time; small weights, large and small activations (fp16 subnormal pieces)."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * astd).to(dev); W = (torch.randn(N, K, generator=g) * wstd).to(dev)
+    b = (torch.randn(N, generator=g) * wstd * astd).to(dev)
+    ref = (A.double() @ W.double().T + b.double()).cpu().numpy()
+    e32 = _rel(eng256.debug_gemm(A, W, b).cpu().numpy(), ref)
+    eng256_h2.lib.gn_debug_set_variant(eng256_h2.ctx, 2, planes)
+    y = eng256_h2.debug_gemm(A, W, b)
+    y2 = eng256_h2.debug_gemm(A, W, b)
+    eng256_h2.lib.gn_debug_set_variant(eng256_h2.ctx, 2, 0)
+    eh2 = _rel(y.cpu().numpy(), ref)
+    assert eh2 < 2e-6 and eh2 < 2 * e32 + 1e-7, (eh2, e32)
     assert torch.equal(y, y2)                                  # bitwise repeatable
 
 
@@ -143,10 +169,10 @@ def test_matcher_matches_oracle_per_layer_and_bit_exact_indices(eng256, state_di
         assert idx.dtype == torch.int64
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn"])
+@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
 @pytest.mark.parametrize("name", ["lightglue_seed0_q96_r80", "lightglue_seed0_q200_r256"])
-def test_golden_fixtures_through_c_abi(eng256, eng256_bf16, eng256_x3, dev, prec, name):
-    eng = {"f32": eng256, "bf16_attn": eng256_bf16, "f32x3_bf16_attn": eng256_x3}[prec]
+def test_golden_fixtures_through_c_abi(eng256, eng256_bf16, eng256_x3, eng256_h2, dev, prec, name):
+    eng = {"f32": eng256, "bf16_attn": eng256_bf16, "f32x3_bf16_attn": eng256_x3, "f16x2_bf16_attn": eng256_h2}[prec]
     eng.set_num_layers(9)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -343,7 +369,7 @@ def full_size(state_dict_np, dev):
     pairs = [make_pair(i) for i in range(32)]
     res = {}
     T = 32 * 2 * 1024
-    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn"):
+    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):
         eng = PoseEngine(0, max_batch=32, max_kpts=1024, precision=prec, state_dict=state_dict_np)
         inp = eng.stage_inputs(pairs)
         idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
@@ -387,7 +413,7 @@ def test_full_size_matches_are_mutual_sorted_and_correct(full_size):
 
 def test_full_size_pose_close_to_ground_truth(full_size):
     pairs, res = full_size
-    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn"):
+    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):
         out = res[prec][3]
         assert out["ok"].all()
         for b, p in enumerate(pairs):
@@ -397,7 +423,7 @@ def test_full_size_pose_close_to_ground_truth(full_size):
             assert out["n_inliers"][b] >= 0.9 * out["n_match"][b]
 
 
-@pytest.mark.parametrize("prec", ["bf16_attn", "f32x3_bf16_attn"])
+@pytest.mark.parametrize("prec", ["bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
 def test_full_size_reduced_modes_give_the_same_correspondences(full_size, prec):
     _, res = full_size
     i0, s0, n0, _ = res["f32"]
@@ -408,7 +434,7 @@ def test_full_size_reduced_modes_give_the_same_correspondences(full_size, prec):
         assert np.abs(s0[b, : n0[b]] - s1[b, : n0[b]]).max() < 5e-3
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn"])
+@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
 def test_full_size_bitwise_repeatable_including_first_run(full_size, prec):
     """Regression guard for a timing-dependent miscompile (SLP-packed v_pk_*_f32 in a GEMM epilogue): the residual
     stream after 9 layers must be bit-identical between the cold first run of a context and a later run."""
@@ -437,6 +463,6 @@ def test_full_size_oracle_spot_check(full_size, state_dict_t):
         assert np.array_equal(idx[b, : nm[b]], oidx.numpy())
         assert np.abs(score[b, : nm[b]] - sc.numpy()[:, 0]).max() < 1e-5
         Ro, to = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), pairs[b].dem)
-        for prec in ("f32", "bf16_attn", "f32x3_bf16_attn"):      # identical correspondences -> identical pose problem
+        for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):      # identical correspondences -> identical pose problem
             o = res[prec][3]
             assert np.linalg.norm(o["R"][b] - Ro) < 1e-8 and np.linalg.norm(o["t"][b] - to) / np.linalg.norm(to) < 1e-8

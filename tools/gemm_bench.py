@@ -49,7 +49,7 @@ def main():
         A = torch.randn(M_, K_, device=dev); W = torch.randn(N_, K_, device=dev) * 0.05; b = torch.randn(N_, device=dev)
         ref = A.double() @ W.double().T + b.double()
         for v in sorted(set(variants)):
-            for planes in ((0, 1) if v == 5 else (0,)):
+            for planes in ((0, 1) if v == 5 else (0, 1, 14) if v == 6 else (0,)):
                 lib.gn_debug_set_variant(ctx, 0, v); lib.gn_debug_set_variant(ctx, 2, planes)
                 errs = []
                 for rep in range(3):
