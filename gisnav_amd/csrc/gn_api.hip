@@ -44,6 +44,10 @@ struct gn_ctx {
   float *desc = nullptr, *cos_t = nullptr, *sin_t = nullptr, *extent = nullptr;
   int32_t* nvalid = nullptr;
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *h = nullptr, *md = nullptr, *ls = nullptr;
+  // f16x2 mode: fp16 plane pairs [2][Tmax][C] of the activations that feed GEMMs (written by their producers)
+  uint16_t *desc_p = nullptr, *x_p = nullptr, *ctx_p = nullptr, *msg_p = nullptr, *h_p = nullptr, *md_p = nullptr;
+  size_t Tmax = 0;         // token slots allocated (max_batch * 2 * npad) = plane stride in rows
+  int planes_mode = 0;     // 1: activations travel as fp16 planes and GEMMs run k_gemm_p2 (default in f16x2 mode)
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
   int attn_variant = 4;    // 0: k_attn_bf16 (in-kernel conversion), 1: k_attn_bf16_v2, 2: k_attn_bf16_v3, 3: k_attn_bf16_v4, 4: k_attn_bf16_v5
@@ -52,6 +56,10 @@ struct gn_ctx {
   int no_planes = 0;       // developer knob: ignore the pre-split weight planes (f32x3 splits B on the fly)
   int dbg_planes = 0;      // gn_debug_gemm: pre-split W into bf16 planes first (exercises the WP path)
   uint16_t* dbg_wp = nullptr; size_t dbg_wp_n = 0;
+  int dbg_out = 0;         // gn_debug_gemm variant 7: 1 = hm16 output only (into scratch), 2 = f32 + hm16 (timing experiments)
+  uint16_t* dbg_yp = nullptr; size_t dbg_yp_n = 0;
+  int dbg_reuse = 0;       // gn_debug_gemm: keep the operand planes of the previous call (micro-benchmarks time the GEMM alone)
+  uint16_t* dbg_ap = nullptr; size_t dbg_ap_n = 0;   // gn_debug_gemm, variant 7: A planes for k_gemm_p2
   int gemm_variant = -1;   // -1: library default (f32 MFMA, LDS-DMA); 5: f32x3 (GN_PREC_F32X3_BF16_ATTN)
   float *rowmax = nullptr, *rowlog = nullptr, *colmax = nullptr, *collog = nullptr, *max0 = nullptr;
   int32_t *m0 = nullptr, *m1 = nullptr;
@@ -125,15 +133,49 @@ struct StageTimer {
   }
 };
 
+// f16x2 planes mode: the hm16 buffer that shadows an f32 activation buffer.  hm16 rows have the byte pitch of the
+// f32 rows, so an element offset into the f32 buffer (whole rows) maps to twice that many fp16 elements.
+bool planes_of(gn_ctx* c, const float* p, uint16_t** planes) {
+  struct { const float* f; uint16_t* q; size_t cols; } tab[] = {
+    {c->desc, c->desc_p, (size_t)kInDim}, {c->x, c->x_p, (size_t)kDim}, {c->ctx, c->ctx_p, (size_t)kDim},
+    {c->msg, c->msg_p, (size_t)kDim}, {c->h, c->h_p, (size_t)2 * kDim}, {c->md, c->md_p, (size_t)kDim}};
+  for (auto& e : tab) {
+    if (e.f && p >= e.f && p < e.f + c->Tmax * e.cols && (size_t)(p - e.f) % e.cols == 0) {
+      *planes = e.q + 2 * (p - e.f);
+      return true;
+    }
+  }
+  return false;
+}
+
 void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t s) {
   if (c->gemm_variant >= 0) gn::g_gemm_variant = c->gemm_variant;
   GemmArgs g = g_in;
   if (c->no_planes) g.Wp = nullptr;
+  bool p2 = false;
+  if (c->planes_mode) {
+    uint16_t* q = nullptr;
+    p2 = planes_of(c, g.A, &q);
+    if (p2) {
+      g.Ap = q;
+      if (g.A2) { uint16_t* q2 = nullptr; p2 = planes_of(c, g.A2, &q2) && g.lda2 == g.lda; g.A2p = q2; }
+    }
+    if (p2 && !g.Wp) {   // similarity GEMM: the B operand is an activation too
+      uint16_t* qw = nullptr;
+      p2 = planes_of(c, g.W, &qw);
+      g.Wp = qw; g.acc_scale = 1.f;
+    }
+    if (p2) {   // outputs that feed later GEMMs leave in hm16; f32 is kept only where something reads it
+      uint16_t* qy = nullptr;
+      if (g.Y == c->x) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; }
+      else if (g.Y == c->msg || g.Y == c->md) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; g.Y = nullptr; }
+    }
+  }
   ++c->launch_count;
   if (c->stop_after && c->launch_count > c->stop_after) return;
   const bool rec = c->ktiming && c->kused < c->kflops.size();
   if (rec) hipEventRecord(c->kev[2 * c->kused], s);
-  launch_gemm_f32(epi, g, batch, s);
+  if (p2) launch_gemm_p2(epi, g, batch, s); else launch_gemm_f32(epi, g, batch, s);
   if (rec) {
     hipEventRecord(c->kev[2 * c->kused + 1], s);
     c->kflops[c->kused] = 2.0 * g.M * (double)g.N * g.K * batch;
@@ -165,7 +207,8 @@ int build_planes(gn_ctx* ctx, Linear& L) {
     if (e < -60) e = -60;
     const float scale = ldexpf(1.0f, e);
     L.acc_scale = ldexpf(1.0f, -e);
-    launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);
+    if (ctx->planes_mode) launch_split_hm16(L.w, L.wp, L.out, L.in, scale, 0);   // hm16 rows for k_gemm_p2
+    else launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);                   // [2][out][in] planes for k_gemm_f16x2
   } else {
     L.acc_scale = 1.f;
     launch_split3_bf16(L.w, L.wp, (long long)n, 0);
@@ -208,7 +251,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
   gemm(c, EPI_BIAS, g, s);
-  launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s);
+  launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s, c->planes_mode ? c->h_p : nullptr);
   GemmArgs g3 = gemm_args(c->h, 2 * kDim, blk.ffn3, c->x, kDim, T);
   g3.resid = c->x; g3.ldr = kDim;
   gemm(c, EPI_RESIDUAL, g3, s);
@@ -222,6 +265,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
   const int vt_perm = (c->attn_variant == 3 || c->attn_variant == 4 || c->attn_variant >= 30) ? 1 : 0;   // k_attn_bf16_v4 reads permuted V^T
+  const bool attn_planes = c->planes_mode && c->attn_variant == 4;   // k_attn_bf16_v5 writes the fp16 planes itself
   c->launch_count = 0;
   {
     StageTimer tm(c, s, ST_PREP);
@@ -231,6 +275,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     p.kpt_format = kpt_format; p.B = B; p.npad = np; p.wr = c->wr;
     p.desc = c->desc; p.kxy = nullptr; p.cos_t = c->cos_t; p.sin_t = c->sin_t; p.nvalid = c->nvalid; p.extent = c->extent;
     launch_prep(p, s);
+    if (c->planes_mode) launch_split_hm16(c->desc, c->desc_p, T, kInDim, 1.0f, s);
     GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
     gemm(c, EPI_BIAS, g, s);
   }
@@ -253,8 +298,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         AttnArgs a;
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
+        a.outp = attn_planes ? c->ctx_p : nullptr;
         a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
         timed_attention(c, a, bf16v2, s);
+        if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -282,8 +329,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         AttnArgs a;
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
+        a.outp = attn_planes ? c->ctx_p : nullptr;
         a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
         timed_attention(c, a, bf16v2, s);
+        if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
       {
         StageTimer tm(c, s, ST_PROJ);
@@ -355,6 +404,12 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(extent, B * 4); GN_ALLOC(nvalid, B * 2);
   GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
   GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
+  ctx->Tmax = T;
+  if (precision == GN_PREC_F16X2_BF16_ATTN) {
+    ctx->planes_mode = 1;
+    GN_ALLOC(desc_p, 2 * T * kInDim); GN_ALLOC(x_p, 2 * T * kDim); GN_ALLOC(ctx_p, 2 * T * kDim);
+    GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
+  }
   GN_ALLOC(sim, B * np * np);
   if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
@@ -624,10 +679,31 @@ int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float*
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = K; g.K1 = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = K;
   g.acc_scale = 1.f;
+  if (ctx->gemm_variant == 7) {   // k_gemm_p2: both operands as fp16 planes (W scaled by 2^(dbg_planes - 1) if dbg_planes > 0)
+    
+    const size_t na = (size_t)M * K, nw = (size_t)N * K;
+    if (ctx->dbg_ap_n < na) { ctx->dbg_ap = nullptr; int rc = dalloc(ctx, &ctx->dbg_ap, 2 * na); if (rc != GN_OK) return rc; ctx->dbg_ap_n = na; }
+    if (ctx->dbg_wp_n < nw) { ctx->dbg_wp = nullptr; int rc = dalloc(ctx, &ctx->dbg_wp, 3 * nw); if (rc != GN_OK) return rc; ctx->dbg_wp_n = nw; }
+    const int e = ctx->dbg_planes > 0 ? ctx->dbg_planes - 1 : 0;
+    if (!ctx->dbg_reuse) {
+      launch_split_hm16(A, ctx->dbg_ap, M, K, 1.0f, (hipStream_t)stream);
+      launch_split_hm16(W, ctx->dbg_wp, N, K, ldexpf(1.0f, e), (hipStream_t)stream);
+    }
+    g.Ap = ctx->dbg_ap; g.Wp = ctx->dbg_wp; g.acc_scale = ldexpf(1.0f, -e);
+    if (ctx->dbg_out) {
+      const size_t ny = (size_t)M * N;
+      if (ctx->dbg_yp_n < ny) { ctx->dbg_yp = nullptr; int rc = dalloc(ctx, &ctx->dbg_yp, 2 * ny); if (rc != GN_OK) return rc; ctx->dbg_yp_n = ny; }
+      g.Yp = ctx->dbg_yp; g.ldyp = N;
+      if (ctx->dbg_out == 1) g.Y = nullptr;
+    }
+    launch_gemm_p2(bias ? EPI_BIAS : EPI_PLAIN, g, 1, (hipStream_t)stream);
+    GN_HIP(hipGetLastError());
+    return GN_OK;
+  }
   if (ctx->dbg_planes) {
     const size_t n = (size_t)N * K;
     if (ctx->dbg_wp_n < n) { ctx->dbg_wp = nullptr; int rc = dalloc(ctx, &ctx->dbg_wp, 3 * n); if (rc != GN_OK) return rc; ctx->dbg_wp_n = n; }
-    if (ctx->gemm_variant == 6) {   // fp16 planes of W * 2^(dbg_planes - 1)
+    if (ctx->gemm_variant == 6 || ctx->gemm_variant >= 60) {   // fp16 planes of W * 2^(dbg_planes - 1)
       launch_split2_f16(W, ctx->dbg_wp, (long long)n, ldexpf(1.0f, ctx->dbg_planes - 1), (hipStream_t)stream);
       g.acc_scale = ldexpf(1.0f, 1 - ctx->dbg_planes);
     } else {
@@ -648,7 +724,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   AttnArgs a;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
-  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0;
+  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr;
   attention(ctx, a, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
   return GN_OK;
@@ -661,6 +737,10 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 2) ctx->dbg_planes = value;
   else if (which == 3) ctx->no_planes = value;
   else if (which == 4) ctx->stop_after = value;
+  else if (which == 5) ctx->planes_mode = (value && ctx->x_p) ? 1 : 0;
+  else if (which == 6) ctx->dbg_reuse = value;
+  else if (which == 7) ctx->dbg_out = value;
+  else if (which == 8) gn::g_p2_wide = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -21,6 +21,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
+// hm16 row format of the f16x2 mode: a value x travels as two fp16 terms x = h + m.  A row of ld values is ld / 16
+// groups of 64 bytes: the 16 high terms of columns 16g .. 16g+15 followed by their 16 residual terms.  Offset (in
+// fp16 elements) of the HIGH term of (row, col); the residual term sits 16 elements further.
+__host__ __device__ inline size_t hm16_off(size_t row, int ld, int col) {
+  return row * (size_t)ld * 2 + (size_t)(col >> 4) * 32 + (col & 15);
+}
+
 // ---- GEMM -----------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
                EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6 };
@@ -45,11 +52,18 @@ struct GemmArgs {
   // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))
   uint16_t* Yb; int ldyb; uint16_t* Vt; int vt_start; int q_cols; float qscale; int npad;
   int vt_perm;                     // 1: V^T tokens permuted within 16-groups for k_attn_bf16_v4 (see the epilogue)
+  // split-fp16 operands / outputs of k_gemm_p2 (gn_gemm_p2.hip) in the hm16 row format (see hm16_off): a row of
+  // ld values occupies ld * 4 bytes, like the f32 row it shadows
+  const uint16_t* Ap;                        // A (k < K1), row pitch lda values
+  const uint16_t* A2p;                       // optional second source (k >= K1), same row pitch
+  uint16_t* Yp; int ldyp;                    // optional hm16 output (Y may then be nullptr)
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
+void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // fp16-plane operands (Ap, Wp)
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
 void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s);
 extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking
+extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 kernel when the shape allows
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {
@@ -60,6 +74,7 @@ struct AttnArgs {
   const float* k; int ldk;
   const float* v; int ldv;
   float* out; int ldo;
+  uint16_t* outp;                        // optional hm16 output (row pitch ldo values) instead of `out` (k_attn_bf16_v5)
   const int32_t* nvalid;     // [BS] valid token count per (pair, side)
   int npad;                  // tokens per (pair, side) slot
   int cross;                 // 1: keys/values come from the other side of the same pair (bs ^ 1)
@@ -84,7 +99,8 @@ struct PrepArgs {
   float* extent;            // [B*2][2] (max_x, max_y)
 };
 void launch_prep(const PrepArgs& a, hipStream_t s);
-void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s);
+void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s,
+                    uint16_t* hp = nullptr);   // hp: write hm16 rows [rows][512] instead of h
 void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s);
 
 struct HeadArgs {
@@ -123,5 +139,6 @@ void launch_epnp_debug(const double* pws, const double* us, double* out, int n, 
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]
 void launch_split2_f16(const float* in, uint16_t* planes, long long n, float scale, hipStream_t s);  // planes[2][n] = fp16 split of in * scale
+void launch_split_hm16(const float* in, uint16_t* out, long long rows, int cols, float scale, hipStream_t s);  // hm16 rows of in * scale
 
 }  // namespace gn

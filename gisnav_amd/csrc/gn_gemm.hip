@@ -1470,6 +1470,17 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);
     return;
   }
+  if (g_gemm_variant >= 60 && epi == EPI_BIAS && a.Wp) {   // f16x2 ablation builds (timing only, wrong numbers)
+    switch (g_gemm_variant) {
+      case 61: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 1>), grid, block, 0, s, a); break;
+      case 62: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 2>), grid, block, 0, s, a); break;
+      case 63: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 3>), grid, block, 0, s, a); break;
+      case 64: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 4>), grid, block, 0, s, a); break;
+      case 67: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 7>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_f16x2<EPI_BIAS, true, 0>), grid, block, 0, s, a); break;
+    }
+    return;
+  }
   if (g_gemm_variant >= 50 && epi == EPI_BIAS && a.Wp) {   // ablation builds (timing only, wrong numbers)
     switch (g_gemm_variant) {
       case 51: hipLaunchKernelGGL((k_gemm_f32x3<EPI_BIAS, true, 1>), grid, block, 0, s, a); break;

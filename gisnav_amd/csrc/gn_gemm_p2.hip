@@ -1,0 +1,460 @@
+// fp16 split-operand GEMM of the f16x2 precision mode (GN_PREC_F16X2_BF16_ATTN): the hot kernel of the matcher.
+//
+//   Y[M][N] = A[M][K] * W[N][K]^T (+ bias) (+ epilogue),   A = Ah + Am,  W = (Wh + Wm) * acc_scale
+//
+// Both operands arrive PRE-SPLIT into two fp16 terms (x = xh + xm + e, |e| <= max(2^-22 |x|, 2^-25)): weights once
+// at load time (gn_load_tensor), activations by the kernel that produced them (this kernel's own epilogue, the
+// attention kernel, k_ln_gelu).  Storage is the "hm16" row format: a row of C values is C/16 groups of 64 bytes,
+// each group = 16 fp16 high terms followed by the 16 fp16 residual terms of the same 16 columns.  A row therefore
+// occupies exactly the bytes of the f32 row it replaces, a 32-wide k-tile is one full 128-byte line per row (the
+// LDS-DMA fetches whole lines, as in the f32 kernels), and the main loop is left with nothing but LDS-DMA,
+// ds_read_b128 and MFMA: per 32x32x16 block three v_mfma_f32_32x32x16_f16 (xm yh, xh ym, xh yh) accumulate in
+// f32 -- error vs fp64 at or below the exact-f32 MFMA path's (tests/test_gpu_parity.py) at 3 x 32 matrix-pipe
+// cycles instead of 8 x 64.
+// Stands in for the nn.Linear calls inside kornia's LightGlue and the similarity einsum of MatchAssignment
+// (reached from ros/gisnav/gisnav/core/pose_node.py:285-287), like gn_gemm.hip.
+//
+// Tiling: 128x128 block tile, 4 waves (2x2) of 64x64 = 2x2 MFMA tiles, BK = 32 per stage, two LDS stages of
+// (A tile | W tile) x [128 rows][128 B] = 32 KB, two blocks per CU.  16-byte chunk c of row r sits at position
+// c ^ ((r ^ (r >> 3)) & 7) (source-side swizzle of the lane-linear LDS-DMA; conflict-free ds_read_b128).
+// The instruction order of the steady-state loop is pinned with sched_barrier: one LDS-DMA or fragment read in
+// the shadow of each MFMA, accumulators visited round-robin (left alone, the machine scheduler clumps the DMAs
+// and issues dependent MFMAs back to back).
+#include "gn_common.h"
+
+namespace gn {
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 32, ES = 68;
+constexpr int TILE_H = BM * 64;           // halves per operand tile: 128 rows x 128 B (16 KB)
+constexpr int STAGE = 2 * TILE_H;         // halves per stage (A tile | W tile, 32 KB)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
+  unsigned int u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// (x0, x1) -> packed fp16 pair h = fp16(x), and the pair of the residuals m = fp16(x - h)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned int& h, unsigned int& m) {
+  const f32x2v x = {x0, x1};
+  const f16x2v hv = __builtin_convertvector(x, f16x2v);
+  const f32x2v r = {x0 - (float)hv[0], x1 - (float)hv[1]};
+  const f16x2v mv = __builtin_convertvector(r, f16x2v);
+  h = __builtin_bit_cast(unsigned int, hv);
+  m = __builtin_bit_cast(unsigned int, mv);
+}
+
+struct Frags { f16x8 A[2][2]; f16x8 B[2][2]; };   // [row/col tile][term: 0 = high, 1 = residual]
+
+// Epilogue of one wave's 64 x 64 sub-tile sitting in its LDS slab (rows rbase.., columns colbase..): bias, scaling,
+// rotary, residual, then f32 / hm16 / bf16 / V^T stores.  Shared by the 128x128 and the 256x256 kernels.
+template <int EPI>
+__device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* slab, float* Y, int rbase, int colbase, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
+    const float ascale = a.acc_scale;
+  if (kBf16Out && colbase >= a.vt_start) {
+    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad] (lane = feature d,
+    // 8 tokens per 16-byte store; token order inside 16-groups as the attention kernel's P^T operand wants it)
+    const int head = (colbase - a.vt_start) >> 6;
+    const int row0 = rbase;
+    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
+    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
+    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
+        const float lo = slab[t0 * ES + lane] * ascale + bias;
+        const float hi = slab[(t0 + 1) * ES + lane] * ascale + bias;
+        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
+  const int c4 = (lane & 15) * 4;
+  const int col = colbase + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
+  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
+  const int rf0 = (col & 63) >> 1;
+  // every row fragment is pulled into its own registers before the first store is issued (see gn_gemm.hip)
+  f32x4 vals[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+  uint2 hpl[16], mpl[16];   // plane outputs (only live when a.Yp)
+  const bool planes_out = !kBf16Out && a.Yp != nullptr;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = rbase + it * 4 + (lane >> 4);
+    f32x4 v = vals[it] * ascale;
+    v += bias4;
+    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
+      if (do_rot) {
+        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + rf0);
+        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + rf0);
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+    }
+    if (kBf16Out) {
+      if (col < a.q_cols) v *= a.qscale;
+      uint2 pk;
+      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
+      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
+    } else {
+      vals[it] = v;
+      if (planes_out) {
+        split_pair(v.x, v.y, hpl[it].x, mpl[it].x);
+        split_pair(v.z, v.w, hpl[it].y, mpl[it].y);
+      }
+    }
+  }
+  // stores go last, from registers nothing writes any more
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = rbase + it * 4 + (lane >> 4);
+    if (kBf16Out) {
+      uint2 pk; pk.x = __float_as_uint(vals[it].x); pk.y = __float_as_uint(vals[it].y);
+      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
+    } else {
+      if (Y != nullptr) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = vals[it];
+      if (planes_out) {
+        uint16_t* yp = a.Yp + hm16_off(row, a.ldyp, col);    // 4 high terms, and 16 halves further their residuals
+        *reinterpret_cast<uint2*>(yp) = hpl[it];
+        *reinterpret_cast<uint2*>(yp + 16) = mpl[it];
+      }
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_p2(GemmArgs a) {
+  constexpr int SLAB = 4 * 64 * ES;                                   // floats; the two stages (64 KB) alias it
+  static_assert(2 * STAGE * 2 <= SLAB * 4, "stages must fit under the epilogue slab");
+  __shared__ __attribute__((aligned(1024))) float smem[SLAB];
+  unsigned short* const ring = reinterpret_cast<unsigned short*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int hh = lane >> 5, ql = lane & 31;
+  int bx, by;
+  {  // XCD-aware bijective block order (see gn_gemm.hip)
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * BM, bn = bx * BN;
+  const int K = a.K, K1 = a.K1, nt = K / BK;
+
+  // ---- LDS-DMA addressing: wave w moves rows [32w, 32w + 32) of the A tile and of the W tile, 8 rows (1 KB) per
+  // instruction.  lane -> (row 32w + 8j + lane / 8, position lane & 7) fetches source chunk pos ^ f(row).
+  // hm16 rows have the byte pitch of f32 rows: k element k0 of a row starts at byte 4 k0.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned int voff_a[4], voff_w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row ^ (row >> 3)) & 7);
+    voff_a[j] = (unsigned int)(((size_t)(bm + row) * a.lda) * 4 + c * 16);
+    voff_w[j] = (unsigned int)(((size_t)(bn + row) * a.ldw) * 4 + c * 16);
+  }
+  const char* const abase = reinterpret_cast<const char*>(a.Ap) + (long long)blockIdx.z * a.strideA * 4;
+  const char* const a2base = a.A2p ? reinterpret_cast<const char*>(a.A2p) + (long long)blockIdx.z * a.strideA * 4 : nullptr;
+  const char* const wbase = reinterpret_cast<const char*>(a.Wp) + (long long)blockIdx.z * a.strideW * 4;
+  const long long a2delta = a2base ? (a2base - abase) - (long long)K1 * 4 : 0;   // byte offset that redirects k >= K1 to A2
+  // piece q (0..7) of k-tile t: q < 4: A rows 8q.., q >= 4: W rows 8(q-4)..   (scalar base + per-lane 32-bit offset)
+  auto dma_piece = [&](int q, int stage, int t) __attribute__((always_inline)) {
+    const int k0 = t * BK;
+    const long long sel = (a2base != nullptr && k0 >= K1) ? a2delta : 0;
+    const char* src = q < 4 ? abase + sel + (size_t)k0 * 4 : wbase + (size_t)k0 * 4;
+    unsigned short* ld = ring + stage * STAGE + (q < 4 ? 0 : TILE_H) + (wave_u * 32 + 8 * (q & 3)) * 64;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (q < 4 ? voff_a[q & 3] : voff_w[q & 3])), (lptr_t)ld, 16, 0, 0);
+  };
+
+  // ---- fragment addressing (halves inside a stage): lane (row, hh), k-step s, term pl -> chunk 4s + 2pl + hh
+  int arow[2], brow[2], fa_[2], fb_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wr * 64 + 32 * i + ql, rb = wc * 64 + 32 * i + ql;
+    arow[i] = ra * 64; brow[i] = TILE_H + rb * 64;
+    fa_[i] = hh ^ ((ra ^ (ra >> 3)) & 7); fb_[i] = hh ^ ((rb ^ (rb >> 3)) & 7);
+  }
+  // fragment n (0..7) of k-step ks: n = 4 * operand + 2 * tile + term
+  auto read_piece = [&](Frags& f, int stage, int ks, int n) __attribute__((always_inline)) {
+    const unsigned short* s_ = ring + stage * STAGE;
+    const int i = (n >> 1) & 1, pl = n & 1;
+    if (n < 4) f.A[i][pl] = *reinterpret_cast<const f16x8*>(s_ + arow[i] + 8 * ((4 * ks + 2 * pl) ^ fa_[i]));
+    else f.B[i][pl] = *reinterpret_cast<const f16x8*>(s_ + brow[i] + 8 * ((4 * ks + 2 * pl) ^ fb_[i]));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // MFMA n (0..11) of a k-step: product n / 4 (0: xm yh, 1: xh ym, 2: xh yh -- small terms first), accumulator n % 4
+  auto mfma_n = [&](const Frags& f, int n) __attribute__((always_inline)) {
+    const int p = n >> 2, i = (n >> 1) & 1, j = n & 1;
+    const int pa = p == 0 ? 1 : 0, pb = p == 1 ? 1 : 0;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[i][pa], f.B[j][pb], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- prologue
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_piece(q, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_piece(q, 1, 1);
+  }
+  Frags f0, f1;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) read_piece(f0, 0, 0, n);
+
+  // One barrier per k-tile: its wait drains the DMA of tile t+1 (issued one k-tile earlier) and every wave has
+  // finished reading stage `cur` by then, so the DMA of tile t+2 goes into `cur` right behind it.
+  // STEADY: tiles t+1 and t+2 exist -> no branches, pinned instruction order.
+  auto ktile = [&](int t, bool steady) __attribute__((always_inline)) {
+    const int cur = t & 1;
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {           // k-step 0 on the matrix pipe, k-step 1 fragments on the way
+      mfma_n(f0, n);
+      if (n < 8) read_piece(f1, cur, 1, n);
+      if (steady) __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {           // k-step 1; DMA of tile t+2, k-step 0 fragments of tile t+1
+      mfma_n(f1, n);
+      if (steady || t + 2 < nt) { if (n < 8) dma_piece(n, cur, t + 2); }
+      if (steady || t + 1 < nt) { if (n >= 4) read_piece(f0, cur ^ 1, 0, n - 4); }
+      if (steady) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int t = 0;
+  for (; t + 2 < nt; ++t) ktile(t, true);
+  for (; t < nt; ++t) ktile(t, false);
+
+  // ---- epilogue: accumulators -> per-wave LDS slab (aliases the stages: every wave must be done reading them)
+  __syncthreads();
+  float* const Y = a.Y ? a.Y + (long long)blockIdx.z * a.strideY : nullptr;
+  float* slab = smem + wave * 64 * ES;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        slab[row * ES + j * 32 + ql] = acc[i][j][r];
+      }
+  epilogue_64x64<EPI>(a, slab, Y, bm + wr * 64, bn + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide variant: 256x256 block tile, 8 waves (2 x 4) of 128x64 = 4x2 MFMA tiles, one block per CU.
+// With two 128x128 blocks per CU the k-loop runs at LDS-DMA latency (a k-tile's DMA is issued exactly one k-tile of
+// compute -- 0.35 us -- before it is needed, the DMA takes ~1.4 us from issue to landed); a 256x256 tile has four
+// times the MFMA work per k-tile on the same two-stage ring (2 x 64 KB), which covers that latency, and 2 MFMAs per
+// fragment read instead of 1.5.
+constexpr int WBM = 256, WBN = 256;
+constexpr int WTILE_H = WBM * 64;         // halves per operand tile: 256 rows x 128 B (32 KB)
+constexpr int WSTAGE = 2 * WTILE_H;       // halves per stage (64 KB)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm_p2w(GemmArgs a) {
+  constexpr int SLAB = 8 * 64 * ES;                                   // floats (136 KB) >= the two stages (128 KB)
+  static_assert(2 * WSTAGE * 2 <= SLAB * 4, "stages must fit under the epilogue slabs");
+  __shared__ __attribute__((aligned(1024))) float smem[SLAB];
+  unsigned short* const ring = reinterpret_cast<unsigned short*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int hh = lane >> 5, ql = lane & 31;
+  int bx, by;
+  {  // XCD-aware bijective block order
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * WBM, bn = bx * WBN;
+  const int K = a.K, K1 = a.K1, nt = K / BK;
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned int voff_a[4], voff_w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row ^ (row >> 3)) & 7);
+    voff_a[j] = (unsigned int)(((size_t)(bm + row) * a.lda) * 4 + c * 16);
+    voff_w[j] = (unsigned int)(((size_t)(bn + row) * a.ldw) * 4 + c * 16);
+  }
+  const char* const abase = reinterpret_cast<const char*>(a.Ap) + (long long)blockIdx.z * a.strideA * 4;
+  const char* const a2base = a.A2p ? reinterpret_cast<const char*>(a.A2p) + (long long)blockIdx.z * a.strideA * 4 : nullptr;
+  const char* const wbase = reinterpret_cast<const char*>(a.Wp) + (long long)blockIdx.z * a.strideW * 4;
+  const long long a2delta = a2base ? (a2base - abase) - (long long)K1 * 4 : 0;
+  auto dma_piece = [&](int q, int stage, int t) __attribute__((always_inline)) {
+    const int k0 = t * BK;
+    const long long sel = (a2base != nullptr && k0 >= K1) ? a2delta : 0;
+    const char* src = q < 4 ? abase + sel + (size_t)k0 * 4 : wbase + (size_t)k0 * 4;
+    unsigned short* ld = ring + stage * WSTAGE + (q < 4 ? 0 : WTILE_H) + (wave_u * 32 + 8 * (q & 3)) * 64;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (q < 4 ? voff_a[q & 3] : voff_w[q & 3])), (lptr_t)ld, 16, 0, 0);
+  };
+
+  int arow[4], fa_[4], brow[2], fb_[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wr * 128 + 32 * i + ql;
+    arow[i] = ra * 64; fa_[i] = hh ^ ((ra ^ (ra >> 3)) & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wc * 64 + 32 * j + ql;
+    brow[j] = WTILE_H + rb * 64; fb_[j] = hh ^ ((rb ^ (rb >> 3)) & 7);
+  }
+  // A fragments live in ONE register set that is refreshed in place: the MFMAs of a k-step run row-tile by row-tile
+  // (6 per A tile, alternating between its two accumulators), and as soon as a tile's last MFMA is issued its two
+  // registers' worth of fragments for the NEXT k-step are fetched.  Only the B fragments are double-buffered.
+  f16x8 fa[4][2], fb[2][2][2];   // fa[row tile][term], fb[buffer][col tile][term]
+  auto read_a = [&](int stage, int ks, int i) __attribute__((always_inline)) {
+    const unsigned short* s_ = ring + stage * WSTAGE;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      fa[i][pl] = *reinterpret_cast<const f16x8*>(s_ + arow[i] + 8 * ((4 * ks + 2 * pl) ^ fa_[i]));
+  };
+  auto read_b = [&](int buf, int stage, int ks, int j) __attribute__((always_inline)) {
+    const unsigned short* s_ = ring + stage * WSTAGE;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      fb[buf][j][pl] = *reinterpret_cast<const f16x8*>(s_ + brow[j] + 8 * ((4 * ks + 2 * pl) ^ fb_[j]));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // MFMA m (0..5) of row tile i: product m / 2 (0: xm yh, 1: xh ym, 2: xh yh -- small terms first), column tile m % 2
+  auto mfma_im = [&](int buf, int i, int m) __attribute__((always_inline)) {
+    const int p = m >> 1, j = m & 1;
+    const int pa = p == 0 ? 1 : 0, pb = p == 1 ? 1 : 0;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][pa], fb[buf][j][pb], acc[i][j], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_piece(q, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_piece(q, 1, 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_a(0, 0, i);
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) read_b(0, 0, 0, jj);
+
+  // k-step `ks` of tile t (B buffer ks); `nstage`, `nks` = where the following k-step's fragments come from;
+  // `dma`: also issue the 8 DMA pieces of tile t+2 into stage t & 1 (second k-step only).
+  auto kstep = [&](int ks, int nstage, int nks, bool fetch_next, bool dma, int t, bool pin) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        mfma_im(ks, i, m);
+        if (dma && (m & 1) == 0 && 3 * i + (m >> 1) < 8) dma_piece(3 * i + (m >> 1), t & 1, t + 2);   // pieces 0..7 behind the first 8 even MFMAs
+        if (fetch_next && i == 0 && (m == 1 || m == 3)) read_b(ks ^ 1, nstage, nks, m >> 1);           // next B fragments early
+        if (pin) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (fetch_next) read_a(nstage, nks, i);        // this row tile's A fragments are free now
+      if (pin) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto ktile = [&](int t, bool steady) __attribute__((always_inline)) {
+    const int cur = t & 1;
+    kstep(0, cur, 1, true, false, t, steady);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kstep(1, cur ^ 1, 0, steady || t + 1 < nt, steady || t + 2 < nt, t, steady);
+  };
+  int t = 0;
+  for (; t + 2 < nt; ++t) ktile(t, true);
+  for (; t < nt; ++t) ktile(t, false);
+
+  // ---- epilogue: two 64-row halves per wave through its private slab
+  __syncthreads();
+  float* const Y = a.Y ? a.Y + (long long)blockIdx.z * a.strideY : nullptr;
+  float* slab = smem + wave * 64 * ES;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          slab[row * ES + j * 32 + ql] = acc[2 * half + i][j][r];
+        }
+    epilogue_64x64<EPI>(a, slab, Y, bm + wr * 128 + half * 64, bn + wc * 64, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+}  // namespace
+
+int g_p2_wide = 1;   // developer knob: 0 = always the 128x128 kernel
+
+void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
+  if (g_p2_wide && a.M % WBM == 0 && a.N % WBN == 0 && a.K >= 256) {   // short-K shapes are faster on the 128x128 kernel
+    dim3 grid(a.N / WBN, a.M / WBM, batch), block(512);
+#define P2W_CASE(E) case E: hipLaunchKernelGGL((k_gemm_p2w<E>), grid, block, 0, s, a); break;
+    switch (epi) {
+      P2W_CASE(EPI_BIAS) P2W_CASE(EPI_SCALE_COLS) P2W_CASE(EPI_ROTARY) P2W_CASE(EPI_RESIDUAL)
+      P2W_CASE(EPI_ROTARY_BF16) P2W_CASE(EPI_SCALE_BF16)
+      default: hipLaunchKernelGGL((k_gemm_p2w<EPI_PLAIN>), grid, block, 0, s, a); break;
+    }
+#undef P2W_CASE
+    return;
+  }
+  dim3 grid(a.N / BN, a.M / BM, batch), block(256);
+#define P2_CASE(E) case E: hipLaunchKernelGGL((k_gemm_p2<E>), grid, block, 0, s, a); break;
+  switch (epi) {
+    P2_CASE(EPI_BIAS) P2_CASE(EPI_SCALE_COLS) P2_CASE(EPI_ROTARY) P2_CASE(EPI_RESIDUAL)
+    P2_CASE(EPI_ROTARY_BF16) P2_CASE(EPI_SCALE_BF16)
+    default: hipLaunchKernelGGL((k_gemm_p2<EPI_PLAIN>), grid, block, 0, s, a); break;
+  }
+#undef P2_CASE
+}
+
+}  // namespace gn

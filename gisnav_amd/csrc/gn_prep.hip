@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
 }
 
 // one wave per 512-wide row, in place
-__global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows) {
+__global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows, uint16_t* hp) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -131,6 +131,18 @@ __global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, c
   };
   v0.x = f(v0.x, g0.x, b0.x); v0.y = f(v0.y, g0.y, b0.y); v0.z = f(v0.z, g0.z, b0.z); v0.w = f(v0.w, g0.w, b0.w);
   v1.x = f(v1.x, g1.x, b1.x); v1.y = f(v1.y, g1.y, b1.y); v1.z = f(v1.z, g1.z, b1.z); v1.w = f(v1.w, g1.w, b1.w);
+  if (hp != nullptr) {   // hm16 rows for the f16x2 GEMM: x = xh + xm, both round-to-nearest
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    uint16_t* q0 = hp + hm16_off((size_t)row, 512, lane * 4), *q1 = hp + hm16_off((size_t)row, 512, 256 + lane * 4);
+    const f32x4v a0 = {v0.x, v0.y, v0.z, v0.w}, a1 = {v1.x, v1.y, v1.z, v1.w};
+    const f16x4 h0 = __builtin_convertvector(a0, f16x4), h1 = __builtin_convertvector(a1, f16x4);
+    const f16x4 m0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x4v), f16x4);
+    const f16x4 m1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4v), f16x4);
+    *reinterpret_cast<f16x4*>(q0) = h0; *reinterpret_cast<f16x4*>(q1) = h1;
+    *reinterpret_cast<f16x4*>(q0 + 16) = m0; *reinterpret_cast<f16x4*>(q1 + 16) = m1;
+    return;
+  }
   *reinterpret_cast<float4*>(p + lane * 4) = v0;
   *reinterpret_cast<float4*>(p + 256 + lane * 4) = v1;
 }
@@ -183,10 +195,32 @@ __global__ void k_split2_f16(const float* in, uint16_t* planes, long long n, flo
     planes[n + i] = __builtin_bit_cast(uint16_t, m);
   }
 }
+// the same split written in the hm16 row format consumed by k_gemm_p2 (4 columns per thread)
+__global__ void k_split_hm16(const float* in, uint16_t* out, long long rows, int cols, float scale) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const long long n4 = rows * cols / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n4; i += step) {
+    const long long e = i * 4, row = e / cols;
+    const int col = (int)(e - row * cols);
+    const f32x4v x = *reinterpret_cast<const f32x4v*>(in + e) * scale;
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    const f16x4 m = __builtin_convertvector(x - __builtin_convertvector(h, f32x4v), f16x4);
+    uint16_t* q = out + hm16_off((size_t)row, cols, col);
+    *reinterpret_cast<f16x4*>(q) = h;
+    *reinterpret_cast<f16x4*>(q + 16) = m;
+  }
+}
 }  // namespace
 
+void launch_split_hm16(const float* in, uint16_t* out, long long rows, int cols, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_split_hm16, dim3(2048), dim3(256), 0, s, in, out, rows, cols, scale);
+}
+
 void launch_split2_f16(const float* in, uint16_t* planes, long long n, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(k_split2_f16, dim3(512), dim3(256), 0, s, in, planes, n, scale);
+  hipLaunchKernelGGL(k_split2_f16, dim3(2048), dim3(256), 0, s, in, planes, n, scale);
 }
 
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s) {
@@ -197,8 +231,8 @@ void launch_prep(const PrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_extent, dim3(a.B * 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_prep, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
 }
-void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows);
+void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s, uint16_t* hp) {
+  hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows, hp);
 }
 void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s) {
   hipLaunchKernelGGL(k_matchability, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, ls, rows);

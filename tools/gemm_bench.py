@@ -35,21 +35,30 @@ def main():
     shapes = [(256, 128), (768, 256), (256, 256), (512, 256), (512, 512), (256, 512), (1024, 256), (512, 2048)]
     variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
     for variant in variants:
+        out_mode = 0
+        if variant >= 70:          # 71: k_gemm_p2 with hm16 output only, 72: f32 + hm16 output
+            out_mode, variant = variant - 70, 7
+        lib.gn_debug_set_variant(ctx, 7, out_mode)
         lib.gn_debug_set_variant(ctx, 0, variant)
         lib.gn_debug_set_variant(ctx, 2, 1 if variant >= 5 else 0)
         tot_ms = tot_fl = 0
         for N, K in shapes:
             A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+            if variant == 7:      # build the operand planes once, then time the GEMM alone
+                lib.gn_debug_set_variant(ctx, 6, 0); eng.debug_gemm(A, W, b); lib.gn_debug_set_variant(ctx, 6, 1)
             ms = timeit(lambda: eng.debug_gemm(A, W, b))
+            lib.gn_debug_set_variant(ctx, 6, 0)
             fl = 2.0 * M * N * K
             tot_ms += ms; tot_fl += fl
             print(f"variant {variant} M={M} N={N} K={K}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TF", flush=True)
-        print(f"variant {variant} aggregate {tot_fl / tot_ms / 1e9:.1f} TF", flush=True)
+        print(f"variant {variant} out_mode {out_mode} aggregate {tot_fl / tot_ms / 1e9:.1f} TF", flush=True)
+    lib.gn_debug_set_variant(ctx, 7, 0)
+    variants = [7 if v >= 70 else v for v in variants]
     for (M_, N_, K_) in ((1024, 384, 512), (65536, 512, 512), (65536, 256, 256)):
         A = torch.randn(M_, K_, device=dev); W = torch.randn(N_, K_, device=dev) * 0.05; b = torch.randn(N_, device=dev)
         ref = A.double() @ W.double().T + b.double()
         for v in sorted(set(variants)):
-            for planes in ((0, 1) if v == 5 else (0, 1, 14) if v == 6 else (0,)):
+            for planes in ((0, 1) if v == 5 else (0, 1, 14) if v == 6 else (1, 14) if v == 7 else (0,)):
                 lib.gn_debug_set_variant(ctx, 0, v); lib.gn_debug_set_variant(ctx, 2, planes)
                 errs = []
                 for rep in range(3):
