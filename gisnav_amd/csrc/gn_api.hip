@@ -65,6 +65,8 @@ struct gn_ctx {
   int32_t *m0 = nullptr, *m1 = nullptr;
   // pipeline scratch for gn_estimate
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
+  // visual-odometry matcher workspace (gn_vo_match)
+  float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
   gn::HypResult* hyp_ws = nullptr;
   std::vector<void*> allocs;
@@ -415,6 +417,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
+  GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
   GN_ALLOC(mask_ws, B * np * 16);
   GN_ALLOC(hyp_ws, B * 16);
 #undef GN_ALLOC
@@ -632,6 +635,60 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                     ctx->e_idx, ctx->e_score, n_match, stream);
   if (rc != GN_OK) return rc;
   rc = gn_gather_points(ctx, B, kpt_format, kpt_q, stride_q, kpt_r, stride_r, ctx->e_idx, n_match, dem, H, W,
+                        ctx->e_mkp, ctx->e_obj, stream);
+  if (rc != GN_OK) return rc;
+  return gn_pnp_ransac(ctx, B, ctx->e_obj, ctx->e_mkp, n_match, ctx->npad, K9, 10, 8.0f, 0.99, min_matches,
+                       R, t, n_inliers, ok, stream);
+}
+
+// TwistNode's matcher for B frame pairs: BFMatcher(L2).knnMatch(k=2) + ratio test (twist_node.py:248-267)
+int gn_vo_match(gn_ctx* ctx, int B, const float* desc_q, const int32_t* n_q, int stride_q,
+                const float* desc_r, const int32_t* n_r, int stride_r, double ratio,
+                int64_t* idx, float* dist, int32_t* n_good, int32_t* nn_idx, float* nn_dist, void* stream) {
+  if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
+  if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
+    return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
+  if (!desc_q || !n_q || !desc_r || !n_r || !idx || !dist || !n_good) return fail(ctx, GN_ERR_ARG, "null argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int np = ctx->npad;
+  VoArgs v;
+  v.desc_q = desc_q; v.n_q = n_q; v.stride_q = stride_q; v.desc_r = desc_r; v.n_r = n_r; v.stride_r = stride_r;
+  v.B = B; v.npad = np; v.ratio = ratio;
+  v.desc = ctx->desc; v.norm2 = ctx->vo_norm2; v.nvalid = ctx->nvalid; v.sim = ctx->sim;
+  v.nn_idx = ctx->vo_nn_idx; v.nn_dist = ctx->vo_nn_dist; v.good = ctx->vo_good;
+  v.idx = idx; v.dist = dist; v.n_good = n_good; v.kmax = np;
+  launch_vo_pack(v, s);
+  // q.r for every (query, train) pair on the exact-f32 MFMA GEMM, whatever the context's precision mode
+  GemmArgs gs;
+  memset(&gs, 0, sizeof gs);
+  gs.A = ctx->desc; gs.lda = kInDim; gs.K1 = kInDim; gs.W = ctx->desc + (size_t)np * kInDim; gs.ldw = kInDim;
+  gs.Y = ctx->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kInDim; gs.acc_scale = 1.f;
+  gs.strideA = gs.strideW = 2LL * np * kInDim; gs.strideY = (long long)np * np;
+  const int saved = gn::g_gemm_variant;
+  gn::g_gemm_variant = 3;
+  launch_gemm_f32(EPI_PLAIN, gs, B, s);
+  gn::g_gemm_variant = saved;
+  launch_vo_knn2(v, s);
+  if (nn_idx) GN_HIP(hipMemcpyAsync(nn_idx, ctx->vo_nn_idx, (size_t)B * np * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (nn_dist) GN_HIP(hipMemcpyAsync(nn_dist, ctx->vo_nn_dist, (size_t)B * np * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+// TwistNode._pose lines 227-289 for B frame pairs: 2-NN match -> ratio test -> MIN_MATCHES gate -> compute_pose with
+// a zero elevation raster (planar PnP)
+int gn_vo_estimate(gn_ctx* ctx, int B, int kpt_format,
+                   const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                   const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                   const double* K9, double ratio, int min_matches,
+                   double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
+  if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  int rc = gn_vo_match(ctx, B, desc_q, n_q, stride_q, desc_r, n_r, stride_r, ratio, ctx->e_idx, ctx->e_score, n_match,
+                       nullptr, nullptr, stream);
+  if (rc != GN_OK) return rc;
+  rc = gn_gather_points(ctx, B, kpt_format, kpt_q, stride_q, kpt_r, stride_r, ctx->e_idx, n_match, nullptr, 0, 0,
                         ctx->e_mkp, ctx->e_obj, stream);
   if (rc != GN_OK) return rc;
   return gn_pnp_ransac(ctx, B, ctx->e_obj, ctx->e_mkp, n_match, ctx->npad, K9, 10, 8.0f, 0.99, min_matches,

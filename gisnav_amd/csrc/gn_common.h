@@ -135,6 +135,22 @@ struct PnpArgs {
 void launch_pnp(const PnpArgs& a, hipStream_t s);
 void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s);
 
+// ---- visual-odometry matcher (TwistNode): brute-force 2-NN + ratio test ------------------------------------
+struct VoArgs {
+  const float* desc_q; const int32_t* n_q; int stride_q;
+  const float* desc_r; const int32_t* n_r; int stride_r;
+  int B; int npad; double ratio;
+  float* desc;              // [B*2*npad][128] packed descriptors (zeros in padding)
+  float* norm2;             // [B*2*npad] squared norms
+  int32_t* nvalid;          // [B*2]
+  const float* sim;         // [B][npad][npad] q.r panel
+  int32_t* nn_idx; float* nn_dist;   // [B][npad][2] best / second best train index and distance per query
+  uint8_t* good;            // [B][npad] ratio test passed
+  int64_t* idx; float* dist; int32_t* n_good; int kmax;   // compacted good matches (query index, train index), distance
+};
+void launch_vo_pack(const VoArgs& a, hipStream_t s);
+void launch_vo_knn2(const VoArgs& a, hipStream_t s);
+
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]

@@ -164,6 +164,36 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_estimate")
         return out
 
+    # ------------------------------------------------------------------ visual-odometry path (TwistNode)
+    def vo_match(self, desc_q, n_q, desc_r, n_r, ratio: float = 0.7, want_knn: bool = False):
+        """gn_vo_match: BFMatcher(L2).knnMatch(k=2) + ratio test.  desc [B,S,128] f32, n [B] i32 (device).
+        Returns (idx [B,kmax,2] i64, dist [B,kmax] f32, n_good [B] i32[, nn_idx [B,kmax,2] i32, nn_dist [B,kmax,2] f32])."""
+        B = desc_q.shape[0]
+        idx = torch.empty((B, self.kmax, 2), dtype=torch.int64, device=self.device)
+        dist = torch.empty((B, self.kmax), dtype=torch.float32, device=self.device)
+        n_good = torch.empty((B,), dtype=torch.int32, device=self.device)
+        nn_idx = torch.empty((B, self.kmax, 2), dtype=torch.int32, device=self.device) if want_knn else None
+        nn_dist = torch.empty((B, self.kmax, 2), dtype=torch.float32, device=self.device) if want_knn else None
+        rc = self.lib.gn_vo_match(self.ctx, B, _ptr(desc_q), _ptr(n_q), desc_q.shape[1], _ptr(desc_r), _ptr(n_r), desc_r.shape[1],
+                                  float(ratio), _ptr(idx), _ptr(dist), _ptr(n_good), _ptr(nn_idx), _ptr(nn_dist), self._stream())
+        _lib.check(self.ctx, rc, "gn_vo_match")
+        return (idx, dist, n_good, nn_idx, nn_dist) if want_knn else (idx, dist, n_good)
+
+    def vo_estimate(self, inputs: dict, K: np.ndarray, ratio: float = 0.7, min_matches: int = 30, out: Optional[dict] = None):
+        """gn_vo_estimate on staged inputs: TwistNode._pose lines 227-289 for the whole batch."""
+        B = inputs["desc_q"].shape[0]
+        if out is None:
+            out = self.alloc_outputs(B)
+        K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+        rc = self.lib.gn_vo_estimate(self.ctx, B, inputs["kpt_format"],
+                                     _ptr(inputs["desc_q"]), _ptr(inputs["kpt_q"]), _ptr(inputs["n_q"]), inputs["desc_q"].shape[1],
+                                     _ptr(inputs["desc_r"]), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["desc_r"].shape[1],
+                                     K9.ctypes.data_as(_lib.c_f64p), float(ratio), min_matches,
+                                     _ptr(out["R"]), _ptr(out["t"]), _ptr(out["n_match"]), _ptr(out["n_inliers"]), _ptr(out["ok"]),
+                                     self._stream())
+        _lib.check(self.ctx, rc, "gn_vo_estimate")
+        return out
+
     def alloc_outputs(self, B: int) -> dict:
         d = self.device
         return dict(R=torch.empty((B, 3, 3), dtype=torch.float64, device=d), t=torch.empty((B, 3, 1), dtype=torch.float64, device=d),

@@ -129,6 +129,26 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                 const uint8_t* dem, int H, int W, const double* K9_host, int min_matches,
                 double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
 
+/* ---- visual-odometry path of TwistNode ---------------------------- */
+/* cv2.BFMatcher(crossCheck=False).knnMatch(desc_qry, desc_ref, k=2) + Lowe ratio test for B frame pairs --
+ * ros/gisnav/gisnav/core/twist_node.py:95,248-267.  Descriptors [B][stride][128] f32 (cv2.SIFT output:
+ * integer-valued, for which distances are bit-identical to OpenCV's; f32 rounding of d^2 otherwise).
+ *   idx  [B][kmax][2] int64 (queryIdx, trainIdx) of the matches with m.distance < ratio * n.distance, in query
+ *        order; dist [B][kmax] f32 = m.distance; n_good [B] (0 when a pair has fewer than 2 train descriptors)
+ *   nn_idx / nn_dist: optional [B][kmax][2] best and second-best train index (int32, -1 = none) / distance
+ *        per query keypoint (the raw knnMatch result), may be NULL. */
+int gn_vo_match(gn_ctx* ctx, int B, const float* desc_q, const int32_t* n_q, int stride_q,
+                const float* desc_r, const int32_t* n_r, int stride_r, double ratio,
+                int64_t* idx, float* dist, int32_t* n_good, int32_t* nn_idx, float* nn_dist, void* stream);
+
+/* TwistNode._pose lines 227-289 for B frame pairs: knnMatch -> ratio test -> MIN_MATCHES gate ->
+ * compute_pose(camera_info, mkp_qry, mkp_ref, zeros) (planar PnP-RANSAC + Rodrigues); outputs as gn_estimate. */
+int gn_vo_estimate(gn_ctx* ctx, int B, int kpt_format,
+                   const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                   const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                   const double* K9_host, double ratio, int min_matches,
+                   double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"

@@ -74,5 +74,16 @@ def main():
                    "weights_seed0_sha256": weights_digest(sd)}, f, indent=1)
 
 
+def make_vo_fixture():
+    """tests/golden/vo_knn_seed5_q300_r280.npz: TwistNode 2-NN + ratio test on one synthetic pair (oracle/bf_knn.py)."""
+    from oracle import bf_knn
+    p = make_pair(5, n_q=300, n_r=280)
+    idx, dist = bf_knn.knn_match2(p.desc_q, p.desc_r)
+    pairs, pd = bf_knn.ratio_test(idx, dist)
+    np.savez_compressed(os.path.join(HERE, "vo_knn_seed5_q300_r280.npz"), desc_q=p.desc_q.astype(np.uint8),
+                        desc_r=p.desc_r.astype(np.uint8), nn_idx=idx, nn_dist=dist, pairs=pairs, pair_dist=pd)
+
+
 if __name__ == "__main__":
     main()
+    make_vo_fixture()
