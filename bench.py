@@ -98,6 +98,8 @@ def main() -> None:
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run the PnP stage of step n on a second stream beside the matcher of step n+1 "
+                                                           "(gn_set_overlap; measured gain < 1 %: the 256-VGPR GEMM waves leave no room for co-resident PnP waves)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -126,14 +128,18 @@ def main() -> None:
     out = eng.alloc_outputs(len(pairs))
     torch.cuda.synchronize()
 
+    if args.overlap:
+        eng.set_overlap(True)      # PnP of step n beside the matcher of step n+1 (HIP streams); flushed before the closing sync
     for _ in range(args.warmup):
         eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush()
     eng.set_kernel_timing((GEMM_LAUNCHES_PER_STEP + ATTN_LAUNCHES_PER_STEP) * args.steps)
     gdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush()
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -184,6 +190,7 @@ def main() -> None:
                 "keypoints_per_side": args.kpts,
                 "precision": args.precision,
                 "parallelism": f"pair-sharded x{world} (no data-path collective)",
+                "pose_stage_overlap": bool(args.overlap),
                 "weights": "seeded synthetic, kornia sift_lightglue state-dict layout",
             },
             "poses_per_s": round(n_ok_all * args.steps / elapsed, 2),

@@ -58,6 +58,7 @@ struct gn_ctx {
   uint16_t* dbg_wp = nullptr; size_t dbg_wp_n = 0;
   int dbg_out = 0;         // gn_debug_gemm variant 7: 1 = hm16 output only (into scratch), 2 = f32 + hm16 (timing experiments)
   uint16_t* dbg_yp = nullptr; size_t dbg_yp_n = 0;
+  int dbg_vt_skip = 0;     // timing probe: projection epilogues skip the V^T panel stores (wrong results)
   int dbg_reuse = 0;       // gn_debug_gemm: keep the operand planes of the previous call (micro-benchmarks time the GEMM alone)
   uint16_t* dbg_ap = nullptr; size_t dbg_ap_n = 0;   // gn_debug_gemm, variant 7: A planes for k_gemm_p2
   int gemm_variant = -1;   // -1: library default (f32 MFMA, LDS-DMA); 5: f32x3 (GN_PREC_F32X3_BF16_ATTN)
@@ -65,6 +66,10 @@ struct gn_ctx {
   int32_t *m0 = nullptr, *m1 = nullptr;
   // pipeline scratch for gn_estimate
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
+  // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
+  int overlap = 0; unsigned long long calls = 0;
+  hipStream_t s_pnp = nullptr; hipEvent_t ev_gather[2] = {nullptr, nullptr}, ev_pnp[2] = {nullptr, nullptr}; bool pnp_pending[2] = {false, false};
+  float* o_mkp[2] = {nullptr, nullptr}; float* o_obj[2] = {nullptr, nullptr}; int32_t* o_nmatch[2] = {nullptr, nullptr};
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -266,7 +271,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
-  const int vt_perm = (c->attn_variant == 3 || c->attn_variant == 4 || c->attn_variant >= 30) ? 1 : 0;   // k_attn_bf16_v4 reads permuted V^T
+  const int vt_perm = ((c->attn_variant == 3 || c->attn_variant == 4 || c->attn_variant >= 30) ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v4 reads permuted V^T
   const bool attn_planes = c->planes_mode && c->attn_variant == 4;   // k_attn_bf16_v5 writes the fp16 planes itself
   c->launch_count = 0;
   {
@@ -444,6 +449,11 @@ void gn_destroy(gn_ctx* ctx) {
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
+  if (ctx->s_pnp) {
+    hipStreamSynchronize(ctx->s_pnp);
+    for (int i = 0; i < 2; ++i) { hipEventDestroy(ctx->ev_gather[i]); hipEventDestroy(ctx->ev_pnp[i]); }
+    hipStreamDestroy(ctx->s_pnp);
+  }
   delete ctx;
 }
 
@@ -631,14 +641,65 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                 const uint8_t* dem, int H, int W, const double* K9, int min_matches,
                 double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (!ctx->overlap) {
+    int rc = gn_match(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r,
+                      ctx->e_idx, ctx->e_score, n_match, stream);
+    if (rc != GN_OK) return rc;
+    rc = gn_gather_points(ctx, B, kpt_format, kpt_q, stride_q, kpt_r, stride_r, ctx->e_idx, n_match, dem, H, W,
+                          ctx->e_mkp, ctx->e_obj, stream);
+    if (rc != GN_OK) return rc;
+    return gn_pnp_ransac(ctx, B, ctx->e_obj, ctx->e_mkp, n_match, ctx->npad, K9, 10, 8.0f, 0.99, min_matches,
+                         R, t, n_inliers, ok, stream);
+  }
+  // Overlapped pose stage: the latency-bound PnP kernels (a few hundred single-wave workgroups) of this call run on an
+  // internal stream while the caller's stream is free to start the next call's matcher.  The PnP inputs are
+  // double-buffered; R / t / n_inliers / ok of this call are complete once gn_flush() has been ordered behind it.
+  hipStream_t s = (hipStream_t)stream;
+  const int slot = (int)(ctx->calls++ & 1);
+  GN_HIP(hipSetDevice(ctx->device));
+  if (ctx->pnp_pending[slot]) GN_HIP(hipStreamWaitEvent(s, ctx->ev_pnp[slot], 0));   // the PnP that last read this slot
   int rc = gn_match(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r,
                     ctx->e_idx, ctx->e_score, n_match, stream);
   if (rc != GN_OK) return rc;
   rc = gn_gather_points(ctx, B, kpt_format, kpt_q, stride_q, kpt_r, stride_r, ctx->e_idx, n_match, dem, H, W,
-                        ctx->e_mkp, ctx->e_obj, stream);
+                        ctx->o_mkp[slot], ctx->o_obj[slot], stream);
   if (rc != GN_OK) return rc;
-  return gn_pnp_ransac(ctx, B, ctx->e_obj, ctx->e_mkp, n_match, ctx->npad, K9, 10, 8.0f, 0.99, min_matches,
-                       R, t, n_inliers, ok, stream);
+  GN_HIP(hipMemcpyAsync(ctx->o_nmatch[slot], n_match, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  GN_HIP(hipEventRecord(ctx->ev_gather[slot], s));
+  GN_HIP(hipStreamWaitEvent(ctx->s_pnp, ctx->ev_gather[slot], 0));
+  rc = gn_pnp_ransac(ctx, B, ctx->o_obj[slot], ctx->o_mkp[slot], ctx->o_nmatch[slot], ctx->npad, K9, 10, 8.0f, 0.99, min_matches,
+                     R, t, n_inliers, ok, ctx->s_pnp);
+  if (rc != GN_OK) return rc;
+  GN_HIP(hipEventRecord(ctx->ev_pnp[slot], ctx->s_pnp));
+  ctx->pnp_pending[slot] = true;
+  return GN_OK;
+}
+
+int gn_set_overlap(gn_ctx* ctx, int enable) {
+  if (!ctx) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  if (enable && !ctx->s_pnp) {
+    GN_HIP(hipStreamCreateWithFlags(&ctx->s_pnp, hipStreamNonBlocking));
+    const size_t B = ctx->max_batch, np = ctx->npad;
+    for (int i = 0; i < 2; ++i) {
+      GN_HIP(hipEventCreateWithFlags(&ctx->ev_gather[i], hipEventDisableTiming));
+      GN_HIP(hipEventCreateWithFlags(&ctx->ev_pnp[i], hipEventDisableTiming));
+      int rc = dalloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return rc;
+      rc = dalloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return rc;
+      rc = dalloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return rc;
+    }
+  }
+  if (!enable && ctx->s_pnp) GN_HIP(hipStreamSynchronize(ctx->s_pnp));
+  ctx->overlap = enable ? 1 : 0;
+  return GN_OK;
+}
+
+int gn_flush(gn_ctx* ctx, void* stream) {
+  if (!ctx) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  for (int i = 0; i < 2; ++i)
+    if (ctx->pnp_pending[i]) { GN_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_pnp[i], 0)); ctx->pnp_pending[i] = false; }
+  return GN_OK;
 }
 
 // TwistNode's matcher for B frame pairs: BFMatcher(L2).knnMatch(k=2) + ratio test (twist_node.py:248-267)
@@ -798,6 +859,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 6) ctx->dbg_reuse = value;
   else if (which == 7) ctx->dbg_out = value;
   else if (which == 8) gn::g_p2_wide = value;
+  else if (which == 9) ctx->dbg_vt_skip = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -147,6 +147,14 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_pnp_ransac")
         return R, t, n_inl, ok
 
+    def set_overlap(self, enable: bool) -> None:
+        """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
+        before reading R / t / n_inliers / ok."""
+        _lib.check(self.ctx, self.lib.gn_set_overlap(self.ctx, int(enable)), "gn_set_overlap")
+
+    def flush(self) -> None:
+        _lib.check(self.ctx, self.lib.gn_flush(self.ctx, self._stream()), "gn_flush")
+
     def estimate(self, inputs: dict, K: np.ndarray, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
         """gn_estimate on staged inputs: PoseNode._pose lines 246-308 for the whole batch."""
         B = inputs["desc_q"].shape[0]

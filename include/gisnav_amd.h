@@ -129,6 +129,14 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                 const uint8_t* dem, int H, int W, const double* K9_host, int min_matches,
                 double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
 
+/* Throughput option for back-to-back gn_estimate calls (batch serving): with overlap enabled the PnP stage of a call
+ * runs on an internal stream beside the matcher of the NEXT call (its inputs are double-buffered).  R / t /
+ * n_inliers / ok of a call are then complete only after gn_flush(ctx, stream) has been issued behind it (it makes
+ * `stream` wait for every outstanding PnP stage); n_match is complete in stream order as before.  Off by default:
+ * without it everything is complete in stream order when gn_estimate returns. */
+int gn_set_overlap(gn_ctx* ctx, int enable);
+int gn_flush(gn_ctx* ctx, void* stream);
+
 /* ---- visual-odometry path of TwistNode ---------------------------- */
 /* cv2.BFMatcher(crossCheck=False).knnMatch(desc_qry, desc_ref, k=2) + Lowe ratio test for B frame pairs --
  * ros/gisnav/gisnav/core/twist_node.py:95,248-267.  Descriptors [B][stride][128] f32 (cv2.SIFT output:

@@ -466,3 +466,30 @@ def test_full_size_oracle_spot_check(full_size, state_dict_t):
         for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):      # identical correspondences -> identical pose problem
             o = res[prec][3]
             assert np.linalg.norm(o["R"][b] - Ro) < 1e-8 and np.linalg.norm(o["t"][b] - to) / np.linalg.norm(to) < 1e-8
+
+
+@pytest.mark.gpu
+def test_overlapped_pose_stage_gives_identical_results(state_dict_np, dev):
+    """gn_set_overlap: PnP of call n on the internal stream beside the matcher of call n+1 -- back-to-back calls on
+    DIFFERENT batches must return exactly what the in-order path returns (double-buffered PnP inputs)."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    batches = [eng.stage_inputs([make_pair(40 + 4 * s + i, n_q=256, n_r=256) for i in range(4)]) for s in range(5)]
+    serial = []
+    for inp in batches:
+        o = eng.estimate(inp, K_MATRIX)
+        torch.cuda.synchronize()
+        serial.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+    eng.set_overlap(True)
+    outs = [eng.alloc_outputs(4) for _ in batches]
+    for inp, o in zip(batches, outs):                   # no host sync in between
+        eng.estimate(inp, K_MATRIX, out=o)
+    eng.flush()
+    torch.cuda.current_stream().synchronize()           # the caller's stream alone must now see every result
+    for s, o in zip(serial, outs):
+        for k in s:
+            assert np.array_equal(s[k], o[k].cpu().numpy()), k
+    eng.set_overlap(False)
+    o = eng.estimate(batches[0], K_MATRIX)
+    torch.cuda.synchronize()
+    assert all(np.array_equal(serial[0][k], o[k].cpu().numpy()) for k in serial[0])
