@@ -40,6 +40,8 @@ SIGNATURES = {
     "gn_vo_match": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP, VP, VP, VP, VP]),
     "gn_vo_estimate": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, c_f64p, C.c_double, C.c_int,
                                  VP, VP, VP, VP, VP, VP]),
+    "gn_rotate_crop_center": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, VP, c_f64p, VP]),
+    "gn_stereo_reference": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, VP, VP, c_f64p, VP]),
     "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
     "gn_debug_gemm": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "gn_debug_attention": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, VP, C.c_int,

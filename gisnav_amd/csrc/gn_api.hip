@@ -756,6 +756,64 @@ int gn_vo_estimate(gn_ctx* ctx, int B, int kpt_format,
                        R, t, n_inliers, ok, stream);
 }
 
+namespace {
+// cv::getRotationMatrix2D + the in-place inversion at the top of cv::warpAffine (f64, same operation order), and the
+// matrix StereoNode._rotate_and_crop_center returns (inverse of the rotation, times the crop translation)
+void rotate_crop_matrices(int H, int W, double angle_degrees, int crop_h, int crop_w, double Minv6[6], int* dx, int* dy, double back9[9]) {
+  const int cxi = W / 2, cyi = H / 2;
+  const double a = angle_degrees * (3.14159265358979323846 / 180.0);
+  const double alpha = std::cos(a), beta = std::sin(a);
+  const double cx = (double)(float)cxi, cy = (double)(float)cyi;
+  const double m[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+  double M[6] = {m[0], m[1], m[2], m[3], m[4], m[5]};
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0 ? 1. / D : 0;
+  const double A11 = M[4] * D, A22 = M[0] * D;
+  M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+  const double b1 = -M[0] * M[2] - M[1] * M[5];
+  const double b2 = -M[3] * M[2] - M[4] * M[5];
+  M[2] = b1; M[5] = b2;
+  for (int i = 0; i < 6; ++i) Minv6[i] = M[i];
+  *dx = cxi - crop_w / 2; *dy = cyi - crop_h / 2;
+  if (back9) {   // inv([[m]; 0 0 1]) @ [[1 0 dx], [0 1 dy], [0 0 1]]  (adjugate form of the 3x3 inverse)
+    const double det = m[0] * m[4] - m[1] * m[3];
+    const double i00 = m[4] / det, i01 = -m[1] / det, i02 = (m[1] * m[5] - m[2] * m[4]) / det;
+    const double i10 = -m[3] / det, i11 = m[0] / det, i12 = (m[2] * m[3] - m[0] * m[5]) / det;
+    back9[0] = i00; back9[1] = i01; back9[2] = i00 * *dx + i01 * *dy + i02;
+    back9[3] = i10; back9[4] = i11; back9[5] = i10 * *dx + i11 * *dy + i12;
+    back9[6] = 0; back9[7] = 0; back9[8] = 1;
+  }
+}
+}  // namespace
+
+// StereoNode._rotate_and_crop_center on a 2-channel u8 stack (stereo_node.py:292-335)
+int gn_rotate_crop_center(gn_ctx* ctx, const uint8_t* stack, int H, int W, double angle_degrees, int crop_h, int crop_w,
+                          uint8_t* out_stack, double* back9_host, void* stream) {
+  if (!ctx || !stack || !out_stack || H < 1 || W < 1 || crop_h < 1 || crop_w < 1 || crop_h > H || crop_w > W)
+    return fail(ctx, GN_ERR_ARG, "bad gn_rotate_crop_center argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  WarpArgs a;
+  a.src0 = stack; a.src1 = nullptr; a.H = H; a.W = W; a.crop_h = crop_h; a.crop_w = crop_w; a.out0 = out_stack; a.out1 = nullptr;
+  rotate_crop_matrices(H, W, angle_degrees, crop_h, crop_w, a.M, &a.dx, &a.dy, back9_host);
+  launch_rotate_crop(a, false, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+// stereo_node.py:229-262 in one pass: BGR -> gray, stack with the DEM, rotate, crop -> reference raster + DEM raster
+int gn_stereo_reference(gn_ctx* ctx, const uint8_t* bgr, const uint8_t* dem, int H, int W, double angle_degrees,
+                        int crop_h, int crop_w, uint8_t* out_ref, uint8_t* out_dem, double* back9_host, void* stream) {
+  if (!ctx || !bgr || !dem || !out_ref || !out_dem || H < 1 || W < 1 || crop_h < 1 || crop_w < 1 || crop_h > H || crop_w > W)
+    return fail(ctx, GN_ERR_ARG, "bad gn_stereo_reference argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  WarpArgs a;
+  a.src0 = bgr; a.src1 = dem; a.H = H; a.W = W; a.crop_h = crop_h; a.crop_w = crop_w; a.out0 = out_ref; a.out1 = out_dem;
+  rotate_crop_matrices(H, W, angle_degrees, crop_h, crop_w, a.M, &a.dx, &a.dy, back9_host);
+  launch_rotate_crop(a, true, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
 int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream) {
   if (!ctx || !name || !host_out) return GN_ERR_ARG;
   hipSetDevice(ctx->device);

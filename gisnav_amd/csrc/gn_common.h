@@ -151,6 +151,16 @@ struct VoArgs {
 void launch_vo_pack(const VoArgs& a, hipStream_t s);
 void launch_vo_knn2(const VoArgs& a, hipStream_t s);
 
+// ---- StereoNode reference raster: rotate about the centre + centre crop (2 u8 channels) --------------------
+struct WarpArgs {
+  const uint8_t* src0; const uint8_t* src1;   // fused: BGR [H][W][3] and DEM [H][W]; else src0 = stack [H][W][2], src1 unused
+  int H, W;
+  double M[6];                                // INVERTED affine map (dst -> src), as cv::warpAffine computes it
+  int dx, dy, crop_h, crop_w;                 // crop window of the (virtual) rotated W x H image
+  uint8_t* out0; uint8_t* out1;               // out1 != nullptr: two planes [crop_h][crop_w]; else interleaved [crop_h][crop_w][2]
+};
+void launch_rotate_crop(const WarpArgs& a, bool fused_gray, hipStream_t s);
+
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]

@@ -288,7 +288,7 @@ constexpr int WBM = 256, WBN = 256;
 constexpr int WTILE_H = WBM * 64;         // halves per operand tile: 256 rows x 128 B (32 KB)
 constexpr int WSTAGE = 2 * WTILE_H;       // halves per stage (64 KB)
 
-template <int EPI>
+template <int EPI, int ABL = 0>   // ABL: timing-only ablations (1: no DMA in the loop, 2: no fragment reads in the loop, 4: no barrier)
 __global__ __launch_bounds__(512) void k_gemm_p2w(GemmArgs a) {
   constexpr int SLAB = 8 * 64 * ES;                                   // floats (136 KB) >= the two stages (128 KB)
   static_assert(2 * WSTAGE * 2 <= SLAB * 4, "stages must fit under the epilogue slabs");
@@ -392,18 +392,18 @@ __global__ __launch_bounds__(512) void k_gemm_p2w(GemmArgs a) {
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         mfma_im(ks, i, m);
-        if (dma && (m & 1) == 0 && 3 * i + (m >> 1) < 8) dma_piece(3 * i + (m >> 1), t & 1, t + 2);   // pieces 0..7 behind the first 8 even MFMAs
-        if (fetch_next && i == 0 && (m == 1 || m == 3)) read_b(ks ^ 1, nstage, nks, m >> 1);           // next B fragments early
+        if (!(ABL & 1) && dma && (m & 1) == 0 && 3 * i + (m >> 1) < 8) dma_piece(3 * i + (m >> 1), t & 1, t + 2);   // pieces 0..7 behind the first 8 even MFMAs
+        if (!(ABL & 2) && fetch_next && i == 0 && (m == 1 || m == 3)) read_b(ks ^ 1, nstage, nks, m >> 1);           // next B fragments early
         if (pin) __builtin_amdgcn_sched_barrier(0);
       }
-      if (fetch_next) read_a(nstage, nks, i);        // this row tile's A fragments are free now
+      if (!(ABL & 2) && fetch_next) read_a(nstage, nks, i);        // this row tile's A fragments are free now
       if (pin) __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto ktile = [&](int t, bool steady) __attribute__((always_inline)) {
     const int cur = t & 1;
     kstep(0, cur, 1, true, false, t, steady);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     kstep(1, cur ^ 1, 0, steady || t + 1 < nt, steady || t + 2 < nt, t, steady);
   };
   int t = 0;
@@ -436,6 +436,17 @@ __global__ __launch_bounds__(512) void k_gemm_p2w(GemmArgs a) {
 int g_p2_wide = 1;   // developer knob: 0 = always the 128x128 kernel
 
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
+  if (g_p2_wide >= 2 && epi == EPI_BIAS && a.M % WBM == 0 && a.N % WBN == 0) {   // timing-only ablations of the wide kernel
+    dim3 grid(a.N / WBN, a.M / WBM, batch), block(512);
+    switch (g_p2_wide) {
+      case 2: hipLaunchKernelGGL((k_gemm_p2w<EPI_BIAS, 1>), grid, block, 0, s, a); break;
+      case 3: hipLaunchKernelGGL((k_gemm_p2w<EPI_BIAS, 2>), grid, block, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((k_gemm_p2w<EPI_BIAS, 3>), grid, block, 0, s, a); break;
+      case 5: hipLaunchKernelGGL((k_gemm_p2w<EPI_BIAS, 4>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_p2w<EPI_BIAS, 7>), grid, block, 0, s, a); break;
+    }
+    return;
+  }
   if (g_p2_wide && a.M % WBM == 0 && a.N % WBN == 0 && a.K >= 256) {   // short-K shapes are faster on the 128x128 kernel
     dim3 grid(a.N / WBN, a.M / WBM, batch), block(512);
 #define P2W_CASE(E) case E: hipLaunchKernelGGL((k_gemm_p2w<E>), grid, block, 0, s, a); break;

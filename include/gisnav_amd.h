@@ -157,6 +157,18 @@ int gn_vo_estimate(gn_ctx* ctx, int B, int kpt_format,
                    const double* K9_host, double ratio, int min_matches,
                    double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
 
+/* ---- StereoNode reference-raster preparation ----------------------- */
+/* StereoNode._rotate_and_crop_center(image, angle_degrees, shape) -- ros/gisnav/gisnav/core/stereo_node.py:292-335:
+ * cv2.getRotationMatrix2D((W//2, H//2), angle, 1.0) + cv2.warpAffine(image, M, (W, H)) [INTER_LINEAR, constant 0
+ * border] + centre crop, on a 2-channel u8 stack [H][W][2] (device).  out_stack [crop_h][crop_w][2] (device);
+ * back9_host: optional HOST 3x3 f64 = the returned matrix (rotated-and-cropped frame -> original frame). */
+int gn_rotate_crop_center(gn_ctx* ctx, const uint8_t* stack, int H, int W, double angle_degrees, int crop_h, int crop_w,
+                          uint8_t* out_stack, double* back9_host, void* stream);
+/* stereo_node.py:229-262 fused: cv2.cvtColor(BGR2GRAY) + np.dstack((gray, dem)) + _rotate_and_crop_center.
+ * bgr [H][W][3] u8, dem [H][W] u8 (device) -> out_ref, out_dem [crop_h][crop_w] u8 (device). */
+int gn_stereo_reference(gn_ctx* ctx, const uint8_t* bgr, const uint8_t* dem, int H, int W, double angle_degrees,
+                        int crop_h, int crop_w, uint8_t* out_ref, uint8_t* out_dem, double* back9_host, void* stream);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"

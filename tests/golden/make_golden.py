@@ -84,6 +84,18 @@ def make_vo_fixture():
                         desc_r=p.desc_r.astype(np.uint8), nn_idx=idx, nn_dist=dist, pairs=pairs, pair_dist=pd)
 
 
+def make_stereo_fixture():
+    """tests/golden/stereo_rot_seed3.npz: StereoNode gray + DEM stack, rotated 23.5 deg and centre-cropped (oracle/stereo_warp.py)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_stereo import _tile
+    from oracle import stereo_warp as sw
+    bgr, dem = _tile(3, 300, 400)
+    ref, do, minv = sw.stereo_reference(bgr, dem, 23.5, (180, 240))
+    np.savez_compressed(os.path.join(HERE, "stereo_rot_seed3.npz"), bgr=bgr, dem=dem, angle=np.float64(23.5), crop=np.array([180, 240]),
+                        ref=ref, dem_out=do, minv=minv)
+
+
 if __name__ == "__main__":
     main()
     make_vo_fixture()
+    make_stereo_fixture()

@@ -36,7 +36,10 @@ def main():
     variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
     for variant in variants:
         out_mode = 0
-        if variant >= 70:          # 71: k_gemm_p2 with hm16 output only, 72: f32 + hm16 output
+        lib.gn_debug_set_variant(ctx, 8, 1)
+        if variant >= 700:         # 70x: k_gemm_p2w timing ablations (g_p2_wide = x)
+            lib.gn_debug_set_variant(ctx, 8, variant - 700); variant = 7
+        elif variant >= 70:          # 71: k_gemm_p2 with hm16 output only, 72: f32 + hm16 output
             out_mode, variant = variant - 70, 7
         lib.gn_debug_set_variant(ctx, 7, out_mode)
         lib.gn_debug_set_variant(ctx, 0, variant)
