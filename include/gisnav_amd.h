@@ -169,6 +169,18 @@ int gn_rotate_crop_center(gn_ctx* ctx, const uint8_t* stack, int H, int W, doubl
 int gn_stereo_reference(gn_ctx* ctx, const uint8_t* bgr, const uint8_t* dem, int H, int W, double angle_degrees,
                         int crop_h, int crop_w, uint8_t* out_ref, uint8_t* out_dem, double* back9_host, void* stream);
 
+/* ---- post-pose georeferencing (host-side scalar code, no context) ---- */
+/* _transformations.py:298-323 proj_to_affine: "+proj=affine +xoff=.. +s11=.. ..." -> 3x4 row-major [s11 s12 s13 xoff; ...]. */
+int gn_proj_to_affine(const char* proj_str, double* affine12);
+/* _transformations.py:326-345 wgs84_to_ecef (pyproj latlong -> geocent on the WGS 84 datum), degrees / metres. */
+int gn_wgs84_to_ecef(double lon_deg, double lat_deg, double alt_m, double* xyz3);
+/* pose_node.py:333-381: r [9] row-major, t [3] of compute_pose + the OrthoStereoImage CRS affine ->
+ * `earth`-frame camera position (ECEF metres) and orientation quaternion (x, y, z, w) of gisnav_camera_link_optical;
+ * lonlatalt3 optional.  Returns GN_OK, or 1 if the camera centre is outside the expected range of the reference
+ * raster (the node returns None, pose_node.py:339-341). */
+int gn_pose_to_earth(const double* R9, const double* t3, const double* affine12, int ref_h, int ref_w,
+                     double* position_ecef3, double* quat_xyzw4, double* lonlatalt3);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"
