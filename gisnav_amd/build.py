@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgisnav_amd.so")
-SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_pnp.hip"]
+SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_pnp.hip"]
 # -fno-slp-vectorize: with SLP packing on, hipcc (ROCm 7.2) turned the rotary epilogue's scalar f32 math into
 # v_pk_mul_f32 / v_pk_fma_f32 sequences with op_sel that produced timing-dependent wrong results on gfx950 when
 # two waves share a SIMD (one float4 component of a 16-lane group, a few elements per 10^7; found with a
@@ -22,7 +22,9 @@ SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_attention.hip", "g
 FLAGS = ["--offload-arch=gfx950", "-fno-slp-vectorize", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
 # attention: keep the MFMA accumulators in VGPRs (the softmax reads the scores and rescales the output every tile;
 # with the default AGPR form each tile paid ~255 v_accvgpr_read/write moves on the VALU, the kernel's bottleneck)
-EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # SIFT: no fused multiply-adds -- every float operation rounds separately, as in the oracle (and in OpenCV's scalar code)
+               "gn_sift.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -70,6 +70,11 @@ struct gn_ctx {
   int overlap = 0; unsigned long long calls = 0;
   hipStream_t s_pnp = nullptr; hipEvent_t ev_gather[2] = {nullptr, nullptr}, ev_pnp[2] = {nullptr, nullptr}; bool pnp_pending[2] = {false, false};
   float* o_mkp[2] = {nullptr, nullptr}; float* o_obj[2] = {nullptr, nullptr}; int32_t* o_nmatch[2] = {nullptr, nullptr};
+  // SIFT workspace (gn_sift_detect_and_compute), sized for the last image shape seen
+  int sift_h = 0, sift_w = 0; std::vector<void*> sift_allocs; SiftPyramid sift_py; float* sift_tmp = nullptr;
+  float* sift_dk = nullptr; std::vector<std::vector<float>> sift_kernels; std::vector<int> sift_koff;   // [0] = initial blur, [1..5] = layer blurs
+  int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr; float* sift_hist = nullptr;
+  int sift_max_cand = 0, sift_max_kp = 0;
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -449,6 +454,7 @@ void gn_destroy(gn_ctx* ctx) {
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
+  for (void* p : ctx->sift_allocs) hipFree(p);
   if (ctx->s_pnp) {
     hipStreamSynchronize(ctx->s_pnp);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(ctx->ev_gather[i]); hipEventDestroy(ctx->ev_pnp[i]); }
@@ -810,6 +816,110 @@ int gn_stereo_reference(gn_ctx* ctx, const uint8_t* bgr, const uint8_t* dem, int
   a.src0 = bgr; a.src1 = dem; a.H = H; a.W = W; a.crop_h = crop_h; a.crop_w = crop_w; a.out0 = out_ref; a.out1 = out_dem;
   rotate_crop_matrices(H, W, angle_degrees, crop_h, crop_w, a.M, &a.dx, &a.dy, back9_host);
   launch_rotate_crop(a, true, (hipStream_t)stream);
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+namespace {
+int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
+  if (ctx->sift_h == H && ctx->sift_w == W && ctx->sift_max_kp >= max_kp) return GN_OK;
+  for (void* p : ctx->sift_allocs) hipFree(p);
+  ctx->sift_allocs.clear();
+  auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; ctx->sift_allocs.push_back(p); return p; };
+  const int bw = 2 * W, bh = 2 * H;
+  int n_oct = (int)std::nearbyint(std::log((double)std::min(bw, bh)) / std::log(2.0) - 2) + 1;
+  if (n_oct < 1) n_oct = 1;
+  if (n_oct > kSiftMaxOctaves) n_oct = kSiftMaxOctaves;
+  SiftPyramid& py = ctx->sift_py;
+  py.n_oct = n_oct;
+  int w = bw, h = bh;
+  for (int o = 0; o < n_oct; ++o) {
+    py.oct[o].w = w; py.oct[o].h = h;
+    const size_t n = (size_t)w * h;
+    float* block = (float*)alloc(11 * n * sizeof(float));
+    if (!block) return fail(ctx, GN_ERR_HIP, "SIFT pyramid allocation failed");
+    for (int i = 0; i < 6; ++i) py.oct[o].gauss[i] = block + i * n;
+    for (int i = 0; i < 5; ++i) py.oct[o].dog[i] = block + (6 + i) * n;
+    w /= 2; h /= 2;
+    if (w < 1 || h < 1) { py.n_oct = o + 1; break; }
+  }
+  ctx->sift_tmp = (float*)alloc((size_t)bw * bh * sizeof(float));
+  // blur kernels: sigma differences of createInitialImage / buildGaussianPyramid (f64 on the host, libm exp)
+  const double sigma = 1.6;
+  std::vector<double> sig(6);
+  ctx->sift_kernels.assign(6, {});
+  sift_gaussian_kernel(std::sqrt(std::max(sigma * sigma - 0.5 * 0.5 * 4, 0.01)), ctx->sift_kernels[0]);
+  const double k = std::pow(2.0, 1.0 / 3.0);
+  for (int i = 1; i < 6; ++i) {
+    const double sp = std::pow(k, (double)(i - 1)) * sigma, st = sp * k;
+    sift_gaussian_kernel(std::sqrt(st * st - sp * sp), ctx->sift_kernels[i]);
+  }
+  size_t tot = 0; ctx->sift_koff.assign(6, 0);
+  for (int i = 0; i < 6; ++i) { ctx->sift_koff[i] = (int)tot; tot += ctx->sift_kernels[i].size(); }
+  ctx->sift_dk = (float*)alloc(tot * sizeof(float));
+  for (int i = 0; i < 6; ++i)
+    if (hipMemcpy(ctx->sift_dk + ctx->sift_koff[i], ctx->sift_kernels[i].data(), ctx->sift_kernels[i].size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ctx, GN_ERR_HIP, "SIFT kernel upload failed");
+  ctx->sift_max_cand = std::max(65536, 16 * max_kp);
+  ctx->sift_max_kp = std::max(max_kp, 1024);
+  ctx->sift_cand = (int4*)alloc((size_t)ctx->sift_max_cand * sizeof(int4));
+  ctx->sift_counts = (int*)alloc(2 * sizeof(int));
+  ctx->sift_kp = (SiftKeypoint*)alloc((size_t)4 * ctx->sift_max_kp * sizeof(SiftKeypoint));
+  ctx->sift_hist = (float*)alloc((size_t)ctx->sift_max_kp * 360 * sizeof(float));
+  if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp || !ctx->sift_hist)
+    return fail(ctx, GN_ERR_HIP, "SIFT workspace allocation failed");
+  ctx->sift_h = H; ctx->sift_w = W;
+  return GN_OK;
+}
+}  // namespace
+
+// cv2.SIFT_create().detectAndCompute(gray, None): pose_node.py:122,230-232, twist_node.py:93,227-245
+int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
+                               float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream) {
+  if (!ctx || !gray || !kpt_xysa || !desc || !n_out_host || H < 16 || W < 16 || max_kpts < 1)
+    return fail(ctx, GN_ERR_ARG, "bad gn_sift_detect_and_compute argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  int rc = sift_prepare(ctx, H, W, max_kpts);
+  if (rc != GN_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  SiftPyramid& py = ctx->sift_py;
+  auto blur = [&](const float* in, float* out, int w, int h, int ki) {
+    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s);
+  };
+  // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
+  sift_base(gray, H, W, py.oct[0].gauss[5], s);                      // scratch: level 5 is overwritten later
+  blur(py.oct[0].gauss[5], py.oct[0].gauss[0], py.oct[0].w, py.oct[0].h, 0);
+  for (int o = 0; o < py.n_oct; ++o) {
+    const SiftOctave& oc = py.oct[o];
+    if (o > 0) sift_half(py.oct[o - 1].gauss[3], py.oct[o - 1].w, oc.gauss[0], oc.w, oc.h, s);
+    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i);
+    for (int i = 0; i < 5; ++i) sift_sub(oc.gauss[i + 1], oc.gauss[i], oc.dog[i], (size_t)oc.w * oc.h, s);
+  }
+  GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 2 * sizeof(int), s));
+  const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);
+  sift_find(py, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
+  const int max_raw = 4 * ctx->sift_max_kp;
+  sift_refine(py, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, ctx->sift_kp, ctx->sift_counts + 1, max_raw, s);
+  int counts[2] = {0, 0};
+  GN_HIP(hipMemcpyAsync(counts, ctx->sift_counts, sizeof counts, hipMemcpyDeviceToHost, s));
+  GN_HIP(hipStreamSynchronize(s));
+  if (counts[0] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
+  if (counts[1] > max_raw) return fail(ctx, GN_ERR_ARG, "SIFT keypoint buffer overflow (raise max_kpts)");
+  std::vector<SiftKeypoint> kp(counts[1]);
+  if (!kp.empty()) GN_HIP(hipMemcpy(kp.data(), ctx->sift_kp, kp.size() * sizeof(SiftKeypoint), hipMemcpyDeviceToHost));
+  sift_sort_dedup(kp);                                               // deterministic order whatever the atomics did
+  if ((int)kp.size() > max_kpts || (int)kp.size() > ctx->sift_max_kp) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
+  const int n = (int)kp.size();
+  *n_out_host = n;
+  if (n == 0) return GN_OK;
+  GN_HIP(hipMemcpyAsync(ctx->sift_kp, kp.data(), (size_t)n * sizeof(SiftKeypoint), hipMemcpyHostToDevice, s));
+  sift_descriptors(py, ctx->sift_kp, n, desc, ctx->sift_hist, s);
+  std::vector<float> xysa((size_t)n * 4), resp(n); std::vector<int32_t> oct(n);
+  for (int i = 0; i < n; ++i) { xysa[4 * i] = kp[i].x; xysa[4 * i + 1] = kp[i].y; xysa[4 * i + 2] = kp[i].size; xysa[4 * i + 3] = kp[i].angle; resp[i] = kp[i].response; oct[i] = kp[i].octave; }
+  GN_HIP(hipMemcpyAsync(kpt_xysa, xysa.data(), xysa.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  if (response) GN_HIP(hipMemcpyAsync(response, resp.data(), resp.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  if (octave) GN_HIP(hipMemcpyAsync(octave, oct.data(), oct.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  GN_HIP(hipStreamSynchronize(s));                                   // the host vectors above must outlive the copies
   GN_HIP(hipGetLastError());
   return GN_OK;
 }

@@ -161,6 +161,21 @@ struct WarpArgs {
 };
 void launch_rotate_crop(const WarpArgs& a, bool fused_gray, hipStream_t s);
 
+// ---- SIFT (cv2.SIFT_create().detectAndCompute) -------------------------------------------------------------
+constexpr int kSiftMaxOctaves = 12;
+struct SiftOctave { float* gauss[6]; float* dog[5]; int w, h; };
+struct SiftPyramid { SiftOctave oct[kSiftMaxOctaves]; int n_oct; };
+struct SiftKeypoint { float x, y, size, angle, response; int octave; };
+void sift_gaussian_kernel(double sigma, std::vector<float>& k);
+void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s);
+void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s);
+void sift_half(const float* in, int w, float* out, int w2, int h2, hipStream_t s);
+void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s);
+void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s);
+void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, int n, float* desc, float* hist_ws, hipStream_t s);
+void sift_sort_dedup(std::vector<SiftKeypoint>& k);
+
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]

@@ -7,9 +7,9 @@ reference / DEM rasters, (re)compute reference-tile features only when the tile 
 after line 308 (debug images, PROJ georeferencing, tf2, message assembly) needs ROS / pyproj and
 is out of scope; an rclpy node would wrap `estimate()` unchanged.
 
-The reference extracts tile features with `cv2.SIFT_create().detectAndCompute`; a GPU SIFT is a
-"next" row, so the extractor is injected: any callable
-`extractor(ref_u8) -> (kp (M,2) f32, desc (M,128) f32, size (M,), angle_deg (M,))`.
+The reference extracts tile features with `cv2.SIFT_create().detectAndCompute` (pose_node.py:122,230); here the default
+extractor is the library's own SIFT (`gisnav_amd.sift.SIFT`, gn_sift_detect_and_compute).  Any
+callable `extractor(ref_u8) -> (kp (M,2) f32, desc (M,128) f32, size (M,), angle_deg (M,))` can be injected instead.
 """
 from __future__ import annotations
 
@@ -27,9 +27,12 @@ class PoseNode:
     CONFIDENCE_THRESHOLD = 0.5   # pose_node.py:60
     MIN_MATCHES = MIN_MATCHES    # pose_node.py:63
 
-    def __init__(self, state_dict, extractor: Callable, device: int = 0, max_kpts: int = 4096, precision: str = "f32"):
+    def __init__(self, state_dict, extractor: Optional[Callable] = None, device: int = 0, max_kpts: int = 4096, precision: str = "f32"):
         self._engine = PoseEngine(device, max_batch=1, max_kpts=max_kpts, precision=precision, state_dict=state_dict,
                                   n_layers=9, filter_threshold=self.CONFIDENCE_THRESHOLD)
+        if extractor is None:
+            from .sift import SIFT
+            extractor = SIFT(engine=self._engine, max_keypoints=max_kpts).as_extractor()
         self._extractor = extractor
         self._cached_stamp_kps_desc = None
         self.camera_info: Optional[CameraInfo] = None

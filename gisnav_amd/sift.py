@@ -1,0 +1,65 @@
+"""Host-side mirror of `cv2.SIFT_create()` as GISNav uses it: `detectAndCompute(image, None)` for
+the reference tile (pose_node.py:122,230-232) and for every camera frame (twist_node.py:93,227-245).  Marshalling only:
+scale space, keypoints and descriptors are produced by libgisnav_amd.so (`gn_sift_detect_and_compute`)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import PoseEngine, _ptr
+
+
+class KeyPoint(NamedTuple):
+    """The cv2.KeyPoint fields GISNav reads (pt, size, angle) plus response / octave."""
+    pt: Tuple[float, float]
+    size: float
+    angle: float
+    response: float
+    octave: int
+
+
+class SIFT:
+    """`cv2.SIFT_create()` stand-in.  `detectAndCompute(image, None)` returns (list of KeyPoint, descriptors [N,128] float32)
+    like cv2; `detect_and_compute_device` keeps everything in HBM in the layout `gn_match` / `gn_estimate` consume."""
+
+    def __init__(self, engine: Optional[PoseEngine] = None, device: int = 0, max_keypoints: int = 8192):
+        self._eng = engine if engine is not None else PoseEngine(device, max_batch=1, max_kpts=128, precision="f32")
+        self._max = int(max_keypoints)
+
+    def detect_and_compute_device(self, image):
+        """image: (H, W) uint8 numpy array or device tensor.  Returns (kpt_xysa [N,4] f32, response [N], octave [N] i32,
+        desc [N,128] f32) as device tensors, N keypoints in OpenCV's order."""
+        eng = self._eng
+        t = image if isinstance(image, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(image, np.uint8), device=eng.device)
+        assert t.dtype == torch.uint8 and t.dim() == 2, "expected a single-channel uint8 image"
+        H, W = int(t.shape[0]), int(t.shape[1])
+        kpt = torch.empty((self._max, 4), dtype=torch.float32, device=eng.device)
+        resp = torch.empty((self._max,), dtype=torch.float32, device=eng.device)
+        octv = torch.empty((self._max,), dtype=torch.int32, device=eng.device)
+        desc = torch.empty((self._max, 128), dtype=torch.float32, device=eng.device)
+        n = C.c_int32(0)
+        rc = eng.lib.gn_sift_detect_and_compute(eng.ctx, _ptr(t.contiguous()), H, W, self._max, _ptr(kpt), _ptr(resp), _ptr(octv), _ptr(desc),
+                                                C.byref(n), eng._stream())
+        _lib.check(eng.ctx, rc, "gn_sift_detect_and_compute")
+        k = int(n.value)
+        return kpt[:k], resp[:k], octv[:k], desc[:k]
+
+    def detectAndCompute(self, image, mask=None):
+        if mask is not None:
+            raise ValueError("masks are not supported (GISNav passes None)")
+        kpt, resp, octv, desc = self.detect_and_compute_device(image)
+        k, r, o = kpt.cpu().numpy(), resp.cpu().numpy(), octv.cpu().numpy()
+        kps: List[KeyPoint] = [KeyPoint((float(k[i, 0]), float(k[i, 1])), float(k[i, 2]), float(k[i, 3]), float(r[i]), int(o[i])) for i in range(len(k))]
+        return kps, desc.cpu().numpy()
+
+    def as_extractor(self):
+        """The `extractor(ref_u8) -> (kp, desc, size, angle)` callable `gisnav_amd.pose_node.PoseNode` takes."""
+        def extractor(ref_u8):
+            kpt, _, _, desc = self.detect_and_compute_device(ref_u8)
+            k = kpt.cpu().numpy()
+            return k[:, :2], desc.cpu().numpy(), k[:, 2], k[:, 3]
+        return extractor

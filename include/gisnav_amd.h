@@ -181,6 +181,17 @@ int gn_wgs84_to_ecef(double lon_deg, double lat_deg, double alt_m, double* xyz3)
 int gn_pose_to_earth(const double* R9, const double* t3, const double* affine12, int ref_h, int ref_w,
                      double* position_ecef3, double* quat_xyzw4, double* lonlatalt3);
 
+/* ---- SIFT feature extraction ------------------------------------------ */
+/* cv2.SIFT_create().detectAndCompute(gray, None) with OpenCV's defaults -- the tile extractor of PoseNode
+ * (pose_node.py:122,230-232) and the frame extractor of TwistNode (twist_node.py:93,227-245).
+ *   gray [H][W] u8 (device).  Outputs (device): kpt_xysa [max_kpts][4] f32 = (x, y, size, angle_deg) -- the
+ *   GN_KPT_XYSA keypoint format of gn_match / gn_estimate; response [max_kpts] f32 and octave [max_kpts] int32
+ *   (packed as cv2.KeyPoint.octave) may be NULL; desc [max_kpts][128] f32 (integer-valued 0..255, as cv2 emits).
+ *   n_out_host: HOST int32, number of keypoints, in OpenCV's order (sorted by x, y, size desc, angle, ...).
+ * Synchronises `stream` (the keypoint list is sorted and de-duplicated on the host, like OpenCV does). */
+int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
+                               float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"

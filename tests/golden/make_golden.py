@@ -95,7 +95,19 @@ def make_stereo_fixture():
                         ref=ref, dem_out=do, minv=minv)
 
 
+def make_sift_fixture():
+    """tests/golden/sift_blobs_seed2.npz: cv2.SIFT_create().detectAndCompute on a 96x128 blob image (oracle/sift.py)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_sift import blob_image
+    from oracle import sift as osift
+    img = blob_image(2, 96, 128)
+    kp, size, ang, resp, octv, desc = osift.detect_and_compute(img)
+    np.savez_compressed(os.path.join(HERE, "sift_blobs_seed2.npz"), image=img, kp=kp, size=size, angle=ang, response=resp, octave=octv,
+                        desc=desc.astype(np.uint8))
+
+
 if __name__ == "__main__":
     main()
     make_vo_fixture()
     make_stereo_fixture()
+    make_sift_fixture()

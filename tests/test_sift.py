@@ -1,0 +1,125 @@
+"""SIFT extraction: oracle sanity on the CPU, the HIP pipeline against the oracle through the C ABI
+on the GPU (bit-exact keypoints and descriptors)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import sift as osift  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def blob_image(seed, h=240, w=320, n=150):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w))
+    for _ in range(n):
+        cx, cy, s, a = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(2, 9), rng.uniform(-80, 80)
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    return np.clip(128 + img + rng.normal(0, 2, (h, w)), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_oracle_scale_space_shapes_and_blur_preserves_constants():
+    img = np.full((64, 96), 77, np.uint8)
+    gauss, dog = osift.build_pyramids(img)
+    assert len(gauss) == int(np.rint(np.log2(128) - 2)) + 1
+    assert gauss[0][0].shape == (128, 192) and gauss[1][0].shape == (64, 96)
+    for o in range(len(gauss)):
+        assert all(np.abs(g - 77).max() < 1e-3 for g in gauss[o])          # Gaussian weights sum to one
+        assert all(np.abs(d).max() < 1e-3 for d in dog[o])
+    assert osift.detect(img) == []
+
+
+def test_oracle_finds_a_blob_at_its_centre_with_the_right_scale():
+    yy, xx = np.mgrid[0:128, 0:128]
+    s = 6.0
+    img = np.clip(40 + 160 * np.exp(-((xx - 70.3) ** 2 + (yy - 50.8) ** 2) / (2 * s * s)), 0, 255).astype(np.uint8)
+    kp, size, ang, resp, octv, desc = osift.detect_and_compute(img)
+    assert len(kp) >= 1
+    i = int(np.argmax(resp))
+    assert abs(kp[i, 0] - 70.3) < 1.0 and abs(kp[i, 1] - 50.8) < 1.0
+    assert 0.6 * 2 * 1.414 * s < size[i] < 1.6 * 2 * 1.414 * s                # diameter ~ 2 sqrt(2) sigma for a Gaussian blob
+    assert desc.shape == (len(kp), 128) and (desc == np.round(desc)).all() and desc.max() <= 255
+    assert abs(np.linalg.norm(desc[i]) - 512) < 40
+
+
+def test_oracle_helpers():
+    y = np.array([0, 1, 1, 0, -1, -1, 1e-3], np.float32); x = np.array([1, 1, 0, -1, -1, 1, -5], np.float32)
+    ref = np.degrees(np.arctan2(y.astype(np.float64), x.astype(np.float64))) % 360
+    assert np.abs(osift.fast_atan2_deg(y, x) - ref).max() < 0.02               # OpenCV documents ~0.3 deg
+    v = np.linspace(-20, 0, 1001).astype(np.float32)
+    assert np.max(np.abs(osift.exp32(v) - np.exp(v.astype(np.float64))) / np.exp(v.astype(np.float64))) < 2e-6
+    k = osift.gaussian_kernel(1.6)
+    assert len(k) == 15 and abs(k.sum() - 1) < 1e-6 and np.array_equal(k, k[::-1])
+
+
+def test_golden_sift_fixture_matches_the_oracle():
+    g = np.load(os.path.join(GOLD, "sift_blobs_seed2.npz"))
+    kp, size, ang, resp, octv, desc = osift.detect_and_compute(g["image"])
+    assert np.array_equal(kp, g["kp"]) and np.array_equal(size, g["size"]) and np.array_equal(ang, g["angle"])
+    assert np.array_equal(octv, g["octave"]) and np.array_equal(desc, g["desc"].astype(np.float32))
+
+
+# ------------------------------------------------------------------ HIP pipeline vs oracle (GPU)
+@pytest.fixture(scope="module")
+def sift_gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from gisnav_amd.sift import SIFT
+    return SIFT(max_keypoints=4096)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape", [(0, (240, 320)), (1, (200, 333)), (2, (96, 128))])
+def test_sift_keypoints_and_descriptors_bit_exact(sift_gpu, seed, shape):
+    img = blob_image(seed, *shape)
+    okp, osize, oang, oresp, ooct, odesc = osift.detect_and_compute(img)
+    kpt, resp, octv, desc = sift_gpu.detect_and_compute_device(img)
+    k = kpt.cpu().numpy()
+    assert len(k) == len(okp) > 20
+    assert np.array_equal(k[:, :2].view(np.int32), okp.view(np.int32))                     # bit-exact float positions
+    assert np.array_equal(k[:, 2].view(np.int32), osize.view(np.int32)) and np.array_equal(k[:, 3].view(np.int32), oang.view(np.int32))
+    assert np.array_equal(resp.cpu().numpy().view(np.int32), oresp.view(np.int32)) and np.array_equal(octv.cpu().numpy(), ooct)
+    assert np.array_equal(desc.cpu().numpy(), odesc)                                       # every descriptor byte
+
+
+@pytest.mark.gpu
+def test_sift_cv2_style_interface_and_golden_fixture(sift_gpu):
+    g = np.load(os.path.join(GOLD, "sift_blobs_seed2.npz"))
+    kps, desc = sift_gpu.detectAndCompute(g["image"], None)
+    assert len(kps) == len(g["kp"])
+    assert np.array_equal(np.array([k.pt for k in kps], np.float32), g["kp"])
+    assert np.array_equal(np.array([k.size for k in kps], np.float32), g["size"]) and np.array_equal(np.array([k.angle for k in kps], np.float32), g["angle"])
+    assert np.array_equal(desc, g["desc"].astype(np.float32))
+    kps2, desc2 = sift_gpu.detectAndCompute(g["image"], None)                              # atomics reorder candidates; output must not move
+    assert kps2 == kps and np.array_equal(desc2, desc)
+
+
+@pytest.mark.gpu
+def test_frames_to_pose_end_to_end_like_twist_node(sift_gpu):
+    """TwistNode._pose from pixels: SIFT on two frames -> BFMatcher 2-NN + ratio test -> planar PnP, every stage on the
+    device, against the same chain of oracles (twist_node.py:227-289)."""
+    from gisnav_amd.synthetic import K_MATRIX
+    from gisnav_amd.vo import twist_pose
+    from oracle import bf_knn
+    big = blob_image(5, 300, 400, n=260)
+    ref, qry = big[20:260, 30:350], big[28:268, 41:361]                   # the camera moved by (11, 8) pixels
+    okr, _, _, _, _, odr = osift.detect_and_compute(ref)
+    okq, _, _, _, _, odq = osift.detect_and_compute(qry)
+    kr, dr = sift_gpu.detectAndCompute(ref, None)
+    kq, dq = sift_gpu.detectAndCompute(qry, None)
+    pr_, pq_ = np.array([k.pt for k in kr], np.float32), np.array([k.pt for k in kq], np.float32)
+    assert np.array_equal(pr_, okr) and np.array_equal(pq_, okq) and np.array_equal(dr, odr) and np.array_equal(dq, odq)
+    pairs, _ = bf_knn.ratio_test(*bf_knn.knn_match2(odq, odr))
+    assert len(pairs) >= 30
+    shift = okq[pairs[:, 0]] - okr[pairs[:, 1]]
+    assert np.abs(np.median(shift, 0) - [-11, -8]).max() < 0.2             # SIFT + ratio test found the motion
+    o = bf_knn.twist_pose(K_MATRIX, okq, odq, okr, odr)
+    g = twist_pose(sift_gpu._eng, K_MATRIX, pq_, dq, pr_, dr)
+    assert o is not None and g is not None
+    assert np.linalg.norm(g[0] - o[0]) < 1e-8 and np.linalg.norm(g[1] - o[1]) / np.linalg.norm(o[1]) < 1e-8
