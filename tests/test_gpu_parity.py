@@ -210,23 +210,29 @@ def test_identity_weights_recover_known_permutation(dev):
     assert idx[0, :n, 0].cpu().tolist() == list(range(n)) and idx[0, :n, 1].cpu().tolist() == perm.tolist()
 
 
-def test_edge_cases_empty_ragged_and_tiny_inputs(eng256, dev):
-    eng256.set_num_layers(9)
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+def test_edge_cases_empty_ragged_and_tiny_inputs(eng256, eng256_h2, state_dict_t, dev, prec):
+    eng = eng256 if prec == "f32" else eng256_h2
+    eng.set_num_layers(9)
     pairs = [make_pair(60, n_q=256, n_r=256), make_pair(61, n_q=1, n_r=200), make_pair(62, n_q=40, n_r=2), make_pair(63, n_q=129, n_r=128)]
-    inp = eng256.stage_inputs(pairs)
+    inp = eng.stage_inputs(pairs)
     inp["n_q"][1] = 0                                   # an empty query cloud
-    idx, score, n_match = eng256.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
     nm = n_match.cpu().numpy()
     assert nm[1] == 0 and nm[0] > 15 and nm[3] > 15    # < 2 descriptors on a side -> no match (kornia _no_match)
     assert 0 <= nm[2] <= 2
-    out = eng256.estimate(inp, K_MATRIX)
+    out = eng.estimate(inp, K_MATRIX)
     ok = out["ok"].cpu().numpy()
     assert ok[0] == 1 and ok[1] == 0 and ok[2] == 0 and ok[3] == 1          # MIN_MATCHES = 15 gate
     assert torch.isfinite(out["R"]).all() and torch.isfinite(out["t"]).all()
     # the other pairs in the batch are unaffected by their neighbours
-    solo = eng256.stage_inputs([pairs[3]])
-    i2, s2, n2 = eng256.match(solo["desc_q"], solo["kpt_q"], solo["n_q"], solo["desc_r"], solo["kpt_r"], solo["n_r"])
+    solo = eng.stage_inputs([pairs[3]])
+    i2, s2, n2 = eng.match(solo["desc_q"], solo["kpt_q"], solo["n_q"], solo["desc_r"], solo["kpt_r"], solo["n_r"])
     assert int(n2[0]) == nm[3] and torch.equal(i2[0, : nm[3]], idx[3, : nm[3]])
+    # and the ragged pairs agree with the oracle index for index
+    for b in (0, 3):
+        _, _, _, oidx = oracle_match(state_dict_t, pairs[b])
+        assert nm[b] == len(oidx) and np.array_equal(idx[b, : nm[b]].cpu().numpy(), oidx.numpy())
 
 
 def test_c_abi_rejects_bad_arguments(eng256, dev):
