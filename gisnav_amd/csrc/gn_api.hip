@@ -66,6 +66,9 @@ struct gn_ctx {
   int32_t *m0 = nullptr, *m1 = nullptr;
   // pipeline scratch for gn_estimate
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
+  // sub-batch streams (gn_set_substreams): the pairs of one call are split into groups that run the whole path on
+  // internal streams, out of phase with each other (fork / join events around them on the caller's stream)
+  int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
   int overlap = 0; unsigned long long calls = 0;
   hipStream_t s_pnp = nullptr; hipEvent_t ev_gather[2] = {nullptr, nullptr}, ev_pnp[2] = {nullptr, nullptr}; bool pnp_pending[2] = {false, false};
@@ -455,6 +458,10 @@ void gn_destroy(gn_ctx* ctx) {
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
+  if (ctx->ev_fork) {
+    for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); }
+    hipEventDestroy(ctx->ev_fork);
+  }
   if (ctx->s_pnp) {
     hipStreamSynchronize(ctx->s_pnp);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(ctx->ev_gather[i]); hipEventDestroy(ctx->ev_pnp[i]); }
@@ -641,12 +648,83 @@ int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const 
   return GN_OK;
 }
 
+namespace {
+// every per-pair workspace pointer of the context moved by `b0` pairs (sign = +1) and back (sign = -1): kernels capture
+// pointer values at launch, so a sub-batch group simply runs the ordinary path on its slice of the workspaces
+void shift_workspaces(gn_ctx* c, long long b0, int sign) {
+  const long long d = sign * b0, np = c->npad, T2 = 2 * np;
+  auto mv = [&](auto*& p, long long per_pair) { if (p) p += d * per_pair; };
+  mv(c->desc, T2 * kInDim); mv(c->cos_t, T2 * kFreq); mv(c->sin_t, T2 * kFreq); mv(c->extent, 4); mv(c->nvalid, 2);
+  mv(c->x, T2 * kDim); mv(c->qkv, T2 * 3 * kDim); mv(c->ctx, T2 * kDim); mv(c->msg, T2 * kDim); mv(c->h, T2 * 2 * kDim);
+  mv(c->md, T2 * kDim); mv(c->ls, T2); mv(c->sim, np * np);
+  mv(c->desc_p, 2 * T2 * kInDim); mv(c->x_p, 2 * T2 * kDim); mv(c->ctx_p, 2 * T2 * kDim); mv(c->msg_p, 2 * T2 * kDim);
+  mv(c->h_p, 2 * T2 * 2 * kDim); mv(c->md_p, 2 * T2 * kDim);
+  mv(c->qkb, T2 * 2 * kDim); mv(c->vtb, T2 * kDim);
+  mv(c->rowmax, np); mv(c->rowlog, np); mv(c->colmax, np); mv(c->collog, np); mv(c->max0, np); mv(c->m0, np); mv(c->m1, np);
+  mv(c->e_idx, np * 2); mv(c->e_score, np); mv(c->e_mkp, np * 2); mv(c->e_obj, np * 3);
+  mv(c->mask_ws, np * 16); mv(c->hyp_ws, 16);
+}
+
+int estimate_impl(gn_ctx* ctx, int B, int kpt_format,
+                  const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                  const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                  const uint8_t* dem, int H, int W, const double* K9, int min_matches,
+                  double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
+}  // namespace
+
 int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                 const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
                 const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                 const uint8_t* dem, int H, int W, const double* K9, int min_matches,
                 double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  const int groups = std::min(ctx->n_sub, B);
+  if (groups <= 1 || ctx->overlap)
+    return estimate_impl(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, dem, H, W, K9, min_matches,
+                         R, t, n_match, n_inliers, ok, stream);
+  if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
+  GN_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  GN_HIP(hipEventRecord(ctx->ev_fork, s));
+  const int kw = (kpt_format & 0xff) == GN_KPT_LAF ? 6 : 4;
+  int rc_all = GN_OK, b0 = 0;
+  for (int g = 0; g < groups; ++g) {
+    const int Bg = B / groups + (g < B % groups ? 1 : 0);
+    GN_HIP(hipStreamWaitEvent(ctx->sub_s[g], ctx->ev_fork, 0));
+    shift_workspaces(ctx, b0, +1);
+    const int rc = estimate_impl(ctx, Bg, kpt_format,
+                                 desc_q + (size_t)b0 * stride_q * kInDim, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
+                                 desc_r + (size_t)b0 * stride_r * kInDim, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
+                                 dem ? dem + (size_t)b0 * H * W : nullptr, H, W, K9, min_matches,
+                                 R + (size_t)b0 * 9, t + (size_t)b0 * 3, n_match + b0, n_inliers + b0, ok + b0, ctx->sub_s[g]);
+    shift_workspaces(ctx, b0, -1);
+    if (rc != GN_OK && rc_all == GN_OK) rc_all = rc;
+    GN_HIP(hipEventRecord(ctx->ev_join[g], ctx->sub_s[g]));
+    ctx->sub_pending[g] = true;                       // joined by gn_flush: consecutive calls pipeline inside each group's stream
+    b0 += Bg;
+  }
+  return rc_all;
+}
+
+int gn_set_substreams(gn_ctx* ctx, int n) {
+  if (!ctx || n < 1 || n > 8) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  if (n > 1 && !ctx->ev_fork) GN_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < n && n > 1; ++i)
+    if (!ctx->sub_s[i]) {
+      GN_HIP(hipStreamCreateWithFlags(&ctx->sub_s[i], hipStreamNonBlocking));
+      GN_HIP(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+  ctx->n_sub = n;
+  return GN_OK;
+}
+
+namespace {
+int estimate_impl(gn_ctx* ctx, int B, int kpt_format,
+                  const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                  const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                  const uint8_t* dem, int H, int W, const double* K9, int min_matches,
+                  double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
   if (!ctx->overlap) {
     int rc = gn_match(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r,
                       ctx->e_idx, ctx->e_score, n_match, stream);
@@ -681,6 +759,8 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   return GN_OK;
 }
 
+}  // namespace
+
 int gn_set_overlap(gn_ctx* ctx, int enable) {
   if (!ctx) return GN_ERR_ARG;
   GN_HIP(hipSetDevice(ctx->device));
@@ -705,6 +785,8 @@ int gn_flush(gn_ctx* ctx, void* stream) {
   GN_HIP(hipSetDevice(ctx->device));
   for (int i = 0; i < 2; ++i)
     if (ctx->pnp_pending[i]) { GN_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_pnp[i], 0)); ctx->pnp_pending[i] = false; }
+  for (int g = 0; g < 8; ++g)
+    if (ctx->sub_pending[g]) { GN_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[g], 0)); ctx->sub_pending[g] = false; }
   return GN_OK;
 }
 

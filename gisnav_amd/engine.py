@@ -152,6 +152,10 @@ class PoseEngine:
         before reading R / t / n_inliers / ok."""
         _lib.check(self.ctx, self.lib.gn_set_overlap(self.ctx, int(enable)), "gn_set_overlap")
 
+    def set_substreams(self, n: int) -> None:
+        """Throughput option: every estimate() call runs its pairs as n out-of-phase groups on internal streams (gn_set_substreams)."""
+        _lib.check(self.ctx, self.lib.gn_set_substreams(self.ctx, int(n)), "gn_set_substreams")
+
     def flush(self) -> None:
         _lib.check(self.ctx, self.lib.gn_flush(self.ctx, self._stream()), "gn_flush")
 

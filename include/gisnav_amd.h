@@ -135,6 +135,12 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
  * `stream` wait for every outstanding PnP stage); n_match is complete in stream order as before.  Off by default:
  * without it everything is complete in stream order when gn_estimate returns. */
 int gn_set_overlap(gn_ctx* ctx, int enable);
+/* Throughput option for back-to-back calls: split the B pairs of every gn_estimate call into n groups (1..8) that run
+ * the whole path on n internal streams, forked from the caller's stream; consecutive calls pipeline inside each
+ * group's stream, the groups drift out of phase, and one group's memory-bound kernels overlap another's matrix-bound
+ * ones.  ALL outputs of a call (n_match included) are complete only after gn_flush(ctx, stream).
+ * Measured on the 32-pair bench: +1..3 % with n = 2, slower with n >= 4 (smaller GEMMs); off (n = 1) by default. */
+int gn_set_substreams(gn_ctx* ctx, int n);
 int gn_flush(gn_ctx* ctx, void* stream);
 
 /* ---- visual-odometry path of TwistNode ---------------------------- */

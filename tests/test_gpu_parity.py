@@ -499,3 +499,21 @@ def test_overlapped_pose_stage_gives_identical_results(state_dict_np, dev):
     o = eng.estimate(batches[0], K_MATRIX)
     torch.cuda.synchronize()
     assert all(np.array_equal(serial[0][k], o[k].cpu().numpy()) for k in serial[0])
+
+
+@pytest.mark.gpu
+def test_substreams_give_identical_results(state_dict_np, dev):
+    """gn_set_substreams: the pairs of a call run as out-of-phase groups on internal streams over shifted workspace
+    slices -- every output must equal the single-stream result, also for uneven group sizes."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=5, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    inp = eng.stage_inputs([make_pair(80 + i, n_q=256 - 7 * i, n_r=256 - 3 * i) for i in range(5)])
+    ref = {k: v.cpu().numpy().copy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    for n in (2, 3, 5):
+        eng.set_substreams(n)
+        outs = [eng.estimate(inp, K_MATRIX, out=eng.alloc_outputs(5)) for _ in range(3)]    # back-to-back, joined once
+        eng.flush()
+        torch.cuda.current_stream().synchronize()
+        for o in outs:
+            assert all(np.array_equal(ref[k], o[k].cpu().numpy()) for k in ref), n
+    eng.set_substreams(1)
