@@ -50,7 +50,7 @@ struct gn_ctx {
   int planes_mode = 0;     // 1: activations travel as fp16 planes and GEMMs run k_gemm_p2 (default in f16x2 mode)
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
-  int attn_variant = 4;    // 0: k_attn_bf16 (in-kernel conversion), 1: k_attn_bf16_v2, 2: k_attn_bf16_v3, 3: k_attn_bf16_v4, 4: k_attn_bf16_v5
+  int attn_variant = 4;    // 0: k_attn_bf16 (f32 inputs, in-kernel conversion), otherwise k_attn_bf16_v5 (4; 41 / 42 = timing ablations)
   int stop_after = 0;      // developer knob: return from run_matcher after this many GEMM/attention launches
   int launch_count = 0;
   int no_planes = 0;       // developer knob: ignore the pre-split weight planes (f32x3 splits B on the fly)
@@ -279,8 +279,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int np = c->npad, T = B * 2 * np, BS = B * 2;
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
-  const int vt_perm = ((c->attn_variant == 3 || c->attn_variant == 4 || c->attn_variant >= 30) ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v4 reads permuted V^T
-  const bool attn_planes = c->planes_mode && c->attn_variant == 4;   // k_attn_bf16_v5 writes the fp16 planes itself
+  const int vt_perm = (bf16v2 ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v5 reads V^T with keys permuted inside 16-groups   // k_attn_bf16_v4 reads permuted V^T
+  const bool attn_planes = c->planes_mode && bf16v2;   // k_attn_bf16_v5 writes the hm16 rows itself
   c->launch_count = 0;
   {
     StageTimer tm(c, s, ST_PREP);

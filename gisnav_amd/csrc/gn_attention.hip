@@ -160,7 +160,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kRing = 64 * 64;         // k_attn_bf16_v5: shorts per ring stage (one 64 x 64 bf16 tile)
-constexpr int kStage = 2 * 64 * 64;   // k_attn_bf16_v4: shorts per LDS stage (K tile + V^T tile, 64 x 64 bf16 each)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -312,528 +311,10 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 variant 2: consumes what the projection GEMM's bf16 epilogue already laid out -- Q and K as
-// bf16 rows, V as bf16 V^T per (slot, head) -- so the tile loop does no conversion and no transposition.
-// K / V^T tiles (64 keys) are double-buffered in LDS with register prefetch: tile t+1 is parked in
-// the idle buffer and tile t+2 is fetched while tile t is multiplied; one barrier per tile.
-__global__ __launch_bounds__(256) void k_attn_bf16_v2(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * KT * HLS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, ql = lane & 31;
-  // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin in linear-id order, and each XCD
-  // has its own L2.  Re-number so that all query blocks of one (slot, head) -- which stream the same K / V^T --
-  // run back to back on ONE XCD (bijective: virtual id = xcd * (N / 8) + sequence number within the XCD).
-  int qblk, h, bs;
-  {
-    const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
-    const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    qblk = v % gx;
-    const int g = v / gx;
-    h = g % kHeads; bs = g / kHeads;
-  }
-  const int kvs = a.cross ? (bs ^ 1) : bs;
-  const int nkv = a.nvalid[kvs];
-  const int q0 = qblk * QB + wave * 32;
-
-  bf16x8 qf[4];
-  {
-    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int ntiles = (nkv + KT - 1) / KT;
-  // loader: thread -> row lr (0..63), two 16-byte chunks at halves lc and lc + 32
-  const int lr = tid >> 2, lc = (tid & 3) * 8;
-  const unsigned short* kg = a.kb + ((size_t)kvs * a.npad + lr) * a.ldkb + h * 64 + lc;
-  const unsigned short* vg = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + lr) * a.npad + lc;
-  const size_t kstep = (size_t)KT * a.ldkb;
-  uint4 rk0, rk1, rv0, rv1;
-#define GN_LOAD_KV(t)                                                                 \
-  {                                                                                   \
-    rk0 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep);                  \
-    rk1 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep + 32);             \
-    rv0 = *reinterpret_cast<const uint4*>(vg + (t) * KT);                             \
-    rv1 = *reinterpret_cast<const uint4*>(vg + (t) * KT + 32);                        \
-  }
-#define GN_STORE_KV(buf)                                                              \
-  {                                                                                   \
-    unsigned short* ks_ = smem + (buf) * 2 * KT * HLS + lr * HLS + lc;                \
-    *reinterpret_cast<uint4*>(ks_) = rk0;                                             \
-    *reinterpret_cast<uint4*>(ks_ + 32) = rk1;                                        \
-    *reinterpret_cast<uint4*>(ks_ + KT * HLS) = rv0;                                  \
-    *reinterpret_cast<uint4*>(ks_ + KT * HLS + 32) = rv1;                             \
-  }
-  if (ntiles > 0) {
-    GN_LOAD_KV(0);
-    GN_STORE_KV(0);
-    if (ntiles > 1) GN_LOAD_KV(1);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const unsigned short* Ks = smem + (t & 1) * 2 * KT * HLS;
-    const unsigned short* Vt = Ks + KT * HLS;
-
-    f32x16 st[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + ql) * HLS + 16 * c + 8 * hh]);
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[kt], 0, 0, 0);
-      }
-    }
-    // park tile t+1 in the idle buffer and fetch tile t+2 (overlaps the softmax VALU work below)
-    if (t + 1 < ntiles) {
-      GN_STORE_KV((t + 1) & 1);
-      if (t + 2 < ntiles) GN_LOAD_KV(t + 2);
-    }
-    if (t * KT + KT > nkv) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= nkv) st[kt][r] = -INFINITY;
-        }
-    }
-    float mloc = st[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - m_new);
-    l_run *= alpha;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float p = __expf(st[kt][8 * u + e] - m_new);
-          const unsigned short pb = f2bf(p);
-          pf[kt][u][e] = (short)pb;
-          l_run += __uint_as_float(((unsigned int)pb) << 16);
-        }
-    m_run = m_new;
-
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kb = kt * 32 + 16 * u + 4 * hh;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const unsigned short* vp = &Vt[(d * 32 + ql) * HLS + kb];
-          const ushort4 lo = *reinterpret_cast<const ushort4*>(vp);
-          const ushort4 hi = *reinterpret_cast<const ushort4*>(vp + 8);
-          bf16x8 vf;
-          vf[0] = (short)lo.x; vf[1] = (short)lo.y; vf[2] = (short)lo.z; vf[3] = (short)lo.w;
-          vf[4] = (short)hi.x; vf[5] = (short)hi.y; vf[6] = (short)hi.z; vf[7] = (short)hi.w;
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
-        }
-      }
-    __syncthreads();
-  }
-#undef GN_LOAD_KV
-#undef GN_STORE_KV
-
-  const float l = l_run + __shfl_xor(l_run, 32);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 w;
-      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
-      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
-      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
-    }
-}
-
-template <int ABL>   // ABL: timing-only ablations (1: no K/V traffic in the loop, 2: no barrier, 4: no exp)
-__global__ __launch_bounds__(256) void k_attn_bf16_v3(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * KT * HLS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, ql = lane & 31;
-  // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin in linear-id order, and each XCD
-  // has its own L2.  Re-number so that all query blocks of one (slot, head) -- which stream the same K / V^T --
-  // run back to back on ONE XCD (bijective: virtual id = xcd * (N / 8) + sequence number within the XCD).
-  int qblk, h, bs;
-  {
-    const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
-    const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    qblk = v % gx;
-    const int g = v / gx;
-    h = g % kHeads; bs = g / kHeads;
-  }
-  const int kvs = a.cross ? (bs ^ 1) : bs;
-  const int nkv = a.nvalid[kvs];
-  const int q0 = qblk * QB + wave * 32;
-
-  bf16x8 qf[4];
-  {
-    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  f32x16 ol;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ol[r] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
-  float m_run = -INFINITY;
-
-  const int ntiles = (nkv + KT - 1) / KT;
-  // loader: thread -> row lr (0..63), two 16-byte chunks at halves lc and lc + 32
-  const int lr = tid >> 2, lc = (tid & 3) * 8;
-  const unsigned short* kg = a.kb + ((size_t)kvs * a.npad + lr) * a.ldkb + h * 64 + lc;
-  const unsigned short* vg = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + lr) * a.npad + lc;
-  const size_t kstep = (size_t)KT * a.ldkb;
-  uint4 rk0, rk1, rv0, rv1;
-#define GN_LOAD_KV(t)                                                                 \
-  {                                                                                   \
-    rk0 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep);                  \
-    rk1 = *reinterpret_cast<const uint4*>(kg + (size_t)(t) * kstep + 32);             \
-    rv0 = *reinterpret_cast<const uint4*>(vg + (t) * KT);                             \
-    rv1 = *reinterpret_cast<const uint4*>(vg + (t) * KT + 32);                        \
-  }
-#define GN_STORE_KV(buf)                                                              \
-  {                                                                                   \
-    unsigned short* ks_ = smem + (buf) * 2 * KT * HLS + lr * HLS + lc;                \
-    *reinterpret_cast<uint4*>(ks_) = rk0;                                             \
-    *reinterpret_cast<uint4*>(ks_ + 32) = rk1;                                        \
-    *reinterpret_cast<uint4*>(ks_ + KT * HLS) = rv0;                                  \
-    *reinterpret_cast<uint4*>(ks_ + KT * HLS + 32) = rv1;                             \
-  }
-  if (ntiles > 0) {
-    GN_LOAD_KV(0);
-    GN_STORE_KV(0);
-    if (ntiles > 1) GN_LOAD_KV(1);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const unsigned short* Ks = smem + (t & 1) * 2 * KT * HLS;
-    const unsigned short* Vt = Ks + KT * HLS;
-
-    f32x16 st[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + ql) * HLS + 16 * c + 8 * hh]);
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[kt], 0, 0, 0);
-      }
-    }
-    // park tile t+1 in the idle buffer and fetch tile t+2 (overlaps the softmax VALU work below)
-    if (!(ABL & 1) && t + 1 < ntiles) {
-      GN_STORE_KV((t + 1) & 1);
-      if (t + 2 < ntiles) GN_LOAD_KV(t + 2);
-    }
-    if (t * KT + KT > nkv) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= nkv) st[kt][r] = -INFINITY;
-        }
-    }
-    float mloc = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 1; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, st[kt][r]), st[kt][(r + 1) & 15]);   // v_max3_f32
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    // rescale the running output only when some query of this wave saw a new maximum (wave-uniform branch;
-    // alpha is exactly 1 otherwise, so skipping is bit-identical to multiplying)
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ol[r] *= alpha;
-      m_run = m_new;
-    }
-    const float mneg = -m_new * kLog2e;
-
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        u32x4 pw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x2 p;
-          p[0] = (ABL & 4) ? __builtin_fmaf(st[kt][8 * u + 2 * e], kLog2e, mneg) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * u + 2 * e], kLog2e, mneg));
-          p[1] = (ABL & 4) ? __builtin_fmaf(st[kt][8 * u + 2 * e + 1], kLog2e, mneg) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * u + 2 * e + 1], kLog2e, mneg));
-          pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
-        }
-        pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
-      }
-
-    // softmax denominator on the matrix pipe: ones x P^T accumulates the sum of the ROUNDED probabilities
-    // (every row of the 32x32 result holds the per-query sum), consistent with the PV numerator
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][u], ol, 0, 0, 0);
-
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kb = kt * 32 + 16 * u + 4 * hh;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const unsigned short* vp = &Vt[(d * 32 + ql) * HLS + kb];
-          const ushort4 lo = *reinterpret_cast<const ushort4*>(vp);
-          const ushort4 hi = *reinterpret_cast<const ushort4*>(vp + 8);
-          bf16x8 vf;
-          vf[0] = (short)lo.x; vf[1] = (short)lo.y; vf[2] = (short)lo.z; vf[3] = (short)lo.w;
-          vf[4] = (short)hi.x; vf[5] = (short)hi.y; vf[6] = (short)hi.z; vf[7] = (short)hi.w;
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
-        }
-      }
-    if (!(ABL & 2)) __syncthreads();
-  }
-#undef GN_LOAD_KV
-#undef GN_STORE_KV
-
-  const float l = ol[0];
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 w;
-      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
-      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
-      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
-    }
-}
-
-template <int ABL>   // ABL: timing-only ablations (1: no K/V traffic in the loop, 2: no barrier, 4: no exp)
-__global__ __launch_bounds__(256) void k_attn_bf16_v4(AttnArgs a) {
-  // 3 stages x (K tile: 64 keys x 128 B | V^T tile: 64 dims x 128 B); unpadded rows, 16-byte chunks XOR-swizzled
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[3 * kStage];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, ql = lane & 31;
-  // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin in linear-id order, and each XCD
-  // has its own L2.  Re-number so that all query blocks of one (slot, head) -- which stream the same K / V^T --
-  // run back to back on ONE XCD (bijective: virtual id = xcd * (N / 8) + sequence number within the XCD).
-  int qblk, h, bs;
-  {
-    const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
-    const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    qblk = v % gx;
-    const int g = v / gx;
-    h = g % kHeads; bs = g / kHeads;
-  }
-  const int kvs = a.cross ? (bs ^ 1) : bs;
-  const int nkv = a.nvalid[kvs];
-  const int q0 = qblk * QB + wave * 32;
-
-  bf16x8 qf[4];
-  {
-    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  f32x16 ol;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ol[r] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
-  float m_run = -INFINITY;
-
-  const int ntiles = (nkv + KT - 1) / KT;
-  // LDS-DMA staging: wave w moves rows [16w, 16w + 16) of the K tile and of the V^T tile, 8 rows (1 KB) per
-  // instruction.  The destination is lane-linear, so the swizzle sits on the source side: LDS position
-  // (row, p) receives source chunk p ^ f(row), f(row) = (row >> 1) & 7 (conflict-free ds_read_b128 for
-  // 16 consecutive rows at a fixed chunk).
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned short* ksrc[2]; const unsigned short* vsrc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (2 * wave + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    ksrc[j] = a.kb + ((size_t)kvs * a.npad + r) * a.ldkb + h * 64 + c * 8;
-    vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + c * 8;
-  }
-  const size_t kstep = (size_t)KT * a.ldkb;
-#define GN_DMA_KV(stage, t)                                                                        \
-  {                                                                                                \
-    unsigned short* lk_ = smem + (stage) * kStage + (2 * wave_u) * 512;                            \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
-      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)(t) * kstep), (lptr_t)(lk_ + j * 512), 16, 0, 0);        \
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (t) * KT), (lptr_t)(lk_ + KT * 64 + j * 512), 16, 0, 0);         \
-    }                                                                                              \
-  }
-  if (ntiles > 0) GN_DMA_KV(0, 0);
-  if (ntiles > 1) GN_DMA_KV(1, 1);
-  // fragment read offsets (shorts) inside a stage: row * 64 + ((chunk ^ f(row)) * 8)
-  int kro[2], vro[2], fsw[2];
-#pragma unroll
-  for (int i2 = 0; i2 < 2; ++i2) {
-    const int row = i2 * 32 + ql;
-    fsw[i2] = (row >> 1) & 7;
-    kro[i2] = row * 64;
-    vro[i2] = KT * 64 + row * 64;
-  }
-  int cur = 0, nxt2 = 2;   // stage of tile t, stage of tile t + 2
-
-  for (int t = 0; t < ntiles; ++t) {
-    // tile t has landed once all but the newest DMA group (tile t+1, 4 instructions) are complete; the barrier
-    // publishes every wave's share and also proves stage nxt2 (read during tile t-1) is free again
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (!(ABL & 1) && t + 2 < ntiles) GN_DMA_KV(nxt2, t + 2);
-    const unsigned short* Ks = smem + cur * kStage;
-
-    f32x16 st[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[kro[kt] + (((2 * c + hh) ^ fsw[kt]) << 3)]);
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[kt], 0, 0, 0);
-      }
-    }
-    if (t * KT + KT > nkv) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= nkv) st[kt][r] = -INFINITY;
-        }
-    }
-    float mloc = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 1; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, st[kt][r]), st[kt][(r + 1) & 15]);   // v_max3_f32
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    // rescale the running output only when some query of this wave saw a new maximum (wave-uniform branch;
-    // alpha is exactly 1 otherwise, so skipping is bit-identical to multiplying)
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ol[r] *= alpha;
-      m_run = m_new;
-    }
-    const float mneg = -m_new * kLog2e;
-
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        u32x4 pw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x2 p;
-          p[0] = (ABL & 4) ? __builtin_fmaf(st[kt][8 * u + 2 * e], kLog2e, mneg) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * u + 2 * e], kLog2e, mneg));
-          p[1] = (ABL & 4) ? __builtin_fmaf(st[kt][8 * u + 2 * e + 1], kLog2e, mneg) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * u + 2 * e + 1], kLog2e, mneg));
-          pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
-        }
-        pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
-      }
-
-    // softmax denominator on the matrix pipe: ones x P^T accumulates the sum of the ROUNDED probabilities
-    // (every row of the 32x32 result holds the per-query sum), consistent with the PV numerator
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][u], ol, 0, 0, 0);
-
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Ks[vro[d] + (((4 * kt + 2 * u + hh) ^ fsw[d]) << 3)]);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
-        }
-      }
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
-  }
-#undef GN_DMA_KV
-
-  const float l = ol[0];
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 w;
-      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
-      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
-      *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
-    }
-}
-
+// The production bf16 kernel below (k_attn_bf16_v5) consumes what the projection GEMM's bf16 epilogue already laid
+// out -- Q and K as bf16 rows, V as bf16 V^T panels per (slot, head) with keys permuted inside 16-groups -- so the
+// tile loop does no conversion and no transposition.  (Generations v2-v4 -- register-staged K/V, hardware bf16
+// convert + matrix-pipe denominator, LDS-DMA ring -- were folded into it and retired.)
 // ------------------------------------------------------------------------------------------------
 // bf16 variant 5: software-pipelined across key tiles.  Measured on gfx950 (tools/probes/overlap.hip): VALU work
 // overlaps MFMA execution only when both sit in the SAME wave's instruction stream; a softmax-phase wave and an
@@ -1055,22 +536,13 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 }  // namespace gn
 
 namespace gn {
-int g_attn_variant = 4;  // developer knob: 1 = k_attn_bf16_v2, 2 = k_attn_bf16_v3, 3 = k_attn_bf16_v4, 4 = k_attn_bf16_v5 (default)
+int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
   switch (g_attn_variant) {
-    case 1: hipLaunchKernelGGL(k_attn_bf16_v2, grid, block, 0, s, a); break;
-    case 31: hipLaunchKernelGGL(k_attn_bf16_v4<1>, grid, block, 0, s, a); break;
-    case 21: hipLaunchKernelGGL(k_attn_bf16_v3<1>, grid, block, 0, s, a); break;   // 2x: timing-only ablations
-    case 22: hipLaunchKernelGGL(k_attn_bf16_v3<2>, grid, block, 0, s, a); break;
-    case 23: hipLaunchKernelGGL(k_attn_bf16_v3<3>, grid, block, 0, s, a); break;
-    case 24: hipLaunchKernelGGL(k_attn_bf16_v3<4>, grid, block, 0, s, a); break;
-    case 27: hipLaunchKernelGGL(k_attn_bf16_v3<7>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_attn_bf16_v3<0>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_attn_bf16_v5<0>, grid, block, 0, s, a); break;
     case 41: hipLaunchKernelGGL(k_attn_bf16_v5<1>, grid, block, 0, s, a); break;
     case 42: hipLaunchKernelGGL(k_attn_bf16_v5<2>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_attn_bf16_v4<0>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_attn_bf16_v5<0>, grid, block, 0, s, a); break;
   }
 }
 }  // namespace gn

@@ -84,7 +84,7 @@ struct AttnArgs {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
-extern int g_attn_variant;  // developer knob: 1 = k_attn_bf16_v2, 2 = k_attn_bf16_v3 (default), 2x = v3 timing ablations
+extern int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
 struct PrepArgs {

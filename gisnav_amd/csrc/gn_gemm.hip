@@ -7,18 +7,19 @@
 // to_v, to_out, ffn.0, ffn.3, final_proj) and the `einsum("bmd,bnd->bmn")` similarity of
 // MatchAssignment -- all reached from ros/gisnav/gisnav/core/pose_node.py:285-287.
 //
-// Tiling: 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA tiles of 32x32,
-// BK = 32 staged through LDS with a 36-float row stride (conflict-free ds_read_b128 / ds_write_b128).
+// Tiling: 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA tiles of 32x32, BK = 32.
 // The MFMA's k index is free to permute as long as A and B agree, so each lane fetches FOUR
 // consecutive k with one ds_read_b128 and feeds them to four back-to-back MFMAs: per 8-deep k chunk a
-// wave issues 4 LDS reads for 16 MFMAs (1024 matrix-pipe cycles), leaving the LDS idle and the
-// matrix pipe saturated from one wave per SIMD.
+// wave issues 4 LDS reads for 16 MFMAs (1024 matrix-pipe cycles).
+// This file holds the f32-input generations: k_gemm_f32_v3 (exact-f32 MFMA), k_gemm_f32x3 (3 x bf16 split) and
+// k_gemm_f16x2 (2 x fp16 split on the fly); the shipped f16x2 path with pre-split operands is gn_gemm_p2.hip.
+// (Earlier register-staged generations v0-v2 were retired once v3 covered every epilogue.)
 #include "gn_common.h"
 
 namespace gn {
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 32, LS = 36;
+constexpr int BM = 128, BN = 128, BK = 32;
 
 __device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
   unsigned int u = __float_as_uint(x);
@@ -26,517 +27,7 @@ __device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
   return (unsigned short)(u >> 16);
 }
 
-__device__ __forceinline__ void load_tile(const float* asrc, size_t astr, const float* wsrc, size_t wstr,
-                                          f32x4 (&ra)[4], f32x4 (&rb)[4]) {
-  ra[0] = *reinterpret_cast<const f32x4*>(asrc);
-  ra[1] = *reinterpret_cast<const f32x4*>(asrc + astr);
-  ra[2] = *reinterpret_cast<const f32x4*>(asrc + 2 * astr);
-  ra[3] = *reinterpret_cast<const f32x4*>(asrc + 3 * astr);
-  rb[0] = *reinterpret_cast<const f32x4*>(wsrc);
-  rb[1] = *reinterpret_cast<const f32x4*>(wsrc + wstr);
-  rb[2] = *reinterpret_cast<const f32x4*>(wsrc + 2 * wstr);
-  rb[3] = *reinterpret_cast<const f32x4*>(wsrc + 3 * wstr);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
-  float* As = smem;
-  float* Bs = smem + BM * LS;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-  const float* A = a.A + (long long)blockIdx.z * a.strideA;
-  const float* W = a.W + (long long)blockIdx.z * a.strideW;
-  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
-
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
-  f32x4 ra[4], rb[4];
-  // kernel arguments are copied to locals so that nothing takes the address of `a` (which would
-  // spill the whole argument struct to scratch)
-  const float* const A2 = a.A2;
-  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
-  const float* const Arow = A + (size_t)(bm + lrow) * lda + lcol;
-  const float* const A2row = A2 ? A2 + (size_t)(bm + lrow) * lda2 + lcol - K1 : nullptr;
-  const float* const Wrow = W + (size_t)(bn + lrow) * ldw + lcol;
-
-#define GN_LOAD_TILE(k0)                                                                          \
-  {                                                                                               \
-    const bool second = (A2 != nullptr) && ((k0) + lcol >= K1);                                   \
-    const float* asrc = second ? A2row + (k0) : Arow + (k0);                                      \
-    const size_t astr = second ? (size_t)32 * lda2 : (size_t)32 * lda;                            \
-    load_tile(asrc, astr, Wrow + (k0), (size_t)32 * ldw, ra, rb);                                 \
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int arow = wr * 64 + (lane & 31), brow = wc * 64 + (lane & 31), khalf = (lane >> 5) * 4;
-
-  GN_LOAD_TILE(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    *reinterpret_cast<f32x4*>(&As[(lrow + 0) * LS + lcol]) = ra[0];
-    *reinterpret_cast<f32x4*>(&As[(lrow + 32) * LS + lcol]) = ra[1];
-    *reinterpret_cast<f32x4*>(&As[(lrow + 64) * LS + lcol]) = ra[2];
-    *reinterpret_cast<f32x4*>(&As[(lrow + 96) * LS + lcol]) = ra[3];
-    *reinterpret_cast<f32x4*>(&Bs[(lrow + 0) * LS + lcol]) = rb[0];
-    *reinterpret_cast<f32x4*>(&Bs[(lrow + 32) * LS + lcol]) = rb[1];
-    *reinterpret_cast<f32x4*>(&Bs[(lrow + 64) * LS + lcol]) = rb[2];
-    *reinterpret_cast<f32x4*>(&Bs[(lrow + 96) * LS + lcol]) = rb[3];
-    __syncthreads();
-    if (k0 + BK < K) GN_LOAD_TILE(k0 + BK);  // register prefetch of the next tile under the MFMAs
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      f32x4 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const f32x4*>(&As[(arow + 32 * i) * LS + kc * 8 + khalf]);
-        bf[i] = *reinterpret_cast<const f32x4*>(&Bs[(brow + 32 * i) * LS + kc * 8 + khalf]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-  }
-
-#undef GN_LOAD_TILE
-  // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = bn + wc * 64 + j * 32 + (lane & 31);
-    const float bias = (EPI != EPI_PLAIN && a.bias != nullptr) ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = bm + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[i][j][r] + bias;
-        if (EPI == EPI_SCALE_COLS) {
-          if (col < a.scale_cols) v *= a.scale;
-        } else if (EPI == EPI_ROTARY) {
-          // apply_cached_rotary_emb: t * cos + rotate_half(t) * sin on interleaved pairs (2i, 2i+1);
-          // the pair partner lives in the neighbouring lane (col ^ 1).
-          const float partner = __shfl_xor(v, 1);
-          if (col < a.rot_cols) {
-            const int f = (col & 63) >> 1;
-            const float c = a.cos_t[(size_t)row * kFreq + f];
-            const float s = a.sin_t[(size_t)row * kFreq + f];
-            const float rot = (col & 1) ? partner : -partner;
-            v = v * c + rot * s;
-          }
-        } else if (EPI == EPI_RESIDUAL) {
-          v += a.resid[(size_t)row * a.ldr + col];
-        }
-        Y[(size_t)row * a.ldy + col] = v;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Variant 1: double-buffered LDS (one barrier per k-tile; the register-staged tile t+1 is written
-// into the idle buffer and tile t+2 is fetched while tile t is multiplied) and an LDS-transposed
-// epilogue: each wave parks its 64x64 accumulator block in its own LDS slab, re-reads it row-wise and
-// issues 16-byte coalesced stores (16 per lane instead of 64 dword stores), with bias / residual as
-// float4 and the rotary pair (2i, 2i+1) inside one lane's float4 (cos/sin fetched as float2).
-constexpr int ES = 68;  // epilogue slab row stride (floats)
-
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_f32_v1(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-  const float* A = a.A + (long long)blockIdx.z * a.strideA;
-  const float* W = a.W + (long long)blockIdx.z * a.strideW;
-  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
-
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
-  f32x4 ra[4], rb[4];
-  const float* const A2 = a.A2;
-  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
-  const float* const Arow = A + (size_t)(bm + lrow) * lda + lcol;
-  const float* const A2row = A2 ? A2 + (size_t)(bm + lrow) * lda2 + lcol - K1 : nullptr;
-  const float* const Wrow = W + (size_t)(bn + lrow) * ldw + lcol;
-
-#define GN_LOAD_TILE(k0)                                                                          \
-  {                                                                                               \
-    const bool second = (A2 != nullptr) && ((k0) + lcol >= K1);                                   \
-    const float* asrc = second ? A2row + (k0) : Arow + (k0);                                      \
-    const size_t astr = second ? (size_t)32 * lda2 : (size_t)32 * lda;                            \
-    load_tile(asrc, astr, Wrow + (k0), (size_t)32 * ldw, ra, rb);                                 \
-  }
-#define GN_STORE_TILE(buf)                                                                        \
-  {                                                                                               \
-    float* As_ = smem + (buf) * (BM + BN) * LS;                                                   \
-    float* Bs_ = As_ + BM * LS;                                                                   \
-    *reinterpret_cast<f32x4*>(&As_[(lrow + 0) * LS + lcol]) = ra[0];                              \
-    *reinterpret_cast<f32x4*>(&As_[(lrow + 32) * LS + lcol]) = ra[1];                             \
-    *reinterpret_cast<f32x4*>(&As_[(lrow + 64) * LS + lcol]) = ra[2];                             \
-    *reinterpret_cast<f32x4*>(&As_[(lrow + 96) * LS + lcol]) = ra[3];                             \
-    *reinterpret_cast<f32x4*>(&Bs_[(lrow + 0) * LS + lcol]) = rb[0];                              \
-    *reinterpret_cast<f32x4*>(&Bs_[(lrow + 32) * LS + lcol]) = rb[1];                             \
-    *reinterpret_cast<f32x4*>(&Bs_[(lrow + 64) * LS + lcol]) = rb[2];                             \
-    *reinterpret_cast<f32x4*>(&Bs_[(lrow + 96) * LS + lcol]) = rb[3];                             \
-  }
-#define GN_COMPUTE_CHUNK(As_, Bs_, kc)                                                            \
-  {                                                                                               \
-    f32x4 af[2], bf[2];                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
-      af[i] = *reinterpret_cast<const f32x4*>(&As_[(arow + 32 * i) * LS + (kc) * 8 + khalf]);     \
-      bf[i] = *reinterpret_cast<const f32x4*>(&Bs_[(brow + 32 * i) * LS + (kc) * 8 + khalf]);     \
-    }                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);   \
-      }                                                                                           \
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int arow = wr * 64 + (lane & 31), brow = wc * 64 + (lane & 31), khalf = (lane >> 5) * 4;
-  const int nt = K / BK;
-
-  GN_LOAD_TILE(0);
-  GN_STORE_TILE(0);
-  if (nt > 1) GN_LOAD_TILE(BK);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const float* As_ = smem + (t & 1) * (BM + BN) * LS;
-    const float* Bs_ = As_ + BM * LS;
-    GN_COMPUTE_CHUNK(As_, Bs_, 0);
-    if (t + 1 < nt) {
-      GN_STORE_TILE((t + 1) & 1);
-      if (t + 2 < nt) GN_LOAD_TILE((t + 2) * BK);
-    }
-    GN_COMPUTE_CHUNK(As_, Bs_, 1);
-    GN_COMPUTE_CHUNK(As_, Bs_, 2);
-    GN_COMPUTE_CHUNK(As_, Bs_, 3);
-    __syncthreads();
-  }
-#undef GN_LOAD_TILE
-#undef GN_STORE_TILE
-#undef GN_COMPUTE_CHUNK
-
-  // ---- epilogue through a wave-private LDS slab -------------------------------------------------
-  float* slab = smem + wave * 64 * ES;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        slab[row * ES + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-  // same-wave LDS ops are ordered; the compiler must not hoist the reads above the writes
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  const int c4 = (lane & 15) * 4;
-  const int col = bn + wc * 64 + c4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-  const bool do_scale = (EPI == EPI_SCALE_COLS) && (col < a.scale_cols);
-  const bool do_rot = (EPI == EPI_ROTARY) && (col < a.rot_cols);
-  const int f0 = (col & 63) >> 1;
-  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
-  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
-  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
-  // of a 16-lane group replaced by the next row's raw accumulator).
-  f32x4 vals[16];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int lr_ = it * 4 + (lane >> 4);
-    const int row = bm + wr * 64 + lr_;
-    f32x4 v = vals[it];
-    v += bias4;
-    if (EPI == EPI_SCALE_COLS) {
-      if (do_scale) v *= a.scale;
-    } else if (EPI == EPI_ROTARY) {
-      if (do_rot) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
-        f32x4 o;
-        o.x = v.x * cs.x + (-v.y) * sn.x;
-        o.y = v.y * cs.x + v.x * sn.x;
-        o.z = v.z * cs.y + (-v.w) * sn.y;
-        o.w = v.w * cs.y + v.z * sn.y;
-        v = o;
-      }
-    } else if (EPI == EPI_RESIDUAL) {
-      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
-    }
-    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Variant 2 = variant 1 + explicit software pipelining inside the wave:
-//   * MFMA operand fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are
-//     issued BEFORE the 16 MFMAs of chunk c, so LDS latency sits under 1024 matrix-pipe cycles;
-//   * the barrier moves in front of the LAST chunk: once every wave has parked tile t+1 in the idle
-//     LDS buffer and holds its chunk-3 fragments in registers, tile t+1's first fragments are fetched
-//     and the chunk-3 MFMAs cover that fetch -- no exposed read after the barrier;
-//   * the ds_write_b128s of the staged tile and the global loads of tile t+2 are interleaved one per
-//     MFMA inside chunk 0 instead of forming a block between chunks;
-//   * XCD-aware block order: the 8 XCDs each walk a contiguous range of output tiles so that the
-//     column blocks sharing one A row-panel hit the same L2.
-template <int EPI, int VAR = 0>
-__global__ __launch_bounds__(256) void k_gemm_f32_v2(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  // XCD-aware remap (bijective for any grid size): hardware places linear block id L on XCD L % 8
-  int bx, by;
-  {
-    const int gx = gridDim.x, nwg = gx * gridDim.y;
-    const int L = blockIdx.y * gx + blockIdx.x;
-    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-    bx = v % gx; by = v / gx;
-  }
-  const int bm = by * BM, bn = bx * BN;
-  const float* A = a.A + (long long)blockIdx.z * a.strideA;
-  const float* W = a.W + (long long)blockIdx.z * a.strideW;
-  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
-
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
-  f32x4 ra[4], rb[4];
-  const float* const A2 = a.A2;
-  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
-  const float* const Arow = A + (size_t)(bm + lrow) * lda + lcol;
-  const float* const A2row = A2 ? A2 + (size_t)(bm + lrow) * lda2 + lcol - K1 : nullptr;
-  const float* const Wrow = W + (size_t)(bn + lrow) * ldw + lcol;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int aoff = (wr * 64 + (lane & 31)) * LS + (lane >> 5) * 4;
-  const int boff = BM * LS + (wc * 64 + (lane & 31)) * LS + (lane >> 5) * 4;
-  const int soff = lrow * LS + lcol;
-  const int nt = K / BK;
-
-#define GN_FRAG_READ(fa, fb, buf, kc)                                                             \
-  {                                                                                               \
-    const float* b_ = smem + (buf) * (BM + BN) * LS + (kc) * 8;                                   \
-    fa[0] = *reinterpret_cast<const f32x4*>(b_ + aoff);                                           \
-    fa[1] = *reinterpret_cast<const f32x4*>(b_ + aoff + 32 * LS);                                 \
-    fb[0] = *reinterpret_cast<const f32x4*>(b_ + boff);                                           \
-    fb[1] = *reinterpret_cast<const f32x4*>(b_ + boff + 32 * LS);                                 \
-  }
-#define GN_MFMA4(i, j, fa, fb)                                                                    \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);         \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);         \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);         \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-#define GN_MFMA1(i, j, fa, fb, e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].e, fb[j].e, acc[i][j], 0, 0, 0);
-#define GN_MFMAROW(fa, fb, e) GN_MFMA1(0, 0, fa, fb, e) GN_MFMA1(0, 1, fa, fb, e) GN_MFMA1(1, 0, fa, fb, e) GN_MFMA1(1, 1, fa, fb, e)
-#define GN_MFMA16(fa, fb)                                                                         \
-  {                                                                                               \
-    if (VAR & 1) { GN_MFMAROW(fa, fb, x) GN_MFMAROW(fa, fb, y) GN_MFMAROW(fa, fb, z) GN_MFMAROW(fa, fb, w) } \
-    else { GN_MFMA4(0, 0, fa, fb) GN_MFMA4(0, 1, fa, fb) GN_MFMA4(1, 0, fa, fb) GN_MFMA4(1, 1, fa, fb) }      \
-  }
-
-  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
-  {
-    const bool second = (A2 != nullptr) && (lcol >= K1);
-    load_tile(second ? A2row : Arow, second ? (size_t)32 * lda2 : (size_t)32 * lda, Wrow, (size_t)32 * ldw, ra, rb);
-  }
-  {
-    float* d_ = smem + soff;
-    *reinterpret_cast<f32x4*>(d_) = ra[0];
-    *reinterpret_cast<f32x4*>(d_ + 32 * LS) = ra[1];
-    *reinterpret_cast<f32x4*>(d_ + 64 * LS) = ra[2];
-    *reinterpret_cast<f32x4*>(d_ + 96 * LS) = ra[3];
-    *reinterpret_cast<f32x4*>(d_ + BM * LS) = rb[0];
-    *reinterpret_cast<f32x4*>(d_ + BM * LS + 32 * LS) = rb[1];
-    *reinterpret_cast<f32x4*>(d_ + BM * LS + 64 * LS) = rb[2];
-    *reinterpret_cast<f32x4*>(d_ + BM * LS + 96 * LS) = rb[3];
-  }
-  if (nt > 1) {
-    const bool second = (A2 != nullptr) && (BK + lcol >= K1);
-    load_tile(second ? A2row + BK : Arow + BK, second ? (size_t)32 * lda2 : (size_t)32 * lda, Wrow + BK, (size_t)32 * ldw, ra, rb);
-  }
-  __syncthreads();
-  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
-  GN_FRAG_READ(fa0, fb0, 0, 0);
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    GN_FRAG_READ(fa1, fb1, cur, 1);
-    if (!(VAR & 4) && t + 1 < nt) {
-      // chunk 0 MFMAs with the staged tile's LDS writes and the next global loads threaded through
-      float* d_ = smem + (cur ^ 1) * (BM + BN) * LS + soff;
-      const int k2 = (t + 2) * BK;
-      const bool more = t + 2 < nt;
-      const bool second = (A2 != nullptr) && (k2 + lcol >= K1);
-      const float* asrc = second ? A2row + k2 : Arow + k2;
-      const size_t astr = second ? (size_t)32 * lda2 : (size_t)32 * lda;
-      const float* wsrc = Wrow + k2;
-      const size_t wstr = (size_t)32 * ldw;
-      GN_MFMA4(0, 0, fa0, fb0)
-      *reinterpret_cast<f32x4*>(d_) = ra[0];
-      *reinterpret_cast<f32x4*>(d_ + 32 * LS) = ra[1];
-      *reinterpret_cast<f32x4*>(d_ + 64 * LS) = ra[2];
-      *reinterpret_cast<f32x4*>(d_ + 96 * LS) = ra[3];
-      if (more) {
-        ra[0] = *reinterpret_cast<const f32x4*>(asrc);
-        ra[1] = *reinterpret_cast<const f32x4*>(asrc + astr);
-        ra[2] = *reinterpret_cast<const f32x4*>(asrc + 2 * astr);
-        ra[3] = *reinterpret_cast<const f32x4*>(asrc + 3 * astr);
-      }
-      GN_MFMA4(0, 1, fa0, fb0)
-      *reinterpret_cast<f32x4*>(d_ + BM * LS) = rb[0];
-      *reinterpret_cast<f32x4*>(d_ + BM * LS + 32 * LS) = rb[1];
-      *reinterpret_cast<f32x4*>(d_ + BM * LS + 64 * LS) = rb[2];
-      *reinterpret_cast<f32x4*>(d_ + BM * LS + 96 * LS) = rb[3];
-      if (more) {
-        rb[0] = *reinterpret_cast<const f32x4*>(wsrc);
-        rb[1] = *reinterpret_cast<const f32x4*>(wsrc + wstr);
-        rb[2] = *reinterpret_cast<const f32x4*>(wsrc + 2 * wstr);
-        rb[3] = *reinterpret_cast<const f32x4*>(wsrc + 3 * wstr);
-      }
-      GN_MFMA4(1, 0, fa0, fb0)
-      GN_MFMA4(1, 1, fa0, fb0)
-    } else {
-      GN_MFMA16(fa0, fb0)
-    }
-    GN_FRAG_READ(fa0, fb0, cur, 2);
-    GN_MFMA16(fa1, fb1)
-    GN_FRAG_READ(fa1, fb1, cur, 3);
-    GN_MFMA16(fa0, fb0)
-    if (!(VAR & 2)) __syncthreads();
-    if (t + 1 < nt) GN_FRAG_READ(fa0, fb0, cur ^ 1, 0);
-    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's first fragment reads AHEAD of the chunk-3 MFMAs
-    GN_MFMA16(fa1, fb1)
-  }
-#undef GN_FRAG_READ
-#undef GN_MFMA4
-#undef GN_MFMA16
-#undef GN_MFMA1
-#undef GN_MFMAROW
-  // (all tile-buffer reads completed before the last barrier: the slabs below may overwrite them)
-
-  float* slab = smem + wave * 64 * ES;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        slab[row * ES + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  constexpr bool kBf16Out = (EPI == EPI_ROTARY_BF16 || EPI == EPI_SCALE_BF16);
-  const int colbase = bn + wc * 64;
-  if (kBf16Out && colbase >= a.vt_start) {
-    // V panel: this wave's 64 columns are one head; emit V^T as bf16 [slot][head][d][npad].
-    // lane = feature d; 8 consecutive tokens are packed into one 16-byte store.
-    const int head = (colbase - a.vt_start) >> 6;
-    const int row0 = bm + wr * 64;
-    const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
-    const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
-    uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      unsigned int w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // vt_perm: within each 16-token group, 16-byte chunk hh holds tokens 4hh + {0..3, 8..11} -- the key order
-        // one lane of the attention kernel's P^T operand carries, so its V^T fragment is one ds_read_b128
-        const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
-        const float lo = slab[t0 * ES + lane] + bias;
-        const float hi = slab[(t0 + 1) * ES + lane] + bias;
-        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
-      }
-      *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    return;
-  }
-  const int c4 = (lane & 15) * 4;
-  const int col = bn + wc * 64 + c4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-  const bool do_scale = (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) && (col < a.scale_cols);
-  const bool do_rot = (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (col < a.rot_cols);
-  const int f0 = (col & 63) >> 1;
-  // All 16 row fragments are pulled out of the slab into their OWN registers before the first store is
-  // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
-  // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
-  // of a 16-lane group replaced by the next row's raw accumulator).
-  f32x4 vals[16];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int lr_ = it * 4 + (lane >> 4);
-    const int row = bm + wr * 64 + lr_;
-    f32x4 v = vals[it];
-    v += bias4;
-    if (EPI == EPI_SCALE_COLS || EPI == EPI_SCALE_BF16) {
-      if (do_scale) v *= a.scale;
-    } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
-      if (do_rot) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
-        f32x4 o;
-        o.x = v.x * cs.x + (-v.y) * sn.x;
-        o.y = v.y * cs.x + v.x * sn.x;
-        o.z = v.z * cs.y + (-v.w) * sn.y;
-        o.w = v.w * cs.y + v.z * sn.y;
-        v = o;
-      }
-    } else if (EPI == EPI_RESIDUAL) {
-      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
-    }
-    if (kBf16Out) {
-      if (col < a.q_cols) v *= a.qscale;
-      uint2 pk;
-      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
-      *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
-    } else {
-      *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-    }
-  }
-}
+constexpr int ES = 68;  // epilogue slab row stride (floats): each wave parks its 64x64 accumulator block in LDS and re-reads it row-wise
 
 // ------------------------------------------------------------------------------------------------
 // Variant 3: tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction),
@@ -1456,16 +947,6 @@ void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
 
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
-  if (g_gemm_variant >= 20 && g_gemm_variant < 50 && epi == EPI_BIAS) {  // ablation builds (timing only; 22+ give wrong numbers)
-    switch (g_gemm_variant) {
-      case 21: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 1>), grid, block, 0, s, a); break;
-      case 22: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 2>), grid, block, 0, s, a); break;
-      case 24: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 4>), grid, block, 0, s, a); break;
-      case 26: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 6>), grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL((k_gemm_f32_v2<EPI_BIAS, 0>), grid, block, 0, s, a); break;
-    }
-    return;
-  }
   if (g_gemm_variant == 4 && epi == EPI_BIAS) {
     hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);
     return;
@@ -1524,46 +1005,15 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
 #undef GN_X3
     return;
   }
-  if (g_gemm_variant == 3) {
-    switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_BIAS>, grid, block, 0, s, a); break;
-      case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
-      case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY>, grid, block, 0, s, a); break;
-      case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_RESIDUAL>, grid, block, 0, s, a); break;
-      case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
-      case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_PLAIN>, grid, block, 0, s, a); break;
-    }
-    return;
-  }
-  if (g_gemm_variant == 2 || epi >= EPI_ROTARY_BF16) {
-    switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_BIAS>, grid, block, 0, s, a); break;
-      case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
-      case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_ROTARY>, grid, block, 0, s, a); break;
-      case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_RESIDUAL>, grid, block, 0, s, a); break;
-      case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
-      case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL(k_gemm_f32_v2<EPI_PLAIN>, grid, block, 0, s, a); break;
-    }
-    return;
-  }
-  if (g_gemm_variant == 1) {
-    switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v1<EPI_BIAS>, grid, block, 0, s, a); break;
-      case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v1<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
-      case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v1<EPI_ROTARY>, grid, block, 0, s, a); break;
-      case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v1<EPI_RESIDUAL>, grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL(k_gemm_f32_v1<EPI_PLAIN>, grid, block, 0, s, a); break;
-    }
-    return;
-  }
+  // exact-f32 MFMA (k_gemm_f32_v3: LDS-DMA, double-buffered, LDS-slab epilogue) -- GN_PREC_F32 / GN_PREC_BF16_ATTN and the VO matcher
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32<EPI_BIAS>, grid, block, 0, s, a); break;
-    case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
-    case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32<EPI_ROTARY>, grid, block, 0, s, a); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32<EPI_RESIDUAL>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_gemm_f32<EPI_PLAIN>, grid, block, 0, s, a); break;
+    case EPI_BIAS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_BIAS>, grid, block, 0, s, a); break;
+    case EPI_SCALE_COLS: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_COLS>, grid, block, 0, s, a); break;
+    case EPI_ROTARY: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY>, grid, block, 0, s, a); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_RESIDUAL>, grid, block, 0, s, a); break;
+    case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
+    case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_PLAIN>, grid, block, 0, s, a); break;
   }
 }
 

@@ -33,7 +33,7 @@ def main():
             print(f"mfma probe blocks={blocks} {label}: {fl / ms / 1e9:.1f} TF", flush=True)
     M = 65536
     shapes = [(256, 128), (768, 256), (256, 256), (512, 256), (512, 512), (256, 512), (1024, 256), (512, 2048)]
-    variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
+    variants = [int(v) for v in (sys.argv[1:] or ["3", "5", "6", "7"])]   # 3 f32 MFMA, 5 f32x3, 6 f16x2 (on-the-fly split), 7 k_gemm_p2
     for variant in variants:
         out_mode = 0
         lib.gn_debug_set_variant(ctx, 8, 1)
