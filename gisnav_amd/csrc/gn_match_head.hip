@@ -46,28 +46,37 @@ __global__ __launch_bounds__(256) void k_row_stats(HeadArgs a) {
   if (lane == 0) { a.rowmax[(size_t)b * a.npad + i] = m; a.rowlog[(size_t)b * a.npad + i] = logf(s); }
 }
 
-// grid (npad/64, B): 4 row groups x 64 columns
-__global__ __launch_bounds__(256) void k_col_stats(HeadArgs a) {
-  __shared__ float red[4][64];
+// grid (npad/64, B): kColGroups row groups x 64 columns (16 waves per workgroup keep the dependent row loop short)
+constexpr int kColGroups = 16;
+__global__ __launch_bounds__(64 * kColGroups) void k_col_stats(HeadArgs a) {
+  __shared__ float red[kColGroups][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6, b = blockIdx.y;
   const int j = blockIdx.x * 64 + c;
   const int n0 = a.nvalid[2 * b], n1 = a.nvalid[2 * b + 1];
   const float* base = a.sim + (size_t)b * a.npad * a.npad + j;
   const bool act = j < n1;
   float m = -INFINITY;
-  if (act) for (int i = g; i < n0; i += 4) m = fmaxf(m, base[(size_t)i * a.npad]);
+  if (act) for (int i = g; i < n0; i += kColGroups) m = fmaxf(m, base[(size_t)i * a.npad]);
   red[g][c] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
+  m = red[0][c];
+#pragma unroll
+  for (int k = 1; k < kColGroups; ++k) m = fmaxf(m, red[k][c]);
   __syncthreads();
   float s = 0.f;
-  if (act) for (int i = g; i < n0; i += 4) s += expf(base[(size_t)i * a.npad] - m);
+  if (act) for (int i = g; i < n0; i += kColGroups) s += expf(base[(size_t)i * a.npad] - m);
   red[g][c] = s;
   __syncthreads();
   if (g == 0 && act) {
-    s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    float t[kColGroups];
+#pragma unroll
+    for (int k = 0; k < kColGroups; ++k) t[k] = red[k][c];
+#pragma unroll
+    for (int w = 1; w < kColGroups; w <<= 1)          // fixed pairwise tree: deterministic
+#pragma unroll
+      for (int k = 0; k < kColGroups; k += 2 * w) t[k] = t[k] + t[k + w];
     a.colmax[(size_t)b * a.npad + j] = m;
-    a.collog[(size_t)b * a.npad + j] = logf(s);
+    a.collog[(size_t)b * a.npad + j] = logf(t[0]);
   }
 }
 
@@ -100,9 +109,9 @@ __global__ __launch_bounds__(256) void k_row_argmax(HeadArgs a) {
 }
 
 // grid (npad/64, B): column arg-max, first (lowest i) index on ties
-__global__ __launch_bounds__(256) void k_col_argmax(HeadArgs a) {
-  __shared__ float rv[4][64];
-  __shared__ int ri[4][64];
+__global__ __launch_bounds__(64 * kColGroups) void k_col_argmax(HeadArgs a) {
+  __shared__ float rv[kColGroups][64];
+  __shared__ int ri[kColGroups][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6, b = blockIdx.y;
   const int j = blockIdx.x * 64 + c;
   const int n0 = a.nvalid[2 * b], n1 = a.nvalid[2 * b + 1];
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void k_col_argmax(HeadArgs a) {
     const float cm = a.colmax[ro + j], cl = a.collog[ro + j];
     const float lj = a.ls[(size_t)(2 * b + 1) * a.npad + j];
     const float* lsi = a.ls + (size_t)(2 * b) * a.npad;
-    for (int i = g; i < n0; i += 4) {
+    for (int i = g; i < n0; i += kColGroups) {
       const float p = score_at(base[(size_t)i * a.npad], a.rowmax[ro + i], a.rowlog[ro + i], cm, cl, lsi[i], lj);
       if (p > best || bi == 0x7fffffff) { best = p; bi = i; }
     }
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void k_col_argmax(HeadArgs a) {
   __syncthreads();
   if (g == 0 && j < n1) {
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 1; k < kColGroups; ++k) {
       const float ob = rv[k][c]; const int oi = ri[k][c];
       if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
     }
@@ -193,9 +202,9 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
 
 void launch_match_head(const HeadArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_row_stats, dim3(a.npad / 4, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_col_stats, dim3(a.npad / 64, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_col_stats, dim3(a.npad / 64, a.B), dim3(64 * kColGroups), 0, s, a);
   hipLaunchKernelGGL(k_row_argmax, dim3(a.npad / 4, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_col_argmax, dim3(a.npad / 64, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_col_argmax, dim3(a.npad / 64, a.B), dim3(64 * kColGroups), 0, s, a);
   hipLaunchKernelGGL(k_compact, dim3(a.B), dim3(256), 0, s, a);
 }
 
