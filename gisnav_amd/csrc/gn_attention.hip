@@ -323,8 +323,9 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // tiles for both), one barrier per tile.  The running maximum is updated lazily: the output is rescaled only when
 // some query's maximum grew by more than 2^8 (probabilities then stay <= 256, exact in f32 / harmless in bf16),
 // which removes the per-tile rescale after the first tiles.
-template <int ABL>
-__global__ __launch_bounds__(256) void k_attn_bf16_v5(AttnArgs a) {
+template <int ABL, int NW>   // NW waves (of 32 queries) share one K / V^T tile stream: 4 or 8
+__global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
+  constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[6 * kRing];   // K ring [3][64 keys][64], V^T ring [3][64 dims][64 keys]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void k_attn_bf16_v5(AttnArgs a) {
   }
   const int kvs = a.cross ? (bs ^ 1) : bs;
   const int nkv = a.nvalid[kvs];
-  const int q0 = qblk * QB + wave * 32;
+  const int q0 = qblk * (NW * 32) + wave * 32;
   const int ntiles = (nkv + KT - 1) / KT;
 
   bf16x8 qf[4];
@@ -361,28 +362,28 @@ __global__ __launch_bounds__(256) void k_attn_bf16_v5(AttnArgs a) {
 
   // LDS-DMA addressing as in variant 4 (source-side swizzle f(row) = (row >> 1) & 7)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned short* ksrc[2]; const unsigned short* vsrc[2];
+  const unsigned short* ksrc[IPW]; const unsigned short* vsrc[IPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (2 * wave + j) * 8 + (lane >> 3);
+  for (int j = 0; j < IPW; ++j) {
+    const int r = (IPW * wave + j) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     ksrc[j] = a.kb + ((size_t)kvs * a.npad + r) * a.ldkb + h * 64 + c * 8;
     vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + c * 8;
     if (ABL & 2) {   // timing probe: the same bytes fetched as contiguous 8 KB tiles (wrong data)
-      ksrc[j] = a.kb + ((size_t)kvs * kHeads + h) * a.npad * 64 + (2 * wave + j) * 512 + lane * 8;
-      vsrc[j] = a.vt + ((size_t)kvs * kHeads + h) * a.npad * 64 + (2 * wave + j) * 512 + lane * 8;
+      ksrc[j] = a.kb + ((size_t)kvs * kHeads + h) * a.npad * 64 + (IPW * wave + j) * 512 + lane * 8;
+      vsrc[j] = a.vt + ((size_t)kvs * kHeads + h) * a.npad * 64 + (IPW * wave + j) * 512 + lane * 8;
     }
   }
   const size_t kstep = (ABL & 2) ? (size_t)KT * 64 : (size_t)KT * a.ldkb;
   const int vstep = (ABL & 2) ? KT * 64 : KT;
 #define GN_DMA_K(stage, t)                                                                                              \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < IPW; ++j)                                                                       \
     __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)(t) * kstep),                                           \
-                                     (lptr_t)(smem + (stage) * kRing + (2 * wave_u + j) * 512), 16, 0, 0);
+                                     (lptr_t)(smem + (stage) * kRing + (IPW * wave_u + j) * 512), 16, 0, 0);
 #define GN_DMA_V(stage, t)                                                                                              \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < IPW; ++j)                                                                       \
     __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (t) * vstep),                                                   \
-                                     (lptr_t)(smem + (3 + (stage)) * kRing + (2 * wave_u + j) * 512), 16, 0, 0);
+                                     (lptr_t)(smem + (3 + (stage)) * kRing + (IPW * wave_u + j) * 512), 16, 0, 0);
   int ro[2], fsw[2];     // fragment row offsets (shorts) and swizzle of rows ql, 32 + ql
 #pragma unroll
   for (int i2 = 0; i2 < 2; ++i2) {
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void k_attn_bf16_v5(AttnArgs a) {
   auto tile = [&](f32x16 (&ST)[2], f32x16 (&SN)[2], int t) __attribute__((always_inline)) {
     // K(t+1) and V^T(t) have landed once everything but the newest DMA group {K(t+2), V^T(t+1)} is complete;
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
-    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    if (t + 2 < ntiles) { if (NW == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (!(ABL & 1)) {
       if (t + 3 < ntiles) GN_DMA_K(s0, t + 3);
@@ -536,13 +537,20 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 }  // namespace gn
 
 namespace gn {
-int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
+int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
+  if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
+    dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
+    switch (g_attn_variant) {
+      default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 8>), grid, block, 0, s, a); break;
+    }
+    return;
+  }
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
   switch (g_attn_variant) {
-    case 41: hipLaunchKernelGGL(k_attn_bf16_v5<1>, grid, block, 0, s, a); break;
-    case 42: hipLaunchKernelGGL(k_attn_bf16_v5<2>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_attn_bf16_v5<0>, grid, block, 0, s, a); break;
+    case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
+    case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
   }
 }
 }  // namespace gn
