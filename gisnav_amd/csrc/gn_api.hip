@@ -393,7 +393,7 @@ int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
 
 extern "C" {
 
-const char* gn_version(void) { return "gisnav_amd 0.1.0 gfx950"; }
+const char* gn_version(void) { return "gisnav_amd 0.2.0 gfx950"; }
 
 const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 

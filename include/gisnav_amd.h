@@ -15,10 +15,18 @@
  *   gn_pnp_ransac                cv2.solvePnPRansac(..., iterationsCount=10) + cv2.Rodrigues
  *                                                                       _shared.py:104-117
  *   gn_estimate                  the whole of PoseNode._pose lines 246-308 for a batch of pairs
+ *   gn_pose_to_earth (+ gn_proj_to_affine, gn_wgs84_to_ecef)   the georeferencing after the pose
+ *                                                 pose_node.py:333-381, _transformations.py:298-393
+ * and, widening to the feeders of that path:
+ *   gn_sift_detect_and_compute   cv2.SIFT_create().detectAndCompute(img, None)
+ *                                                 pose_node.py:122,230-232; twist_node.py:93,227-245
+ *   gn_rotate_crop_center / gn_stereo_reference   StereoNode reference raster   stereo_node.py:229-262,292-335
+ *   gn_vo_match / gn_vo_estimate cv2.BFMatcher.knnMatch(k=2) + ratio test + compute_pose   twist_node.py:95,248-289
  *
  * Conventions: plain C, no torch types.  Every data pointer is a DEVICE pointer unless the
  * parameter is marked "host".  `stream` is a hipStream_t passed as void* (NULL = default
- * stream).  All work is stream-ordered; no entry point synchronises except gn_debug_read.
+ * stream).  All work is stream-ordered; no entry point synchronises except gn_debug_read and
+ * gn_sift_detect_and_compute (host-side keypoint sort).
  * Return value: 0 on success, negative gn_status on failure; nothing throws.  One context
  * per GPU; a context is thread-compatible, not thread-safe (PoseNode calls from one executor
  * thread at a time, gisnav/__init__.py:140-154).
