@@ -447,7 +447,8 @@ void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
     }
     return;
   }
-  if (g_p2_wide && a.M % WBM == 0 && a.N % WBN == 0 && a.K >= 256) {   // short-K shapes are faster on the 128x128 kernel
+  // the 256x256 kernel needs enough tiles to occupy the chip (small batches) and K >= 256 (short-K shapes are faster on 128x128)
+  if (g_p2_wide && a.M % WBM == 0 && a.N % WBN == 0 && a.K >= 256 && (long long)(a.M / WBM) * (a.N / WBN) * batch >= 192) {
     dim3 grid(a.N / WBN, a.M / WBM, batch), block(512);
 #define P2W_CASE(E) case E: hipLaunchKernelGGL((k_gemm_p2w<E>), grid, block, 0, s, a); break;
     switch (epi) {
