@@ -276,10 +276,16 @@ __device__ inline void spd_solve(const double N[K][K], const double b[K], double
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-parallel cyclic Jacobi for an n x n symmetric matrix in LDS (n <= 12).  On return the
-// eigenvalues are on the diagonal of A, eigenvectors are the COLUMNS of V, and ord[] lists the
-// column indices by ASCENDING eigenvalue.  Called by the whole (single-wave) block.
+// Lane-parallel Jacobi for an n x n symmetric matrix in LDS (n <= 12), PARALLEL ordering: a sweep is m - 1 rounds
+// (m = n rounded up to even) of m / 2 rotations on disjoint index pairs (round-robin tournament), and the
+// rotations of one round commute, so their angles are computed side by side by m / 2 lanes and applied together
+// (column phase, then row phase): 3 barriers per ROUND instead of per rotation.  On return the eigenvalues are on
+// the diagonal of A, eigenvectors are the COLUMNS of V, and ord[] lists the column indices by ASCENDING
+// eigenvalue.  Called by the whole (single-wave) block.
 __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
+  __shared__ double rot_c[6], rot_s[6];
+  __shared__ int rot_p[6], rot_q[6];
+  const int m = (n + 1) & ~1, half = m >> 1;
   for (int idx = lane; idx < n * n; idx += 64) V[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
   wave_sync();
   for (int sweep = 0; sweep < 40; ++sweep) {
@@ -290,30 +296,48 @@ __device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
     }
     off = wsum(off); dg = wsum(dg);
     if (off <= 1e-30 * dg || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
-        const double app = A[p * n + p], aqq = A[q * n + q];
-        if (fabs(apq) <= 1e-18 * sqrt(fabs(app * aqq)) || fabs(apq) < 1e-300) continue;  // wave-uniform
-        const double tau = (aqq - app) / (2.0 * apq);
-        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-        wave_sync();
-        if (lane < n) {
-          const int k = lane;
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+    for (int r = 0; r < m - 1; ++r) {
+      if (lane < half) {
+        int p = lane == 0 ? r % (m - 1) : (r + lane) % (m - 1);
+        int q = lane == 0 ? m - 1 : (r - lane + (m - 1)) % (m - 1);
+        if (p > q) { const int t_ = p; p = q; q = t_; }
+        double c = 1.0, sn = 0.0;
+        if (q < n) {
+          const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+          if (!(fabs(apq) <= 1e-18 * sqrt(fabs(app * aqq)) || fabs(apq) < 1e-300)) {
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
+          }
+        } else {
+          q = p;                                        // dummy partner (odd n): identity
         }
-        wave_sync();
-        if (lane < n) {
-          const int k = lane;
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
-        }
-        wave_sync();
+        rot_p[lane] = p; rot_q[lane] = q; rot_c[lane] = c; rot_s[lane] = sn;
       }
+      wave_sync();
+      for (int idx = lane; idx < n * half; idx += 64) {   // columns p, q of A and V
+        const int k = idx / half, i = idx - k * half;
+        const int p = rot_p[i], q = rot_q[i];
+        const double c = rot_c[i], sn = rot_s[i];
+        if (p != q && sn != 0.0) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq;
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+      wave_sync();
+      for (int idx = lane; idx < n * half; idx += 64) {   // rows p, q of A
+        const int k = idx / half, i = idx - k * half;
+        const int p = rot_p[i], q = rot_q[i];
+        const double c = rot_c[i], sn = rot_s[i];
+        if (p != q && sn != 0.0) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk;
+        }
+      }
+      wave_sync();
+    }
   }
   if (lane == 0) {
     for (int i = 0; i < n; ++i) ord[i] = i;
