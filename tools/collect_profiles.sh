@@ -14,6 +14,9 @@ cp $(ls $O/${TAG}_prof/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/${TAG}_pmc_$c && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
+# matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) against GRBM_GUI_ACTIVE (summed over the 8 XCDs)
+rm -rf $O/${TAG}_pmc_MFMA && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_pmc_mfma_raw.json
 python $R/tools/pmc_summary.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE > $O/${TAG}_pmc_raw.json
 python - <<PY
 import json
@@ -35,6 +38,15 @@ for k, v in sorted(raw.items()):
 out["k_gemm_f32_all_variants"] = {"dispatches": tot_n, "hbm_bytes_per_launch_corrected": int(tot_b / max(tot_n, 1)),
                                   "note": "call-weighted over all GEMM launches of a step (75 per step)"}
 json.dump(out, open("$O/${TAG}_pmc_hbm_traffic.json", "w"), indent=1)
+mraw = json.load(open("$O/${TAG}_pmc_mfma_raw.json"))
+busy = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 2 --warmup 1 (precision %s)" % bench["config"]["precision"],
+        "definition": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE): busy cycles summed over 1024 SIMDs, active cycles summed over 8 XCDs", "kernels": {}}
+for k, v in sorted(mraw.items()):
+    b = v.get("SQ_VALU_MFMA_BUSY_CYCLES"); g = v.get("GRBM_GUI_ACTIVE")
+    if b and g and g["sum"] > 0 and b["sum"] > 0:
+        busy["kernels"][k] = {"dispatches": b["dispatches"], "mfma_busy": round(b["sum"] / (128.0 * g["sum"]), 4)}
+json.dump(busy, open("$O/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
+print(json.dumps(busy["kernels"]))
 print(json.dumps(out["k_gemm_f32_all_variants"]))
 PY
 cat $O/${TAG}_bench_n1.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['cpu_baseline']['value'])"
