@@ -89,6 +89,19 @@ def measured_gemm_traffic(precision: str):
         return None, None
 
 
+def measured_mfma_busy(precision: str):
+    """Matrix-pipe busy fraction of the dominant GEMM kernel from the committed PMC pass (call-weighted), or None."""
+    if precision != "f16x2_bf16_attn":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy_f16x2.json")) as f:
+            ks = json.load(f)["kernels"]
+        rows = [(v["dispatches"], v["mfma_busy"]) for k, v in ks.items() if k.startswith("k_gemm")]
+        return round(sum(n * b for n, b in rows) / max(sum(n for n, _ in rows), 1), 4)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +225,7 @@ def main() -> None:
                 "executed_mfma_tflops": round(ach * mult, 1),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "mfma_busy_pmc": measured_mfma_busy(args.precision) if (args.batch == 32 and args.kpts == 1024) else None,
                 "launches_timed": int(kstats["launches"]),
                 "avg_launch_us": round(kstats["ms"] * 1e3 / max(kstats["launches"], 1), 2),
                 "algorithmic_gflop_per_launch": round(kstats["flops"] / max(kstats["launches"], 1) / 1e9, 3),
