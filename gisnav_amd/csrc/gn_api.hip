@@ -965,8 +965,8 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
   if (rc != GN_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   SiftPyramid& py = ctx->sift_py;
-  auto blur = [&](const float* in, float* out, int w, int h, int ki) {
-    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s);
+  auto blur = [&](const float* in, float* out, int w, int h, int ki, float* dog = nullptr) {
+    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s, dog);
   };
   // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
   sift_base(gray, H, W, py.oct[0].gauss[5], s);                      // scratch: level 5 is overwritten later
@@ -974,8 +974,7 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
   for (int o = 0; o < py.n_oct; ++o) {
     const SiftOctave& oc = py.oct[o];
     if (o > 0) sift_half(py.oct[o - 1].gauss[3], py.oct[o - 1].w, oc.gauss[0], oc.w, oc.h, s);
-    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i);
-    for (int i = 0; i < 5; ++i) sift_sub(oc.gauss[i + 1], oc.gauss[i], oc.dog[i], (size_t)oc.w * oc.h, s);
+    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // DoG level fused into the column pass
   }
   GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 2 * sizeof(int), s));
   const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);

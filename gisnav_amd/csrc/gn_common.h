@@ -168,7 +168,7 @@ struct SiftPyramid { SiftOctave oct[kSiftMaxOctaves]; int n_oct; };
 struct SiftKeypoint { float x, y, size, angle, response; int octave; };
 void sift_gaussian_kernel(double sigma, std::vector<float>& k);
 void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s);
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s);
+void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog = nullptr);   // dog = out - in
 void sift_half(const float* in, int w, float* out, int w2, int h2, hipStream_t s);
 void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s);

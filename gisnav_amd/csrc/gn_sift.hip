@@ -7,7 +7,7 @@
 // oracle writes them, so scale space, keypoints and descriptors agree with it bit for bit.  Stages:
 //   k_sift_base (u8 -> f32, 2x bilinear) -> separable Gaussian (k_blur_row / k_blur_col, BORDER_REFLECT_101) ->
 //   k_half_nearest between octaves -> k_sub (DoG) -> k_sift_find (26-neighbour extrema) ->
-//   k_sift_refine (quadratic fit, contrast / edge tests, orientation histogram; one thread per candidate) ->
+//   k_sift_refine (quadratic fit, contrast / edge tests, orientation histogram; one wave per candidate) ->
 //   host: sort, duplicate removal, first-octave rescale (KeyPointsFilter::removeDuplicatedSorted) ->
 //   k_sift_descriptor (4x4x8 histogram; one wave per keypoint: samples evaluated 64 at a time, committed in OpenCV's order).
 #include "gn_common.h"
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_blur_row(const float* in, float* out, i
   out[(size_t)y * w + x] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, int w, int h, const float* k, int n) {
+// optional fused DoG: dog = blurred - prev (prev = the level this blur started from), saves one launch per level
+__global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, int w, int h, const float* k, int n, const float* prev, float* dog) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   const int r = n >> 1;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
   for (int t = 1; t <= r; ++t)
     acc = acc + k[r + t] * (in[(size_t)reflect101(y + t, h) * w + x] + in[(size_t)reflect101(y - t, h) * w + x]);
   out[(size_t)y * w + x] = acc;
+  if (dog != nullptr) dog[(size_t)y * w + x] = acc - prev[(size_t)y * w + x];
 }
 
 __global__ __launch_bounds__(256) void k_half_nearest(const float* in, int w, float* out, int w2, int h2) {
@@ -158,104 +160,113 @@ __global__ __launch_bounds__(256) void k_sift_find(SiftOctave oc, int octave, in
   if (slot < max_cand) cand[slot] = make_int4(octave, layer, r, c);
 }
 
-// ---- adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one thread per candidate
+// ---- adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one WAVE per candidate.
+// The quadratic refinement is scalar work (every lane computes it redundantly); the orientation histogram evaluates 64
+// raster positions per step in parallel and commits them in raster order -- bin b of the histogram lives in a register of
+// lane b, each sample is broadcast with v_readlane and added by its owner lane -- so the float sums keep OpenCV's order.
 __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* cand, const int* n_cand, int max_cand,
                                                      SiftKeypoint* kp, int* n_kp, int max_kp) {
-  const int id = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x;
   const int nc = min(*n_cand, max_cand);
-  if (id >= nc) return;
-  const int octv = cand[id].x;
-  int layer = cand[id].y, r = cand[id].z, c = cand[id].w;
-  const SiftOctave& oc = py.oct[octv];
-  const int rows = oc.h, cols = oc.w;
-  const float img_scale = 1.0f / 255.0f, deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
+  for (int id = blockIdx.x; id < nc; id += gridDim.x) {
+    const int octv = cand[id].x;
+    int layer = cand[id].y, r = cand[id].z, c = cand[id].w;
+    const SiftOctave& oc = py.oct[octv];
+    const int rows = oc.h, cols = oc.w;
+    const float img_scale = 1.0f / 255.0f, deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
 #define AT(p, rr, cc) (p)[(size_t)(rr) * cols + (cc)]
-  float xi = 0.f, xr = 0.f, xc = 0.f;
-  int i = 0;
-  for (; i < kMaxInterp; ++i) {
-    const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
-    float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
-                   (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
-    const float v2 = AT(img, r, c) * 2.0f;
-    const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
-    const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
-    const float dss = (AT(nxt, r, c) + AT(prv, r, c) - v2) * second_scale;
-    const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
-    const float dxs = (AT(nxt, r, c + 1) - AT(nxt, r, c - 1) - AT(prv, r, c + 1) + AT(prv, r, c - 1)) * cross_scale;
-    const float dys = (AT(nxt, r + 1, c) - AT(nxt, r - 1, c) - AT(prv, r + 1, c) + AT(prv, r - 1, c)) * cross_scale;
-    float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-    float X[3] = {dD[0], dD[1], dD[2]};
-    if (!lu_solve3(H, X)) { X[0] = X[1] = X[2] = 0.f; }
-    xi = -X[2]; xr = -X[1]; xc = -X[0];
-    if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
-    if ((double)fabsf(xi) > 715827882.0 || (double)fabsf(xr) > 715827882.0 || (double)fabsf(xc) > 715827882.0) return;
-    c += (int)rintf(xc); r += (int)rintf(xr); layer += (int)rintf(xi);
-    if (layer < 1 || layer > kLayers || c < kBorder || c >= cols - kBorder || r < kBorder || r >= rows - kBorder) return;
-  }
-  if (i >= kMaxInterp) return;
-  float contr;
-  {
-    const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
-    const float d0 = (AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, d1 = (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
-                d2 = (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale;
-    const float t = (d0 * xc + d1 * xr) + d2 * xi;
-    contr = AT(img, r, c) * img_scale + t * 0.5f;
-    if (fabsf(contr) * (float)kLayers < 0.04f) return;
-    const float v2 = AT(img, r, c) * 2.0f;
-    const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
-    const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
-    const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
-    const float tr = dxx + dyy;
-    const float det = dxx * dyy - dxy * dxy;
-    if (det <= 0.f || (tr * tr) * 10.0f >= (11.0f * 11.0f) * det) return;
-  }
-  const float scale = (float)(1 << octv);
-  const float kx = ((float)c + xc) * scale, ky = ((float)r + xr) * scale;
-  const int octave = octv + (layer << 8) + ((int)rintf((xi + 0.5f) * 255.0f) << 16);
-  const float e = ((float)layer + xi) / (float)kLayers;
-  const float size = ((1.6f * (float)pow(2.0, (double)e)) * scale) * 2.0f;
-  const float response = fabsf(contr);
-
-  // orientation histogram on the Gaussian level of the refined layer
-  const float scl_octv = (size * 0.5f) / scale;
-  const int radius = (int)rintf(4.5f * scl_octv);
-  const float sigma_w = 1.5f * scl_octv;
-  const float expf_scale = -1.0f / (2.0f * (sigma_w * sigma_w));
-  const float* g = oc.gauss[layer];
-  __shared__ float temph_lds[kOriBins * 64];
-  float* const temph_ = temph_lds + threadIdx.x;
-#define temph(b) temph_[(b) * 64]
-  for (int b = 0; b < kOriBins; ++b) temph(b) = 0.f;
-  for (int ii = -radius; ii <= radius; ++ii) {
-    const int y = r + ii;
-    if (y <= 0 || y >= rows - 1) continue;
-    for (int jj = -radius; jj <= radius; ++jj) {
-      const int x = c + jj;
-      if (x <= 0 || x >= cols - 1) continue;
-      const float dx = AT(g, y, x + 1) - AT(g, y, x - 1);
-      const float dy = AT(g, y - 1, x) - AT(g, y + 1, x);
-      const float W = exp32((float)(ii * ii + jj * jj) * expf_scale);
-      const float ori = fast_atan2_deg(dy, dx);
-      const float mag = sqrtf(dx * dx + dy * dy);
-      int bin = (int)rintf((float)(kOriBins / 360.0) * ori);
-      if (bin >= kOriBins) bin -= kOriBins;
-      if (bin < 0) bin += kOriBins;
-      temph(bin) = temph(bin) + W * mag;
+    float xi = 0.f, xr = 0.f, xc = 0.f;
+    int i = 0;
+    bool dead = false;                                  // the candidate left the volume or diverged
+    for (; i < kMaxInterp; ++i) {
+      const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
+      float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                     (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
+      const float v2 = AT(img, r, c) * 2.0f;
+      const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+      const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+      const float dss = (AT(nxt, r, c) + AT(prv, r, c) - v2) * second_scale;
+      const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+      const float dxs = (AT(nxt, r, c + 1) - AT(nxt, r, c - 1) - AT(prv, r, c + 1) + AT(prv, r, c - 1)) * cross_scale;
+      const float dys = (AT(nxt, r + 1, c) - AT(nxt, r - 1, c) - AT(prv, r + 1, c) + AT(prv, r - 1, c)) * cross_scale;
+      float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+      float X[3] = {dD[0], dD[1], dD[2]};
+      if (!lu_solve3(H, X)) { X[0] = X[1] = X[2] = 0.f; }
+      xi = -X[2]; xr = -X[1]; xc = -X[0];
+      if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+      if ((double)fabsf(xi) > 715827882.0 || (double)fabsf(xr) > 715827882.0 || (double)fabsf(xc) > 715827882.0) { dead = true; break; }
+      c += (int)rintf(xc); r += (int)rintf(xr); layer += (int)rintf(xi);
+      if (layer < 1 || layer > kLayers || c < kBorder || c >= cols - kBorder || r < kBorder || r >= rows - kBorder) { dead = true; break; }
     }
-  }
-  float hist[kOriBins];
-  float omax = 0.f;
-  for (int b = 0; b < kOriBins; ++b) {
-    const float m2 = temph((b + kOriBins - 2) % kOriBins), m1 = temph((b + kOriBins - 1) % kOriBins), p1 = temph((b + 1) % kOriBins),
-                p2 = temph((b + 2) % kOriBins);
-    hist[b] = ((m2 + p2) * (float)(1.0 / 16.0) + (m1 + p1) * (float)(4.0 / 16.0)) + temph(b) * (float)(6.0 / 16.0);
-    omax = b == 0 ? hist[0] : fmaxf(omax, hist[b]);
-  }
-  const float mag_thr = omax * 0.8f;
-  for (int j = 0; j < kOriBins; ++j) {
-    const int l = j > 0 ? j - 1 : kOriBins - 1, r2 = j < kOriBins - 1 ? j + 1 : 0;
-    if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
-      float bin = (float)j + (0.5f * (hist[l] - hist[r2])) / ((hist[l] - 2.0f * hist[j]) + hist[r2]);
+    if (dead || i >= kMaxInterp) continue;
+    float contr;
+    {
+      const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
+      const float d0 = (AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, d1 = (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                  d2 = (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale;
+      const float t = (d0 * xc + d1 * xr) + d2 * xi;
+      contr = AT(img, r, c) * img_scale + t * 0.5f;
+      if (fabsf(contr) * (float)kLayers < 0.04f) continue;
+      const float v2 = AT(img, r, c) * 2.0f;
+      const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+      const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+      const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+      const float tr = dxx + dyy;
+      const float det = dxx * dyy - dxy * dxy;
+      if (det <= 0.f || (tr * tr) * 10.0f >= (11.0f * 11.0f) * det) continue;
+    }
+    const float scale = (float)(1 << octv);
+    const float kx = ((float)c + xc) * scale, ky = ((float)r + xr) * scale;
+    const int octave = octv + (layer << 8) + ((int)rintf((xi + 0.5f) * 255.0f) << 16);
+    const float e = ((float)layer + xi) / (float)kLayers;
+    const float size = ((1.6f * (float)pow(2.0, (double)e)) * scale) * 2.0f;
+    const float response = fabsf(contr);
+
+    // orientation histogram on the Gaussian level of the refined layer
+    const float scl_octv = (size * 0.5f) / scale;
+    const int radius = (int)rintf(4.5f * scl_octv);
+    const float sigma_w = 1.5f * scl_octv;
+    const float expf_scale = -1.0f / (2.0f * (sigma_w * sigma_w));
+    const float* g = oc.gauss[layer];
+    const int side = 2 * radius + 1, total = side * side;
+    float acc = 0.f;                                    // temphist[lane] for lane < 36
+    for (int base = 0; base < total; base += 64) {
+      const int p = base + lane;
+      int mybin = -1; float myval = 0.f;
+      if (p < total) {
+        const int ii = p / side - radius, jj = p % side - radius;
+        const int y = r + ii, x = c + jj;
+        if (!(y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1)) {
+          const float dx = AT(g, y, x + 1) - AT(g, y, x - 1);
+          const float dy = AT(g, y - 1, x) - AT(g, y + 1, x);
+          const float W = exp32((float)(ii * ii + jj * jj) * expf_scale);
+          const float ori = fast_atan2_deg(dy, dx);
+          const float mag = sqrtf(dx * dx + dy * dy);
+          int bin = (int)rintf((float)(kOriBins / 360.0) * ori);
+          if (bin >= kOriBins) bin -= kOriBins;
+          if (bin < 0) bin += kOriBins;
+          mybin = bin; myval = W * mag;
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 64; ++sidx) {            // commit in raster order
+        const int b = __builtin_amdgcn_readlane(mybin, sidx);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), sidx));
+        if (lane == b) acc = acc + v;
+      }
+    }
+    // smoothing, maximum, peaks: lane b < 36 owns bin b
+    const int bl = lane < kOriBins ? lane : 0;
+    const float m2 = __shfl(acc, (bl + kOriBins - 2) % kOriBins), m1 = __shfl(acc, (bl + kOriBins - 1) % kOriBins);
+    const float p1 = __shfl(acc, (bl + 1) % kOriBins), p2 = __shfl(acc, (bl + 2) % kOriBins);
+    const float hj = ((m2 + p2) * (float)(1.0 / 16.0) + (m1 + p1) * (float)(4.0 / 16.0)) + acc * (float)(6.0 / 16.0);
+    float omax = lane < kOriBins ? hj : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
+    const float mag_thr = omax * 0.8f;
+    const float hl = __shfl(hj, bl > 0 ? bl - 1 : kOriBins - 1), hr = __shfl(hj, bl < kOriBins - 1 ? bl + 1 : 0);
+    if (lane < kOriBins && hj > hl && hj > hr && hj >= mag_thr) {
+      float bin = (float)lane + (0.5f * (hl - hr)) / ((hl - 2.0f * hj) + hr);
       bin = bin < 0 ? (float)kOriBins + bin : (bin >= (float)kOriBins ? bin - (float)kOriBins : bin);
       float ang = 360.0f - (float)(360.0 / kOriBins) * bin;
       if (fabsf(ang - 360.0f) < kFltEps) ang = 0.f;
@@ -264,7 +275,6 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
     }
   }
 #undef AT
-#undef temph
 }
 
 // ---- calcSIFTDescriptor: one WAVE per keypoint.  The 4x4x8 histogram must receive its contributions in OpenCV's raster
@@ -387,9 +397,9 @@ void sift_gaussian_kernel(double sigma, std::vector<float>& k) {
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s) {
+void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog) {
   hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);
-  hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, out, w, h, dk, n);
+  hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, out, w, h, dk, n, in, dog);
 }
 void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sift_base, grid2d(2 * w, 2 * h), dim3(256), 0, s, gray, h, w, out);
@@ -409,7 +419,7 @@ void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, 
   }
 }
 void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s) {
-  hipLaunchKernelGGL(k_sift_refine, dim3((max_cand + 63) / 64), dim3(64), 0, s, py, cand, n_cand, max_cand, kp, n_kp, max_kp);
+  hipLaunchKernelGGL(k_sift_refine, dim3(std::min(max_cand, 4096)), dim3(64), 0, s, py, cand, n_cand, max_cand, kp, n_kp, max_kp);
 }
 void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, int n, float* desc, float* /*unused*/, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_sift_descriptor, dim3(n), dim3(64), 0, s, py, kp, n, desc);
