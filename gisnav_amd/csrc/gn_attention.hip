@@ -323,10 +323,10 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // tiles for both), one barrier per tile.  The running maximum is updated lazily: the output is rescaled only when
 // some query's maximum grew by more than 2^8 (probabilities then stay <= 256, exact in f32 / harmless in bf16),
 // which removes the per-tile rescale after the first tiles.
-template <int ABL, int NW>   // NW waves (of 32 queries) share one K / V^T tile stream: 4 or 8
+template <int ABL, int NW, int ND = 3>   // NW waves (of 32 queries) share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster)
 __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[6 * kRing];   // K ring [3][64 keys][64], V^T ring [3][64 dims][64 keys]
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, ql = lane & 31;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
 #define GN_DMA_V(stage, t)                                                                                              \
   _Pragma("unroll") for (int j = 0; j < IPW; ++j)                                                                       \
     __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (t) * vstep),                                                   \
-                                     (lptr_t)(smem + (3 + (stage)) * kRing + (IPW * wave_u + j) * 512), 16, 0, 0);
+                                     (lptr_t)(smem + (ND + (stage)) * kRing + (IPW * wave_u + j) * 512), 16, 0, 0);
   int ro[2], fsw[2];     // fragment row offsets (shorts) and swizzle of rows ql, 32 + ql
 #pragma unroll
   for (int i2 = 0; i2 < 2; ++i2) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
   };
 
   f32x16 sa[2], sb[2];
-  int s0 = 0, s1 = 1, s2 = 2;          // ring stages of tiles t, t+1, t+2 (mod 3)
+  int s0 = 0, s1 = 1, s2 = 2, s3 = 3;  // ring stages of tiles t, t+1, t+2 (, t+3) modulo ND
   if (ntiles > 0) {
     GN_DMA_K(0, 0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -415,17 +415,24 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     GN_DMA_V(0, 0);
     if (ntiles > 2) GN_DMA_K(2, 2);
     if (ntiles > 1) GN_DMA_V(1, 1);
+    if (ND == 4) { if (ntiles > 3) GN_DMA_K(3, 3); if (ntiles > 2) GN_DMA_V(2, 2); }
     qk_tile(sa, 0);
   }
 
   auto tile = [&](f32x16 (&ST)[2], f32x16 (&SN)[2], int t) __attribute__((always_inline)) {
-    // K(t+1) and V^T(t) have landed once everything but the newest DMA group {K(t+2), V^T(t+1)} is complete;
+    // K(t+1) and V^T(t) have landed once everything but the ND - 2 newest DMA groups ({K(t+2), V^T(t+1)}, ...) is complete;
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
-    if (t + 2 < ntiles) { if (NW == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    constexpr int G = 2 * (8 / NW);                       // DMA instructions per wave per group (K tile + V^T tile)
+    if (t + ND - 1 < ntiles) {
+      if (G * (ND - 2) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else if (G * (ND - 2) == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (!(ABL & 1)) {
-      if (t + 3 < ntiles) GN_DMA_K(s0, t + 3);
-      if (t + 2 < ntiles) GN_DMA_V(s2, t + 2);
+      if (t + ND < ntiles) GN_DMA_K(s0, t + ND);                          // K(t) was consumed one iteration ago
+      if (t + ND - 1 < ntiles) GN_DMA_V(ND == 4 ? s3 : s2, t + ND - 1);   // the stage V^T(t-1) was read from
     }
     if (t * KT + KT > nkv) {
 #pragma unroll
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
         }
         pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
       }
-    const unsigned short* Vs = smem + (3 + s0) * kRing;
+    const unsigned short* Vs = smem + (ND + s0) * kRing;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -482,7 +489,8 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
         }
       }
-    const int s_ = s0; s0 = s1; s1 = s2; s2 = s_;
+    const int s_ = s0; s0 = s1; s1 = s2;
+    if (ND == 4) { s2 = s3; s3 = s_; } else { s2 = s_; }
   };
 
   for (int t = 0; t < ntiles; t += 2) {
@@ -537,7 +545,7 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 }  // namespace gn
 
 namespace gn {
-int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 41 / 42 = timing-only ablations
+int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
     dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
@@ -548,6 +556,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   }
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
   switch (g_attn_variant) {
+    case 43: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 4>), grid, block, 0, s, a); break;  // 4-deep rings
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;

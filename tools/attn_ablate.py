@@ -15,7 +15,7 @@ def main():
     eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f32x3_bf16_attn", state_dict=synthetic_state_dict(0))
     inp = eng.stage_inputs([make_pair(i, n_q=1024, n_r=1024) for i in range(B)])
     out = eng.alloc_outputs(B)
-    for v in [int(a) for a in sys.argv[1:]] or [4, 48, 41]:
+    for v in [int(a) for a in sys.argv[1:]] or [4, 43, 41]:
         eng.lib.gn_debug_set_variant(eng.ctx, 1, v)
         for _ in range(2):
             eng.estimate(inp, K_MATRIX, out=out)
