@@ -25,6 +25,8 @@ def env_world() -> Tuple[int, int, int]:
 
 def init(backend: str) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
+    if backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))   # RCCL binds its communicator to the current device
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -67,7 +69,10 @@ def broadcast_state_dict(sd: Dict[str, np.ndarray], device: torch.device, src: i
 
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
