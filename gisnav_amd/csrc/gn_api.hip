@@ -77,7 +77,7 @@ struct gn_ctx {
   int sift_h = 0, sift_w = 0; std::vector<void*> sift_allocs; SiftPyramid sift_py; float* sift_tmp = nullptr;
   float* sift_dk = nullptr; std::vector<std::vector<float>> sift_kernels; std::vector<int> sift_koff;   // [0] = initial blur, [1..5] = layer blurs
   int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr; float* sift_hist = nullptr;
-  int sift_max_cand = 0, sift_max_kp = 0;
+  int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0;
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -945,8 +945,10 @@ int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
   ctx->sift_max_cand = std::max(65536, 16 * max_kp);
   ctx->sift_max_kp = std::max(max_kp, 1024);
   ctx->sift_cand = (int4*)alloc((size_t)ctx->sift_max_cand * sizeof(int4));
-  ctx->sift_counts = (int*)alloc(2 * sizeof(int));
-  ctx->sift_kp = (SiftKeypoint*)alloc((size_t)4 * ctx->sift_max_kp * sizeof(SiftKeypoint));
+  ctx->sift_counts = (int*)alloc(4 * sizeof(int));
+  ctx->sift_raw_cap = 1;
+  while (ctx->sift_raw_cap < 4 * ctx->sift_max_kp) ctx->sift_raw_cap <<= 1;
+  ctx->sift_kp = (SiftKeypoint*)alloc(((size_t)ctx->sift_raw_cap + ctx->sift_max_kp) * sizeof(SiftKeypoint));
   ctx->sift_hist = (float*)alloc((size_t)ctx->sift_max_kp * 360 * sizeof(float));
   if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp || !ctx->sift_hist)
     return fail(ctx, GN_ERR_HIP, "SIFT workspace allocation failed");
@@ -971,36 +973,33 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
   // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
   sift_base(gray, H, W, py.oct[0].gauss[5], s);                      // scratch: level 5 is overwritten later
   blur(py.oct[0].gauss[5], py.oct[0].gauss[0], py.oct[0].w, py.oct[0].h, 0);
-  for (int o = 0; o < py.n_oct; ++o) {
+  int ksize[6];
+  for (int i = 0; i < 6; ++i) ksize[i] = (int)ctx->sift_kernels[i].size();
+  const int o_tail = sift_tail_first(py, ksize);                     // octaves from here on: one single-workgroup launch
+  for (int o = 0; o < o_tail; ++o) {
     const SiftOctave& oc = py.oct[o];
     if (o > 0) sift_half(py.oct[o - 1].gauss[3], py.oct[o - 1].w, oc.gauss[0], oc.w, oc.h, s);
-    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // DoG level fused into the column pass
+    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // row + column pass + DoG level in one launch
   }
-  GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 2 * sizeof(int), s));
+  sift_tail(py, o_tail, ctx->sift_dk, ctx->sift_koff.data(), ksize, s);
+  GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 3 * sizeof(int), s));
   const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);
   sift_find(py, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
-  const int max_raw = 4 * ctx->sift_max_kp;
+  // raw keypoint capacity: a power of two (the bitonic network pads to one), final list stored behind it
+  const int max_raw_alloc = ctx->sift_raw_cap, max_raw = max_raw_alloc;
   sift_refine(py, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, ctx->sift_kp, ctx->sift_counts + 1, max_raw, s);
-  int counts[2] = {0, 0};
+  // sort / de-duplicate / rescale on the device, then descriptors for the *n final keypoints; one sync at the very end
+  SiftKeypoint* kp_final = ctx->sift_kp + max_raw_alloc;
+  const int max_out = std::min(max_kpts, ctx->sift_max_kp);
+  sift_sort_dedup(ctx->sift_kp, ctx->sift_counts + 1, max_raw, kp_final, ctx->sift_counts + 2, max_out, kpt_xysa, response, octave, s);
+  sift_descriptors(py, kp_final, ctx->sift_counts + 2, max_out, desc, s);
+  int counts[3] = {0, 0, 0};
   GN_HIP(hipMemcpyAsync(counts, ctx->sift_counts, sizeof counts, hipMemcpyDeviceToHost, s));
   GN_HIP(hipStreamSynchronize(s));
   if (counts[0] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
   if (counts[1] > max_raw) return fail(ctx, GN_ERR_ARG, "SIFT keypoint buffer overflow (raise max_kpts)");
-  std::vector<SiftKeypoint> kp(counts[1]);
-  if (!kp.empty()) GN_HIP(hipMemcpy(kp.data(), ctx->sift_kp, kp.size() * sizeof(SiftKeypoint), hipMemcpyDeviceToHost));
-  sift_sort_dedup(kp);                                               // deterministic order whatever the atomics did
-  if ((int)kp.size() > max_kpts || (int)kp.size() > ctx->sift_max_kp) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
-  const int n = (int)kp.size();
-  *n_out_host = n;
-  if (n == 0) return GN_OK;
-  GN_HIP(hipMemcpyAsync(ctx->sift_kp, kp.data(), (size_t)n * sizeof(SiftKeypoint), hipMemcpyHostToDevice, s));
-  sift_descriptors(py, ctx->sift_kp, n, desc, ctx->sift_hist, s);
-  std::vector<float> xysa((size_t)n * 4), resp(n); std::vector<int32_t> oct(n);
-  for (int i = 0; i < n; ++i) { xysa[4 * i] = kp[i].x; xysa[4 * i + 1] = kp[i].y; xysa[4 * i + 2] = kp[i].size; xysa[4 * i + 3] = kp[i].angle; resp[i] = kp[i].response; oct[i] = kp[i].octave; }
-  GN_HIP(hipMemcpyAsync(kpt_xysa, xysa.data(), xysa.size() * sizeof(float), hipMemcpyHostToDevice, s));
-  if (response) GN_HIP(hipMemcpyAsync(response, resp.data(), resp.size() * sizeof(float), hipMemcpyHostToDevice, s));
-  if (octave) GN_HIP(hipMemcpyAsync(octave, oct.data(), oct.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  GN_HIP(hipStreamSynchronize(s));                                   // the host vectors above must outlive the copies
+  if (counts[2] > max_out) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
+  *n_out_host = counts[2];
   GN_HIP(hipGetLastError());
   return GN_OK;
 }

@@ -170,11 +170,14 @@ void sift_gaussian_kernel(double sigma, std::vector<float>& k);
 void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s);
 void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog = nullptr);   // dog = out - in
 void sift_half(const float* in, int w, float* out, int w2, int h2, hipStream_t s);
+int sift_tail_first(const SiftPyramid& py, const int* ksize);
+void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s);
 void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s);
 void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s);
-void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, int n, float* desc, float* hist_ws, hipStream_t s);
-void sift_sort_dedup(std::vector<SiftKeypoint>& k);
+void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* n_dev, int max_n, float* desc, hipStream_t s);
+void sift_sort_dedup(SiftKeypoint* kp_raw, const int* n_raw, int max_raw, SiftKeypoint* kp_out, int* n_out, int max_out,
+                     float* kpt_xysa, float* response, int32_t* octave, hipStream_t s);
 
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);

@@ -8,8 +8,8 @@
 //   k_sift_base (u8 -> f32, 2x bilinear) -> separable Gaussian (k_blur_row / k_blur_col, BORDER_REFLECT_101) ->
 //   k_half_nearest between octaves -> k_sub (DoG) -> k_sift_find (26-neighbour extrema) ->
 //   k_sift_refine (quadratic fit, contrast / edge tests, orientation histogram; one wave per candidate) ->
-//   host: sort, duplicate removal, first-octave rescale (KeyPointsFilter::removeDuplicatedSorted) ->
-//   k_sift_descriptor (4x4x8 histogram; one wave per keypoint: samples evaluated 64 at a time, committed in OpenCV's order).
+//   k_sift_sort_dedup (bitonic sort in OpenCV's keypoint order, duplicate removal, first-octave rescale; one workgroup) ->
+//   k_sift_descriptor (4x4x8 histogram; producer waves evaluate 64 samples at a time, one wave commits them in OpenCV's order).
 #include "gn_common.h"
 
 #include <algorithm>
@@ -70,6 +70,152 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
     acc = acc + k[r + t] * (in[(size_t)reflect101(y + t, h) * w + x] + in[(size_t)reflect101(y - t, h) * w + x]);
   out[(size_t)y * w + x] = acc;
   if (dog != nullptr) dog[(size_t)y * w + x] = acc - prev[(size_t)y * w + x];
+}
+
+// ---- both passes of one Gaussian level in ONE launch: a workgroup owns a 64 x 32 output tile, stages the input tile
+// (+ R columns/rows of BORDER_REFLECT_101 halo) in LDS, row-filters the 32 + 2R rows it needs into a second LDS tile and
+// column-filters those.  Every output is the same expression, in the same order, as k_blur_row followed by k_blur_col;
+// a thread produces 4 adjacent outputs of a row (8 of a column) from one register window, so an LDS word is read once per
+// 4 (8) outputs instead of once per tap.  N (taps) is a template parameter: the pyramid only has 11/13/17/21/27.
+constexpr int kFtW = 64, kFtH = 32;
+template <int N>
+__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog) {
+  constexpr int R = N / 2, ROWS = kFtH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float s_in[ROWS * COLS];
+  __shared__ __attribute__((aligned(16))) float s_row[ROWS * kFtW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+  float kk[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) kk[t] = k[t];
+  for (int ry = wave; ry < ROWS; ry += 4) {
+    const float* row = in + (size_t)reflect101(y0 - R + ry, h) * w;
+    for (int rx = lane; rx < kFtW + 2 * R; rx += 64) s_in[ry * COLS + rx] = row[reflect101(x0 - R + rx, w)];
+  }
+  __syncthreads();
+  for (int item = tid; item < ROWS * (kFtW / 4); item += 256) {
+    const int ry = item / (kFtW / 4), xq = item % (kFtW / 4);
+    float v[N + 3];
+    const float4* src = reinterpret_cast<const float4*>(s_in + ry * COLS + 4 * xq);
+#pragma unroll
+    for (int j = 0; j < (N + 3 + 3) / 4; ++j) {
+      const float4 q = src[j];
+      if (4 * j < N + 3) v[4 * j] = q.x;
+      if (4 * j + 1 < N + 3) v[4 * j + 1] = q.y;
+      if (4 * j + 2 < N + 3) v[4 * j + 2] = q.z;
+      if (4 * j + 3 < N + 3) v[4 * j + 3] = q.w;
+    }
+    float o4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float acc = kk[0] * v[q];
+#pragma unroll
+      for (int t = 1; t < N; ++t) acc = acc + kk[t] * v[q + t];
+      o4[q] = acc;
+    }
+    *reinterpret_cast<float4*>(s_row + ry * kFtW + 4 * xq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+  }
+  __syncthreads();
+  {
+    const int x = x0 + lane, ly0 = wave * 8;             // 4 waves x 8 rows = the 32 rows of the tile
+    float v[8 + 2 * R];
+#pragma unroll
+    for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(ly0 + j) * kFtW + lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float acc = kk[R] * v[q + R];
+#pragma unroll
+      for (int t = 1; t <= R; ++t) acc = acc + kk[R + t] * (v[q + R + t] + v[q + R - t]);
+      const int y = y0 + ly0 + q;
+      if (x < w && y < h) {
+        out[(size_t)y * w + x] = acc;
+        if (dog != nullptr) dog[(size_t)y * w + x] = acc - s_in[(ly0 + q + R) * COLS + lane + R];
+      }
+    }
+  }
+}
+
+// ---- the tail of the pyramid (every octave of at most kTailPx pixels, sides <= kTailSide) in ONE launch of one workgroup:
+// the levels live in LDS -- two x-padded buffers (current / next level) and one y-padded buffer (row-filtered) whose
+// halos hold the BORDER_REFLECT_101 samples, so the tap loops are branch-free and fully unrolled -- and only the results
+// (Gaussian levels, DoG levels) go to global memory.  Same expressions, same order, as k_blur_row / k_blur_col.
+constexpr int kTailPx = 4800, kTailSide = 128, kTailPad = 13, kTailBuf = kTailPx + 2 * kTailPad * kTailSide;
+struct SiftBlurPlan { int off[6], n[6]; };
+
+template <int N>
+__device__ __forceinline__ void tail_level(const float* cur, float* tmp, float* nxt, int w, int h, const float* kg, float* g_out, float* d_out) {
+  constexpr int R = N / 2, P = kTailPad;
+  const int tid = threadIdx.x, wp = w + 2 * P, px = w * h;
+  float kk[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) kk[t] = kg[t];
+  for (int i = tid; i < px; i += 1024) {
+    const int y = i / w, x = i - y * w;
+    const float* row = cur + y * wp + P + x - R;
+    float acc = kk[0] * row[0];
+#pragma unroll
+    for (int t = 1; t < N; ++t) acc = acc + kk[t] * row[t];
+    tmp[(y + P) * w + x] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * R * w; i += 1024) {           // reflected rows above and below
+    const int j = i / w, x = i - j * w;
+    const int y = j < R ? -1 - j : h + (j - R);
+    tmp[(y + P) * w + x] = tmp[(reflect101(y, h) + P) * w + x];
+  }
+  __syncthreads();
+  for (int i = tid; i < px; i += 1024) {
+    const int y = i / w, x = i - y * w;
+    const float* col = tmp + (y + P) * w + x;
+    float acc = kk[R] * col[0];
+#pragma unroll
+    for (int t = 1; t <= R; ++t) acc = acc + kk[R + t] * (col[t * w] + col[-t * w]);
+    nxt[y * wp + P + x] = acc;
+    g_out[i] = acc;
+    d_out[i] = acc - cur[y * wp + P + x];
+  }
+  __syncthreads();
+}
+
+// reflected columns left and right of an x-padded level (the widest kernel needs kTailPad of them)
+__device__ __forceinline__ void tail_pad_x(float* buf, int w, int h) {
+  constexpr int P = kTailPad;
+  const int wp = w + 2 * P;
+  for (int i = threadIdx.x; i < 2 * P * h; i += 1024) {
+    const int y = i / (2 * P), j = i - y * (2 * P);
+    const int x = j < P ? -1 - j : w + (j - P);
+    buf[y * wp + P + x] = buf[y * wp + P + reflect101(x, w)];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sift_tail(SiftPyramid py, int o_first, const float* dk, SiftBlurPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) float s_tail[];
+  float* cur = s_tail; float* nxt = s_tail + kTailBuf; float* tmp = s_tail + 2 * kTailBuf;
+  const int tid = threadIdx.x;
+  for (int o = o_first; o < py.n_oct; ++o) {
+    const SiftOctave& oc = py.oct[o];
+    const int w = oc.w, h = oc.h, px = w * h, wp = w + 2 * kTailPad;
+    {   // base level: every second pixel of level 3 of the octave above (written by an earlier launch or by this workgroup)
+      const float* src = py.oct[o - 1].gauss[3];
+      const int ws = py.oct[o - 1].w;
+      for (int i = tid; i < px; i += 1024) { const int y = i / w, x = i - y * w; const float v = src[(size_t)(2 * y) * ws + 2 * x]; cur[y * wp + kTailPad + x] = v; oc.gauss[0][i] = v; }
+    }
+    __syncthreads();
+    for (int lvl = 1; lvl < 6; ++lvl) {
+      tail_pad_x(cur, w, h);
+      const float* kg = dk + plan.off[lvl];
+      switch (plan.n[lvl]) {
+        case 11: tail_level<11>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+        case 13: tail_level<13>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+        case 17: tail_level<17>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+        case 21: tail_level<21>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+        default: tail_level<27>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+      }
+      float* t2 = cur; cur = nxt; nxt = t2;
+    }
+    __syncthreads();                                   // level 3 of this octave is read back from global memory by the next one
+  }
 }
 
 __global__ __launch_bounds__(256) void k_half_nearest(const float* in, int w, float* out, int w2, int h2) {
@@ -139,8 +285,15 @@ __device__ bool lu_solve3(float A[3][3], float x[3]) {
 }
 
 // ---- candidates: |DoG| above the threshold and a 26-neighbour extremum
-__global__ __launch_bounds__(256) void k_sift_find(SiftOctave oc, int octave, int layer, float threshold, int4* cand, int* n_cand, int max_cand) {
-  const int c = kBorder + blockIdx.x * 64 + (threadIdx.x & 63), r = kBorder + blockIdx.y * 4 + (threadIdx.x >> 6);
+// one launch for all octaves and layers: blockIdx.x runs over the 64 x 4 tiles of every octave back to back
+struct SiftFindPlan { int first_tile[kSiftMaxOctaves + 1]; int tiles_x[kSiftMaxOctaves]; };
+__global__ __launch_bounds__(256) void k_sift_find(SiftPyramid py, SiftFindPlan plan, float threshold, int4* cand, int* n_cand, int max_cand) {
+  int octave = 0;
+  while (octave + 1 < py.n_oct && (int)blockIdx.x >= plan.first_tile[octave + 1]) ++octave;
+  const SiftOctave& oc = py.oct[octave];
+  const int layer = 1 + blockIdx.y;
+  const int tile = blockIdx.x - plan.first_tile[octave];
+  const int c = kBorder + (tile % plan.tiles_x[octave]) * 64 + (threadIdx.x & 63), r = kBorder + (tile / plan.tiles_x[octave]) * 4 + (threadIdx.x >> 6);
   if (c >= oc.w - kBorder || r >= oc.h - kBorder) return;
   const float* img = oc.dog[layer];
   const float val = img[(size_t)r * oc.w + c];
@@ -277,19 +430,25 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
 #undef AT
 }
 
-// ---- calcSIFTDescriptor: one WAVE per keypoint.  The 4x4x8 histogram must receive its contributions in OpenCV's raster
-// order (float sums do not commute), but everything else about a sample is independent: the 64 lanes evaluate 64
-// consecutive raster positions at once (rotation, Gaussian weight, gradient, trilinear shares) into LDS, then the
-// samples are committed one at a time -- lanes 0..7 add the eight shares of one sample, which always hit eight different
-// bins -- so the accumulation order is exactly the serial one.
-__global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyramid py, const SiftKeypoint* kp, int n, float* desc) {
-  constexpr int d = 4, nb = 8, HL = (d + 2) * (d + 2) * (nb + 2);
-  __shared__ float hist[HL];
-  __shared__ int s_idx[64];
-  __shared__ float s_val[8][64];
+// ---- calcSIFTDescriptor: one workgroup of 1 + kDescProducers waves per keypoint.  The 4x4x8 histogram must receive its
+// contributions in OpenCV's raster order (float sums do not commute), but everything else about a sample is independent:
+// each PRODUCER wave evaluates 64 consecutive raster positions at once (rotation, Gaussian weight, gradient, trilinear
+// shares), drops the positions outside the rotated window (ballot/popcount, order kept) and leaves (LDS address, share)
+// pairs in LDS.  The COMMITTER wave walks the batches of the previous round in raster order and adds the shares with LDS
+// float atomics (ds_add_f32: an exact IEEE f32 add, subnormals included -- tools/probes/lds_fadd.hip): one instruction per
+// position, its eight lanes adding the eight shares, which always hit eight different bins.  DS instructions of one wave
+// execute in issue order, so every bin sees exactly the serial sequence of additions.
+constexpr int kDescProducers = 4;
+
+__global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(SiftPyramid py, const SiftKeypoint* kp, const int* n_p, int max_n, float* desc) {
+  const int n = min(*n_p, max_n);
+  constexpr int d = 4, nb = 8, HL = (d + 2) * (d + 2) * (nb + 2), NP = kDescProducers, NT = 64 * (NP + 1);
+  __shared__ float hist[HL + 8];                     // [HL..HL+7]: sink for the padding lanes of a partial group of eight
+  __shared__ int2 s_pair[2][NP][64 * 8];             // [round parity][producer]: (LDS address of the bin, share bits), 8 per live position
+  __shared__ int s_live[2][NP];
   __shared__ float s_dst[128];
   __shared__ float s_nrm;
-  const int id = blockIdx.x, lane = threadIdx.x;
+  const int id = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (id >= n) return;
   const SiftKeypoint k = kp[id];
   int o = k.octave & 255; const int layer = (k.octave >> 8) & 255;
@@ -311,15 +470,16 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyramid py, const Si
   int radius = (int)rintf(((hist_width * 1.4142135623730951f) * (float)(d + 1)) * 0.5f);
   radius = min(radius, (int)sqrt((double)cols * cols + (double)rows * rows));
   cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
-  for (int q = lane; q < HL; q += 64) hist[q] = 0.f;
+  for (int q = tid; q < HL + 8; q += NT) hist[q] = 0.f;
+  const uint32_t hist_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)hist;   // LDS byte address of bin 0
   const int side = 2 * radius + 1, total = side * side;
-  const int off = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? (nb + 2) : lane == 3 ? (nb + 3) : lane == 4 ? (d + 2) * (nb + 2)
-                  : lane == 5 ? (d + 2) * (nb + 2) + 1 : lane == 6 ? (d + 3) * (nb + 2) : (d + 3) * (nb + 2) + 1;
+  const int n_rounds = ((total + 63) / 64 + NP - 1) / NP;
   __syncthreads();
-  for (int base = 0; base < total; base += 64) {
-    const int p = base + lane;
-    int idx = -1;
-    if (p < total) {
+  for (int round = 0; round <= n_rounds; ++round) {
+    if (wave > 0 && round < n_rounds) {
+      // ---- producer: raster positions [base, base + 64)
+      const int w = wave - 1;
+      const int p = (round * NP + w) * 64 + lane;
       const int ii = p / side - radius, jj = p % side - radius;
       const float fi = (float)ii, fj = (float)jj;
       const float c_rot = fj * cos_t - fi * sin_t;
@@ -327,7 +487,9 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyramid py, const Si
       float rbin = r_rot + (float)(d / 2) - 0.5f;
       float cbin = c_rot + (float)(d / 2) - 0.5f;
       const int r = pyi + ii, c = px + jj;
-      if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+      int idx = -1;
+      float v[8];
+      if (p < total && rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
         const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
         const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
         const float W = exp32((c_rot * c_rot + r_rot * r_rot) * exp_scale);
@@ -343,33 +505,65 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyramid py, const Si
         const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
         const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
         const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-        const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
-        const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
-        const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
-        const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
+        v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7];
+        v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
+        v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
+        v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
         idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
-        s_val[0][lane] = v000; s_val[1][lane] = v001; s_val[2][lane] = v010; s_val[3][lane] = v011;
-        s_val[4][lane] = v100; s_val[5][lane] = v101; s_val[6][lane] = v110; s_val[7][lane] = v111;
       }
-    }
-    s_idx[lane] = idx;
-    __syncthreads();
-    for (int sidx = 0; sidx < 64; ++sidx) {           // commit in raster order; the eight shares of a sample hit distinct bins
-      const int ib = s_idx[sidx];
-      if (ib < 0) continue;
-      if (lane < 8) hist[ib + off] = hist[ib + off] + s_val[lane][sidx];
+      const unsigned long long live_mask = __ballot(idx >= 0);
+      const int rank = __popcll(live_mask & ((1ull << lane) - 1ull));
+      if (idx >= 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+          const int boff = (l & 1) + ((l >> 1) & 1) * (nb + 2) + (l >> 2) * (d + 2) * (nb + 2);
+          s_pair[round & 1][w][rank * 8 + l] = make_int2((int)(hist_lds + 4u * (uint32_t)(idx + boff)), __float_as_int(v[l]));
+        }
+      }
+      if (lane == 0) s_live[round & 1][w] = __popcll(live_mask);
+    } else if (wave == 0 && round > 0) {
+      // ---- committer: the batches of the previous round, in raster order.  Lane L holds share (L & 7) of live position
+      // 8 t + (L >> 3); eight ds_add_f32, each with only the eight lanes of ONE position enabled (exec set by hand: a
+      // compiler-generated branch per position costs more than the add itself)
+      const int par = (round - 1) & 1;
+      for (int w = 0; w < NP; ++w) {
+        const int n_live = s_live[par][w];
+        for (int t = 0; t * 8 < n_live; ++t) {
+          const int2 pr = s_pair[par][w][t * 64 + lane];
+          const bool live = t * 8 + (lane >> 3) < n_live;
+          const uint32_t addr = live ? (uint32_t)pr.x : hist_lds + 4u * (uint32_t)(HL + (lane & 7));
+          const float val = live ? __int_as_float(pr.y) : 0.f;
+          unsigned long long saved;
+          asm volatile(
+              "s_mov_b64 %[sv], exec\n\t"
+              "s_mov_b32 exec_hi, 0\n\t"
+              "s_mov_b32 exec_lo, 0xff\n\t"        "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_lo, 0xff00\n\t"      "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_lo, 0xff0000\n\t"    "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_lo, 0xff000000\n\t"  "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_lo, 0\n\t"
+              "s_mov_b32 exec_hi, 0xff\n\t"        "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_hi, 0xff00\n\t"      "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_hi, 0xff0000\n\t"    "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b32 exec_hi, 0xff000000\n\t"  "ds_add_f32 %[a], %[v]\n\t"
+              "s_mov_b64 exec, %[sv]\n\t"
+              : [sv] "=&s"(saved)
+              : [a] "v"(addr), [v] "v"(val)
+              : "memory");
+        }
+      }
     }
     __syncthreads();
   }
-  if (lane < d * d) {
-    const int i = lane / d, j = lane % d;
+  if (tid < d * d) {
+    const int i = tid / d, j = tid % d;
     const int idx = ((i + 1) * (d + 2) + (j + 1)) * (nb + 2);
     hist[idx] = hist[idx] + hist[idx + nb];
     hist[idx + 1] = hist[idx + 1] + hist[idx + nb + 1];
     for (int q = 0; q < nb; ++q) s_dst[(i * d + j) * nb + q] = hist[idx + q];
   }
   __syncthreads();
-  if (lane == 0) {                                    // the two norms are sequential float sums in OpenCV
+  if (tid == 0) {                                     // the two norms are sequential float sums in OpenCV
     float nrm2 = 0.f;
     for (int q = 0; q < 128; ++q) nrm2 = nrm2 + s_dst[q] * s_dst[q];
     const float thr = sqrtf(nrm2) * 0.2f;
@@ -379,8 +573,88 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyramid py, const Si
   }
   __syncthreads();
   float* dst = desc + (size_t)id * 128;
-  for (int q = lane; q < 128; q += 64) dst[q] = fminf(fmaxf(rintf(s_dst[q] * s_nrm), 0.f), 255.f);   // saturate_cast<uchar>
+  if (tid < 128) dst[tid] = fminf(fmaxf(rintf(s_dst[tid] * s_nrm), 0.f), 255.f);   // saturate_cast<uchar>
 }
+// ---- KeyPointsFilter::removeDuplicatedSorted + the first-octave rescale, on the device: one workgroup sorts the raw
+// keypoints (appended in arbitrary order by the atomics) with a bitonic network under OpenCV's KeyPoint_LessThan order
+// (x, y, size descending, angle, response descending, octave descending), drops repeats of (x, y, size, angle), rescales
+// and writes the final list in place -- the order is therefore deterministic whatever the atomics did.
+constexpr int kSortLds = 4096;
+__device__ __forceinline__ bool kp_less(const SiftKeypoint& a, const SiftKeypoint& b) {
+  if (a.x != b.x) return a.x < b.x;
+  if (a.y != b.y) return a.y < b.y;
+  if (a.size != b.size) return a.size > b.size;
+  if (a.angle != b.angle) return a.angle < b.angle;
+  if (a.response != b.response) return a.response > b.response;
+  return a.octave > b.octave;
+}
+
+__global__ __launch_bounds__(1024) void k_sift_sort_dedup(SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* out, int* n_out,
+                                                            int max_out, float* kpt_xysa, float* response, int32_t* octave) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  const int n = min(*n_raw_p, max_raw);
+  int npad = 1;
+  while (npad < n) npad <<= 1;
+  // up to kSortLds keypoints are sorted in LDS (96 KB), longer lists in place in global memory (L2-resident)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_sort_raw[];
+  if (npad <= kSortLds) {
+    SiftKeypoint* sk = reinterpret_cast<SiftKeypoint*>(s_sort_raw);
+    for (int i = tid; i < n; i += 1024) sk[i] = kp[i];
+    kp = sk;
+  }
+  for (int i = n + tid; i < npad; i += 1024) { SiftKeypoint z; z.x = INFINITY; z.y = 0.f; z.size = 0.f; z.angle = 0.f; z.response = 0.f; z.octave = 0; kp[i] = z; }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const SiftKeypoint a = kp[i], b = kp[l];
+          const bool up = (i & k) == 0;
+          if (up ? kp_less(b, a) : kp_less(a, b)) { kp[i] = b; kp[l] = a; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  // duplicate flags + order-preserving compaction (block-wide scan over chunks of 1024)
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    bool keep = false;
+    SiftKeypoint q;
+    if (i < n) {
+      q = kp[i];
+      keep = true;
+      if (i > 0) { const SiftKeypoint p = kp[i - 1]; keep = !(p.x == q.x && p.y == q.y && p.size == q.size && p.angle == q.angle); }
+    }
+    s_scan[tid] = keep ? 1 : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int v = tid >= off ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const int pos = s_base + s_scan[tid] - 1;
+    if (keep && pos < max_out) {
+      q.octave = (q.octave & ~255) | ((q.octave + (-1 & 255)) & 255);        // firstOctave = -1
+      q.x = q.x * 0.5f; q.y = q.y * 0.5f; q.size = q.size * 0.5f;
+      out[pos] = q;
+      kpt_xysa[4 * pos] = q.x; kpt_xysa[4 * pos + 1] = q.y; kpt_xysa[4 * pos + 2] = q.size; kpt_xysa[4 * pos + 3] = q.angle;
+      if (response) response[pos] = q.response;
+      if (octave) octave[pos] = q.octave;
+    }
+    __syncthreads();
+    if (tid == 1023) s_base += s_scan[1023];
+    __syncthreads();
+  }
+  if (tid == 0) *n_out = s_base;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -397,9 +671,35 @@ void sift_gaussian_kernel(double sigma, std::vector<float>& k) {
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
+static inline bool sift_fused_taps(int n) { return n == 11 || n == 13 || n == 17 || n == 21 || n == 27; }
 void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog) {
-  hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);
+  const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH);
+  switch (n) {
+    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    default: break;
+  }
+  hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);       // other sigma: two plain passes
   hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, out, w, h, dk, n, in, dog);
+}
+// octaves [o_first, n_oct) in one launch; o_first = sift_tail_first(py) (>= 1; n_oct when the kernel sizes are not the stock ones)
+int sift_tail_first(const SiftPyramid& py, const int* ksize) {
+  for (int i = 1; i < 6; ++i) if (!sift_fused_taps(ksize[i])) return py.n_oct;
+  int o = 1;
+  while (o < py.n_oct && (py.oct[o].w * py.oct[o].h > kTailPx || py.oct[o].w > kTailSide || py.oct[o].h > kTailSide)) ++o;
+  return o;
+}
+void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s) {
+  if (o_first >= py.n_oct) return;
+  SiftBlurPlan plan;
+  for (int i = 0; i < 6; ++i) { plan.off[i] = koff[i]; plan.n[i] = ksize[i]; }
+  constexpr int lds = 3 * kTailBuf * (int)sizeof(float);
+  static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sift_tail), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+  (void)attr_set;
+  hipLaunchKernelGGL(k_sift_tail, dim3(1), dim3(1024), lds, s, py, o_first, dk, plan);
 }
 void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sift_base, grid2d(2 * w, 2 * h), dim3(256), 0, s, gray, h, w, out);
@@ -411,40 +711,33 @@ void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t 
   hipLaunchKernelGGL(k_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
 }
 void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s) {
-  for (int o = 0; o < py.n_oct; ++o) {
+  SiftFindPlan plan;
+  int total = 0;
+  for (int o = 0; o < kSiftMaxOctaves; ++o) {
+    plan.first_tile[o] = total; plan.tiles_x[o] = 1;
+    if (o >= py.n_oct) continue;
     const SiftOctave& oc = py.oct[o];
     if (oc.h <= 2 * kBorder || oc.w <= 2 * kBorder) continue;
-    for (int l = 1; l <= kLayers; ++l)
-      hipLaunchKernelGGL(k_sift_find, grid2d(oc.w - 2 * kBorder, oc.h - 2 * kBorder), dim3(256), 0, s, oc, o, l, threshold, cand, n_cand, max_cand);
+    const dim3 g = grid2d(oc.w - 2 * kBorder, oc.h - 2 * kBorder);
+    plan.tiles_x[o] = (int)g.x;
+    total += (int)(g.x * g.y);
   }
+  plan.first_tile[kSiftMaxOctaves] = total;
+  if (total > 0) hipLaunchKernelGGL(k_sift_find, dim3(total, kLayers), dim3(256), 0, s, py, plan, threshold, cand, n_cand, max_cand);
 }
 void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s) {
   hipLaunchKernelGGL(k_sift_refine, dim3(std::min(max_cand, 4096)), dim3(64), 0, s, py, cand, n_cand, max_cand, kp, n_kp, max_kp);
 }
-void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, int n, float* desc, float* /*unused*/, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_sift_descriptor, dim3(n), dim3(64), 0, s, py, kp, n, desc);
+void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* n_dev, int max_n, float* desc, hipStream_t s) {
+  hipLaunchKernelGGL(k_sift_descriptor, dim3(max_n), dim3(64 * (kDescProducers + 1)), 0, s, py, kp, n_dev, max_n, desc);   // blocks beyond *n_dev exit at once
 }
 
-// KeyPointsFilter::removeDuplicatedSorted + the first-octave rescale of SIFT_Impl::detectAndCompute
-void sift_sort_dedup(std::vector<SiftKeypoint>& k) {
-  std::stable_sort(k.begin(), k.end(), [](const SiftKeypoint& a, const SiftKeypoint& b) {
-    if (a.x != b.x) return a.x < b.x;
-    if (a.y != b.y) return a.y < b.y;
-    if (a.size != b.size) return a.size > b.size;
-    if (a.angle != b.angle) return a.angle < b.angle;
-    if (a.response != b.response) return a.response > b.response;
-    return a.octave > b.octave;
-  });
-  std::vector<SiftKeypoint> out;
-  for (const SiftKeypoint& q : k) {
-    if (!out.empty() && out.back().x == q.x && out.back().y == q.y && out.back().size == q.size && out.back().angle == q.angle) continue;
-    out.push_back(q);
-  }
-  for (SiftKeypoint& q : out) {
-    q.octave = (q.octave & ~255) | ((q.octave + (-1 & 255)) & 255);
-    q.x = q.x * 0.5f; q.y = q.y * 0.5f; q.size = q.size * 0.5f;
-  }
-  k.swap(out);
+void sift_sort_dedup(SiftKeypoint* kp_raw, const int* n_raw, int max_raw, SiftKeypoint* kp_out, int* n_out, int max_out,
+                     float* kpt_xysa, float* response, int32_t* octave, hipStream_t s) {
+  static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sift_sort_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(kSortLds * sizeof(SiftKeypoint))) == hipSuccess);
+  (void)attr_set;
+  hipLaunchKernelGGL(k_sift_sort_dedup, dim3(1), dim3(1024), kSortLds * sizeof(SiftKeypoint), s, kp_raw, n_raw, max_raw, kp_out, n_out, max_out, kpt_xysa, response, octave);
 }
 
 }  // namespace gn
