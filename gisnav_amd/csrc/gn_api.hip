@@ -948,7 +948,7 @@ int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
   ctx->sift_counts = (int*)alloc(4 * sizeof(int));
   ctx->sift_raw_cap = 1;
   while (ctx->sift_raw_cap < 4 * ctx->sift_max_kp) ctx->sift_raw_cap <<= 1;
-  ctx->sift_kp = (SiftKeypoint*)alloc(((size_t)ctx->sift_raw_cap + ctx->sift_max_kp) * sizeof(SiftKeypoint));
+  ctx->sift_kp = (SiftKeypoint*)alloc(((size_t)2 * ctx->sift_raw_cap + ctx->sift_max_kp) * sizeof(SiftKeypoint));   // raw | sorted | final
   ctx->sift_hist = (float*)alloc((size_t)ctx->sift_max_kp * 360 * sizeof(float));
   if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp || !ctx->sift_hist)
     return fail(ctx, GN_ERR_HIP, "SIFT workspace allocation failed");
@@ -985,11 +985,11 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
   GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 3 * sizeof(int), s));
   const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);
   sift_find(py, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
-  // raw keypoint capacity: a power of two (the bitonic network pads to one), final list stored behind it
+  // raw keypoints, their sorted copy and the final list live back to back in one allocation
   const int max_raw_alloc = ctx->sift_raw_cap, max_raw = max_raw_alloc;
   sift_refine(py, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, ctx->sift_kp, ctx->sift_counts + 1, max_raw, s);
   // sort / de-duplicate / rescale on the device, then descriptors for the *n final keypoints; one sync at the very end
-  SiftKeypoint* kp_final = ctx->sift_kp + max_raw_alloc;
+  SiftKeypoint* kp_final = ctx->sift_kp + 2 * max_raw_alloc;
   const int max_out = std::min(max_kpts, ctx->sift_max_kp);
   sift_sort_dedup(ctx->sift_kp, ctx->sift_counts + 1, max_raw, kp_final, ctx->sift_counts + 2, max_out, kpt_xysa, response, octave, s);
   sift_descriptors(py, kp_final, ctx->sift_counts + 2, max_out, desc, s);

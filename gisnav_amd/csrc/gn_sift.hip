@@ -8,7 +8,7 @@
 //   k_sift_base (u8 -> f32, 2x bilinear) -> separable Gaussian (k_blur_row / k_blur_col, BORDER_REFLECT_101) ->
 //   k_half_nearest between octaves -> k_sub (DoG) -> k_sift_find (26-neighbour extrema) ->
 //   k_sift_refine (quadratic fit, contrast / edge tests, orientation histogram; one wave per candidate) ->
-//   k_sift_sort_dedup (bitonic sort in OpenCV's keypoint order, duplicate removal, first-octave rescale; one workgroup) ->
+//   k_sift_rank + k_sift_dedup_emit (OpenCV's keypoint order, duplicate removal, first-octave rescale) ->
 //   k_sift_descriptor (4x4x8 histogram; producer waves evaluate 64 samples at a time, one wave commits them in OpenCV's order).
 #include "gn_common.h"
 
@@ -88,9 +88,21 @@ __global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out,
   float kk[N];
 #pragma unroll
   for (int t = 0; t < N; ++t) kk[t] = k[t];
-  for (int ry = wave; ry < ROWS; ry += 4) {
-    const float* row = in + (size_t)reflect101(y0 - R + ry, h) * w;
-    for (int rx = lane; rx < kFtW + 2 * R; rx += 64) s_in[ry * COLS + rx] = row[reflect101(x0 - R + rx, w)];
+  {   // stage the tile: all global loads of a thread are issued before the first LDS store (one memory latency, not ~20)
+    constexpr int CW = kFtW + 2 * R, TOTAL = ROWS * CW, PER = (TOTAL + 255) / 256;
+    float stage[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      const int ry = idx / CW, rx = idx - ry * CW;
+      stage[i] = idx < TOTAL ? in[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      const int ry = idx / CW, rx = idx - ry * CW;
+      if (idx < TOTAL) s_in[ry * COLS + rx] = stage[i];
+    }
   }
   __syncthreads();
   for (int item = tid; item < ROWS * (kFtW / 4); item += 256) {
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
 // float atomics (ds_add_f32: an exact IEEE f32 add, subnormals included -- tools/probes/lds_fadd.hip): one instruction per
 // position, its eight lanes adding the eight shares, which always hit eight different bins.  DS instructions of one wave
 // execute in issue order, so every bin sees exactly the serial sequence of additions.
-constexpr int kDescProducers = 4;
+constexpr int kDescProducers = 7;
 
 __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(SiftPyramid py, const SiftKeypoint* kp, const int* n_p, int max_n, float* desc) {
   const int n = min(*n_p, max_n);
@@ -528,13 +540,20 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
       const int par = (round - 1) & 1;
       for (int w = 0; w < NP; ++w) {
         const int n_live = s_live[par][w];
+        const uint32_t pair_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int2*)&s_pair[par][w][lane];
+        unsigned long long pr = n_live > 0 ? *reinterpret_cast<const unsigned long long*>(&s_pair[par][w][lane]) : 0ull;
         for (int t = 0; t * 8 < n_live; ++t) {
-          const int2 pr = s_pair[par][w][t * 64 + lane];
           const bool live = t * 8 + (lane >> 3) < n_live;
-          const uint32_t addr = live ? (uint32_t)pr.x : hist_lds + 4u * (uint32_t)(HL + (lane & 7));
-          const float val = live ? __int_as_float(pr.y) : 0.f;
-          unsigned long long saved;
+          const uint32_t addr = live ? (uint32_t)pr : hist_lds + 4u * (uint32_t)(HL + (lane & 7));
+          const float val = live ? __int_as_float((int)(pr >> 32)) : 0.f;
+          const uint32_t next_lds = pair_lds + (uint32_t)(min(t + 1, 7) * 64 * sizeof(int2));
+          unsigned long long saved, nxt;
+          // the pairs of the next group are fetched ahead of this group's adds (DS ops complete in order: once at most the
+          // eight adds are outstanding the read has landed), so the atomic unit never waits for a read round trip.
+          // (Measured, tools/probes/lds_atomic_rate.hip: the LDS atomic unit of a CU retires ~1 lane per 3 clocks, shared by
+          // all its waves -- a second committer wave, or narrowing exec with v_cmpx to skip border-cell shares, buys nothing.)
           asm volatile(
+              "ds_read_b64 %[nx], %[na]\n\t"
               "s_mov_b64 %[sv], exec\n\t"
               "s_mov_b32 exec_hi, 0\n\t"
               "s_mov_b32 exec_lo, 0xff\n\t"        "ds_add_f32 %[a], %[v]\n\t"
@@ -547,9 +566,11 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
               "s_mov_b32 exec_hi, 0xff0000\n\t"    "ds_add_f32 %[a], %[v]\n\t"
               "s_mov_b32 exec_hi, 0xff000000\n\t"  "ds_add_f32 %[a], %[v]\n\t"
               "s_mov_b64 exec, %[sv]\n\t"
-              : [sv] "=&s"(saved)
-              : [a] "v"(addr), [v] "v"(val)
+              "s_waitcnt lgkmcnt(8)\n\t"
+              : [sv] "=&s"(saved), [nx] "=&v"(nxt)
+              : [a] "v"(addr), [v] "v"(val), [na] "v"(next_lds)
               : "memory");
+          pr = nxt;
         }
       }
     }
@@ -565,21 +586,34 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
   __syncthreads();
   if (tid == 0) {                                     // the two norms are sequential float sums in OpenCV
     float nrm2 = 0.f;
-    for (int q = 0; q < 128; ++q) nrm2 = nrm2 + s_dst[q] * s_dst[q];
+#pragma unroll 4
+    for (int q = 0; q < 128; q += 8) {                // (loads batched eight at a time; the sums stay strictly sequential)
+      float e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = s_dst[q + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nrm2 = nrm2 + e[u] * e[u];
+    }
     const float thr = sqrtf(nrm2) * 0.2f;
     nrm2 = 0.f;
-    for (int q = 0; q < 128; ++q) { const float v = fminf(s_dst[q], thr); s_dst[q] = v; nrm2 = nrm2 + v * v; }
+#pragma unroll 4
+    for (int q = 0; q < 128; q += 8) {
+      float e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = fminf(s_dst[q + u], thr);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s_dst[q + u] = e[u]; nrm2 = nrm2 + e[u] * e[u]; }
+    }
     s_nrm = 512.0f / fmaxf(sqrtf(nrm2), kFltEps);
   }
   __syncthreads();
   float* dst = desc + (size_t)id * 128;
   if (tid < 128) dst[tid] = fminf(fmaxf(rintf(s_dst[tid] * s_nrm), 0.f), 255.f);   // saturate_cast<uchar>
 }
-// ---- KeyPointsFilter::removeDuplicatedSorted + the first-octave rescale, on the device: one workgroup sorts the raw
-// keypoints (appended in arbitrary order by the atomics) with a bitonic network under OpenCV's KeyPoint_LessThan order
-// (x, y, size descending, angle, response descending, octave descending), drops repeats of (x, y, size, angle), rescales
-// and writes the final list in place -- the order is therefore deterministic whatever the atomics did.
-constexpr int kSortLds = 4096;
+// ---- KeyPointsFilter::removeDuplicatedSorted + the first-octave rescale, on the device: the raw keypoints (appended in
+// arbitrary order by the atomics) are put in OpenCV's KeyPoint_LessThan order (x, y, size descending, angle, response
+// descending, octave descending) by a rank sort, then one workgroup drops repeats of (x, y, size, angle), rescales and
+// writes the final list -- the order is therefore deterministic whatever the atomics did.
 __device__ __forceinline__ bool kp_less(const SiftKeypoint& a, const SiftKeypoint& b) {
   if (a.x != b.x) return a.x < b.x;
   if (a.y != b.y) return a.y < b.y;
@@ -589,37 +623,54 @@ __device__ __forceinline__ bool kp_less(const SiftKeypoint& a, const SiftKeypoin
   return a.octave > b.octave;
 }
 
-__global__ __launch_bounds__(1024) void k_sift_sort_dedup(SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* out, int* n_out,
-                                                            int max_out, float* kpt_xysa, float* response, int32_t* octave) {
-  __shared__ int s_scan[1024];
-  __shared__ int s_base;
-  const int tid = threadIdx.x;
+// rank sort: thread i counts the keypoints that precede its own (ties between identical keypoints broken by the raw
+// index, so ranks are a permutation) and stores it at that position.  O(n^2) comparisons spread over n / 64 workgroups,
+// the list streamed through LDS in tiles of 256 (x as a separate float4-readable array; the full record is only touched
+// when x ties) -- no barrier per sorting stage as in a bitonic network.
+__global__ __launch_bounds__(256) void k_sift_rank(const SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* sorted) {
+  __shared__ SiftKeypoint s_tile[256];
+  __shared__ __attribute__((aligned(16))) float s_x[256];
+  __shared__ int s_rank[4][64];
   const int n = min(*n_raw_p, max_raw);
-  int npad = 1;
-  while (npad < n) npad <<= 1;
-  // up to kSortLds keypoints are sorted in LDS (96 KB), longer lists in place in global memory (L2-resident)
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_sort_raw[];
-  if (npad <= kSortLds) {
-    SiftKeypoint* sk = reinterpret_cast<SiftKeypoint*>(s_sort_raw);
-    for (int i = tid; i < n; i += 1024) sk[i] = kp[i];
-    kp = sk;
-  }
-  for (int i = n + tid; i < npad; i += 1024) { SiftKeypoint z; z.x = INFINITY; z.y = 0.f; z.size = 0.f; z.angle = 0.f; z.response = 0.f; z.octave = 0; kp[i] = z; }
-  __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npad; i += 1024) {
-        const int l = i ^ j;
-        if (l > i) {
-          const SiftKeypoint a = kp[i], b = kp[l];
-          const bool up = (i & k) == 0;
-          if (up ? kp_less(b, a) : kp_less(a, b)) { kp[i] = b; kp[l] = a; }
-        }
+  if ((int)blockIdx.x * 64 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * 64 + lane;                // the four waves share 64 keypoints and split every tile of 256 four ways
+  SiftKeypoint me;
+  me.x = __int_as_float(0x7fc00000); me.y = 0.f; me.size = 0.f; me.angle = 0.f; me.response = 0.f; me.octave = 0;   // NaN: precedes / follows nothing
+  if (i < n) me = kp[i];
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    if (j0 + tid < n) { const SiftKeypoint t = kp[j0 + tid]; s_tile[tid] = t; s_x[tid] = t.x; }
+    else s_x[tid] = __int_as_float(0x7fc00000);
+    __syncthreads();
+    const float4* xs = reinterpret_cast<const float4*>(s_x + 64 * wave);
+    auto visit = [&](float xj, int jl) {
+      if (xj < me.x) ++rank;
+      else if (xj == me.x && j0 + jl != i) {          // x ties beyond the keypoint itself: several orientations of one extremum
+        const SiftKeypoint o = s_tile[jl];
+        if (kp_less(o, me) || (!kp_less(me, o) && j0 + jl < i)) ++rank;
       }
-      __threadfence_block();
-      __syncthreads();
+    };
+#pragma unroll 1
+    for (int g = 0; g < 16; ++g) {                     // kept rolled: the kernel is launched cold, code size is latency
+      const float4 q = xs[g];                          // same address for every lane: an LDS broadcast
+      const int jl = 64 * wave + 4 * g;
+      visit(q.x, jl); visit(q.y, jl + 1); visit(q.z, jl + 2); visit(q.w, jl + 3);
     }
-  // duplicate flags + order-preserving compaction (block-wide scan over chunks of 1024)
+  }
+  s_rank[wave][lane] = rank;
+  __syncthreads();
+  if (wave == 0 && i < n) sorted[s_rank[0][lane] + s_rank[1][lane] + s_rank[2][lane] + s_rank[3][lane]] = me;
+}
+
+// removeDuplicatedSorted + first-octave rescale + the output arrays, one workgroup over the sorted list
+__global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* out, int* n_out,
+                                                            int max_out, float* kpt_xysa, float* response, int32_t* octave) {
+  __shared__ int s_wcount[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(*n_raw_p, max_raw);
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += 1024) {
@@ -631,15 +682,11 @@ __global__ __launch_bounds__(1024) void k_sift_sort_dedup(SiftKeypoint* kp, cons
       keep = true;
       if (i > 0) { const SiftKeypoint p = kp[i - 1]; keep = !(p.x == q.x && p.y == q.y && p.size == q.size && p.angle == q.angle); }
     }
-    s_scan[tid] = keep ? 1 : 0;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wcount[wave] = __popcll(bal);
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int v = tid >= off ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
-    }
-    const int pos = s_base + s_scan[tid] - 1;
+    int pos = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int wv = 0; wv < wave; ++wv) pos += s_wcount[wv];
     if (keep && pos < max_out) {
       q.octave = (q.octave & ~255) | ((q.octave + (-1 & 255)) & 255);        // firstOctave = -1
       q.x = q.x * 0.5f; q.y = q.y * 0.5f; q.size = q.size * 0.5f;
@@ -649,7 +696,7 @@ __global__ __launch_bounds__(1024) void k_sift_sort_dedup(SiftKeypoint* kp, cons
       if (octave) octave[pos] = q.octave;
     }
     __syncthreads();
-    if (tid == 1023) s_base += s_scan[1023];
+    if (tid == 0) { int t = 0; for (int wv = 0; wv < 16; ++wv) t += s_wcount[wv]; s_base += t; }
     __syncthreads();
   }
   if (tid == 0) *n_out = s_base;
@@ -732,12 +779,12 @@ void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* 
   hipLaunchKernelGGL(k_sift_descriptor, dim3(max_n), dim3(64 * (kDescProducers + 1)), 0, s, py, kp, n_dev, max_n, desc);   // blocks beyond *n_dev exit at once
 }
 
+// kp_raw: max_raw raw keypoints followed by max_raw slots for the sorted copy
 void sift_sort_dedup(SiftKeypoint* kp_raw, const int* n_raw, int max_raw, SiftKeypoint* kp_out, int* n_out, int max_out,
                      float* kpt_xysa, float* response, int32_t* octave, hipStream_t s) {
-  static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sift_sort_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)(kSortLds * sizeof(SiftKeypoint))) == hipSuccess);
-  (void)attr_set;
-  hipLaunchKernelGGL(k_sift_sort_dedup, dim3(1), dim3(1024), kSortLds * sizeof(SiftKeypoint), s, kp_raw, n_raw, max_raw, kp_out, n_out, max_out, kpt_xysa, response, octave);
+  SiftKeypoint* sorted = kp_raw + max_raw;
+  hipLaunchKernelGGL(k_sift_rank, dim3((max_raw + 63) / 64), dim3(256), 0, s, kp_raw, n_raw, max_raw, sorted);
+  hipLaunchKernelGGL(k_sift_dedup_emit, dim3(1), dim3(1024), 0, s, sorted, n_raw, max_raw, kp_out, n_out, max_out, kpt_xysa, response, octave);
 }
 
 }  // namespace gn

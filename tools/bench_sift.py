@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
+    ap.add_argument("--max-kp", type=int, default=16384)
     args = ap.parse_args()
     H, W = args.size
     img = blob_image(11, H, W, n=900)
-    sift = SIFT(max_keypoints=16384)
+    sift = SIFT(max_keypoints=args.max_kp)
     t = torch.as_tensor(img, device=sift._eng.device)
     for _ in range(args.warmup):
         out = sift.detect_and_compute_device(t)
