@@ -967,22 +967,22 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
   if (rc != GN_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   SiftPyramid& py = ctx->sift_py;
-  auto blur = [&](const float* in, float* out, int w, int h, int ki, float* dog = nullptr) {
-    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s, dog);
+  auto blur = [&](const float* in, float* out, int w, int h, int ki, float* dog = nullptr, int in_step = 1, int in_w = 0, float* half_scratch = nullptr) {
+    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s, dog, in_step, in_w, half_scratch);
   };
   // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
-  sift_base(gray, H, W, py.oct[0].gauss[5], s);                      // scratch: level 5 is overwritten later
+  sift_base(gray, H, W, py.oct[0].gauss[5], ctx->sift_counts, s);   // scratch: level 5 is overwritten later; also zeroes the counters
   blur(py.oct[0].gauss[5], py.oct[0].gauss[0], py.oct[0].w, py.oct[0].h, 0);
   int ksize[6];
   for (int i = 0; i < 6; ++i) ksize[i] = (int)ctx->sift_kernels[i].size();
   const int o_tail = sift_tail_first(py, ksize);                     // octaves from here on: one single-workgroup launch
   for (int o = 0; o < o_tail; ++o) {
     const SiftOctave& oc = py.oct[o];
-    if (o > 0) sift_half(py.oct[o - 1].gauss[3], py.oct[o - 1].w, oc.gauss[0], oc.w, oc.h, s);
-    for (int i = 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // row + column pass + DoG level in one launch
+    // level 1 of octave o > 0 samples level 3 of the octave above directly (its level 0 is never stored)
+    if (o > 0) blur(py.oct[o - 1].gauss[3], oc.gauss[1], oc.w, oc.h, 1, oc.dog[0], 2, py.oct[o - 1].w, oc.gauss[0]);
+    for (int i = o > 0 ? 2 : 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // row + column pass + DoG level in one launch
   }
   sift_tail(py, o_tail, ctx->sift_dk, ctx->sift_koff.data(), ksize, s);
-  GN_HIP(hipMemsetAsync(ctx->sift_counts, 0, 3 * sizeof(int), s));
   const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);
   sift_find(py, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
   // raw keypoints, their sorted copy and the final list live back to back in one allocation

@@ -167,12 +167,12 @@ struct SiftOctave { float* gauss[6]; float* dog[5]; int w, h; };
 struct SiftPyramid { SiftOctave oct[kSiftMaxOctaves]; int n_oct; };
 struct SiftKeypoint { float x, y, size, angle, response; int octave; };
 void sift_gaussian_kernel(double sigma, std::vector<float>& k);
-void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s);
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog = nullptr);   // dog = out - in
-void sift_half(const float* in, int w, float* out, int w2, int h2, hipStream_t s);
+void sift_base(const uint8_t* gray, int h, int w, float* out, int* counters, hipStream_t s);   // also zeroes counters[0..2]
+// dog = out - in; in_step 2 reads every second pixel of a source image of row stride in_w (half_scratch: only used for non-stock kernel sizes)
+void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog = nullptr, int in_step = 1, int in_w = 0,
+               float* half_scratch = nullptr);
 int sift_tail_first(const SiftPyramid& py, const int* ksize);
 void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s);
-void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s);
 void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s);
 void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* n_dev, int max_n, float* desc, hipStream_t s);

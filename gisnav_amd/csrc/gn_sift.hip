@@ -5,8 +5,10 @@
 //
 // Compiled with -ffp-contract=off: every float operation below is a separate IEEE multiply / add / divide in the order the
 // oracle writes them, so scale space, keypoints and descriptors agree with it bit for bit.  Stages:
-//   k_sift_base (u8 -> f32, 2x bilinear) -> separable Gaussian (k_blur_row / k_blur_col, BORDER_REFLECT_101) ->
-//   k_half_nearest between octaves -> k_sub (DoG) -> k_sift_find (26-neighbour extrema) ->
+//   k_sift_base (u8 -> f32, 2x bilinear) -> separable Gaussian with BORDER_REFLECT_101, both passes and the DoG level in one
+//   launch per level (k_blur_fused: LDS tiles, register windows); the first level of an octave samples level 3 of the
+//   octave above directly; every octave of <= 4800 pixels is finished by ONE workgroup in LDS (k_sift_tail) ->
+//   k_sift_find (26-neighbour extrema, all octaves and layers in one launch) ->
 //   k_sift_refine (quadratic fit, contrast / edge tests, orientation histogram; one wave per candidate) ->
 //   k_sift_rank + k_sift_dedup_emit (OpenCV's keypoint order, duplicate removal, first-octave rescale) ->
 //   k_sift_descriptor (4x4x8 histogram; producer waves evaluate 64 samples at a time, one wave commits them in OpenCV's order).
@@ -30,7 +32,8 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out) {
+__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out, int* counters) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[threadIdx.x] = 0;   // candidate / raw / final counts of this call
   const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (dx >= 2 * w || dy >= 2 * h) return;
   auto taps = [](int d, int n_src, int& s, int& s1, float& a0, float& a1) {
@@ -77,9 +80,11 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
 // column-filters those.  Every output is the same expression, in the same order, as k_blur_row followed by k_blur_col;
 // a thread produces 4 adjacent outputs of a row (8 of a column) from one register window, so an LDS word is read once per
 // 4 (8) outputs instead of once per tap.  N (taps) is a template parameter: the pyramid only has 11/13/17/21/27.
+// The first level of an octave reads its input straight from level 3 of the octave above (in_step = 2), so the
+// half-size base image is never materialised.
 constexpr int kFtW = 64, kFtH = 32;
 template <int N>
-__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog) {
+__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w) {
   constexpr int R = N / 2, ROWS = kFtH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float s_in[ROWS * COLS];
   __shared__ __attribute__((aligned(16))) float s_row[ROWS * kFtW];
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out,
     for (int i = 0; i < PER; ++i) {
       const int idx = tid + 256 * i;
       const int ry = idx / CW, rx = idx - ry * CW;
-      stage[i] = idx < TOTAL ? in[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)] : 0.f;
+      stage[i] = idx < TOTAL ? in[(size_t)(reflect101(y0 - R + ry, h) * in_step) * in_w + reflect101(x0 - R + rx, w) * in_step] : 0.f;   // in_step 2: every second pixel of the octave above
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -236,10 +241,6 @@ __global__ __launch_bounds__(256) void k_half_nearest(const float* in, int w, fl
   out[(size_t)y * w2 + x] = in[(size_t)(2 * y) * w + 2 * x];
 }
 
-__global__ __launch_bounds__(256) void k_sub(const float* a, const float* b, float* out, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = a[i] - b[i];
-}
 
 // ---- restated math (identical in oracle/sift.py)
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -719,17 +720,20 @@ void sift_gaussian_kernel(double sigma, std::vector<float>& k) {
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 static inline bool sift_fused_taps(int n) { return n == 11 || n == 13 || n == 17 || n == 21 || n == 27; }
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog) {
+void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog, int in_step, int in_w, float* half_scratch) {
   const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH);
+  if (in_w <= 0) in_w = w;
   switch (n) {
-    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
-    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
-    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
-    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
-    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog); return;
+    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
+    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
+    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
+    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
+    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
     default: break;
   }
-  hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);       // other sigma: two plain passes
+  // other sigma: materialise the half-size image if needed, then two plain passes
+  if (in_step == 2) { hipLaunchKernelGGL(k_half_nearest, grid2d(w, h), dim3(256), 0, s, in, in_w, half_scratch, w, h); in = half_scratch; }
+  hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);
   hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, out, w, h, dk, n, in, dog);
 }
 // octaves [o_first, n_oct) in one launch; o_first = sift_tail_first(py) (>= 1; n_oct when the kernel sizes are not the stock ones)
@@ -748,14 +752,8 @@ void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* k
   (void)attr_set;
   hipLaunchKernelGGL(k_sift_tail, dim3(1), dim3(1024), lds, s, py, o_first, dk, plan);
 }
-void sift_base(const uint8_t* gray, int h, int w, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_sift_base, grid2d(2 * w, 2 * h), dim3(256), 0, s, gray, h, w, out);
-}
-void sift_half(const float* in, int w, float* out, int w2, int h2, hipStream_t s) {
-  hipLaunchKernelGGL(k_half_nearest, grid2d(w2, h2), dim3(256), 0, s, in, w, out, w2, h2);
-}
-void sift_sub(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+void sift_base(const uint8_t* gray, int h, int w, float* out, int* counters, hipStream_t s) {
+  hipLaunchKernelGGL(k_sift_base, grid2d(2 * w, 2 * h), dim3(256), 0, s, gray, h, w, out, counters);
 }
 void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s) {
   SiftFindPlan plan;

@@ -39,17 +39,17 @@ def main():
     n_kp = int(out[0].shape[0])
     from oracle import sift as osift
     t1 = time.perf_counter(); okp = osift.detect_and_compute(img)[0]; cpu_s = time.perf_counter() - t1
-    # scale space: every level of the doubled pyramid is written once per blur pass and read by the next (2 passes per level)
+    # scale space: every level of the doubled pyramid is read once and written once (+ its DoG level) by the fused blur
     px = sum((2 * H >> o) * (2 * W >> o) for o in range(12) if min(2 * H >> o, 2 * W >> o) >= 1)
-    alg_bytes = px * 4 * (6 * 2 * 2 + 5 * 3)          # 6 levels x (row + column pass) x (read + write) + 5 DoG levels x (2 reads + 1 write)
+    alg_bytes = px * 4 * (6 * 2 + 5)                  # 6 levels x (read + write) + 5 DoG levels x 1 write
     line = {"metric": "SIFT detectAndCompute images/sec (cv2.SIFT_create() defaults)", "value": round(1e3 / ms, 1), "unit": "images/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (no FMA contraction; bit-identical to the oracle)", "data": "synthetic",
             "config": {"workload": f"{H}x{W} u8 image, {n_kp} keypoints (oracle: {len(okp)})"},
-            "roofline": {"kernel": "scale space (k_blur_row / k_blur_col / k_sub) + k_sift_refine + k_sift_descriptor", "bound": "hbm",
+            "roofline": {"kernel": "whole call: k_blur_fused x21 + k_sift_tail + k_sift_find + k_sift_refine + k_sift_rank + k_sift_descriptor", "bound": "hbm",
                          "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, 5),
-                         "traffic": None, "note": "whole call incl. the host-side sort and ~130 small launches (9 octaves x 6 levels); launch-latency bound at "
-                                                  "this image size -- batching the octave-level launches is the next lever"},
+                         "traffic": None, "note": "fully stream-ordered (one host sync at the end to read the keypoint count); ~31 dependent launches, each >= 4-5 us "
+                                                  "of dispatch latency at this image size, so the call is latency- not bandwidth-bound (see DESIGN.md 7)"},
             "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "images/s", "cores": 1, "kind": "port",
                              "sample": f"1 image; numpy restatement of cv2.SIFT (oracle/sift.py); cpu={platform.processor() or platform.machine()}"}}
     print(json.dumps(line), flush=True)
