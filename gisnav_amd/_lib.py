@@ -47,6 +47,7 @@ SIGNATURES = {
     "gn_wgs84_to_ecef": (C.c_int, [C.c_double, C.c_double, C.c_double, c_f64p]),
     "gn_pose_to_earth": (C.c_int, [c_f64p, c_f64p, c_f64p, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p]),
     "gn_sift_detect_and_compute": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, C.POINTER(C.c_int32), VP]),
+    "gn_sift_detect_and_compute_batch": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, C.POINTER(C.c_int32), VP]),
     "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
     "gn_debug_gemm": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "gn_debug_attention": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, VP, C.c_int,

@@ -76,8 +76,8 @@ struct gn_ctx {
   // SIFT workspace (gn_sift_detect_and_compute), sized for the last image shape seen
   int sift_h = 0, sift_w = 0; std::vector<void*> sift_allocs; SiftPyramid sift_py; float* sift_tmp = nullptr;
   float* sift_dk = nullptr; std::vector<std::vector<float>> sift_kernels; std::vector<int> sift_koff;   // [0] = initial blur, [1..5] = layer blurs
-  int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr; float* sift_hist = nullptr;
-  int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0;
+  int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr;
+  int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0, sift_batch = 0; long long sift_kp_stride = 0;
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -903,10 +903,12 @@ int gn_stereo_reference(gn_ctx* ctx, const uint8_t* bgr, const uint8_t* dem, int
 }
 
 namespace {
-int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
-  if (ctx->sift_h == H && ctx->sift_w == W && ctx->sift_max_kp >= max_kp) return GN_OK;
+int sift_prepare(gn_ctx* ctx, int B, int H, int W, int max_kp) {
+  if (ctx->sift_h == H && ctx->sift_w == W && ctx->sift_max_kp >= max_kp && ctx->sift_batch >= B) return GN_OK;
+  B = std::max(B, ctx->sift_h == H && ctx->sift_w == W ? ctx->sift_batch : 1);
   for (void* p : ctx->sift_allocs) hipFree(p);
   ctx->sift_allocs.clear();
+  ctx->sift_h = ctx->sift_w = 0; ctx->sift_batch = 0;
   auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; ctx->sift_allocs.push_back(p); return p; };
   const int bw = 2 * W, bh = 2 * H;
   int n_oct = (int)std::nearbyint(std::log((double)std::min(bw, bh)) / std::log(2.0) - 2) + 1;
@@ -918,7 +920,8 @@ int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
   for (int o = 0; o < n_oct; ++o) {
     py.oct[o].w = w; py.oct[o].h = h;
     const size_t n = (size_t)w * h;
-    float* block = (float*)alloc(11 * n * sizeof(float));
+    py.oct[o].stride = (long long)(11 * n);            // per image: 6 Gaussian + 5 DoG levels, images back to back
+    float* block = (float*)alloc((size_t)B * 11 * n * sizeof(float));
     if (!block) return fail(ctx, GN_ERR_HIP, "SIFT pyramid allocation failed");
     for (int i = 0; i < 6; ++i) py.oct[o].gauss[i] = block + i * n;
     for (int i = 0; i < 5; ++i) py.oct[o].dog[i] = block + (6 + i) * n;
@@ -944,64 +947,72 @@ int sift_prepare(gn_ctx* ctx, int H, int W, int max_kp) {
       return fail(ctx, GN_ERR_HIP, "SIFT kernel upload failed");
   ctx->sift_max_cand = std::max(65536, 16 * max_kp);
   ctx->sift_max_kp = std::max(max_kp, 1024);
-  ctx->sift_cand = (int4*)alloc((size_t)ctx->sift_max_cand * sizeof(int4));
-  ctx->sift_counts = (int*)alloc(4 * sizeof(int));
+  ctx->sift_cand = (int4*)alloc((size_t)B * ctx->sift_max_cand * sizeof(int4));
+  ctx->sift_counts = (int*)alloc((size_t)B * 4 * sizeof(int));
   ctx->sift_raw_cap = 1;
   while (ctx->sift_raw_cap < 4 * ctx->sift_max_kp) ctx->sift_raw_cap <<= 1;
-  ctx->sift_kp = (SiftKeypoint*)alloc(((size_t)2 * ctx->sift_raw_cap + ctx->sift_max_kp) * sizeof(SiftKeypoint));   // raw | sorted | final
-  ctx->sift_hist = (float*)alloc((size_t)ctx->sift_max_kp * 360 * sizeof(float));
-  if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp || !ctx->sift_hist)
+  ctx->sift_kp_stride = (long long)2 * ctx->sift_raw_cap + ctx->sift_max_kp;                        // per image: raw | sorted | final
+  ctx->sift_kp = (SiftKeypoint*)alloc((size_t)B * ctx->sift_kp_stride * sizeof(SiftKeypoint));
+  if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp)
     return fail(ctx, GN_ERR_HIP, "SIFT workspace allocation failed");
-  ctx->sift_h = H; ctx->sift_w = W;
+  ctx->sift_h = H; ctx->sift_w = W; ctx->sift_batch = B;
   return GN_OK;
 }
 }  // namespace
 
-// cv2.SIFT_create().detectAndCompute(gray, None): pose_node.py:122,230-232, twist_node.py:93,227-245
-int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
-                               float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream) {
-  if (!ctx || !gray || !kpt_xysa || !desc || !n_out_host || H < 16 || W < 16 || max_kpts < 1)
+// cv2.SIFT_create().detectAndCompute(gray, None): pose_node.py:122,230-232, twist_node.py:93,227-245 -- for a batch of
+// equally sized images in one pass (every launch covers all images; the reference extracts one image per message)
+int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, int H, int W, int max_kpts,
+                                     float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream) {
+  if (!ctx || !gray || !kpt_xysa || !desc || !n_out_host || B < 1 || B > 4096 || H < 16 || W < 16 || max_kpts < 1)
     return fail(ctx, GN_ERR_ARG, "bad gn_sift_detect_and_compute argument");
   GN_HIP(hipSetDevice(ctx->device));
-  int rc = sift_prepare(ctx, H, W, max_kpts);
+  int rc = sift_prepare(ctx, B, H, W, max_kpts);
   if (rc != GN_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   SiftPyramid& py = ctx->sift_py;
-  auto blur = [&](const float* in, float* out, int w, int h, int ki, float* dog = nullptr, int in_step = 1, int in_w = 0, float* half_scratch = nullptr) {
-    sift_blur(in, ctx->sift_tmp, out, w, h, ctx->sift_dk + ctx->sift_koff[ki], (int)ctx->sift_kernels[ki].size(), s, dog, in_step, in_w, half_scratch);
+  auto blur = [&](int o_in, const float* in, int o_out, float* out, int ki, float* dog = nullptr, int in_step = 1, float* half_scratch = nullptr) {
+    sift_blur(B, py.oct[o_in].stride, py.oct[o_out].stride, in, ctx->sift_tmp, out, py.oct[o_out].w, py.oct[o_out].h, ctx->sift_dk + ctx->sift_koff[ki],
+              (int)ctx->sift_kernels[ki].size(), s, dog, in_step, py.oct[o_in].w, half_scratch);
   };
   // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
-  sift_base(gray, H, W, py.oct[0].gauss[5], ctx->sift_counts, s);   // scratch: level 5 is overwritten later; also zeroes the counters
-  blur(py.oct[0].gauss[5], py.oct[0].gauss[0], py.oct[0].w, py.oct[0].h, 0);
+  sift_base(gray, B, H, W, py.oct[0].gauss[5], py.oct[0].stride, ctx->sift_counts, s);   // scratch: level 5 is overwritten later; also zeroes the counters
+  blur(0, py.oct[0].gauss[5], 0, py.oct[0].gauss[0], 0);
   int ksize[6];
   for (int i = 0; i < 6; ++i) ksize[i] = (int)ctx->sift_kernels[i].size();
-  const int o_tail = sift_tail_first(py, ksize);                     // octaves from here on: one single-workgroup launch
+  const int o_tail = sift_tail_first(py, ksize);                     // octaves from here on: one single-workgroup launch per image
   for (int o = 0; o < o_tail; ++o) {
     const SiftOctave& oc = py.oct[o];
     // level 1 of octave o > 0 samples level 3 of the octave above directly (its level 0 is never stored)
-    if (o > 0) blur(py.oct[o - 1].gauss[3], oc.gauss[1], oc.w, oc.h, 1, oc.dog[0], 2, py.oct[o - 1].w, oc.gauss[0]);
-    for (int i = o > 0 ? 2 : 1; i < 6; ++i) blur(oc.gauss[i - 1], oc.gauss[i], oc.w, oc.h, i, oc.dog[i - 1]);   // row + column pass + DoG level in one launch
+    if (o > 0) blur(o - 1, py.oct[o - 1].gauss[3], o, oc.gauss[1], 1, oc.dog[0], 2, oc.gauss[0]);
+    for (int i = o > 0 ? 2 : 1; i < 6; ++i) blur(o, oc.gauss[i - 1], o, oc.gauss[i], i, oc.dog[i - 1]);   // row + column pass + DoG level in one launch
   }
-  sift_tail(py, o_tail, ctx->sift_dk, ctx->sift_koff.data(), ksize, s);
+  sift_tail(py, B, o_tail, ctx->sift_dk, ctx->sift_koff.data(), ksize, s);
   const float threshold = (float)(int)std::floor(0.5 * 0.04 / 3 * 255);
-  sift_find(py, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
-  // raw keypoints, their sorted copy and the final list live back to back in one allocation
-  const int max_raw_alloc = ctx->sift_raw_cap, max_raw = max_raw_alloc;
-  sift_refine(py, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, ctx->sift_kp, ctx->sift_counts + 1, max_raw, s);
-  // sort / de-duplicate / rescale on the device, then descriptors for the *n final keypoints; one sync at the very end
-  SiftKeypoint* kp_final = ctx->sift_kp + 2 * max_raw_alloc;
+  sift_find(py, B, threshold, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, s);
+  // raw keypoints, their sorted copy and the final list of an image live back to back in one allocation
+  const int max_raw = ctx->sift_raw_cap;
+  sift_refine(py, B, ctx->sift_cand, ctx->sift_counts, ctx->sift_max_cand, ctx->sift_kp, ctx->sift_kp_stride, max_raw, s);
+  // sort / de-duplicate / rescale on the device, then descriptors for the final keypoints; one sync at the very end
   const int max_out = std::min(max_kpts, ctx->sift_max_kp);
-  sift_sort_dedup(ctx->sift_kp, ctx->sift_counts + 1, max_raw, kp_final, ctx->sift_counts + 2, max_out, kpt_xysa, response, octave, s);
-  sift_descriptors(py, kp_final, ctx->sift_counts + 2, max_out, desc, s);
-  int counts[3] = {0, 0, 0};
-  GN_HIP(hipMemcpyAsync(counts, ctx->sift_counts, sizeof counts, hipMemcpyDeviceToHost, s));
+  sift_sort_dedup(B, ctx->sift_kp, ctx->sift_kp_stride, ctx->sift_counts, max_raw, max_out, kpt_xysa, response, octave, max_kpts, s);
+  sift_descriptors(py, B, ctx->sift_kp + 2 * max_raw, ctx->sift_kp_stride, ctx->sift_counts, max_out, desc, max_kpts, s);
+  std::vector<int> counts((size_t)B * 4, 0);
+  GN_HIP(hipMemcpyAsync(counts.data(), ctx->sift_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   GN_HIP(hipStreamSynchronize(s));
-  if (counts[0] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
-  if (counts[1] > max_raw) return fail(ctx, GN_ERR_ARG, "SIFT keypoint buffer overflow (raise max_kpts)");
-  if (counts[2] > max_out) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
-  *n_out_host = counts[2];
+  for (int b = 0; b < B; ++b) {
+    if (counts[4 * b] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
+    if (counts[4 * b + 1] > max_raw) return fail(ctx, GN_ERR_ARG, "SIFT keypoint buffer overflow (raise max_kpts)");
+    if (counts[4 * b + 2] > max_out) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
+    n_out_host[b] = counts[4 * b + 2];
+  }
   GN_HIP(hipGetLastError());
   return GN_OK;
+}
+
+int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
+                               float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream) {
+  return gn_sift_detect_and_compute_batch(ctx, gray, 1, H, W, max_kpts, kpt_xysa, response, octave, desc, n_out_host, stream);
 }
 
 int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream) {

@@ -163,21 +163,22 @@ void launch_rotate_crop(const WarpArgs& a, bool fused_gray, hipStream_t s);
 
 // ---- SIFT (cv2.SIFT_create().detectAndCompute) -------------------------------------------------------------
 constexpr int kSiftMaxOctaves = 12;
-struct SiftOctave { float* gauss[6]; float* dog[5]; int w, h; };
+struct SiftOctave { float* gauss[6]; float* dog[5]; int w, h; long long stride; };   // stride: floats between consecutive images of a batch
 struct SiftPyramid { SiftOctave oct[kSiftMaxOctaves]; int n_oct; };
 struct SiftKeypoint { float x, y, size, angle, response; int octave; };
 void sift_gaussian_kernel(double sigma, std::vector<float>& k);
-void sift_base(const uint8_t* gray, int h, int w, float* out, int* counters, hipStream_t s);   // also zeroes counters[0..2]
+void sift_base(const uint8_t* gray, int B, int h, int w, float* out, long long out_stride, int* counters, hipStream_t s);   // also zeroes counters[4b + 0..2]
 // dog = out - in; in_step 2 reads every second pixel of a source image of row stride in_w (half_scratch: only used for non-stock kernel sizes)
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog = nullptr, int in_step = 1, int in_w = 0,
-               float* half_scratch = nullptr);
+void sift_blur(int B, long long stride_in, long long stride_out, const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s,
+               float* dog = nullptr, int in_step = 1, int in_w = 0, float* half_scratch = nullptr);
 int sift_tail_first(const SiftPyramid& py, const int* ksize);
-void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s);
-void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s);
-void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s);
-void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* n_dev, int max_n, float* desc, hipStream_t s);
-void sift_sort_dedup(SiftKeypoint* kp_raw, const int* n_raw, int max_raw, SiftKeypoint* kp_out, int* n_out, int max_out,
-                     float* kpt_xysa, float* response, int32_t* octave, hipStream_t s);
+void sift_tail(const SiftPyramid& py, int B, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s);
+void sift_find(const SiftPyramid& py, int B, float threshold, int4* cand, int* counters, int max_cand, hipStream_t s);
+// counters: int[4] per image = {candidates, raw keypoints, final keypoints, -}; kp: per image [max_raw raw | max_raw sorted | final], kp_stride records apart
+void sift_refine(const SiftPyramid& py, int B, const int4* cand, int* counters, int max_cand, SiftKeypoint* kp, long long kp_stride, int max_raw, hipStream_t s);
+void sift_descriptors(const SiftPyramid& py, int B, const SiftKeypoint* kp_final, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride, hipStream_t s);
+void sift_sort_dedup(int B, SiftKeypoint* kp, long long kp_stride, int* counters, int max_raw, int max_out,
+                     float* kpt_xysa, float* response, int32_t* octave, long long out_stride, hipStream_t s);
 
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);

@@ -32,8 +32,10 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out, int* counters) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[threadIdx.x] = 0;   // candidate / raw / final counts of this call
+__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out, long long out_stride, int* counters) {
+  const int b = blockIdx.z;
+  g += (size_t)b * h * w; out += (long long)b * out_stride;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[4 * b + threadIdx.x] = 0;   // candidate / raw / final counts of this image
   const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (dx >= 2 * w || dy >= 2 * h) return;
   auto taps = [](int d, int n_src, int& s, int& s1, float& a0, float& a1) {
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
 // half-size base image is never materialised.
 constexpr int kFtW = 64, kFtH = 32;
 template <int N>
-__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w) {
+__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w, long long stride_in, long long stride_out) {
+  in += (long long)blockIdx.z * stride_in; out += (long long)blockIdx.z * stride_out;   // image blockIdx.z of the batch
+  if (dog != nullptr) dog += (long long)blockIdx.z * stride_out;
   constexpr int R = N / 2, ROWS = kFtH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float s_in[ROWS * COLS];
   __shared__ __attribute__((aligned(16))) float s_row[ROWS * kFtW];
@@ -210,24 +214,26 @@ __global__ __launch_bounds__(1024) void k_sift_tail(SiftPyramid py, int o_first,
   extern __shared__ __attribute__((aligned(16))) float s_tail[];
   float* cur = s_tail; float* nxt = s_tail + kTailBuf; float* tmp = s_tail + 2 * kTailBuf;
   const int tid = threadIdx.x;
+  const int b = blockIdx.x;                            // one workgroup per image
   for (int o = o_first; o < py.n_oct; ++o) {
     const SiftOctave& oc = py.oct[o];
+    const long long boff = (long long)b * oc.stride;   // image b of the batch (a by-value copy of the octave record would go to scratch)
     const int w = oc.w, h = oc.h, px = w * h, wp = w + 2 * kTailPad;
     {   // base level: every second pixel of level 3 of the octave above (written by an earlier launch or by this workgroup)
-      const float* src = py.oct[o - 1].gauss[3];
+      const float* src = py.oct[o - 1].gauss[3] + (long long)b * py.oct[o - 1].stride;
       const int ws = py.oct[o - 1].w;
-      for (int i = tid; i < px; i += 1024) { const int y = i / w, x = i - y * w; const float v = src[(size_t)(2 * y) * ws + 2 * x]; cur[y * wp + kTailPad + x] = v; oc.gauss[0][i] = v; }
+      for (int i = tid; i < px; i += 1024) { const int y = i / w, x = i - y * w; const float v = src[(size_t)(2 * y) * ws + 2 * x]; cur[y * wp + kTailPad + x] = v; oc.gauss[0][boff + i] = v; }
     }
     __syncthreads();
     for (int lvl = 1; lvl < 6; ++lvl) {
       tail_pad_x(cur, w, h);
       const float* kg = dk + plan.off[lvl];
       switch (plan.n[lvl]) {
-        case 11: tail_level<11>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
-        case 13: tail_level<13>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
-        case 17: tail_level<17>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
-        case 21: tail_level<21>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
-        default: tail_level<27>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl], oc.dog[lvl - 1]); break;
+        case 11: tail_level<11>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl] + boff, oc.dog[lvl - 1] + boff); break;
+        case 13: tail_level<13>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl] + boff, oc.dog[lvl - 1] + boff); break;
+        case 17: tail_level<17>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl] + boff, oc.dog[lvl - 1] + boff); break;
+        case 21: tail_level<21>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl] + boff, oc.dog[lvl - 1] + boff); break;
+        default: tail_level<27>(cur, tmp, nxt, w, h, kg, oc.gauss[lvl] + boff, oc.dog[lvl - 1] + boff); break;
       }
       float* t2 = cur; cur = nxt; nxt = t2;
     }
@@ -298,46 +304,80 @@ __device__ bool lu_solve3(float A[3][3], float x[3]) {
 }
 
 // ---- candidates: |DoG| above the threshold and a 26-neighbour extremum
-// one launch for all octaves and layers: blockIdx.x runs over the 64 x 4 tiles of every octave back to back
+// one launch for all octaves and layers: blockIdx.x runs over the 64 x 32 tiles of every octave back to back
+constexpr int kFindRows = 32;
 struct SiftFindPlan { int first_tile[kSiftMaxOctaves + 1]; int tiles_x[kSiftMaxOctaves]; };
 __global__ __launch_bounds__(256) void k_sift_find(SiftPyramid py, SiftFindPlan plan, float threshold, int4* cand, int* n_cand, int max_cand) {
+  const int b = blockIdx.z;
+  cand += (size_t)b * max_cand; n_cand += 4 * b;
   int octave = 0;
   while (octave + 1 < py.n_oct && (int)blockIdx.x >= plan.first_tile[octave + 1]) ++octave;
   const SiftOctave& oc = py.oct[octave];
-  const int layer = 1 + blockIdx.y;
+  const long long boff = (long long)b * oc.stride;
   const int tile = blockIdx.x - plan.first_tile[octave];
-  const int c = kBorder + (tile % plan.tiles_x[octave]) * 64 + (threadIdx.x & 63), r = kBorder + (tile / plan.tiles_x[octave]) * 4 + (threadIdx.x >> 6);
-  if (c >= oc.w - kBorder || r >= oc.h - kBorder) return;
-  const float* img = oc.dog[layer];
-  const float val = img[(size_t)r * oc.w + c];
-  if (!(fabsf(val) > threshold) || val == 0.f) return;
-  bool is_max = val > 0, is_min = val < 0;
-  for (int l = layer - 1; l <= layer + 1; ++l) {
-    const float* p = oc.dog[l];
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const float nb = p[(size_t)(r + dy) * oc.w + c + dx];
-        is_max = is_max && (val >= nb);
-        is_min = is_min && (val <= nb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = kBorder + (tile % plan.tiles_x[octave]) * 64 + lane;
+  const int rbeg = kBorder + (tile / plan.tiles_x[octave]) * kFindRows + wave * (kFindRows / 4);
+  const int rend = min(rbeg + kFindRows / 4, oc.h - kBorder);
+  if (c >= oc.w - kBorder || rbeg >= rend) return;
+  // a thread walks down a column strip with the 5 x 3 x 3 DoG neighbourhood in registers: 15 loads per row serve the three
+  // layers (5 per tested value instead of 1 + 27 from L1 -- this kernel was bound by L1 request rate, not by HBM)
+  const int w = oc.w;
+  float win[5][3][3];
+  auto load_row = [&](int r, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+      const float* p = oc.dog[l] + boff + (size_t)r * w + c;
+      win[l][slot][0] = p[-1]; win[l][slot][1] = p[0]; win[l][slot][2] = p[1];
+    }
+  };
+  load_row(rbeg - 1, 0);
+  load_row(rbeg, 1);
+  for (int r = rbeg; r < rend; ++r) {
+    load_row(r + 1, 2);
+#pragma unroll
+    for (int layer = 1; layer <= kLayers; ++layer) {
+      const float val = win[layer][1][1];
+      if (fabsf(val) > threshold && val != 0.f) {
+        bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+        for (int l = layer - 1; l <= layer + 1; ++l)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const float nbv = win[l][dy][dx];
+              is_max = is_max && (val >= nbv);
+              is_min = is_min && (val <= nbv);
+            }
+        if (is_max || is_min) {
+          const int slot = atomicAdd(n_cand, 1);
+          if (slot < max_cand) cand[slot] = make_int4(octave, layer, r, c);
+        }
       }
+    }
+#pragma unroll
+    for (int l = 0; l < 5; ++l)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) { win[l][0][dx] = win[l][1][dx]; win[l][1][dx] = win[l][2][dx]; }
   }
-  if (!(is_max || is_min)) return;
-  const int slot = atomicAdd(n_cand, 1);
-  if (slot < max_cand) cand[slot] = make_int4(octave, layer, r, c);
 }
 
 // ---- adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one WAVE per candidate.
 // The quadratic refinement is scalar work (every lane computes it redundantly); the orientation histogram evaluates 64
 // raster positions per step in parallel and commits them in raster order -- bin b of the histogram lives in a register of
 // lane b, each sample is broadcast with v_readlane and added by its owner lane -- so the float sums keep OpenCV's order.
-__global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* cand, const int* n_cand, int max_cand,
-                                                     SiftKeypoint* kp, int* n_kp, int max_kp) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* cand, int* counters, int max_cand,
+                                                     SiftKeypoint* kp, long long kp_stride, int max_kp) {
+  const int lane = threadIdx.x, b = blockIdx.y;
+  cand += (size_t)b * max_cand; kp += (long long)b * kp_stride;
+  const int* n_cand = counters + 4 * b; int* n_kp = counters + 4 * b + 1;
   const int nc = min(*n_cand, max_cand);
   for (int id = blockIdx.x; id < nc; id += gridDim.x) {
     const int octv = cand[id].x;
     int layer = cand[id].y, r = cand[id].z, c = cand[id].w;
     const SiftOctave& oc = py.oct[octv];
+    const long long boff = (long long)b * oc.stride;
     const int rows = oc.h, cols = oc.w;
     const float img_scale = 1.0f / 255.0f, deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
 #define AT(p, rr, cc) (p)[(size_t)(rr) * cols + (cc)]
@@ -345,7 +385,7 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
     int i = 0;
     bool dead = false;                                  // the candidate left the volume or diverged
     for (; i < kMaxInterp; ++i) {
-      const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
+      const float *img = oc.dog[layer] + boff, *prv = oc.dog[layer - 1] + boff, *nxt = oc.dog[layer + 1] + boff;
       float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                      (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
       const float v2 = AT(img, r, c) * 2.0f;
@@ -367,7 +407,7 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
     if (dead || i >= kMaxInterp) continue;
     float contr;
     {
-      const float *img = oc.dog[layer], *prv = oc.dog[layer - 1], *nxt = oc.dog[layer + 1];
+      const float *img = oc.dog[layer] + boff, *prv = oc.dog[layer - 1] + boff, *nxt = oc.dog[layer + 1] + boff;
       const float d0 = (AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, d1 = (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                   d2 = (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale;
       const float t = (d0 * xc + d1 * xr) + d2 * xi;
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
     const int radius = (int)rintf(4.5f * scl_octv);
     const float sigma_w = 1.5f * scl_octv;
     const float expf_scale = -1.0f / (2.0f * (sigma_w * sigma_w));
-    const float* g = oc.gauss[layer];
+    const float* g = oc.gauss[layer] + boff;
     const int side = 2 * radius + 1, total = side * side;
     float acc = 0.f;                                    // temphist[lane] for lane < 36
     for (int base = 0; base < total; base += 64) {
@@ -453,8 +493,10 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyramid py, const int4* 
 // execute in issue order, so every bin sees exactly the serial sequence of additions.
 constexpr int kDescProducers = 7;
 
-__global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(SiftPyramid py, const SiftKeypoint* kp, const int* n_p, int max_n, float* desc) {
-  const int n = min(*n_p, max_n);
+__global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(SiftPyramid py, const SiftKeypoint* kp, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride) {
+  const int b = blockIdx.y;
+  kp += (long long)b * kp_stride; desc += (long long)b * out_stride * 128;
+  const int n = min(counters[4 * b + 2], max_n);
   constexpr int d = 4, nb = 8, HL = (d + 2) * (d + 2) * (nb + 2), NP = kDescProducers, NT = 64 * (NP + 1);
   __shared__ float hist[HL + 8];                     // [HL..HL+7]: sink for the padding lanes of a partial group of eight
   __shared__ int2 s_pair[2][NP][64 * 8];             // [round parity][producer]: (LDS address of the bin, share bits), 8 per live position
@@ -469,7 +511,7 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
   const float kscale = o >= 0 ? 1.0f / (float)(1 << o) : (float)(1 << -o);
   const SiftOctave& oc = py.oct[o + 1];
   const int rows = oc.h, cols = oc.w;
-  const float* img = oc.gauss[layer];
+  const float* img = oc.gauss[layer] + (long long)b * oc.stride;
   const float size = k.size * kscale;
   const float ptx = k.x * kscale, pty = k.y * kscale;
   float ori = 360.0f - k.angle;
@@ -611,6 +653,141 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
   float* dst = desc + (size_t)id * 128;
   if (tid < 128) dst[tid] = fminf(fmaxf(rintf(s_dst[tid] * s_nrm), 0.f), 255.f);   // saturate_cast<uchar>
 }
+// Throughput variant for batches: ONE wave per keypoint, plain LDS read-add-write by lanes 0..7 per position instead of
+// LDS atomics.  A single wave walks its positions ~130 clocks apart (latency of the read-modify-write chain), but 20+
+// such waves share a CU and their chains interleave, while the LDS float-atomic unit retires only ~1 lane per 3 clocks for
+// the whole CU -- so with thousands of keypoints in flight this is several times the throughput of the atomic committer,
+// and with one image the atomic version has the lower latency.  Same arithmetic, same order, same bits.
+__global__ __launch_bounds__(64) void k_sift_descriptor_tp(SiftPyramid py, const SiftKeypoint* kp, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride) {
+  const int b = blockIdx.y;
+  kp += (long long)b * kp_stride; desc += (long long)b * out_stride * 128;
+  const int n = min(counters[4 * b + 2], max_n);
+  constexpr int d = 4, nb = 8, HL = (d + 2) * (d + 2) * (nb + 2), NT = 64;
+  __shared__ float hist[HL + 8];
+  __shared__ int2 s_pair1[64 * 8];                  // (bin, share bits), 8 per live position, raster order
+  __shared__ float s_dst[128];
+  __shared__ float s_nrm;
+  const int id = blockIdx.x, tid = threadIdx.x, lane = tid;
+  if (id >= n) return;
+  const SiftKeypoint k = kp[id];
+  int o = k.octave & 255; const int layer = (k.octave >> 8) & 255;
+  o = o < 128 ? o : (-128 | o);
+  const float kscale = o >= 0 ? 1.0f / (float)(1 << o) : (float)(1 << -o);
+  const SiftOctave& oc = py.oct[o + 1];
+  const int rows = oc.h, cols = oc.w;
+  const float* img = oc.gauss[layer] + (long long)b * oc.stride;
+  const float size = k.size * kscale;
+  const float ptx = k.x * kscale, pty = k.y * kscale;
+  float ori = 360.0f - k.angle;
+  if (fabsf(ori - 360.0f) < kFltEps) ori = 0.f;
+  const float scl = size * 0.5f;
+  const int px = (int)rintf(ptx), pyi = (int)rintf(pty);
+  float cos_t = (float)cos((double)ori * (3.141592653589793 / 180.0)), sin_t = (float)sin((double)ori * (3.141592653589793 / 180.0));
+  const float bins_per_deg = (float)(nb / 360.0);
+  const float exp_scale = -1.0f / (float)(d * d * 0.5);
+  const float hist_width = 3.0f * scl;
+  int radius = (int)rintf(((hist_width * 1.4142135623730951f) * (float)(d + 1)) * 0.5f);
+  radius = min(radius, (int)sqrt((double)cols * cols + (double)rows * rows));
+  cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
+  for (int q = tid; q < HL + 8; q += NT) hist[q] = 0.f;
+  const int side = 2 * radius + 1, total = side * side;
+  __syncthreads();
+  for (int base = 0; base < total; base += 64) {
+    {
+      const int p = base + lane;
+      const int ii = p / side - radius, jj = p % side - radius;
+      const float fi = (float)ii, fj = (float)jj;
+      const float c_rot = fj * cos_t - fi * sin_t;
+      const float r_rot = fj * sin_t + fi * cos_t;
+      float rbin = r_rot + (float)(d / 2) - 0.5f;
+      float cbin = c_rot + (float)(d / 2) - 0.5f;
+      const int r = pyi + ii, c = px + jj;
+      int idx = -1;
+      float v[8];
+      if (p < total && rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+        const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
+        const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+        const float W = exp32((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+        const float Ori = fast_atan2_deg(dy, dx);
+        const float Mag = sqrtf(dx * dx + dy * dy);
+        float obin = (Ori - ori) * bins_per_deg;
+        const float mag = Mag * W;
+        const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+        int o0 = (int)floorf(obin);
+        rbin = rbin - (float)r0; cbin = cbin - (float)c0; obin = obin - (float)o0;
+        if (o0 < 0) o0 += nb;
+        if (o0 >= nb) o0 -= nb;
+        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+        const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+        v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7];
+        v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
+        v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
+        v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
+        idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
+      }
+      const unsigned long long live_mask = __ballot(idx >= 0);
+      const int n_live = __popcll(live_mask);
+      const int rank = __popcll(live_mask & ((1ull << lane) - 1ull));
+      if (idx >= 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+          const int boff = (l & 1) + ((l >> 1) & 1) * (nb + 2) + (l >> 2) * (d + 2) * (nb + 2);
+          s_pair1[rank * 8 + l] = make_int2(idx + boff, __float_as_int(v[l]));
+        }
+      }
+      asm volatile("" ::: "memory");                 // one wave: DS ops execute in issue order, a compiler fence is all it takes
+      // commit in raster order; the eight shares of a position hit eight different bins
+      if (lane < 8) {
+        int s0 = 0;
+        for (; s0 + 4 <= n_live; s0 += 4) {          // pairs fetched four positions ahead of the dependent read-add-write chain
+          const int2 p0 = s_pair1[(s0 + 0) * 8 + lane], p1 = s_pair1[(s0 + 1) * 8 + lane], p2 = s_pair1[(s0 + 2) * 8 + lane], p3 = s_pair1[(s0 + 3) * 8 + lane];
+          hist[p0.x] = hist[p0.x] + __int_as_float(p0.y);
+          hist[p1.x] = hist[p1.x] + __int_as_float(p1.y);
+          hist[p2.x] = hist[p2.x] + __int_as_float(p2.y);
+          hist[p3.x] = hist[p3.x] + __int_as_float(p3.y);
+        }
+        for (; s0 < n_live; ++s0) { const int2 p0 = s_pair1[s0 * 8 + lane]; hist[p0.x] = hist[p0.x] + __int_as_float(p0.y); }
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (tid < d * d) {
+    const int i = tid / d, j = tid % d;
+    const int idx = ((i + 1) * (d + 2) + (j + 1)) * (nb + 2);
+    hist[idx] = hist[idx] + hist[idx + nb];
+    hist[idx + 1] = hist[idx + 1] + hist[idx + nb + 1];
+    for (int q = 0; q < nb; ++q) s_dst[(i * d + j) * nb + q] = hist[idx + q];
+  }
+  __syncthreads();
+  if (tid == 0) {                                     // the two norms are sequential float sums in OpenCV
+    float nrm2 = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 128; q += 8) {                // (loads batched eight at a time; the sums stay strictly sequential)
+      float e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = s_dst[q + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nrm2 = nrm2 + e[u] * e[u];
+    }
+    const float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 128; q += 8) {
+      float e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = fminf(s_dst[q + u], thr);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s_dst[q + u] = e[u]; nrm2 = nrm2 + e[u] * e[u]; }
+    }
+    s_nrm = 512.0f / fmaxf(sqrtf(nrm2), kFltEps);
+  }
+  __syncthreads();
+  float* dst = desc + (size_t)id * 128;
+  for (int q = tid; q < 128; q += 64) dst[q] = fminf(fmaxf(rintf(s_dst[q] * s_nrm), 0.f), 255.f);   // saturate_cast<uchar>
+}
+
 // ---- KeyPointsFilter::removeDuplicatedSorted + the first-octave rescale, on the device: the raw keypoints (appended in
 // arbitrary order by the atomics) are put in OpenCV's KeyPoint_LessThan order (x, y, size descending, angle, response
 // descending, octave descending) by a rank sort, then one workgroup drops repeats of (x, y, size, angle), rescales and
@@ -628,7 +805,9 @@ __device__ __forceinline__ bool kp_less(const SiftKeypoint& a, const SiftKeypoin
 // index, so ranks are a permutation) and stores it at that position.  O(n^2) comparisons spread over n / 64 workgroups,
 // the list streamed through LDS in tiles of 256 (x as a separate float4-readable array; the full record is only touched
 // when x ties) -- no barrier per sorting stage as in a bitonic network.
-__global__ __launch_bounds__(256) void k_sift_rank(const SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* sorted) {
+__global__ __launch_bounds__(256) void k_sift_rank(const SiftKeypoint* kp, long long kp_stride, const int* counters, int max_raw, SiftKeypoint* sorted) {
+  kp += (long long)blockIdx.y * kp_stride; sorted += (long long)blockIdx.y * kp_stride;
+  const int* n_raw_p = counters + 4 * blockIdx.y + 1;
   __shared__ SiftKeypoint s_tile[256];
   __shared__ __attribute__((aligned(16))) float s_x[256];
   __shared__ int s_rank[4][64];
@@ -666,8 +845,14 @@ __global__ __launch_bounds__(256) void k_sift_rank(const SiftKeypoint* kp, const
 }
 
 // removeDuplicatedSorted + first-octave rescale + the output arrays, one workgroup over the sorted list
-__global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp, const int* n_raw_p, int max_raw, SiftKeypoint* out, int* n_out,
-                                                            int max_out, float* kpt_xysa, float* response, int32_t* octave) {
+__global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp, SiftKeypoint* out, long long kp_stride, int* counters, int max_raw,
+                                                            int max_out, float* kpt_xysa, float* response, int32_t* octave, long long out_stride) {
+  const int b = blockIdx.x;
+  kp += (long long)b * kp_stride; out += (long long)b * kp_stride;
+  kpt_xysa += (long long)b * out_stride * 4;
+  if (response) response += (long long)b * out_stride;
+  if (octave) octave += (long long)b * out_stride;
+  const int* n_raw_p = counters + 4 * b + 1; int* n_out = counters + 4 * b + 2;
   __shared__ int s_wcount[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -720,21 +905,31 @@ void sift_gaussian_kernel(double sigma, std::vector<float>& k) {
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 static inline bool sift_fused_taps(int n) { return n == 11 || n == 13 || n == 17 || n == 21 || n == 27; }
-void sift_blur(const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s, float* dog, int in_step, int in_w, float* half_scratch) {
-  const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH);
+void sift_blur(int B, long long stride_in, long long stride_out, const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s,
+               float* dog, int in_step, int in_w, float* half_scratch) {
+  const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH, B);
   if (in_w <= 0) in_w = w;
   switch (n) {
-    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
-    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
-    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
-    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
-    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w); return;
+    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
+    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
+    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
+    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
+    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
     default: break;
   }
-  // other sigma: materialise the half-size image if needed, then two plain passes
-  if (in_step == 2) { hipLaunchKernelGGL(k_half_nearest, grid2d(w, h), dim3(256), 0, s, in, in_w, half_scratch, w, h); in = half_scratch; }
-  hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, in, tmp, w, h, dk, n);
-  hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, out, w, h, dk, n, in, dog);
+  // other sigma: image by image, materialise the half-size image if needed, then two plain passes
+  for (int b = 0; b < B; ++b) {
+    const float* src = in + (long long)b * stride_in;
+    float* dst = out + (long long)b * stride_out;
+    float* dg = dog ? dog + (long long)b * stride_out : nullptr;
+    if (in_step == 2) {
+      float* hs = half_scratch + (long long)b * stride_out;
+      hipLaunchKernelGGL(k_half_nearest, grid2d(w, h), dim3(256), 0, s, src, in_w, hs, w, h);
+      src = hs;
+    }
+    hipLaunchKernelGGL(k_blur_row, grid2d(w, h), dim3(256), 0, s, src, tmp, w, h, dk, n);
+    hipLaunchKernelGGL(k_blur_col, grid2d(w, h), dim3(256), 0, s, tmp, dst, w, h, dk, n, src, dg);
+  }
 }
 // octaves [o_first, n_oct) in one launch; o_first = sift_tail_first(py) (>= 1; n_oct when the kernel sizes are not the stock ones)
 int sift_tail_first(const SiftPyramid& py, const int* ksize) {
@@ -743,19 +938,20 @@ int sift_tail_first(const SiftPyramid& py, const int* ksize) {
   while (o < py.n_oct && (py.oct[o].w * py.oct[o].h > kTailPx || py.oct[o].w > kTailSide || py.oct[o].h > kTailSide)) ++o;
   return o;
 }
-void sift_tail(const SiftPyramid& py, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s) {
+void sift_tail(const SiftPyramid& py, int B, int o_first, const float* dk, const int* koff, const int* ksize, hipStream_t s) {
   if (o_first >= py.n_oct) return;
   SiftBlurPlan plan;
   for (int i = 0; i < 6; ++i) { plan.off[i] = koff[i]; plan.n[i] = ksize[i]; }
   constexpr int lds = 3 * kTailBuf * (int)sizeof(float);
   static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sift_tail), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
   (void)attr_set;
-  hipLaunchKernelGGL(k_sift_tail, dim3(1), dim3(1024), lds, s, py, o_first, dk, plan);
+  hipLaunchKernelGGL(k_sift_tail, dim3(B), dim3(1024), lds, s, py, o_first, dk, plan);
 }
-void sift_base(const uint8_t* gray, int h, int w, float* out, int* counters, hipStream_t s) {
-  hipLaunchKernelGGL(k_sift_base, grid2d(2 * w, 2 * h), dim3(256), 0, s, gray, h, w, out, counters);
+void sift_base(const uint8_t* gray, int B, int h, int w, float* out, long long out_stride, int* counters, hipStream_t s) {
+  dim3 g = grid2d(2 * w, 2 * h); g.z = B;
+  hipLaunchKernelGGL(k_sift_base, g, dim3(256), 0, s, gray, h, w, out, out_stride, counters);
 }
-void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s) {
+void sift_find(const SiftPyramid& py, int B, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s) {
   SiftFindPlan plan;
   int total = 0;
   for (int o = 0; o < kSiftMaxOctaves; ++o) {
@@ -763,26 +959,28 @@ void sift_find(const SiftPyramid& py, float threshold, int4* cand, int* n_cand, 
     if (o >= py.n_oct) continue;
     const SiftOctave& oc = py.oct[o];
     if (oc.h <= 2 * kBorder || oc.w <= 2 * kBorder) continue;
-    const dim3 g = grid2d(oc.w - 2 * kBorder, oc.h - 2 * kBorder);
-    plan.tiles_x[o] = (int)g.x;
-    total += (int)(g.x * g.y);
+    const int gx = (oc.w - 2 * kBorder + 63) / 64, gy = (oc.h - 2 * kBorder + kFindRows - 1) / kFindRows;
+    plan.tiles_x[o] = gx;
+    total += gx * gy;
   }
   plan.first_tile[kSiftMaxOctaves] = total;
-  if (total > 0) hipLaunchKernelGGL(k_sift_find, dim3(total, kLayers), dim3(256), 0, s, py, plan, threshold, cand, n_cand, max_cand);
+  if (total > 0) hipLaunchKernelGGL(k_sift_find, dim3(total, 1, B), dim3(256), 0, s, py, plan, threshold, cand, n_cand, max_cand);
 }
-void sift_refine(const SiftPyramid& py, const int4* cand, const int* n_cand, int max_cand, SiftKeypoint* kp, int* n_kp, int max_kp, hipStream_t s) {
-  hipLaunchKernelGGL(k_sift_refine, dim3(std::min(max_cand, 4096)), dim3(64), 0, s, py, cand, n_cand, max_cand, kp, n_kp, max_kp);
+void sift_refine(const SiftPyramid& py, int B, const int4* cand, int* counters, int max_cand, SiftKeypoint* kp, long long kp_stride, int max_raw, hipStream_t s) {
+  hipLaunchKernelGGL(k_sift_refine, dim3(std::min(max_cand, 4096), B), dim3(64), 0, s, py, cand, counters, max_cand, kp, kp_stride, max_raw);
 }
-void sift_descriptors(const SiftPyramid& py, const SiftKeypoint* kp, const int* n_dev, int max_n, float* desc, hipStream_t s) {
-  hipLaunchKernelGGL(k_sift_descriptor, dim3(max_n), dim3(64 * (kDescProducers + 1)), 0, s, py, kp, n_dev, max_n, desc);   // blocks beyond *n_dev exit at once
+void sift_descriptors(const SiftPyramid& py, int B, const SiftKeypoint* kp_final, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride, hipStream_t s) {
+  // blocks beyond an image's keypoint count exit at once.  One image: latency matters (producer waves + atomic committer);
+  // a batch: throughput matters (one wave per keypoint, plain LDS read-add-write)
+  if (B >= 4) { hipLaunchKernelGGL(k_sift_descriptor_tp, dim3(max_n, B), dim3(64), 0, s, py, kp_final, kp_stride, counters, max_n, desc, out_stride); return; }
+  hipLaunchKernelGGL(k_sift_descriptor, dim3(max_n, B), dim3(64 * (kDescProducers + 1)), 0, s, py, kp_final, kp_stride, counters, max_n, desc, out_stride);
 }
 
-// kp_raw: max_raw raw keypoints followed by max_raw slots for the sorted copy
-void sift_sort_dedup(SiftKeypoint* kp_raw, const int* n_raw, int max_raw, SiftKeypoint* kp_out, int* n_out, int max_out,
-                     float* kpt_xysa, float* response, int32_t* octave, hipStream_t s) {
-  SiftKeypoint* sorted = kp_raw + max_raw;
-  hipLaunchKernelGGL(k_sift_rank, dim3((max_raw + 63) / 64), dim3(256), 0, s, kp_raw, n_raw, max_raw, sorted);
-  hipLaunchKernelGGL(k_sift_dedup_emit, dim3(1), dim3(1024), 0, s, sorted, n_raw, max_raw, kp_out, n_out, max_out, kpt_xysa, response, octave);
+// kp: per image [max_raw raw | max_raw sorted | final list], kp_stride records apart
+void sift_sort_dedup(int B, SiftKeypoint* kp, long long kp_stride, int* counters, int max_raw, int max_out,
+                     float* kpt_xysa, float* response, int32_t* octave, long long out_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_sift_rank, dim3((max_raw + 63) / 64, B), dim3(256), 0, s, kp, kp_stride, counters, max_raw, kp + max_raw);
+  hipLaunchKernelGGL(k_sift_dedup_emit, dim3(B), dim3(1024), 0, s, kp + max_raw, kp + 2 * max_raw, kp_stride, counters, max_raw, max_out, kpt_xysa, response, octave, out_stride);
 }
 
 }  // namespace gn

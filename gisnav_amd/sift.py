@@ -1,6 +1,6 @@
 """Host-side mirror of `cv2.SIFT_create()` as GISNav uses it: `detectAndCompute(image, None)` for
 the reference tile (pose_node.py:122,230-232) and for every camera frame (twist_node.py:93,227-245).  Marshalling only:
-scale space, keypoints and descriptors are produced by libgisnav_amd.so (`gn_sift_detect_and_compute`)."""
+scale space, keypoints and descriptors are produced by libgisnav_amd.so (`gn_sift_detect_and_compute`, `gn_sift_detect_and_compute_batch`)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -47,6 +47,24 @@ class SIFT:
         _lib.check(eng.ctx, rc, "gn_sift_detect_and_compute")
         k = int(n.value)
         return kpt[:k], resp[:k], octv[:k], desc[:k]
+
+    def detect_and_compute_batch_device(self, images):
+        """images: (B, H, W) uint8 numpy array or device tensor, all of one size.  One pass over the whole batch
+        (`gn_sift_detect_and_compute_batch`).  Returns (kpt_xysa [B,max,4], response [B,max], octave [B,max], desc [B,max,128],
+        n [B] int32 on the host): image b's keypoints are rows [0, n[b]) -- the padded layout `PoseEngine.estimate` takes."""
+        eng = self._eng
+        t = images if isinstance(images, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(images, np.uint8), device=eng.device)
+        assert t.dtype == torch.uint8 and t.dim() == 3, "expected a (B, H, W) uint8 stack"
+        B, H, W = (int(v) for v in t.shape)
+        kpt = torch.empty((B, self._max, 4), dtype=torch.float32, device=eng.device)
+        resp = torch.empty((B, self._max), dtype=torch.float32, device=eng.device)
+        octv = torch.empty((B, self._max), dtype=torch.int32, device=eng.device)
+        desc = torch.empty((B, self._max, 128), dtype=torch.float32, device=eng.device)
+        n = (C.c_int32 * B)()
+        rc = eng.lib.gn_sift_detect_and_compute_batch(eng.ctx, _ptr(t.contiguous()), B, H, W, self._max, _ptr(kpt), _ptr(resp), _ptr(octv), _ptr(desc),
+                                                      C.cast(n, C.POINTER(C.c_int32)), eng._stream())
+        _lib.check(eng.ctx, rc, "gn_sift_detect_and_compute_batch")
+        return kpt, resp, octv, desc, np.frombuffer(n, dtype=np.int32).copy()
 
     def detectAndCompute(self, image, mask=None):
         if mask is not None:

@@ -18,7 +18,7 @@
  *   gn_pose_to_earth (+ gn_proj_to_affine, gn_wgs84_to_ecef)   the georeferencing after the pose
  *                                                 pose_node.py:333-381, _transformations.py:298-393
  * and, widening to the feeders of that path:
- *   gn_sift_detect_and_compute   cv2.SIFT_create().detectAndCompute(img, None)
+ *   gn_sift_detect_and_compute(_batch)   cv2.SIFT_create().detectAndCompute(img, None)
  *                                                 pose_node.py:122,230-232; twist_node.py:93,227-245
  *   gn_rotate_crop_center / gn_stereo_reference   StereoNode reference raster   stereo_node.py:229-262,292-335
  *   gn_vo_match / gn_vo_estimate cv2.BFMatcher.knnMatch(k=2) + ratio test + compute_pose   twist_node.py:95,248-289
@@ -26,7 +26,7 @@
  * Conventions: plain C, no torch types.  Every data pointer is a DEVICE pointer unless the
  * parameter is marked "host".  `stream` is a hipStream_t passed as void* (NULL = default
  * stream).  All work is stream-ordered; no entry point synchronises except gn_debug_read and
- * gn_sift_detect_and_compute (host-side keypoint sort).
+ * gn_sift_detect_and_compute(_batch) (one sync at the end, to return the keypoint counts).
  * Return value: 0 on success, negative gn_status on failure; nothing throws.  One context
  * per GPU; a context is thread-compatible, not thread-safe (PoseNode calls from one executor
  * thread at a time, gisnav/__init__.py:140-154).
@@ -202,9 +202,16 @@ int gn_pose_to_earth(const double* R9, const double* t3, const double* affine12,
  *   GN_KPT_XYSA keypoint format of gn_match / gn_estimate; response [max_kpts] f32 and octave [max_kpts] int32
  *   (packed as cv2.KeyPoint.octave) may be NULL; desc [max_kpts][128] f32 (integer-valued 0..255, as cv2 emits).
  *   n_out_host: HOST int32, number of keypoints, in OpenCV's order (sorted by x, y, size desc, angle, ...).
- * Synchronises `stream` (the keypoint list is sorted and de-duplicated on the host, like OpenCV does). */
+ * Everything -- scale space, extrema, refinement, the sort / duplicate removal, descriptors -- runs on the device in
+ * stream order; the call synchronises `stream` once, at the end, to hand the keypoint count to the host. */
 int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
                                float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream);
+/* The same for B equally sized images in ONE pass (every kernel launch covers all images): gray [B][H][W]; outputs
+ * [B][max_kpts][...] with image b's keypoints in rows [0, n_out_host[b]); n_out_host: HOST int32 [B].  The reference
+ * extracts one image per ROS message; batching is this build's addition for the frames -> pose pipeline, whose matcher
+ * (gn_estimate) already takes batches of pairs in this keypoint format. */
+int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, int H, int W, int max_kpts,
+                                     float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream);
 
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.

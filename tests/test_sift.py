@@ -89,6 +89,27 @@ def test_sift_keypoints_and_descriptors_bit_exact(sift_gpu, seed, shape):
 
 
 @pytest.mark.gpu
+def test_sift_batch_equals_image_by_image(sift_gpu):
+    """gn_sift_detect_and_compute_batch: one pass over B images gives, image for image, exactly the single-image result
+    (and therefore the oracle's); also after the workspace was sized for a smaller / larger batch."""
+    imgs = np.stack([blob_image(seed, 200, 264, n=150 + 40 * seed) for seed in range(5)])
+    singles = [sift_gpu.detect_and_compute_device(im) for im in imgs]
+    for B in (5, 2):
+        kpt, resp, octv, desc, n = sift_gpu.detect_and_compute_batch_device(imgs[:B])
+        assert kpt.shape[0] == B and len(n) == B
+        for b in range(B):
+            sk, sr, so, sd = singles[b]
+            assert n[b] == len(sk) > 20
+            assert np.array_equal(kpt[b, : n[b]].cpu().numpy().view(np.int32), sk.cpu().numpy().view(np.int32))
+            assert np.array_equal(resp[b, : n[b]].cpu().numpy().view(np.int32), sr.cpu().numpy().view(np.int32))
+            assert np.array_equal(octv[b, : n[b]].cpu().numpy(), so.cpu().numpy())
+            assert np.array_equal(desc[b, : n[b]].cpu().numpy(), sd.cpu().numpy())
+    okp, _, _, _, _, odesc = osift.detect_and_compute(imgs[3])
+    kpt, _, _, desc, n = sift_gpu.detect_and_compute_batch_device(imgs)
+    assert np.array_equal(kpt[3, : n[3], :2].cpu().numpy(), okp) and np.array_equal(desc[3, : n[3]].cpu().numpy(), odesc)
+
+
+@pytest.mark.gpu
 def test_sift_cv2_style_interface_and_golden_fixture(sift_gpu):
     g = np.load(os.path.join(GOLD, "sift_blobs_seed2.npz"))
     kps, desc = sift_gpu.detectAndCompute(g["image"], None)
