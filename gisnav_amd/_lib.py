@@ -38,6 +38,7 @@ SIGNATURES = {
     "gn_set_overlap": (C.c_int, [VP, C.c_int]),
     "gn_flush": (C.c_int, [VP, VP]),
     "gn_set_substreams": (C.c_int, [VP, C.c_int]),
+    "gn_set_active_kpts": (C.c_int, [VP, C.c_int]),
     "gn_vo_match": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP, VP, VP, VP, VP]),
     "gn_vo_estimate": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, c_f64p, C.c_double, C.c_int,
                                  VP, VP, VP, VP, VP, VP]),

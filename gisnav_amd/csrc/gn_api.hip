@@ -30,6 +30,7 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
+  int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
   int n_layers = kMaxLayers;
   float threshold = 0.5f;
   std::string err;
@@ -276,7 +277,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
                 const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
                 const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                 int64_t* idx, float* score, int32_t* n_match, hipStream_t s) {
-  const int np = c->npad, T = B * 2 * np, BS = B * 2;
+  const int np = c->npad_run, T = B * 2 * np, BS = B * 2;
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
   const int vt_perm = (bf16v2 ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v5 reads V^T with keys permuted inside 16-groups   // k_attn_bf16_v4 reads permuted V^T
@@ -374,7 +375,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     hd.sim = c->sim; hd.ls = c->ls; hd.nvalid = c->nvalid; hd.B = B; hd.npad = np; hd.threshold = c->threshold;
     hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
     hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
-    hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = np;
+    hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = c->npad;   // output stride: gn_kmax(), whatever the active size
     launch_match_head(hd, s);
   }
   return GN_OK;
@@ -412,6 +413,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision;
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   ctx->npad = ((max_kpts + 127) / 128) * 128;
+  ctx->npad_run = ctx->npad;
   const size_t np = ctx->npad, T = (size_t)max_batch * 2 * np, B = max_batch;
 #define GN_ALLOC(field, count)                                     \
   do { int rc_ = dalloc(ctx, &ctx->field, (count)); if (rc_ != GN_OK) { gn_destroy(ctx); return rc_; } } while (0)
@@ -652,7 +654,7 @@ namespace {
 // every per-pair workspace pointer of the context moved by `b0` pairs (sign = +1) and back (sign = -1): kernels capture
 // pointer values at launch, so a sub-batch group simply runs the ordinary path on its slice of the workspaces
 void shift_workspaces(gn_ctx* c, long long b0, int sign) {
-  const long long d = sign * b0, np = c->npad, T2 = 2 * np;
+  const long long d = sign * b0, np = c->npad_run, T2 = 2 * np;
   auto mv = [&](auto*& p, long long per_pair) { if (p) p += d * per_pair; };
   mv(c->desc, T2 * kInDim); mv(c->cos_t, T2 * kFreq); mv(c->sin_t, T2 * kFreq); mv(c->extent, 4); mv(c->nvalid, 2);
   mv(c->x, T2 * kDim); mv(c->qkv, T2 * 3 * kDim); mv(c->ctx, T2 * kDim); mv(c->msg, T2 * kDim); mv(c->h, T2 * 2 * kDim);
@@ -704,6 +706,12 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
     b0 += Bg;
   }
   return rc_all;
+}
+
+int gn_set_active_kpts(gn_ctx* ctx, int max_kpts_per_side) {
+  if (!ctx || max_kpts_per_side < 1) return GN_ERR_ARG;
+  ctx->npad_run = std::min(ctx->npad, ((max_kpts_per_side + 127) / 128) * 128);
+  return ctx->npad_run;
 }
 
 int gn_set_substreams(gn_ctx* ctx, int n) {

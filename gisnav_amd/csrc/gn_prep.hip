@@ -44,7 +44,7 @@ __device__ inline void read_kpt(const float* kp, int fmt, float& x, float& y, fl
 
 __global__ __launch_bounds__(256) void k_extent(PrepArgs a) {
   const int bs = blockIdx.x, b = bs >> 1, side = bs & 1;
-  const int n = side ? a.n_r[b] : a.n_q[b];
+  const int n = min(side ? a.n_r[b] : a.n_q[b], a.npad);   // keypoints beyond the padded size of this call are ignored (gn_set_active_kpts)
   const int stride = side ? a.stride_r : a.stride_q;
   const int fmt = a.kpt_format & 0xff;
   const int w = fmt == GN_KPT_LAF ? 6 : 4;

@@ -156,6 +156,14 @@ class PoseEngine:
         """Throughput option: every estimate() call runs its pairs as n out-of-phase groups on internal streams (gn_set_substreams)."""
         _lib.check(self.ctx, self.lib.gn_set_substreams(self.ctx, int(n)), "gn_set_substreams")
 
+    def set_active_kpts(self, max_kpts_per_side: int) -> int:
+        """Padded keypoint count the following match()/estimate() calls run at (gn_set_active_kpts): pass the largest keypoint
+        count of the batch when it is well below max_kpts.  Returns the padded size in effect."""
+        rc = self.lib.gn_set_active_kpts(self.ctx, int(max_kpts_per_side))
+        if rc < 0:
+            _lib.check(self.ctx, rc, "gn_set_active_kpts")
+        return rc
+
     def flush(self) -> None:
         _lib.check(self.ctx, self.lib.gn_flush(self.ctx, self._stream()), "gn_flush")
 

@@ -15,6 +15,7 @@
  *   gn_pnp_ransac                cv2.solvePnPRansac(..., iterationsCount=10) + cv2.Rodrigues
  *                                                                       _shared.py:104-117
  *   gn_estimate                  the whole of PoseNode._pose lines 246-308 for a batch of pairs
+ *                                (gn_set_active_kpts: padded size per call, for batches well below max_kpts)
  *   gn_pose_to_earth (+ gn_proj_to_affine, gn_wgs84_to_ecef)   the georeferencing after the pose
  *                                                 pose_node.py:333-381, _transformations.py:298-393
  * and, widening to the feeders of that path:
@@ -149,6 +150,13 @@ int gn_set_overlap(gn_ctx* ctx, int enable);
  * ones.  ALL outputs of a call (n_match included) are complete only after gn_flush(ctx, stream).
  * Measured on the 32-pair bench: +1..3 % with n = 2, slower with n >= 4 (smaller GEMMs); off (n = 1) by default. */
 int gn_set_substreams(gn_ctx* ctx, int n);
+/* The matcher pads every image to a multiple of 128 keypoints; by default that is max_kpts of gn_create.  When the caller
+ * knows an upper bound of the keypoint counts of the coming calls (the SIFT entry points return them), this sets the padded
+ * size those calls run at -- attention cost falls with its square, the GEMMs linearly.  Keypoints beyond it are ignored.
+ * Results do not depend on the padded size (padding is masked out exactly).  Returns the padded size now in effect
+ * (min(round_up(max_kpts_per_side, 128), padded max_kpts of the context)) or a negative status.  Output strides (gn_kmax)
+ * do not change.  Host-side state: takes effect for calls issued after it. */
+int gn_set_active_kpts(gn_ctx* ctx, int max_kpts_per_side);
 int gn_flush(gn_ctx* ctx, void* stream);
 
 /* ---- visual-odometry path of TwistNode ---------------------------- */

@@ -517,3 +517,32 @@ def test_substreams_give_identical_results(state_dict_np, dev):
         for o in outs:
             assert all(np.array_equal(ref[k], o[k].cpu().numpy()) for k in ref), n
     eng.set_substreams(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+def test_active_kpts_padding_does_not_change_results(state_dict_np, dev, prec):
+    """gn_set_active_kpts: running a batch at a smaller padded size (640 -> 256 slots per image; attention cost / 6) gives
+    exactly the outputs of the full-size run -- padding is masked out exactly -- also with sub-batch streams."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=640, precision=prec, state_dict=state_dict_np)
+    inp = eng.stage_inputs([make_pair(90 + i, n_q=250 - 9 * i, n_r=256 - 5 * i) for i in range(4)])
+    ref = {k: v.cpu().numpy().copy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    ridx, rscore, rn = (v.cpu().numpy().copy() for v in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+    assert (ref["n_match"] > 30).all() and ref["ok"].all()
+    assert eng.set_active_kpts(250) == 256 and eng.kmax == 640
+    out = {k: v.cpu().numpy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    assert all(np.array_equal(ref[k], out[k]) for k in ref)
+    idx, score, n = (v.cpu().numpy() for v in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+    assert np.array_equal(n, rn)
+    for b in range(4):
+        assert np.array_equal(idx[b, : n[b]], ridx[b, : n[b]]) and np.array_equal(score[b, : n[b]].view(np.int32), rscore[b, : n[b]].view(np.int32))
+    eng.set_substreams(2)
+    o2 = eng.estimate(inp, K_MATRIX, out=eng.alloc_outputs(4))
+    eng.flush()
+    torch.cuda.current_stream().synchronize()
+    assert all(np.array_equal(ref[k], o2[k].cpu().numpy()) for k in ref)
+    eng.set_substreams(1)
+    assert eng.set_active_kpts(10_000) == 640                              # clamped to the context's padded maximum
+    out = {k: v.cpu().numpy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    assert all(np.array_equal(ref[k], out[k]) for k in ref)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
+    ap.add_argument("--no-active", dest="active", action="store_false", help="always pad the matcher to --kpts (skip gn_set_active_kpts)")
     args = ap.parse_args()
     B, (H, W) = args.batch, args.size
     eng = PoseEngine(0, max_batch=B, max_kpts=args.kpts, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
@@ -45,6 +46,8 @@ def main():
     def step():
         kpt, _, _, desc, n = sift.detect_and_compute_batch_device(imgs)
         nd = torch.as_tensor(n, device=eng.device)
+        if args.active:
+            eng.set_active_kpts(int(n.max()))                   # run the matcher at round_up(max keypoints, 128) slots instead of --kpts
         inp = dict(desc_q=desc[:B], kpt_q=kpt[:B], n_q=nd[:B], desc_r=desc[B:], kpt_r=kpt[B:], n_r=nd[B:], dem=dem, kpt_format=_lib.GN_KPT_XYSA)
         eng.estimate(inp, K_MATRIX, out=out)
         return n
@@ -66,7 +69,7 @@ def main():
                       "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                       "ms_sift_per_step": round(ms_sift, 3), "higher_is_better": True, "data": "synthetic", "dtype": "f32 SIFT; f16x2 / bf16-attention matcher",
                       "config": {"workload": f"{B} pairs of {H}x{W} u8 images, {int(n.mean())} keypoints per image on average (max {int(n.max())}), "
-                                             f"matcher padded to {args.kpts}; random-init matcher weights (timing only)"}}), flush=True)
+                                             f"matcher padded to {eng.set_active_kpts(int(n.max())) if args.active else args.kpts}; random-init matcher weights (timing only)"}}), flush=True)
 
 
 if __name__ == "__main__":
