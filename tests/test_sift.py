@@ -110,6 +110,33 @@ def test_sift_batch_equals_image_by_image(sift_gpu):
 
 
 @pytest.mark.gpu
+def test_sift_edge_cases_flat_tiny_and_overflow(sift_gpu):
+    """No keypoints at all, the smallest pyramids (every octave inside the single-workgroup tail kernel, extrema search
+    skipping the octaves thinner than the border), and the error path when the caller's buffers are too small."""
+    from gisnav_amd.sift import SIFT
+    kpt, resp, octv, desc = sift_gpu.detect_and_compute_device(np.full((64, 80), 128, np.uint8))
+    assert kpt.shape == (0, 4) and desc.shape == (0, 128) and resp.shape == (0,) and octv.shape == (0,)
+    kps, d = sift_gpu.detectAndCompute(np.zeros((16, 16), np.uint8), None)
+    assert kps == [] and d.shape == (0, 128)
+    total = 0
+    for seed, shape, n in ((7, (24, 40), 20), (8, (33, 17), 10), (9, (48, 48), 30), (10, (40, 72), 40), (11, (21, 64), 25)):
+        img = blob_image(seed, *shape, n=n)
+        okp, osize, oang, _, ooct, odesc = osift.detect_and_compute(img)
+        kpt, _, octv, desc = sift_gpu.detect_and_compute_device(img)
+        k = kpt.cpu().numpy()
+        assert len(k) == len(okp)
+        total += len(k)
+        assert np.array_equal(k[:, :2], okp) and np.array_equal(k[:, 2], osize) and np.array_equal(k[:, 3], oang)
+        assert np.array_equal(octv.cpu().numpy(), ooct) and np.array_equal(desc.cpu().numpy(), odesc)
+    assert total >= 15
+    small = SIFT(engine=sift_gpu._eng, max_keypoints=16)
+    with pytest.raises(RuntimeError, match="max_kpts"):
+        small.detect_and_compute_device(blob_image(0, 240, 320))
+    kpt, _, _, _ = sift_gpu.detect_and_compute_device(blob_image(0, 240, 320))          # the context is usable afterwards
+    assert len(kpt) > 20
+
+
+@pytest.mark.gpu
 def test_sift_cv2_style_interface_and_golden_fixture(sift_gpu):
     g = np.load(os.path.join(GOLD, "sift_blobs_seed2.npz"))
     kps, desc = sift_gpu.detectAndCompute(g["image"], None)
