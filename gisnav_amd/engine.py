@@ -184,6 +184,28 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_estimate")
         return out
 
+    def estimate_images(self, frames, tiles, K: np.ndarray, dem=None, sift=None, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
+        """Frames -> pose from pixels for B pairs, everything in HBM: one batched SIFT pass over the B camera frames and the
+        B map tiles (`gn_sift_detect_and_compute_batch`), the matcher padded to what the batch needs (`gn_set_active_kpts`),
+        then `gn_estimate`.  frames / tiles: (B, H, W) uint8 (numpy or device tensors, one size); dem: (B, H, W) uint8 or
+        None (flat).  Returns (estimate outputs, n_keypoints [2B] int32 on the host: frames first)."""
+        from .sift import SIFT
+        if sift is None:
+            if getattr(self, "_sift", None) is None:
+                self._sift = SIFT(engine=self, max_keypoints=self.kmax)
+            sift = self._sift
+        to_dev = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a, np.uint8), device=self.device)  # noqa: E731
+        f, t = to_dev(frames), to_dev(tiles)
+        assert f.shape == t.shape and f.dim() == 3, "expected two (B, H, W) uint8 stacks of one size"
+        B = int(f.shape[0])
+        kpt, _, _, desc, n = sift.detect_and_compute_batch_device(torch.cat([f, t], 0))
+        nd = torch.as_tensor(n, device=self.device)
+        self.set_active_kpts(max(int(n.max()), 1))
+        if dem is None:
+            dem = torch.zeros((B, int(f.shape[1]), int(f.shape[2])), dtype=torch.uint8, device=self.device)
+        inputs = dict(desc_q=desc[:B], kpt_q=kpt[:B], n_q=nd[:B], desc_r=desc[B:], kpt_r=kpt[B:], n_r=nd[B:], dem=to_dev(dem), kpt_format=_lib.GN_KPT_XYSA)
+        return self.estimate(inputs, K, min_matches, out=out), n
+
     # ------------------------------------------------------------------ visual-odometry path (TwistNode)
     def vo_match(self, desc_q, n_q, desc_r, n_r, ratio: float = 0.7, want_knn: bool = False):
         """gn_vo_match: BFMatcher(L2).knnMatch(k=2) + ratio test.  desc [B,S,128] f32, n [B] i32 (device).

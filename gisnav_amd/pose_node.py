@@ -35,6 +35,7 @@ class PoseNode:
             extractor = SIFT(engine=self._engine, max_keypoints=max_kpts).as_extractor()
         self._extractor = extractor
         self._cached_stamp_kps_desc = None
+        self._cached_n_r = 0
         self.camera_info: Optional[CameraInfo] = None
         self.pose_image: Optional[OrthoStereoImage] = None
         self.last_num_matches = 0
@@ -58,6 +59,7 @@ class PoseNode:
             cached = (f(desc_r, 128), f(np.column_stack([kp_r, size_r, angle_r]), 4),
                       torch.tensor([len(kp_r)], dtype=torch.int32, device=dev))
             self._cached_stamp_kps_desc = (stamp, cached)
+            self._cached_n_r = len(kp_r)
         desc_r_t, kpt_r_t, n_r_t = self._cached_stamp_kps_desc[1]
         n = len(kp_q)
         if n == 0:
@@ -69,6 +71,7 @@ class PoseNode:
                       desc_r=desc_r_t, kpt_r=kpt_r_t, n_r=n_r_t,
                       dem=torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev),
                       kpt_format=_lib.GN_KPT_XYSA)
+        eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)
         out = eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES)
         self.last_num_matches = int(out["n_match"].cpu()[0])
         if self.last_num_matches < self.MIN_MATCHES:        # pose_node.py:299-303

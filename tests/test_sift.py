@@ -171,3 +171,34 @@ def test_frames_to_pose_end_to_end_like_twist_node(sift_gpu):
     g = twist_pose(sift_gpu._eng, K_MATRIX, pq_, dq, pr_, dr)
     assert o is not None and g is not None
     assert np.linalg.norm(g[0] - o[0]) < 1e-8 and np.linalg.norm(g[1] - o[1]) / np.linalg.norm(o[1]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_estimate_images_equals_the_manual_chain():
+    """PoseEngine.estimate_images (batched SIFT -> gn_set_active_kpts -> gn_estimate, all in HBM) against the same steps done
+    image by image at the context's full padding."""
+    import torch
+    from gisnav_amd import _lib
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.sift import SIFT
+    from gisnav_amd.synthetic import K_MATRIX
+    from gisnav_amd.weights import synthetic_state_dict
+    B, H, W = 3, 200, 264
+    eng = PoseEngine(0, max_batch=B, max_kpts=512, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
+    bigs = [blob_image(40 + b, H + 12, W + 12, n=160 + 30 * b) for b in range(B)]
+    tiles = np.stack([g[:H, :W] for g in bigs]); frames = np.stack([g[7:H + 7, 9:W + 9] for g in bigs])
+    out, n = eng.estimate_images(frames, tiles, K_MATRIX)
+    got = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    sift = SIFT(engine=eng, max_keypoints=512)
+    desc = torch.zeros((2 * B, 512, 128), dtype=torch.float32, device=eng.device); kpt = torch.zeros((2 * B, 512, 4), dtype=torch.float32, device=eng.device)
+    counts = []
+    for i, im in enumerate(list(frames) + list(tiles)):
+        k, _, _, d = sift.detect_and_compute_device(im)
+        counts.append(len(k)); kpt[i, : len(k)] = k; desc[i, : len(k)] = d
+    assert np.array_equal(n, np.array(counts, np.int32)) and min(counts) > 40 and max(counts) <= 384
+    assert eng.set_active_kpts(512) == 512
+    nd = torch.tensor(counts, dtype=torch.int32, device=eng.device)
+    ref = eng.estimate(dict(desc_q=desc[:B], kpt_q=kpt[:B], n_q=nd[:B], desc_r=desc[B:], kpt_r=kpt[B:], n_r=nd[B:],
+                            dem=torch.zeros((B, H, W), dtype=torch.uint8, device=eng.device), kpt_format=_lib.GN_KPT_XYSA), K_MATRIX)
+    for k in got:
+        assert np.array_equal(got[k], ref[k].cpu().numpy()), k
