@@ -984,8 +984,8 @@ int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, in
               (int)ctx->sift_kernels[ki].size(), s, dog, in_step, py.oct[o_in].w, half_scratch);
   };
   // createInitialImage: 2x bilinear, blur to sigma 1.6; then the Gaussian and DoG pyramids
-  sift_base(gray, B, H, W, py.oct[0].gauss[5], py.oct[0].stride, ctx->sift_counts, s);   // scratch: level 5 is overwritten later; also zeroes the counters
-  blur(0, py.oct[0].gauss[5], 0, py.oct[0].gauss[0], 0);
+  sift_base_blur(gray, B, H, W, py.oct[0].gauss[5], ctx->sift_tmp, py.oct[0].gauss[0], py.oct[0].stride, ctx->sift_dk + ctx->sift_koff[0],
+                 (int)ctx->sift_kernels[0].size(), ctx->sift_counts, s);   // (scratch = level 5, overwritten later); also zeroes the counters
   int ksize[6];
   for (int i = 0; i < 6; ++i) ksize[i] = (int)ctx->sift_kernels[i].size();
   const int o_tail = sift_tail_first(py, ksize);                     // octaves from here on: one single-workgroup launch per image

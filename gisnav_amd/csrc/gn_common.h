@@ -167,7 +167,7 @@ struct SiftOctave { float* gauss[6]; float* dog[5]; int w, h; long long stride; 
 struct SiftPyramid { SiftOctave oct[kSiftMaxOctaves]; int n_oct; };
 struct SiftKeypoint { float x, y, size, angle, response; int octave; };
 void sift_gaussian_kernel(double sigma, std::vector<float>& k);
-void sift_base(const uint8_t* gray, int B, int h, int w, float* out, long long out_stride, int* counters, hipStream_t s);   // also zeroes counters[4b + 0..2]
+void sift_base_blur(const uint8_t* gray, int B, int h, int w, float* scratch, float* tmp, float* out, long long out_stride, const float* dk, int n, int* counters, hipStream_t s);
 // dog = out - in; in_step 2 reads every second pixel of a source image of row stride in_w (half_scratch: only used for non-stock kernel sizes)
 void sift_blur(int B, long long stride_in, long long stride_out, const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s,
                float* dog = nullptr, int in_step = 1, int in_w = 0, float* half_scratch = nullptr);

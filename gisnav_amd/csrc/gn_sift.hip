@@ -32,14 +32,10 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out, long long out_stride, int* counters) {
-  const int b = blockIdx.z;
-  g += (size_t)b * h * w; out += (long long)b * out_stride;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[4 * b + threadIdx.x] = 0;   // candidate / raw / final counts of this image
-  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (dx >= 2 * w || dy >= 2 * h) return;
+// createInitialImage's 2x bilinear upsampling (cv::resize INTER_LINEAR): pixel (dy, dx) of the doubled image from the u8 image g [h][w]
+__device__ __forceinline__ float sift_base_sample(const uint8_t* g, int h, int w, int dy, int dx) {
   auto taps = [](int d, int n_src, int& s, int& s1, float& a0, float& a1) {
-    float f = (float)(((double)d + 0.5) * 0.5 - 0.5);
+    float f = (float)d * 0.5f - 0.25f;                 // (d + 0.5) / 2 - 0.5, exact in f32
     s = (int)floorf(f);
     f = f - (float)s;
     if (s < 0) { f = 0.f; s = 0; }
@@ -52,7 +48,17 @@ __global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int 
   taps(dy, h, sy, sy1, b0, b1);
   const float h0 = (float)g[(size_t)sy * w + sx] * a0 + (float)g[(size_t)sy * w + sx1] * a1;
   const float h1 = (float)g[(size_t)sy1 * w + sx] * a0 + (float)g[(size_t)sy1 * w + sx1] * a1;
-  out[(size_t)dy * 2 * w + dx] = h0 * b0 + h1 * b1;
+  return h0 * b0 + h1 * b1;
+}
+
+// stand-alone form (only used when the initial blur is not the stock 11-tap kernel; otherwise k_blur_fused samples on the fly)
+__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* g, int h, int w, float* out, long long out_stride, int* counters) {
+  const int b = blockIdx.z;
+  g += (size_t)b * h * w; out += (long long)b * out_stride;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[4 * b + threadIdx.x] = 0;   // candidate / raw / final counts of this image
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= 2 * w || dy >= 2 * h) return;
+  out[(size_t)dy * 2 * w + dx] = sift_base_sample(g, h, w, dy, dx);
 }
 
 __global__ __launch_bounds__(256) void k_blur_row(const float* in, float* out, int w, int h, const float* k, int n) {
@@ -85,8 +91,13 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
 // The first level of an octave reads its input straight from level 3 of the octave above (in_step = 2), so the
 // half-size base image is never materialised.
 constexpr int kFtW = 64, kFtH = 32;
-template <int N>
-__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w, long long stride_in, long long stride_out) {
+// BASE: `in` is the u8 camera image [h / 2][w / 2] (images stride_in BYTES apart) and the tile is sampled from its 2x bilinear
+// upsampling on the fly -- the initial blur of createInitialImage without ever storing the doubled image; `counters` are zeroed.
+template <int N, bool BASE = false>
+__global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w, long long stride_in, long long stride_out,
+                                                    int* counters = nullptr) {
+  const uint8_t* gray = reinterpret_cast<const uint8_t*>(in) + (long long)blockIdx.z * stride_in;
+  if (BASE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[4 * blockIdx.z + threadIdx.x] = 0;   // candidate / raw / final counts of this image
   in += (long long)blockIdx.z * stride_in; out += (long long)blockIdx.z * stride_out;   // image blockIdx.z of the batch
   if (dog != nullptr) dog += (long long)blockIdx.z * stride_out;
   constexpr int R = N / 2, ROWS = kFtH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
@@ -104,7 +115,8 @@ __global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out,
     for (int i = 0; i < PER; ++i) {
       const int idx = tid + 256 * i;
       const int ry = idx / CW, rx = idx - ry * CW;
-      stage[i] = idx < TOTAL ? in[(size_t)(reflect101(y0 - R + ry, h) * in_step) * in_w + reflect101(x0 - R + rx, w) * in_step] : 0.f;   // in_step 2: every second pixel of the octave above
+      if (BASE) stage[i] = idx < TOTAL ? sift_base_sample(gray, h / 2, w / 2, reflect101(y0 - R + ry, h), reflect101(x0 - R + rx, w)) : 0.f;
+      else stage[i] = idx < TOTAL ? in[(size_t)(reflect101(y0 - R + ry, h) * in_step) * in_w + reflect101(x0 - R + rx, w) * in_step] : 0.f;   // in_step 2: every second pixel of the octave above
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -321,7 +333,9 @@ __global__ __launch_bounds__(256) void k_sift_find(SiftPyramid py, SiftFindPlan 
   const int rend = min(rbeg + kFindRows / 4, oc.h - kBorder);
   if (c >= oc.w - kBorder || rbeg >= rend) return;
   // a thread walks down a column strip with the 5 x 3 x 3 DoG neighbourhood in registers: 15 loads per row serve the three
-  // layers (5 per tested value instead of 1 + 27 from L1 -- this kernel was bound by L1 request rate, not by HBM)
+  // layers (5 per tested value instead of 1 + 27 from L1 -- this kernel was bound by L1 request rate, not by HBM).
+  // (Fetching the left / right neighbours from adjacent lanes with DPP wave shifts instead -- 5 full loads + 10 one-lane edge
+  // loads per row -- was 2x SLOWER: the texture path is charged per load instruction, not per lane.)
   const int w = oc.w;
   float win[5][3][3];
   auto load_row = [&](int r, int slot) __attribute__((always_inline)) {
@@ -947,9 +961,18 @@ void sift_tail(const SiftPyramid& py, int B, int o_first, const float* dk, const
   (void)attr_set;
   hipLaunchKernelGGL(k_sift_tail, dim3(B), dim3(1024), lds, s, py, o_first, dk, plan);
 }
-void sift_base(const uint8_t* gray, int B, int h, int w, float* out, long long out_stride, int* counters, hipStream_t s) {
+// createInitialImage for B images: gray [B][h][w] u8 -> level 0 of octave 0 (2h x 2w, blurred to sigma 1.6); zeroes counters[4b + 0..2].
+// Stock kernel (11 taps): one launch, the doubled image is sampled on the fly; otherwise k_sift_base into `scratch` + the generic blur.
+void sift_base_blur(const uint8_t* gray, int B, int h, int w, float* scratch, float* tmp, float* out, long long out_stride, const float* dk, int n, int* counters, hipStream_t s) {
+  if (n == 11) {
+    const dim3 g((2 * w + kFtW - 1) / kFtW, (2 * h + kFtH - 1) / kFtH, B);
+    hipLaunchKernelGGL((k_blur_fused<11, true>), g, dim3(256), 0, s, reinterpret_cast<const float*>(gray), out, 2 * w, 2 * h, dk, (float*)nullptr, 1, 2 * w,
+                       (long long)h * w, out_stride, counters);
+    return;
+  }
   dim3 g = grid2d(2 * w, 2 * h); g.z = B;
-  hipLaunchKernelGGL(k_sift_base, g, dim3(256), 0, s, gray, h, w, out, out_stride, counters);
+  hipLaunchKernelGGL(k_sift_base, g, dim3(256), 0, s, gray, h, w, scratch, out_stride, counters);
+  sift_blur(B, out_stride, out_stride, scratch, tmp, out, 2 * w, 2 * h, dk, n, s);
 }
 void sift_find(const SiftPyramid& py, int B, float threshold, int4* cand, int* n_cand, int max_cand, hipStream_t s) {
   SiftFindPlan plan;
