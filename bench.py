@@ -114,6 +114,7 @@ def main() -> None:
     ap.add_argument("--overlap", action="store_true", help="run the PnP stage of step n on a second stream beside the matcher of step n+1 "
                                                            "(gn_set_overlap; measured gain < 1 %: the 256-VGPR GEMM waves leave no room for co-resident PnP waves)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE", help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
@@ -133,6 +134,10 @@ def main() -> None:
             sd = {k: np.zeros_like(v) for k, v in sd.items()}
         sd = gdist.broadcast_state_dict(sd, dev, src=0)
     eng = PoseEngine(local_rank, max_batch=args.batch, max_kpts=args.kpts, precision=args.precision, state_dict=sd)
+
+    for kv in args.debug_variant:
+        which, value = (int(v) for v in kv.split(":"))
+        eng.lib.gn_debug_set_variant(eng.ctx, which, value)
 
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
     shard = gdist.shard_range(args.batch * world, rank, world)
