@@ -230,6 +230,22 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
   // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
   // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
   // of a 16-lane group replaced by the next row's raw accumulator).
+  // rotary tables / residual rows of the 16 rows this lane touches, requested back to back and outside any per-lane
+  // branch (a 64-column sub-tile is entirely inside or outside the rotated range): one L2 latency, not one per row
+  float2 cs16[16], sn16[16];
+  f32x4 res16[16];
+  if ((EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (bn + wc * 64) < a.rot_cols) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const size_t row = (size_t)(bm + wr * 64 + it * 4 + (lane >> 4));
+      cs16[it] = *reinterpret_cast<const float2*>(a.cos_t + row * kFreq + f0);
+      sn16[it] = *reinterpret_cast<const float2*>(a.sin_t + row * kFreq + f0);
+    }
+  }
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) res16[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(bm + wr * 64 + it * 4 + (lane >> 4)) * a.ldr + col);
+  }
   f32x4 vals[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
@@ -243,8 +259,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
       if (do_scale) v *= a.scale;
     } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
       if (do_rot) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        const float2 cs = cs16[it], sn = sn16[it];
         f32x4 o;
         o.x = v.x * cs.x + (-v.y) * sn.x;
         o.y = v.y * cs.x + v.x * sn.x;
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
         v = o;
       }
     } else if (EPI == EPI_RESIDUAL) {
-      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+      v += res16[it];
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
@@ -525,6 +540,22 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
   // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
   // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
   // of a 16-lane group replaced by the next row's raw accumulator).
+  // rotary tables / residual rows of the 16 rows this lane touches, requested back to back and outside any per-lane
+  // branch (a 64-column sub-tile is entirely inside or outside the rotated range): one L2 latency, not one per row
+  float2 cs16[16], sn16[16];
+  f32x4 res16[16];
+  if ((EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (bn + wc * 64) < a.rot_cols) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const size_t row = (size_t)(bm + wr * 64 + it * 4 + (lane >> 4));
+      cs16[it] = *reinterpret_cast<const float2*>(a.cos_t + row * kFreq + f0);
+      sn16[it] = *reinterpret_cast<const float2*>(a.sin_t + row * kFreq + f0);
+    }
+  }
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) res16[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(bm + wr * 64 + it * 4 + (lane >> 4)) * a.ldr + col);
+  }
   f32x4 vals[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
@@ -538,8 +569,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
       if (do_scale) v *= a.scale;
     } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
       if (do_rot) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        const float2 cs = cs16[it], sn = sn16[it];
         f32x4 o;
         o.x = v.x * cs.x + (-v.y) * sn.x;
         o.y = v.y * cs.x + v.x * sn.x;
@@ -548,7 +578,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
         v = o;
       }
     } else if (EPI == EPI_RESIDUAL) {
-      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+      v += res16[it];
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
@@ -825,6 +855,22 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
   // issued: a 16-byte global store followed by an LDS read that returns into the store's data registers can
   // corrupt the store when the memory pipeline is back-pressured (observed on gfx950: one float4 component
   // of a 16-lane group replaced by the next row's raw accumulator).
+  // rotary tables / residual rows of the 16 rows this lane touches, requested back to back and outside any per-lane
+  // branch (a 64-column sub-tile is entirely inside or outside the rotated range): one L2 latency, not one per row
+  float2 cs16[16], sn16[16];
+  f32x4 res16[16];
+  if ((EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) && (bn + wc * 64) < a.rot_cols) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const size_t row = (size_t)(bm + wr * 64 + it * 4 + (lane >> 4));
+      cs16[it] = *reinterpret_cast<const float2*>(a.cos_t + row * kFreq + f0);
+      sn16[it] = *reinterpret_cast<const float2*>(a.sin_t + row * kFreq + f0);
+    }
+  }
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) res16[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(bm + wr * 64 + it * 4 + (lane >> 4)) * a.ldr + col);
+  }
   f32x4 vals[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
@@ -838,8 +884,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
       if (do_scale) v *= a.scale;
     } else if (EPI == EPI_ROTARY || EPI == EPI_ROTARY_BF16) {
       if (do_rot) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.cos_t + (size_t)row * kFreq + f0);
-        const float2 sn = *reinterpret_cast<const float2*>(a.sin_t + (size_t)row * kFreq + f0);
+        const float2 cs = cs16[it], sn = sn16[it];
         f32x4 o;
         o.x = v.x * cs.x + (-v.y) * sn.x;
         o.y = v.y * cs.x + v.x * sn.x;
@@ -848,7 +893,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
         v = o;
       }
     } else if (EPI == EPI_RESIDUAL) {
-      v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+      v += res16[it];
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
