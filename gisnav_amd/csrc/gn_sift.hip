@@ -90,21 +90,21 @@ __global__ __launch_bounds__(256) void k_blur_col(const float* in, float* out, i
 // 4 (8) outputs instead of once per tap.  N (taps) is a template parameter: the pyramid only has 11/13/17/21/27.
 // The first level of an octave reads its input straight from level 3 of the octave above (in_step = 2), so the
 // half-size base image is never materialised.
-constexpr int kFtW = 64, kFtH = 32;
+constexpr int kFtW = 64, kFtH = 32;   // (64-row tiles -- 1.4x instead of 1.8x halo work in the row pass -- measured 10 % SLOWER on batches: half the blocks per CU)
 // BASE: `in` is the u8 camera image [h / 2][w / 2] (images stride_in BYTES apart) and the tile is sampled from its 2x bilinear
 // upsampling on the fly -- the initial blur of createInitialImage without ever storing the doubled image; `counters` are zeroed.
-template <int N, bool BASE = false>
+template <int N, bool BASE = false, int TH = kFtH>
 __global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out, int w, int h, const float* k, float* dog, int in_step, int in_w, long long stride_in, long long stride_out,
                                                     int* counters = nullptr) {
   const uint8_t* gray = reinterpret_cast<const uint8_t*>(in) + (long long)blockIdx.z * stride_in;
   if (BASE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[4 * blockIdx.z + threadIdx.x] = 0;   // candidate / raw / final counts of this image
   in += (long long)blockIdx.z * stride_in; out += (long long)blockIdx.z * stride_out;   // image blockIdx.z of the batch
   if (dog != nullptr) dog += (long long)blockIdx.z * stride_out;
-  constexpr int R = N / 2, ROWS = kFtH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
+  constexpr int R = N / 2, ROWS = TH + 2 * R, COLS = (kFtW + 2 * R + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float s_in[ROWS * COLS];
   __shared__ __attribute__((aligned(16))) float s_row[ROWS * kFtW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+  const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * TH;
   float kk[N];
 #pragma unroll
   for (int t = 0; t < N; ++t) kk[t] = k[t];
@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void k_blur_fused(const float* in, float* out,
     *reinterpret_cast<float4*>(s_row + ry * kFtW + 4 * xq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
   }
   __syncthreads();
-  {
-    const int x = x0 + lane, ly0 = wave * 8;             // 4 waves x 8 rows = the 32 rows of the tile
+#pragma unroll 1
+  for (int pass = 0; pass < TH / 32; ++pass) {
+    const int x = x0 + lane, ly0 = pass * 32 + wave * 8;  // 4 waves x 8 rows per pass of 32 rows
     float v[8 + 2 * R];
 #pragma unroll
     for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(ly0 + j) * kFtW + lane];
@@ -672,13 +673,14 @@ __global__ __launch_bounds__(64 * (kDescProducers + 1)) void k_sift_descriptor(S
 // such waves share a CU and their chains interleave, while the LDS float-atomic unit retires only ~1 lane per 3 clocks for
 // the whole CU -- so with thousands of keypoints in flight this is several times the throughput of the atomic committer,
 // and with one image the atomic version has the lower latency.  Same arithmetic, same order, same bits.
-__global__ __launch_bounds__(64) void k_sift_descriptor_tp(SiftPyramid py, const SiftKeypoint* kp, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sift_descriptor_tp(SiftPyramid py, const SiftKeypoint* kp, long long kp_stride, const int* counters, int max_n, float* desc, long long out_stride) {
   const int b = blockIdx.y;
   kp += (long long)b * kp_stride; desc += (long long)b * out_stride * 128;
   const int n = min(counters[4 * b + 2], max_n);
   constexpr int d = 4, nb = 8, HL = (d + 2) * (d + 2) * (nb + 2), NT = 64;
   __shared__ float hist[HL + 8];
-  __shared__ int2 s_pair1[64 * 8];                  // (bin, share bits), 8 per live position, raster order
+  __shared__ float s_val1[64 * 8];                  // shares, 8 per live position, raster order ...
+  __shared__ unsigned short s_bin1[64 * 8];         // ... and their bins (5 KB of LDS per keypoint in all: 32 waves fit a CU)
   __shared__ float s_dst[128];
   __shared__ float s_nrm;
   const int id = blockIdx.x, tid = threadIdx.x, lane = tid;
@@ -747,21 +749,22 @@ __global__ __launch_bounds__(64) void k_sift_descriptor_tp(SiftPyramid py, const
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
           const int boff = (l & 1) + ((l >> 1) & 1) * (nb + 2) + (l >> 2) * (d + 2) * (nb + 2);
-          s_pair1[rank * 8 + l] = make_int2(idx + boff, __float_as_int(v[l]));
+          s_val1[rank * 8 + l] = v[l]; s_bin1[rank * 8 + l] = (unsigned short)(idx + boff);
         }
       }
       asm volatile("" ::: "memory");                 // one wave: DS ops execute in issue order, a compiler fence is all it takes
       // commit in raster order; the eight shares of a position hit eight different bins
       if (lane < 8) {
         int s0 = 0;
-        for (; s0 + 4 <= n_live; s0 += 4) {          // pairs fetched four positions ahead of the dependent read-add-write chain
-          const int2 p0 = s_pair1[(s0 + 0) * 8 + lane], p1 = s_pair1[(s0 + 1) * 8 + lane], p2 = s_pair1[(s0 + 2) * 8 + lane], p3 = s_pair1[(s0 + 3) * 8 + lane];
-          hist[p0.x] = hist[p0.x] + __int_as_float(p0.y);
-          hist[p1.x] = hist[p1.x] + __int_as_float(p1.y);
-          hist[p2.x] = hist[p2.x] + __int_as_float(p2.y);
-          hist[p3.x] = hist[p3.x] + __int_as_float(p3.y);
+        for (; s0 + 4 <= n_live; s0 += 4) {          // shares fetched four positions ahead of the dependent read-add-write chain
+          const int b0 = s_bin1[(s0 + 0) * 8 + lane], b1 = s_bin1[(s0 + 1) * 8 + lane], b2 = s_bin1[(s0 + 2) * 8 + lane], b3 = s_bin1[(s0 + 3) * 8 + lane];
+          const float v0 = s_val1[(s0 + 0) * 8 + lane], v1 = s_val1[(s0 + 1) * 8 + lane], v2 = s_val1[(s0 + 2) * 8 + lane], v3 = s_val1[(s0 + 3) * 8 + lane];
+          hist[b0] = hist[b0] + v0;
+          hist[b1] = hist[b1] + v1;
+          hist[b2] = hist[b2] + v2;
+          hist[b3] = hist[b3] + v3;
         }
-        for (; s0 < n_live; ++s0) { const int2 p0 = s_pair1[s0 * 8 + lane]; hist[p0.x] = hist[p0.x] + __int_as_float(p0.y); }
+        for (; s0 < n_live; ++s0) { const int b0 = s_bin1[s0 * 8 + lane]; hist[b0] = hist[b0] + s_val1[s0 * 8 + lane]; }
       }
       asm volatile("" ::: "memory");
     }
@@ -921,14 +924,14 @@ static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4
 static inline bool sift_fused_taps(int n) { return n == 11 || n == 13 || n == 17 || n == 21 || n == 27; }
 void sift_blur(int B, long long stride_in, long long stride_out, const float* in, float* tmp, float* out, int w, int h, const float* dk, int n, hipStream_t s,
                float* dog, int in_step, int in_w, float* half_scratch) {
-  const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH, B);
   if (in_w <= 0) in_w = w;
+  const dim3 g((w + kFtW - 1) / kFtW, (h + kFtH - 1) / kFtH, B);
   switch (n) {
-    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
-    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
-    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
-    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
-    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out); return;
+    case 11: hipLaunchKernelGGL(k_blur_fused<11>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out, (int*)nullptr); return;
+    case 13: hipLaunchKernelGGL(k_blur_fused<13>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out, (int*)nullptr); return;
+    case 17: hipLaunchKernelGGL(k_blur_fused<17>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out, (int*)nullptr); return;
+    case 21: hipLaunchKernelGGL(k_blur_fused<21>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out, (int*)nullptr); return;
+    case 27: hipLaunchKernelGGL(k_blur_fused<27>, g, dim3(256), 0, s, in, out, w, h, dk, dog, in_step, in_w, stride_in, stride_out, (int*)nullptr); return;
     default: break;
   }
   // other sigma: image by image, materialise the half-size image if needed, then two plain passes
