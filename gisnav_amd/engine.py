@@ -236,6 +236,24 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_vo_estimate")
         return out
 
+    def vo_estimate_images(self, frames_q, frames_r, K: np.ndarray, sift=None, ratio: float = 0.7, min_matches: int = 30, out: Optional[dict] = None):
+        """TwistNode._pose from pixels for B frame pairs (twist_node.py:227-289), everything in HBM: one batched SIFT pass over
+        the B query frames and the B reference (previous) frames, then brute-force 2-NN + ratio test + planar PnP
+        (`gn_vo_estimate`).  Returns (outputs, n_keypoints [2B] int32 on the host: query frames first)."""
+        from .sift import SIFT
+        if sift is None:
+            if getattr(self, "_sift", None) is None:
+                self._sift = SIFT(engine=self, max_keypoints=self.kmax)
+            sift = self._sift
+        to_dev = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a, np.uint8), device=self.device)  # noqa: E731
+        q, r = to_dev(frames_q), to_dev(frames_r)
+        assert q.shape == r.shape and q.dim() == 3, "expected two (B, H, W) uint8 stacks of one size"
+        B = int(q.shape[0])
+        kpt, _, _, desc, n = sift.detect_and_compute_batch_device(torch.cat([q, r], 0))
+        nd = torch.as_tensor(n, device=self.device)
+        inputs = dict(desc_q=desc[:B], kpt_q=kpt[:B], n_q=nd[:B], desc_r=desc[B:], kpt_r=kpt[B:], n_r=nd[B:], kpt_format=_lib.GN_KPT_XYSA)
+        return self.vo_estimate(inputs, K, ratio, min_matches, out=out), n
+
     def alloc_outputs(self, B: int) -> dict:
         d = self.device
         return dict(R=torch.empty((B, 3, 3), dtype=torch.float64, device=d), t=torch.empty((B, 3, 1), dtype=torch.float64, device=d),

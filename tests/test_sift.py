@@ -202,3 +202,29 @@ def test_estimate_images_equals_the_manual_chain():
                             dem=torch.zeros((B, H, W), dtype=torch.uint8, device=eng.device), kpt_format=_lib.GN_KPT_XYSA), K_MATRIX)
     for k in got:
         assert np.array_equal(got[k], ref[k].cpu().numpy()), k
+
+
+@pytest.mark.gpu
+def test_vo_estimate_images_matches_the_oracle_chain():
+    """PoseEngine.vo_estimate_images (batched SIFT -> 2-NN + ratio test -> planar PnP, all in HBM) against the chain of
+    oracles pair by pair (twist_node.py:227-289)."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.synthetic import K_MATRIX
+    from oracle import bf_knn
+    B, H, W = 3, 240, 320
+    eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f32")
+    bigs = [blob_image(60 + b, H + 30, W + 30, n=260) for b in range(B)]
+    shifts = [(11, 8), (5, 14), (17, 3)]
+    ref = np.stack([g[10:H + 10, 10:W + 10] for g in bigs])
+    qry = np.stack([g[10 + dy:H + 10 + dy, 10 + dx:W + 10 + dx] for g, (dx, dy) in zip(bigs, shifts)])
+    out, n = eng.vo_estimate_images(qry, ref, K_MATRIX)
+    ok, R, t = out["ok"].cpu().numpy(), out["R"].cpu().numpy(), out["t"].cpu().numpy()
+    for b in range(B):
+        okq, _, _, _, _, odq = osift.detect_and_compute(qry[b])
+        okr, _, _, _, _, odr = osift.detect_and_compute(ref[b])
+        assert n[b] == len(okq) and n[B + b] == len(okr)
+        o = bf_knn.twist_pose(K_MATRIX, okq, odq, okr, odr)
+        assert (o is not None) == bool(ok[b])
+        if o is not None:
+            assert np.linalg.norm(R[b] - o[0]) < 1e-8 and np.linalg.norm(t[b] - o[1]) / np.linalg.norm(o[1]) < 1e-8
+    assert ok.sum() >= 2
