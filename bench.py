@@ -34,6 +34,7 @@ from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (the 2:1-sparsity figure is never used)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
 GEMM_LAUNCHES_PER_STEP = 1 + 9 * 8 + 2  # input_proj + 9 x (4 proj + 2 x 2 ffn) + final_proj + sim
 ATTN_LAUNCHES_PER_STEP = 9 * 2           # one self + one (two-sided) cross attention launch per layer
 
@@ -180,6 +181,24 @@ def main() -> None:
         mult = 6 if x3 else 3 if h2 else 1      # matrix-pipe flops issued per algorithmic flop
         peak = PEAK_BF16_MFMA_TFLOPS / mult if (x3 or h2) else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = measured_gemm_traffic(args.precision) if (args.batch == 32 and args.kpts == 1024) else (None, None)
+        # which roof binds these launches: arithmetic intensity (algorithmic flops per compulsory HBM byte) x 8 TB/s against the matrix pipe
+        alg_bytes = kstats["bytes"] / max(kstats["launches"], 1)
+        alg_flops = kstats["flops"] / max(kstats["launches"], 1)
+        intensity = alg_flops / max(alg_bytes, 1.0)
+        hbm_roof_tflops = intensity * PEAK_HBM_GBS * 1e9 / 1e12
+        gbs = kstats["bytes"] / (kstats["ms"] * 1e-3) / 1e9 if kstats["ms"] > 0 else 0.0
+        if hbm_roof_tflops < peak:
+            gemm_roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "note": (f"the GEMMs of this path are skinny (K, N in 256..768): {intensity:.0f} algorithmic flops per compulsory HBM byte puts their "
+                                  f"HBM roof at {hbm_roof_tflops:.0f} TFLOP/s, below the {peak:.0f} TFLOP/s matrix-pipe roof, so HBM is the binding roof; "
+                                  "achieved = algorithmic bytes (A, W, every output array, residual rows, rotary tables -- each once) / HIP-event time"),
+                         "algorithmic_mb_per_launch": round(alg_bytes / 1e6, 1), "flops_per_byte": round(intensity, 1),
+                         "hbm_roof_tflops": round(hbm_roof_tflops, 1)}
+        else:
+            gemm_roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "note": f"matrix-pipe roof {peak:.0f} TFLOP/s is below the HBM roof ({intensity:.0f} flops per byte x 8 TB/s = {hbm_roof_tflops:.0f} TFLOP/s)",
+                         "algorithmic_mb_per_launch": round(alg_bytes / 1e6, 1), "flops_per_byte": round(intensity, 1),
+                         "hbm_roof_tflops": round(hbm_roof_tflops, 1), "achieved_gbs": round(gbs, 1)}
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
             "value": round(pairs_per_s, 2),
@@ -219,14 +238,11 @@ def main() -> None:
                 "kernel": ("k_gemm_f32x3 (projection/FFN/similarity GEMM: 3 x bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)"
                            if x3 else "k_gemm_f16x2 (projection/FFN/similarity GEMM: 2 x fp16 split, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block)"
                            if h2 else "k_gemm_f32_v3 (projection/FFN/similarity GEMM on v_mfma_f32_32x32x2_f32)"),
-                "bound": "mfma",
-                "achieved": round(ach, 2),
-                "peak": round(peak, 1),
-                "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4),
-                "note": (f"achieved = algorithmic 2*M*N*K flops / HIP-event time; the kernel issues {mult} 16-bit MFMA flops per algorithmic "
-                         f"flop, so peak = 2500 TF dense / {mult} and frac is the fraction of the 16-bit matrix-pipe roofline actually used"
-                         if (x3 or h2) else "achieved = algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak"),
+                **gemm_roof,
+                "matrix_pipe": {"achieved_tflops": round(ach, 2), "peak_tflops": round(peak, 1), "frac": round(ach / peak, 4),
+                                "note": (f"algorithmic 2*M*N*K flops / HIP-event time; the kernel issues {mult} 16-bit MFMA flops per algorithmic "
+                                         f"flop, so the matrix-pipe ceiling is 2500 TF dense / {mult}"
+                                         if (x3 or h2) else "algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak")},
                 "executed_mfma_tflops": round(ach * mult, 1),
                 "traffic": traffic,
                 "traffic_source": traffic_src,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "gn_debug_lds_dma_probe": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
     "gn_set_kernel_timing": (C.c_int, [VP, C.c_int]),
     "gn_get_kernel_stats": (C.c_int, [VP, C.c_int, c_f64p]),
+    "gn_get_kernel_bytes": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double)]),
 }
 
 STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")

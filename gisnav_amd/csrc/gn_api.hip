@@ -93,6 +93,7 @@ struct gn_ctx {
   bool ktiming = false;
   std::vector<hipEvent_t> kev;      // pairs (start, stop)
   std::vector<double> kflops;       // algorithmic flops of each recorded launch
+  std::vector<double> kbytes;       // algorithmic HBM bytes of each recorded launch (operands in, results out, each once)
   std::vector<int> kclass;          // 0 = projection/FFN/similarity GEMM, 1 = attention
   size_t kused = 0;
 };
@@ -195,6 +196,16 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
   if (rec) {
     hipEventRecord(c->kev[2 * c->kused + 1], s);
     c->kflops[c->kused] = 2.0 * g.M * (double)g.N * g.K * batch;
+    {   // compulsory bytes: A and W once (4 B per element as f32 or as an hm16 pair), every output array once, residual rows and
+        // rotary tables once
+      const double mn = (double)g.M * g.N * batch;
+      double by = 4.0 * ((double)g.M * g.K * batch + (double)g.N * g.K * (g.strideW ? batch : 1));
+      if (epi == EPI_ROTARY_BF16 || epi == EPI_SCALE_BF16) by += 2.0 * mn;
+      else by += (g.Y ? 4.0 * mn : 0.0) + (g.Yp ? 4.0 * mn : 0.0);
+      if (epi == EPI_RESIDUAL) by += 4.0 * mn;
+      if (epi == EPI_ROTARY || epi == EPI_ROTARY_BF16) by += 2.0 * 4.0 * (double)g.M * kFreq;
+      c->kbytes[c->kused] = by;
+    }
     c->kclass[c->kused] = 0;
     ++c->kused;
   }
@@ -257,6 +268,7 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
   if (rec) {
     hipEventRecord(c->kev[2 * c->kused + 1], s);
     c->kflops[c->kused] = 4.0 * a.BS * kHeads * (double)a.npad * a.npad * kHeadDim;
+    c->kbytes[c->kused] = (double)a.BS * a.npad * kDim * (a.qb ? 2.0 + 2.0 + 2.0 : 12.0) + (double)a.BS * a.npad * kDim * 4.0;   // q, k, v in; context rows out
     c->kclass[c->kused] = 1;
     ++c->kused;
   }
@@ -1161,7 +1173,7 @@ int gn_set_kernel_timing(gn_ctx* ctx, int max_launches) {
   while ((int)ctx->kflops.size() < max_launches) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GN_ERR_HIP;
-    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0); ctx->kclass.push_back(0);
+    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0); ctx->kbytes.push_back(0.0); ctx->kclass.push_back(0);
   }
   ctx->ktiming = max_launches > 0;
   ctx->kused = 0;
@@ -1180,6 +1192,15 @@ int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3) {
     ms += t; fl += ctx->kflops[i]; n += 1.0;
   }
   out3[0] = n; out3[1] = ms; out3[2] = fl;
+  return GN_OK;
+}
+
+int gn_get_kernel_bytes(gn_ctx* ctx, int kernel_class, double* out1) {
+  if (!ctx || !out1 || kernel_class < 0 || kernel_class > 1) return GN_ERR_ARG;
+  double by = 0.0;
+  for (size_t i = 0; i < ctx->kused; ++i)
+    if (ctx->kclass[i] == kernel_class) by += ctx->kbytes[i];
+  *out1 = by;
   return GN_OK;
 }
 

@@ -283,7 +283,9 @@ class PoseEngine:
         """HIP-event totals of the recorded launches; kernel_class 0 = GEMMs, 1 = attention."""
         buf = (C.c_double * 3)()
         _lib.check(self.ctx, self.lib.gn_get_kernel_stats(self.ctx, kernel_class, buf), "gn_get_kernel_stats")
-        return {"launches": buf[0], "ms": buf[1], "flops": buf[2]}
+        by = C.c_double(0.0)
+        _lib.check(self.ctx, self.lib.gn_get_kernel_bytes(self.ctx, kernel_class, C.byref(by)), "gn_get_kernel_bytes")
+        return {"launches": buf[0], "ms": buf[1], "flops": buf[2], "bytes": by.value}
 
     def debug_gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         M, K = A.shape

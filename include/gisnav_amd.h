@@ -255,6 +255,8 @@ int gn_debug_epnp(gn_ctx* ctx, int n, const double* pws, const double* us, doubl
  * similarity GEMMs, 1 = attention; out3 = {launches, summed ms, summed algorithmic flops}. */
 int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
 int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3);
+/* summed ALGORITHMIC HBM bytes of the same launches (every operand / result array once: the compulsory traffic). */
+int gn_get_kernel_bytes(gn_ctx* ctx, int kernel_class, double* out1);
 
 #ifdef __cplusplus
 }
