@@ -675,8 +675,10 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   mv(c->h_p, 2 * T2 * 2 * kDim); mv(c->md_p, 2 * T2 * kDim);
   mv(c->qkb, T2 * 2 * kDim); mv(c->vtb, T2 * kDim);
   mv(c->rowmax, np); mv(c->rowlog, np); mv(c->colmax, np); mv(c->collog, np); mv(c->max0, np); mv(c->m0, np); mv(c->m1, np);
-  mv(c->e_idx, np * 2); mv(c->e_score, np); mv(c->e_mkp, np * 2); mv(c->e_obj, np * 3);
-  mv(c->mask_ws, np * 16); mv(c->hyp_ws, 16);
+  // match lists and the PnP masks are strided by the context's padded maximum (gn_kmax), whatever the active size
+  const long long km = c->npad;
+  mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
+  mv(c->mask_ws, km * 16); mv(c->hyp_ws, 16);
 }
 
 int estimate_impl(gn_ctx* ctx, int B, int kpt_format,

@@ -543,6 +543,15 @@ def test_active_kpts_padding_does_not_change_results(state_dict_np, dev, prec):
     torch.cuda.current_stream().synchronize()
     assert all(np.array_equal(ref[k], o2[k].cpu().numpy()) for k in ref)
     eng.set_substreams(1)
+    # keypoints beyond the active size are ignored: the same as handing in truncated lists
+    assert eng.set_active_kpts(128) == 128
+    cut = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    cut = [v.cpu().numpy().copy() for v in cut]
+    n128 = torch.full_like(inp["n_q"], 128)
+    tr = [v.cpu().numpy() for v in eng.match(inp["desc_q"], inp["kpt_q"], n128, inp["desc_r"], inp["kpt_r"], n128)]
+    assert np.array_equal(cut[2], tr[2]) and (cut[2] > 10).all()
+    for b in range(4):
+        assert np.array_equal(cut[0][b, : cut[2][b]], tr[0][b, : tr[2][b]]) and cut[0][b, : cut[2][b]].max() < 128
     assert eng.set_active_kpts(10_000) == 640                              # clamped to the context's padded maximum
     out = {k: v.cpu().numpy() for k, v in eng.estimate(inp, K_MATRIX).items()}
     assert all(np.array_equal(ref[k], out[k]) for k in ref)
