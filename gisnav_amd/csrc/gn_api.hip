@@ -30,6 +30,7 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
+  int ffn_fused = 1;       // f16x2 mode: ffn.0 + LayerNorm + GELU in one launch (k_gemm_p2ln); 0 = separate k_ln_gelu (developer knob 10)
   int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
   int n_layers = kMaxLayers;
   float threshold = 0.5f;
@@ -186,6 +187,7 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
       uint16_t* qy = nullptr;
       if (g.Y == c->x) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; }
       else if (g.Y == c->msg || g.Y == c->md) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; g.Y = nullptr; }
+      else if (epi == EPI_LN_GELU && g.Y == c->h) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; g.Y = nullptr; }
     }
   }
   ++c->launch_count;
@@ -201,7 +203,8 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
       const double mn = (double)g.M * g.N * batch;
       double by = 4.0 * ((double)g.M * g.K * batch + (double)g.N * g.K * (g.strideW ? batch : 1));
       if (epi == EPI_ROTARY_BF16 || epi == EPI_SCALE_BF16) by += 2.0 * mn;
-      else by += (g.Y ? 4.0 * mn : 0.0) + (g.Yp ? 4.0 * mn : 0.0);
+      else if (epi == EPI_LN_GELU) by += 4.0 * mn;
+      else if (epi != EPI_LN_GELU) by += (g.Y ? 4.0 * mn : 0.0) + (g.Yp ? 4.0 * mn : 0.0);
       if (epi == EPI_RESIDUAL) by += 4.0 * mn;
       if (epi == EPI_ROTARY || epi == EPI_ROTARY_BF16) by += 2.0 * 4.0 * (double)g.M * kFreq;
       c->kbytes[c->kused] = by;
@@ -278,8 +281,13 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
-  gemm(c, EPI_BIAS, g, s);
-  launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s, c->planes_mode ? c->h_p : nullptr);
+  if (c->planes_mode && c->ffn_fused && T % 128 == 0) {   // LayerNorm + GELU in the GEMM's epilogue: the hidden tensor leaves once, as hm16
+    g.ln_g = blk.ln_g; g.ln_b = blk.ln_b;
+    gemm(c, EPI_LN_GELU, g, s);
+  } else {
+    gemm(c, EPI_BIAS, g, s);
+    launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s, c->planes_mode ? c->h_p : nullptr);
+  }
   GemmArgs g3 = gemm_args(c->h, 2 * kDim, blk.ffn3, c->x, kDim, T);
   g3.resid = c->x; g3.ldr = kDim;
   gemm(c, EPI_RESIDUAL, g3, s);
@@ -1139,6 +1147,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 5) ctx->planes_mode = (value && ctx->x_p) ? 1 : 0;
   else if (which == 6) ctx->dbg_reuse = value;
   else if (which == 7) ctx->dbg_out = value;
+  else if (which == 10) ctx->ffn_fused = value;
   else if (which == 8) gn::g_p2_wide = value;
   else if (which == 9) ctx->dbg_vt_skip = value;
   else return GN_ERR_ARG;

@@ -21,6 +21,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
+// Exact (erf) GELU, 0.5 y (1 + erf(y / sqrt 2)), with erf(t) = 1 - 2^(-q(t)) for t = min(|y| / sqrt 2, 4): q is the
+// degree-8 weighted-minimax fit of -log2(erfc(t)) on [0, 4] (no constant term: erf(0) = 0 exactly).  In f32 the result is
+// within 1 ulp-of-the-output of the f64 value over [-8, 8] (max abs error 4.7e-7 at |y| = 4.4, the same as rounding
+// libm's erff), at half the instructions of ocml's two-branch erff -- k_ln_gelu is VALU-bound, not HBM-bound.
+__device__ __forceinline__ float gelu_erf(float y) {
+  const float t = fminf(fabsf(y) * 0.70710678118654752440f, 4.0f);
+  float q = 4.6081331674940884e-05f;
+  q = q * t + -0.00045161080197431147f;
+  q = q * t + 0.0015096671413630247f;
+  q = q * t + 0.0007409505778923631f;
+  q = q * t + -0.028223754838109016f;
+  q = q * t + 0.1484677642583847f;
+  q = q * t + 0.918419361114502f;
+  q = q * t + 1.6279083490371704f;
+  const float e = 1.0f - __builtin_amdgcn_exp2f(-(q * t));
+  return 0.5f * y * (1.0f + copysignf(e, y));
+}
+
 // hm16 row format of the f16x2 mode: a value x travels as two fp16 terms x = h + m.  A row of ld values is ld / 16
 // groups of 64 bytes: the 16 high terms of columns 16g .. 16g+15 followed by their 16 residual terms.  Offset (in
 // fp16 elements) of the HIGH term of (row, col); the residual term sits 16 elements further.
@@ -30,7 +48,8 @@ __host__ __device__ inline size_t hm16_off(size_t row, int ld, int col) {
 
 // ---- GEMM -----------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
-               EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6 };
+               EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6,
+               EPI_LN_GELU = 7 };   // bias -> LayerNorm over the N = 512 outputs of a row -> erf GELU -> hm16 (k_gemm_p2ln only)
 
 struct GemmArgs {
   const float* A;    int lda;      // A[M][K1] (k < K1)
@@ -48,6 +67,7 @@ struct GemmArgs {
   float scale; int scale_cols;     // EPI_SCALE_COLS: cols < scale_cols multiplied by scale (after bias)
   const float* cos_t; const float* sin_t; int rot_cols;  // EPI_ROTARY: [M][32] tables, cols < rot_cols rotated
   const float* resid; int ldr;     // EPI_RESIDUAL
+  const float* ln_g; const float* ln_b;   // EPI_LN_GELU: LayerNorm weight / bias over the N = 512 outputs (eps 1e-5)
   // EPI_*_BF16: columns < vt_start go to Yb (bf16 row-major, q columns < q_cols scaled by qscale),
   // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))
   uint16_t* Yb; int ldyb; uint16_t* Vt; int vt_start; int q_cols; float qscale; int npad;

@@ -448,11 +448,244 @@ __global__ __launch_bounds__(512) void k_gemm_p2w(GemmArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
+// ------------------------------------------------------------------------------------------------
+// FFN variant of the wide kernel: block tile 128 rows x 512 columns = ALL outputs of 128 tokens, so that LayerNorm(512) + GELU run
+// in the epilogue and the hidden tensor leaves the kernel once, as hm16 -- instead of f32 out, k_ln_gelu in, hm16 out (268 MB of
+// the 670 MB the two launches moved).  8 waves side by side (1 x 8) of 128 x 64, the k-loop of k_gemm_p2w unchanged; the two stages
+// (128 + 512 rows) x 128 B are exactly the CU's 160 KB of LDS.
+constexpr int LBM = 128, LBN = 512;
+constexpr int LA_H = LBM * 64;            // halves of the A tile (16 KB)
+constexpr int LSTAGE = (LBM + LBN) * 64;  // halves per stage (80 KB)
+
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void k_gemm_p2ln(GemmArgs a) {
+  constexpr int SLAB = 8 * 64 * ES;                                   // floats: eight per-wave epilogue slabs (136 KB)
+  constexpr int SMEM = 2 * LSTAGE / 2;                                // floats: the two stages = all 160 KB of the CU's LDS
+  static_assert(SLAB + 8 * LBM + 2 * LBM <= SMEM, "slabs + LayerNorm scratch must fit under the stages");
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM];
+  unsigned short* const ring = reinterpret_cast<unsigned short*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave;                                                // 1 x 8 waves: every wave owns all 128 rows x its 64 columns
+  const int hh = lane >> 5, ql = lane & 31;
+  int bx, by;
+  {  // XCD-aware bijective block order
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int L = blockIdx.y * gx + blockIdx.x;
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = v % gx; by = v / gx;
+  }
+  const int bm = by * LBM, bn = bx * LBN;
+  const int K = a.K, K1 = a.K1, nt = K / BK;
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // LDS-DMA: wave w moves rows [16w, 16w + 16) of the A tile (2 pieces of 8 rows) and rows [64w, 64w + 64) of the W tile (8 pieces)
+  unsigned int voff_a[2], voff_w[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row ^ (row >> 3)) & 7);
+    voff_a[j] = (unsigned int)(((size_t)(bm + row) * a.lda) * 4 + c * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 64 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row ^ (row >> 3)) & 7);
+    voff_w[j] = (unsigned int)(((size_t)(bn + row) * a.ldw) * 4 + c * 16);
+  }
+  const char* const abase = reinterpret_cast<const char*>(a.Ap) + (long long)blockIdx.z * a.strideA * 4;
+  const char* const a2base = a.A2p ? reinterpret_cast<const char*>(a.A2p) + (long long)blockIdx.z * a.strideA * 4 : nullptr;
+  const char* const wbase = reinterpret_cast<const char*>(a.Wp) + (long long)blockIdx.z * a.strideW * 4;
+  const long long a2delta = a2base ? (a2base - abase) - (long long)K1 * 4 : 0;
+  // piece q (0..9) of k-tile t: q < 2: A rows 8q.., q >= 2: W rows 8(q-2)..
+  auto dma_piece = [&](int q, int stage, int t) __attribute__((always_inline)) {
+    const int k0 = t * BK;
+    const long long sel = (a2base != nullptr && k0 >= K1) ? a2delta : 0;
+    const char* src = q < 2 ? abase + sel + (size_t)k0 * 4 : wbase + (size_t)k0 * 4;
+    unsigned short* ld = ring + stage * LSTAGE + (q < 2 ? (wave_u * 16 + 8 * q) * 64 : LA_H + (wave_u * 64 + 8 * (q - 2)) * 64);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + (q < 2 ? voff_a[q] : voff_w[q - 2])), (lptr_t)ld, 16, 0, 0);
+  };
+
+  int arow[4], fa_[4], brow[2], fb_[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = 32 * i + ql;
+    arow[i] = ra * 64; fa_[i] = hh ^ ((ra ^ (ra >> 3)) & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wc * 64 + 32 * j + ql;
+    brow[j] = LA_H + rb * 64; fb_[j] = hh ^ ((rb ^ (rb >> 3)) & 7);
+  }
+  // A fragments live in ONE register set that is refreshed in place: the MFMAs of a k-step run row-tile by row-tile
+  // (6 per A tile, alternating between its two accumulators), and as soon as a tile's last MFMA is issued its two
+  // registers' worth of fragments for the NEXT k-step are fetched.  Only the B fragments are double-buffered.
+  f16x8 fa[4][2], fb[2][2][2];   // fa[row tile][term], fb[buffer][col tile][term]
+  auto read_a = [&](int stage, int ks, int i) __attribute__((always_inline)) {
+    const unsigned short* s_ = ring + stage * LSTAGE;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      fa[i][pl] = *reinterpret_cast<const f16x8*>(s_ + arow[i] + 8 * ((4 * ks + 2 * pl) ^ fa_[i]));
+  };
+  auto read_b = [&](int buf, int stage, int ks, int j) __attribute__((always_inline)) {
+    const unsigned short* s_ = ring + stage * LSTAGE;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      fb[buf][j][pl] = *reinterpret_cast<const f16x8*>(s_ + brow[j] + 8 * ((4 * ks + 2 * pl) ^ fb_[j]));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // MFMA m (0..5) of row tile i: product m / 2 (0: xm yh, 1: xh ym, 2: xh yh -- small terms first), column tile m % 2
+  auto mfma_im = [&](int buf, int i, int m) __attribute__((always_inline)) {
+    const int p = m >> 1, j = m & 1;
+    const int pa = p == 0 ? 1 : 0, pb = p == 1 ? 1 : 0;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][pa], fb[buf][j][pb], acc[i][j], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int q = 0; q < 10; ++q) dma_piece(q, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) dma_piece(q, 1, 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_a(0, 0, i);
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) read_b(0, 0, 0, jj);
+
+  // k-step `ks` of tile t (B buffer ks); `nstage`, `nks` = where the following k-step's fragments come from;
+  // `dma`: also issue the 8 DMA pieces of tile t+2 into stage t & 1 (second k-step only).
+  auto kstep = [&](int ks, int nstage, int nks, bool fetch_next, bool dma, int t, bool pin) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        mfma_im(ks, i, m);
+        if (!(ABL & 1) && dma && (m & 1) == 0 && 3 * i + (m >> 1) < 10) dma_piece(3 * i + (m >> 1), t & 1, t + 2);   // pieces 0..9 behind the first 10 even MFMAs
+        if (!(ABL & 2) && fetch_next && i == 0 && (m == 1 || m == 3)) read_b(ks ^ 1, nstage, nks, m >> 1);           // next B fragments early
+        if (pin) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(ABL & 2) && fetch_next) read_a(nstage, nks, i);        // this row tile's A fragments are free now
+      if (pin) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto ktile = [&](int t, bool steady) __attribute__((always_inline)) {
+    const int cur = t & 1;
+    kstep(0, cur, 1, true, false, t, steady);
+    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kstep(1, cur ^ 1, 0, steady || t + 1 < nt, steady || t + 2 < nt, t, steady);
+  };
+  int t = 0;
+  for (; t + 2 < nt; ++t) ktile(t, true);
+  for (; t < nt; ++t) ktile(t, false);
+
+  // ---- epilogue: bias -> LayerNorm over the 512 outputs of a row (two-pass: mean, then centred squares, as k_ln_gelu) ->
+  // erf GELU -> hm16 rows.  A row's 512 values sit in the eight waves' slabs, 64 each; the row statistics go through a
+  // small LDS scratch behind the slabs.  Each pass stages the accumulators through the wave's slab again (two 64-row halves).
+  __syncthreads();
+  float* slab = smem + wave * 64 * ES;
+  float* stat = smem + SLAB;                  // [8 waves][128 rows] partial sums
+  float* mr = stat + 8 * LBM;                 // [128 rows][2]: mean, 1 / sqrt(var + eps)
+  const float ascale = a.acc_scale;
+  const int colbase = bn + wc * 64;
+  auto stage_half = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          slab[row * ES + j * 32 + ql] = acc[2 * half + i][j][r];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto wave_sync = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // lane = row of the half: this wave's 64 columns of that row, bias added
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      stage_half(half);
+      const float m = pass ? mr[(half * 64 + lane) * 2] : 0.f;
+      float s_ = 0.f;
+#pragma unroll
+      for (int c = 0; c < 64; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[lane * ES + c]) * ascale + *reinterpret_cast<const f32x4*>(a.bias + colbase + c);
+        if (pass == 0) s_ += (v.x + v.y) + (v.z + v.w);
+        else { const f32x4 d = v - m; s_ += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+      }
+      stat[wave * LBM + half * 64 + lane] = s_;
+      wave_sync();
+    }
+    __syncthreads();
+    if (tid < LBM) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) t_ += stat[w8 * LBM + tid];
+      if (pass == 0) mr[tid * 2] = t_ * (1.0f / 512.0f);
+      else mr[tid * 2 + 1] = 1.0f / sqrtf(t_ * (1.0f / 512.0f) + 1e-5f);
+    }
+    __syncthreads();
+  }
+  const int c4 = (lane & 15) * 4, col = colbase + c4;
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.ln_g + col), b4 = *reinterpret_cast<const f32x4*>(a.ln_b + col);
+  float* const Y = a.Y ? a.Y + (long long)blockIdx.z * a.strideY : nullptr;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    stage_half(half);
+    f32x4 vals[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+    uint2 hpl[16], mpl[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int lr = half * 64 + it * 4 + (lane >> 4);
+      const float mean = mr[lr * 2], rstd = mr[lr * 2 + 1];
+      f32x4 v = vals[it] * ascale + bias4;
+      v = (v - mean) * rstd * g4 + b4;
+      v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      vals[it] = v;
+      split_pair(v.x, v.y, hpl[it].x, mpl[it].x);
+      split_pair(v.z, v.w, hpl[it].y, mpl[it].y);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = bm + half * 64 + it * 4 + (lane >> 4);
+      if (Y != nullptr) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = vals[it];
+      uint16_t* yp = a.Yp + hm16_off(row, a.ldyp, col);
+      *reinterpret_cast<uint2*>(yp) = hpl[it];
+      *reinterpret_cast<uint2*>(yp + 16) = mpl[it];
+    }
+    wave_sync();
+  }
+}
 }  // namespace
 
 int g_p2_wide = 1;   // developer knob: 0 = always the 128x128 kernel
 
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
+  if (epi == EPI_LN_GELU) {   // ffn.0 + LayerNorm + GELU (caller guarantees N == 512, M % 128 == 0, hm16 output)
+    dim3 grid(1, a.M / LBM, batch), block(512);
+    hipLaunchKernelGGL((k_gemm_p2ln<0>), grid, block, 0, s, a);
+    return;
+  }
   if (g_p2_wide >= 2 && epi == EPI_BIAS && a.M % WBM == 0 && a.N % WBN == 0) {   // timing-only ablations of the wide kernel
     dim3 grid(a.N / WBN, a.M / WBM, batch), block(512);
     switch (g_p2_wide) {

@@ -108,24 +108,6 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
 }
 
 // one wave per 512-wide row, in place
-// Exact (erf) GELU, 0.5 y (1 + erf(y / sqrt 2)), with erf(t) = 1 - 2^(-q(t)) for t = min(|y| / sqrt 2, 4): q is the
-// degree-8 weighted-minimax fit of -log2(erfc(t)) on [0, 4] (no constant term: erf(0) = 0 exactly).  In f32 the result is
-// within 1 ulp-of-the-output of the f64 value over [-8, 8] (max abs error 4.7e-7 at |y| = 4.4, the same as rounding
-// libm's erff), at half the instructions of ocml's two-branch erff -- k_ln_gelu is VALU-bound, not HBM-bound.
-__device__ __forceinline__ float gelu_erf(float y) {
-  const float t = fminf(fabsf(y) * 0.70710678118654752440f, 4.0f);
-  float q = 4.6081331674940884e-05f;
-  q = q * t + -0.00045161080197431147f;
-  q = q * t + 0.0015096671413630247f;
-  q = q * t + 0.0007409505778923631f;
-  q = q * t + -0.028223754838109016f;
-  q = q * t + 0.1484677642583847f;
-  q = q * t + 0.918419361114502f;
-  q = q * t + 1.6279083490371704f;
-  const float e = 1.0f - __builtin_amdgcn_exp2f(-(q * t));
-  return 0.5f * y * (1.0f + copysignf(e, y));
-}
-
 __global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows, uint16_t* hp) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
