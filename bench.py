@@ -191,7 +191,8 @@ def main() -> None:
             gemm_roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "note": (f"the GEMMs of this path are skinny (K, N in 256..768): {intensity:.0f} algorithmic flops per compulsory HBM byte puts their "
                                   f"HBM roof at {hbm_roof_tflops:.0f} TFLOP/s, below the {peak:.0f} TFLOP/s matrix-pipe roof, so HBM is the binding roof; "
-                                  "achieved = algorithmic bytes (A, W, every output array, residual rows, rotary tables -- each once) / HIP-event time"),
+                                  "achieved = algorithmic bytes (A, W, every output array, residual rows, rotary tables -- each once) / HIP-event time; the 18 ffn.0 launches "
+                                  "of a step also carry LayerNorm + GELU in their epilogue (k_gemm_p2ln), work that is not counted as bytes or flops"),
                          "algorithmic_mb_per_launch": round(alg_bytes / 1e6, 1), "flops_per_byte": round(intensity, 1),
                          "hbm_roof_tflops": round(hbm_roof_tflops, 1)}
         else:
