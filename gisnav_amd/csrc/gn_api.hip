@@ -281,7 +281,9 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
-  if (c->planes_mode && c->ffn_fused && T % 128 == 0) {   // LayerNorm + GELU in the GEMM's epilogue: the hidden tensor leaves once, as hm16
+  // LayerNorm + GELU in the GEMM's epilogue (the hidden tensor leaves once, as hm16) when there are enough 128-row tiles to fill the chip:
+  // measured 9.64 vs 9.86 ms at 512 tiles (32 pairs), 5.68 vs 5.90 at 256, but 3.95 vs 3.73 ms at 128 tiles and 3.00 vs 2.40 ms at 16 (knob 10: 2 = always)
+  if (c->planes_mode && T % 128 == 0 && (c->ffn_fused == 2 || (c->ffn_fused == 1 && T / 128 >= 256))) {
     g.ln_g = blk.ln_g; g.ln_b = blk.ln_b;
     gemm(c, EPI_LN_GELU, g, s);
   } else {
