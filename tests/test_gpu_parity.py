@@ -555,3 +555,37 @@ def test_active_kpts_padding_does_not_change_results(state_dict_np, dev, prec):
     assert eng.set_active_kpts(10_000) == 640                              # clamped to the context's padded maximum
     out = {k: v.cpu().numpy() for k, v in eng.estimate(inp, K_MATRIX).items()}
     assert all(np.array_equal(ref[k], out[k]) for k in ref)
+
+
+@pytest.mark.gpu
+def test_fused_ffn_launch_matches_the_two_launch_form(state_dict_np, state_dict_t, dev):
+    """k_gemm_p2ln (ffn.0 + LayerNorm + GELU in one launch, picked for >= 256 row tiles) against ffn.0 followed by k_ln_gelu:
+    same correspondences and scores, and the final features of the fused form as close to the oracle as those of the two-launch
+    form (the two differ from each other by LayerNorm-statistics rounding amplified through nine layers)."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=512, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    pairs = [make_pair(120 + i, n_q=512 - 11 * i, n_r=500 - 7 * i) for i in range(4)]
+    inp = eng.stage_inputs(pairs)
+    args = (inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    T = 4 * 2 * 512
+    res = {}
+    for mode in (0, 2):                                   # developer knob 10: 0 = two launches, 2 = fused whatever the size
+        eng.lib.gn_debug_set_variant(eng.ctx, 10, mode)
+        idx, score, n = (v.cpu().numpy().copy() for v in eng.match(*args))
+        res[mode] = (idx, score, n, eng.debug_read("x", T * 256).copy())
+    eng.lib.gn_debug_set_variant(eng.ctx, 10, 1)
+    (i0, s0, n0, x0), (i2, s2, n2, x2) = res[0], res[2]
+    assert np.array_equal(n0, n2) and (n0 > 100).all()
+    for b in range(4):
+        assert np.array_equal(i0[b, : n0[b]], i2[b, : n2[b]])
+        assert np.abs(s0[b, : n0[b]] - s2[b, : n0[b]]).max() < 1e-5
+    assert _rel(x2, x0) < 3e-5
+    taps = {}
+    oracle_match(state_dict_t, pairs[0], taps=taps)
+    nq, nr = len(pairs[0].kp_q), len(pairs[0].kp_r)
+    err = []
+    for x in (x0, x2):
+        xb = x.reshape(4, 2, 512, 256)
+        err.append(max(_rel(xb[0, 0, :nq], taps["layer8_0"][0].numpy()), _rel(xb[0, 1, :nr], taps["layer8_1"][0].numpy())))
+    # bf16 attention puts this precision mode ~4e-5 from the f32 oracle after nine layers; the fused form must not be further away
+    assert err[0] < 1e-4 and err[1] < 1.25 * err[0] + 5e-6, err
