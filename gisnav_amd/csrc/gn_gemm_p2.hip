@@ -20,6 +20,9 @@
 // The instruction order of the steady-state loop is pinned with sched_barrier: one LDS-DMA or fragment read in
 // the shadow of each MFMA, accumulators visited round-robin (left alone, the machine scheduler clumps the DMAs
 // and issues dependent MFMAs back to back).
+// Three kernels share this scheme: k_gemm_p2 (128x128 tiles, 2 blocks per CU: short-K and small launches), k_gemm_p2w
+// (256x256 tiles, one block per CU: the bulk of the matcher) and k_gemm_p2ln (128x512 tiles = whole rows of the FFN hidden
+// layer, LayerNorm + GELU in the epilogue).
 #include "gn_common.h"
 
 namespace gn {
