@@ -104,6 +104,13 @@ def test_sift_batch_equals_image_by_image(sift_gpu):
             assert np.array_equal(resp[b, : n[b]].cpu().numpy().view(np.int32), sr.cpu().numpy().view(np.int32))
             assert np.array_equal(octv[b, : n[b]].cpu().numpy(), so.cpu().numpy())
             assert np.array_equal(desc[b, : n[b]].cpu().numpy(), sd.cpu().numpy())
+    odd = np.stack([blob_image(30 + b, 97, 131, n=60) for b in range(3)])             # odd width / height: unaligned rows, partial tiles
+    ko, _, _, do, no = sift_gpu.detect_and_compute_batch_device(odd)
+    for b in range(3):
+        sk, _, _, sd = sift_gpu.detect_and_compute_device(odd[b])
+        okp_b, _, _, _, _, odesc_b = osift.detect_and_compute(odd[b])
+        assert no[b] == len(sk) == len(okp_b) > 5
+        assert np.array_equal(ko[b, : no[b], :2].cpu().numpy(), okp_b) and np.array_equal(do[b, : no[b]].cpu().numpy(), odesc_b)
     okp, _, _, _, _, odesc = osift.detect_and_compute(imgs[3])
     kpt, _, _, desc, n = sift_gpu.detect_and_compute_batch_device(imgs)
     assert np.array_equal(kpt[3, : n[3], :2].cpu().numpy(), okp) and np.array_equal(desc[3, : n[3]].cpu().numpy(), odesc)
