@@ -30,6 +30,7 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
+  int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
   int ffn_fused = 1;       // f16x2 mode: ffn.0 + LayerNorm + GELU in one launch (k_gemm_p2ln); 0 = separate k_ln_gelu (developer knob 10)
   int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
   int n_layers = kMaxLayers;
@@ -185,7 +186,7 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
     }
     if (p2) {   // outputs that feed later GEMMs leave in hm16; f32 is kept only where something reads it
       uint16_t* qy = nullptr;
-      if (g.Y == c->x) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; }
+      if (g.Y == c->x) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; if (g.drop_f32) g.Y = nullptr; }
       else if (g.Y == c->msg || g.Y == c->md) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; g.Y = nullptr; }
       else if (epi == EPI_LN_GELU && g.Y == c->h) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; g.Y = nullptr; }
     }
@@ -278,7 +279,7 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
 }
 
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
-void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
+void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
   // LayerNorm + GELU in the GEMM's epilogue (the hidden tensor leaves once, as hm16) when there are enough 128-row tiles to fill the chip:
@@ -292,6 +293,10 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s) {
   }
   GemmArgs g3 = gemm_args(c->h, 2 * kDim, blk.ffn3, c->x, kDim, T);
   g3.resid = c->x; g3.ldr = kDim;
+  if (c->planes_mode && c->x_planes_only) {   // the residual stream between layers lives in hm16 only (f32 x is written by the last block, for the head)
+    uint16_t* xp = nullptr;
+    if (planes_of(c, c->x, &xp)) { g3.residp = xp; g3.ldrp = kDim; g3.resid = nullptr; g3.drop_f32 = keep_f32 ? 0 : 1; }
+  }
   gemm(c, EPI_RESIDUAL, g3, s);
 }
 
@@ -315,6 +320,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     launch_prep(p, s);
     if (c->planes_mode) launch_split_hm16(c->desc, c->desc_p, T, kInDim, 1.0f, s);
     GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
+    g.drop_f32 = (c->planes_mode && c->x_planes_only && c->n_layers > 0) ? 1 : 0;
     gemm(c, EPI_BIAS, g, s);
   }
   for (int i = 0; i < c->n_layers; ++i) {
@@ -346,7 +352,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
       }
-      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s); }
+      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s, false); }
     }
     {  // CrossBlock
       const Block& blk = c->cross_blk[i];
@@ -377,7 +383,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
       }
-      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s); }
+      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s, i == c->n_layers - 1); }   // the last block leaves f32 x for the match head
     }
   }
   {
@@ -1150,6 +1156,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 6) ctx->dbg_reuse = value;
   else if (which == 7) ctx->dbg_out = value;
   else if (which == 10) ctx->ffn_fused = value;
+  else if (which == 11) ctx->x_planes_only = value;
   else if (which == 8) gn::g_p2_wide = value;
   else if (which == 9) ctx->dbg_vt_skip = value;
   else return GN_ERR_ARG;

@@ -67,6 +67,8 @@ struct GemmArgs {
   float scale; int scale_cols;     // EPI_SCALE_COLS: cols < scale_cols multiplied by scale (after bias)
   const float* cos_t; const float* sin_t; int rot_cols;  // EPI_ROTARY: [M][32] tables, cols < rot_cols rotated
   const float* resid; int ldr;     // EPI_RESIDUAL
+  const uint16_t* residp; int ldrp;        // EPI_RESIDUAL, k_gemm_p2*: the residual rows as hm16 pairs (h + m) instead of f32 (resid may then be nullptr)
+  int drop_f32;                            // k_gemm_p2*: when the output also leaves as hm16 (Yp), do not write the f32 copy
   const float* ln_g; const float* ln_b;   // EPI_LN_GELU: LayerNorm weight / bias over the N = 512 outputs (eps 1e-5)
   // EPI_*_BF16: columns < vt_start go to Yb (bf16 row-major, q columns < q_cols scaled by qscale),
   // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))

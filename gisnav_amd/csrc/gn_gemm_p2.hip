@@ -108,8 +108,21 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
   // likewise the residual rows: requested before the slab is read back, consumed after the scaling
   f32x4 res16[16];
   if (EPI == EPI_RESIDUAL) {
+    if (a.residp != nullptr) {   // the residual stream travels as hm16 only: x = h + m (22 significant bits, like every GEMM operand of this mode)
+      typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+      f16x4r rh[16], rm[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) res16[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(rbase + it * 4 + (lane >> 4)) * a.ldr + col);
+      for (int it = 0; it < 16; ++it) {
+        const uint16_t* rp = a.residp + hm16_off((size_t)(rbase + it * 4 + (lane >> 4)), a.ldrp, col);
+        rh[it] = *reinterpret_cast<const f16x4r*>(rp);
+        rm[it] = *reinterpret_cast<const f16x4r*>(rp + 16);
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) res16[it] = __builtin_convertvector(rh[it], f32x4) + __builtin_convertvector(rm[it], f32x4);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) res16[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(rbase + it * 4 + (lane >> 4)) * a.ldr + col);
+    }
   }
   // every row fragment is pulled into its own registers before the first store is issued (see gn_gemm.hip)
   f32x4 vals[16];
