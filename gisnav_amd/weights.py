@@ -46,12 +46,17 @@ def _ffn(rng, sd, p, d, ffn_out_std):
 
 def synthetic_state_dict(seed: int = 0, n_layers: int = N_LAYERS, qk_gain: float = 30.0,
                          ffn_out_std: float = 2.4e-4, final_scale: float = 28.0,
-                         identity_blocks: bool = False) -> Dict[str, np.ndarray]:
+                         identity_blocks: bool = False, matchability_bias: float = 10.0,
+                         matchability_std: float = 0.01) -> Dict[str, np.ndarray]:
     """Seeded weights, kornia key layout (``transformers.{i}.self_attn.*`` ...).
 
     ``identity_blocks=True`` zeroes every ``ffn.3`` so each block is the identity on the
     residual stream: the matcher then reduces to mutual-NN of RootSIFT descriptors
     (SURVEY.md 8(c) KAT 2).
+
+    The defaults build a wide decision margin (the match is dominated by the projected descriptor).  A LOW-MARGIN set --
+    e.g. ``ffn_out_std=4.8e-3`` (each block perturbs the stream ~100 %), ``final_scale=4``, ``matchability_bias=0``,
+    ``matchability_std=0.05`` -- makes near-ties common, which is what the precision-mode mismatch tests need.
     """
     rng = np.random.default_rng(seed)
     d = DESC_DIM
@@ -85,8 +90,8 @@ def synthetic_state_dict(seed: int = 0, n_layers: int = N_LAYERS, qk_gain: float
         p = f"log_assignment.{i}"
         sd[p + ".final_proj.weight"] = (final_scale * _orthogonal(rng, d)).astype(np.float32)
         sd[p + ".final_proj.bias"] = (0.01 * rng.normal(size=d)).astype(np.float32)
-        sd[p + ".matchability.weight"] = (0.01 * rng.normal(size=(1, d))).astype(np.float32)
-        sd[p + ".matchability.bias"] = np.array([10.0], np.float32)
+        sd[p + ".matchability.weight"] = (matchability_std * rng.normal(size=(1, d))).astype(np.float32)
+        sd[p + ".matchability.bias"] = np.array([matchability_bias], np.float32)
     for i in range(n_layers - 1):
         p = f"token_confidence.{i}.token.0"  # unused when depth/width_confidence = -1
         sd[p + ".weight"] = _uniform(rng, (1, d), b)
