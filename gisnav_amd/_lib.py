@@ -39,6 +39,9 @@ SIGNATURES = {
     "gn_flush": (C.c_int, [VP, VP]),
     "gn_set_substreams": (C.c_int, [VP, C.c_int]),
     "gn_set_active_kpts": (C.c_int, [VP, C.c_int]),
+    "gn_set_deferred_join": (C.c_int, [VP, C.c_int]),
+    "gn_set_guard": (C.c_int, [VP, C.c_int]),
+    "gn_get_guard_status": (C.c_int, [VP, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "gn_vo_match": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP, VP, VP, VP, VP]),
     "gn_vo_estimate": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, c_f64p, C.c_double, C.c_int,
                                  VP, VP, VP, VP, VP, VP]),
@@ -49,6 +52,7 @@ SIGNATURES = {
     "gn_pose_to_earth": (C.c_int, [c_f64p, c_f64p, c_f64p, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p]),
     "gn_sift_detect_and_compute": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, C.POINTER(C.c_int32), VP]),
     "gn_sift_detect_and_compute_batch": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, C.POINTER(C.c_int32), VP]),
+    "gn_sift_last_totals": (C.c_int, [VP, C.c_int, C.POINTER(C.c_int32)]),
     "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
     "gn_debug_gemm": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "gn_debug_attention": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, VP, C.c_int,

@@ -32,6 +32,10 @@ struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
   int ffn_fused = 1;       // f16x2 mode: ffn.0 + LayerNorm + GELU in one launch (k_gemm_p2ln); 0 = separate k_ln_gelu (developer knob 10)
+  // f16x2 domain guard (gn_set_guard): device word raised by any hm16 writer whose value does not fit fp16
+  unsigned int* ovf = nullptr; unsigned int* ovf_host = nullptr;   // device word, pinned host mirror
+  int guard = 1;           // 0 off, 1 flag (a tripped call reports zero matches), 2 flag + synchronous re-run in the f32x3 mode
+  long long guard_trips = 0;   // calls that tripped (counted when observed: guard 2, or gn_get_guard_status)
   int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
   int n_layers = kMaxLayers;
   float threshold = 0.5f;
@@ -71,6 +75,7 @@ struct gn_ctx {
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
   // sub-batch streams (gn_set_substreams): the pairs of one call are split into groups that run the whole path on
   // internal streams, out of phase with each other (fork / join events around them on the caller's stream)
+  int defer_join = 0, sub_last_B = 0, sub_last_np = 0;   // gn_set_deferred_join; shape of the last unjoined sub-stream call
   int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
   int overlap = 0; unsigned long long calls = 0;
@@ -81,6 +86,7 @@ struct gn_ctx {
   float* sift_dk = nullptr; std::vector<std::vector<float>> sift_kernels; std::vector<int> sift_koff;   // [0] = initial blur, [1..5] = layer blurs
   int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr;
   int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0, sift_batch = 0; long long sift_kp_stride = 0;
+  std::vector<int32_t> sift_totals;   // distinct keypoints found per image by the last call (before the max_kpts cap)
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -184,6 +190,7 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
       p2 = planes_of(c, g.W, &qw);
       g.Wp = qw; g.acc_scale = 1.f;
     }
+    if (p2) g.ovf = c->guard ? c->ovf : nullptr;
     if (p2) {   // outputs that feed later GEMMs leave in hm16; f32 is kept only where something reads it
       uint16_t* qy = nullptr;
       if (g.Y == c->x) { planes_of(c, g.Y, &qy); g.Yp = qy; g.ldyp = g.ldy; if (g.drop_f32) g.Y = nullptr; }
@@ -289,7 +296,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     gemm(c, EPI_LN_GELU, g, s);
   } else {
     gemm(c, EPI_BIAS, g, s);
-    launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s, c->planes_mode ? c->h_p : nullptr);
+    launch_ln_gelu(c->h, blk.ln_g, blk.ln_b, T, s, c->planes_mode ? c->h_p : nullptr, c->planes_mode && c->guard ? c->ovf : nullptr);
   }
   GemmArgs g3 = gemm_args(c->h, 2 * kDim, blk.ffn3, c->x, kDim, T);
   g3.resid = c->x; g3.ldr = kDim;
@@ -310,6 +317,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int vt_perm = (bf16v2 ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v5 reads V^T with keys permuted inside 16-groups   // k_attn_bf16_v4 reads permuted V^T
   const bool attn_planes = c->planes_mode && bf16v2;   // k_attn_bf16_v5 writes the hm16 rows itself
   c->launch_count = 0;
+  if (c->planes_mode && c->guard) hipMemsetAsync(c->ovf, 0, sizeof(unsigned int), s);
   {
     StageTimer tm(c, s, ST_PREP);
     PrepArgs p;
@@ -339,10 +347,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
       }
       {
         StageTimer tm(c, s, ST_ATTN);
-        AttnArgs a;
+        AttnArgs a; a.ovf = nullptr;
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
-        a.outp = attn_planes ? c->ctx_p : nullptr;
+        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
         a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -370,10 +378,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
       }
       {
         StageTimer tm(c, s, ST_ATTN);
-        AttnArgs a;
+        AttnArgs a; a.ovf = nullptr;
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
-        a.outp = attn_planes ? c->ctx_p : nullptr;
+        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
         a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -403,6 +411,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     hd.sim = c->sim; hd.ls = c->ls; hd.nvalid = c->nvalid; hd.B = B; hd.npad = np; hd.threshold = c->threshold;
     hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
     hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
+    hd.ovf = (c->planes_mode && c->guard) ? c->ovf : nullptr;
     hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = c->npad;   // output stride: gn_kmax(), whatever the active size
     launch_match_head(hd, s);
   }
@@ -463,7 +472,10 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
   GN_ALLOC(mask_ws, B * np * 16);
   GN_ALLOC(hyp_ws, B * 16);
+  GN_ALLOC(ovf, 4);
 #undef GN_ALLOC
+  if (hipHostMalloc((void**)&ctx->ovf_host, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  *ctx->ovf_host = 0u;
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
   // required tensor names
@@ -485,6 +497,7 @@ void gn_destroy(gn_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (void* p : ctx->allocs) hipFree(p);
+  if (ctx->ovf_host) hipHostFree(ctx->ovf_host);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
@@ -639,7 +652,41 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
   rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
                    (hipStream_t)stream);
   if (rc != GN_OK) return rc;
+  if (ctx->planes_mode && ctx->guard == 2) {
+    // guarded mode: observe the domain word of THIS call (one stream synchronisation -- the reference's call site synchronises
+    // right after the matcher anyway, pose_node.py:296-297) and, if an activation left the fp16 range, run the call again with
+    // every operand split exactly into three bf16 terms (the f32x3 mode: f32 range, f32 accuracy), on the f32 workspaces
+    GN_HIP(hipMemcpyAsync(ctx->ovf_host, ctx->ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (*ctx->ovf_host != 0u) {
+      ++ctx->guard_trips;
+      const int pm = ctx->planes_mode, gv = ctx->gemm_variant, npl = ctx->no_planes;
+      ctx->planes_mode = 0; ctx->gemm_variant = 5; ctx->no_planes = 1;   // weights stay as hm16 planes: f32x3 splits the f32 weights on the fly
+      rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
+                       (hipStream_t)stream);
+      ctx->planes_mode = pm; ctx->gemm_variant = gv; ctx->no_planes = npl;
+      if (rc != GN_OK) return rc;
+    }
+  }
   GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_set_guard(gn_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return GN_ERR_ARG;
+  ctx->guard = mode;
+  return GN_OK;
+}
+
+int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, int64_t* trips_total) {
+  if (!ctx) return GN_ERR_ARG;
+  GN_HIP(hipSetDevice(ctx->device));
+  GN_HIP(hipMemcpyAsync(ctx->ovf_host, ctx->ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  const int tripped = (ctx->planes_mode && ctx->guard && *ctx->ovf_host != 0u) ? 1 : 0;
+  if (tripped && ctx->guard == 1) ++ctx->guard_trips;
+  if (last_call_tripped) *last_call_tripped = tripped;
+  if (trips_total) *trips_total = ctx->guard_trips;
   return GN_OK;
 }
 
@@ -717,6 +764,13 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
   GN_HIP(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
+  // deferred joins still pending from a call of another shape: group g of this call would overlap the workspace slice of a
+  // different group of that call on another stream -> join them first (the fork event below is recorded behind the joins)
+  if (ctx->defer_join && (ctx->sub_last_B != B || ctx->sub_last_np != ctx->npad_run)) {
+    const int rcj = gn_flush(ctx, stream);
+    if (rcj != GN_OK) return rcj;
+  }
+  ctx->sub_last_B = B; ctx->sub_last_np = ctx->npad_run;
   GN_HIP(hipEventRecord(ctx->ev_fork, s));
   const int kw = (kpt_format & 0xff) == GN_KPT_LAF ? 6 : 4;
   int rc_all = GN_OK, b0 = 0;
@@ -732,10 +786,20 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
     shift_workspaces(ctx, b0, -1);
     if (rc != GN_OK && rc_all == GN_OK) rc_all = rc;
     GN_HIP(hipEventRecord(ctx->ev_join[g], ctx->sub_s[g]));
-    ctx->sub_pending[g] = true;                       // joined by gn_flush: consecutive calls pipeline inside each group's stream
+    ctx->sub_pending[g] = true;
     b0 += Bg;
   }
+  // default: the caller's stream continues only after every group is done -- inputs may be released and outputs read in
+  // stream order, like any other call.  gn_set_deferred_join(1) leaves the join to gn_flush (consecutive calls then pipeline
+  // inside each group's stream; the caller keeps the INPUT buffers alive until it has flushed).
+  if (!ctx->defer_join) { const int rcj = gn_flush(ctx, stream); if (rcj != GN_OK && rc_all == GN_OK) rc_all = rcj; }
   return rc_all;
+}
+
+int gn_set_deferred_join(gn_ctx* ctx, int enable) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->defer_join = enable ? 1 : 0;
+  return GN_OK;
 }
 
 int gn_set_active_kpts(gn_ctx* ctx, int max_kpts_per_side) {
@@ -987,8 +1051,8 @@ int sift_prepare(gn_ctx* ctx, int B, int H, int W, int max_kp) {
   ctx->sift_max_kp = std::max(max_kp, 1024);
   ctx->sift_cand = (int4*)alloc((size_t)B * ctx->sift_max_cand * sizeof(int4));
   ctx->sift_counts = (int*)alloc((size_t)B * 4 * sizeof(int));
-  ctx->sift_raw_cap = 1;
-  while (ctx->sift_raw_cap < 4 * ctx->sift_max_kp) ctx->sift_raw_cap <<= 1;
+  ctx->sift_raw_cap = 16384;                                   // raw keypoints (several orientations per extremum, duplicates) before the sort
+  while (ctx->sift_raw_cap < 8 * ctx->sift_max_kp) ctx->sift_raw_cap <<= 1;
   ctx->sift_kp_stride = (long long)2 * ctx->sift_raw_cap + ctx->sift_max_kp;                        // per image: raw | sorted | final
   ctx->sift_kp = (SiftKeypoint*)alloc((size_t)B * ctx->sift_kp_stride * sizeof(SiftKeypoint));
   if (!ctx->sift_tmp || !ctx->sift_dk || !ctx->sift_cand || !ctx->sift_counts || !ctx->sift_kp)
@@ -1041,9 +1105,10 @@ int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, in
   for (int b = 0; b < B; ++b) {
     if (counts[4 * b] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
     if (counts[4 * b + 1] > max_raw) return fail(ctx, GN_ERR_ARG, "SIFT keypoint buffer overflow (raise max_kpts)");
-    if (counts[4 * b + 2] > max_out) return fail(ctx, GN_ERR_ARG, "more SIFT keypoints than max_kpts");
-    n_out_host[b] = counts[4 * b + 2];
+    n_out_host[b] = counts[4 * b + 2];     // <= max_out: beyond it the strongest max_out by response were kept (k_sift_dedup_emit)
   }
+  ctx->sift_totals.assign((size_t)B, 0);
+  for (int b = 0; b < B; ++b) ctx->sift_totals[b] = counts[4 * b + 3];
   GN_HIP(hipGetLastError());
   return GN_OK;
 }
@@ -1051,6 +1116,12 @@ int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, in
 int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
                                float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream) {
   return gn_sift_detect_and_compute_batch(ctx, gray, 1, H, W, max_kpts, kpt_xysa, response, octave, desc, n_out_host, stream);
+}
+
+int gn_sift_last_totals(gn_ctx* ctx, int B, int32_t* totals_host) {
+  if (!ctx || !totals_host || B < 1 || (size_t)B > ctx->sift_totals.size()) return fail(ctx, GN_ERR_ARG, "gn_sift_last_totals: no SIFT call of that batch size yet");
+  for (int b = 0; b < B; ++b) totals_host[b] = ctx->sift_totals[b];
+  return GN_OK;
 }
 
 int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream) {
@@ -1136,7 +1207,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   if (!ctx || !q || !k || !v || !nkv || !out || npad % 128 || BS < 1 || (cross && (BS & 1)))
     return fail(ctx, GN_ERR_ARG, "bad gn_debug_attention argument");
   GN_HIP(hipSetDevice(ctx->device));
-  AttnArgs a;
+  AttnArgs a; a.ovf = nullptr;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
   a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr;

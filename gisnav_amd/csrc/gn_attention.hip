@@ -506,17 +506,20 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const size_t row = (size_t)bs * a.npad + q0 + ql;
+    float amax = 0.f;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4v w = {o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+        ovf_track(amax, w.x, w.y); ovf_track(amax, w.z, w.w);
         const f16x4 hv = __builtin_convertvector(w, f16x4);
         const f16x4 mv = __builtin_convertvector(w - __builtin_convertvector(hv, f32x4v), f16x4);
         uint16_t* pp = a.outp + hm16_off(row, a.ldo, h * 64 + d * 32 + 8 * g + 4 * hh);
         *reinterpret_cast<f16x4*>(pp) = hv;
         *reinterpret_cast<f16x4*>(pp + 16) = mv;
       }
+    ovf_commit(a.ovf, amax);
     return;
   }
   float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;

@@ -46,6 +46,12 @@ __host__ __device__ inline size_t hm16_off(size_t row, int ld, int col) {
   return row * (size_t)ld * 2 + (size_t)(col >> 4) * 32 + (col & 15);
 }
 
+// f16x2 domain guard: every kernel that writes an activation as hm16 tracks max |x| of what it writes and raises the context's
+// overflow word when a value does not fit fp16 (|x| >= 65504 -> the high term would be inf).  The match head then reports
+// zero matches for the call (never a silent inf / NaN) and gn_match can re-run it in the exact-split f32x3 mode (gn_set_guard).
+__device__ __forceinline__ void ovf_track(float& amax, float a, float b) { amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ void ovf_commit(unsigned int* flag, float amax) { if (flag != nullptr && !(amax < 65504.0f)) atomicOr(flag, 1u); }
+
 // ---- GEMM -----------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
                EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6,
@@ -79,6 +85,7 @@ struct GemmArgs {
   const uint16_t* Ap;                        // A (k < K1), row pitch lda values
   const uint16_t* A2p;                       // optional second source (k >= K1), same row pitch
   uint16_t* Yp; int ldyp;                    // optional hm16 output (Y may then be nullptr)
+  unsigned int* ovf;                         // f16x2 domain guard word (see ovf_track), or nullptr
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // fp16-plane operands (Ap, Wp)
@@ -102,6 +109,7 @@ struct AttnArgs {
   int cross;                 // 1: keys/values come from the other side of the same pair (bs ^ 1)
   float qscale;              // multiplied into q before QK^T
   int BS;                    // number of (pair, side) slots
+  unsigned int* ovf;         // f16x2 domain guard word for the hm16 output, or nullptr
 };
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
@@ -122,7 +130,7 @@ struct PrepArgs {
 };
 void launch_prep(const PrepArgs& a, hipStream_t s);
 void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s,
-                    uint16_t* hp = nullptr);   // hp: write hm16 rows [rows][512] instead of h
+                    uint16_t* hp = nullptr, unsigned int* ovf = nullptr);   // hp: write hm16 rows [rows][512] instead of h
 void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s);
 
 struct HeadArgs {
@@ -133,6 +141,7 @@ struct HeadArgs {
   float* rowmax; float* rowlog; float* colmax; float* collog;   // [B][npad] each
   int32_t* m0; float* max0; int32_t* m1;                        // [B][npad]
   int64_t* idx; float* score; int32_t* n_match; int kmax;       // outputs
+  const unsigned int* ovf;  // f16x2 domain guard word: non-zero -> the call reports zero matches
 };
 void launch_match_head(const HeadArgs& a, hipStream_t s);
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
 #define GN_MFMA16(fa, fb) { GN_MFMA4(0, 0, fa, fb) GN_MFMA4(0, 1, fa, fb) GN_MFMA4(1, 0, fa, fb) GN_MFMA4(1, 1, fa, fb) }
 
   GN_DMA_TILE(0, 0);
-  __syncthreads();
+  { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
   GN_FRAG_READ(fa0, fb0, 0, 0);
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
     GN_MFMA16(fa1, fb1)
     GN_FRAG_READ(fa1, fb1, cur, 3);
     GN_MFMA16(fa0, fb0)
-    __syncthreads();
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     if (t + 1 < nt) GN_FRAG_READ(fa0, fb0, cur ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     GN_MFMA16(fa1, fb1)
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
   }
 
   GN_DMA_TILE(0, 0);
-  __syncthreads();
+  { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   if (nt > 1) GN_DMA_TILE(1, BK);
   f32x4 rawa[2][2], rawb[2][2];
   bf16x8 A0[2][3], B0[2][3], A1[2][3], B1[2][3];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
     if (WP) GN_BPLANE_READ(B1, cur, 1);
     GN_MFMA24(A0, B0)
     GN_SPLIT(rawa, rawb, A1, B1);
-    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     if (!(ABL & 2) && t + 2 < nt) GN_DMA_TILE(cur, (t + 2) * BK);
     if (t + 1 < nt) {
       GN_RAW_READ(rawa, rawb, cur ^ 1, 0);
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
   }
 
   GN_DMA_TILE(0, 0);
-  __syncthreads();
+  { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   if (nt > 1) GN_DMA_TILE(1, BK);
   f32x4 rawa[2][2], rawb[2][2];
   f16x8 A0[2][2], B0[2][2], A1[2][2], B1[2][2];
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
     if (WP) GN_BPLANE_READ(B1, cur, 1);
     GN_MFMA24(A0, B0)
     GN_SPLIT(rawa, rawb, A1, B1);
-    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     if (!(ABL & 2) && t + 2 < nt) GN_DMA_TILE(cur, (t + 2) * BK);
     if (t + 1 < nt) {
       GN_RAW_READ(rawa, rawb, cur ^ 1, 0);

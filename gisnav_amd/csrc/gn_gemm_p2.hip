@@ -130,6 +130,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
   for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
   uint2 hpl[16], mpl[16];   // plane outputs (only live when a.Yp)
   const bool planes_out = !kBf16Out && a.Yp != nullptr;
+  float amax = 0.f;
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int row = rbase + it * 4 + (lane >> 4);
@@ -161,9 +162,11 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
       if (planes_out) {
         split_pair(v.x, v.y, hpl[it].x, mpl[it].x);
         split_pair(v.z, v.w, hpl[it].y, mpl[it].y);
+        ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w);
       }
     }
   }
+  if (planes_out) ovf_commit(a.ovf, amax);
   // stores go last, from registers nothing writes any more
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(512) void k_gemm_p2ln(GemmArgs a) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
     uint2 hpl[16], mpl[16];
+    float amax = 0.f;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int lr = half * 64 + it * 4 + (lane >> 4);
@@ -679,7 +683,9 @@ __global__ __launch_bounds__(512) void k_gemm_p2ln(GemmArgs a) {
       vals[it] = v;
       split_pair(v.x, v.y, hpl[it].x, mpl[it].x);
       split_pair(v.z, v.w, hpl[it].y, mpl[it].y);
+      ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w);
     }
+    ovf_commit(a.ovf, amax);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
   const size_t ro = (size_t)b * a.npad;
   if (tid == 0) base_s = 0;
   __syncthreads();
-  if (n0 < 2 || n1 < 2) {  // kornia LightGlueMatcher._no_match
+  if (n0 < 2 || n1 < 2 || (a.ovf != nullptr && *a.ovf != 0u)) {  // kornia LightGlueMatcher._no_match; or the f16x2 domain guard tripped (gn_common.h)
     if (tid == 0) a.n_match[b] = 0;
     return;
   }

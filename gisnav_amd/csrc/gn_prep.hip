@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
 }
 
 // one wave per 512-wide row, in place
-__global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows, uint16_t* hp) {
+__global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, const float* beta, int rows, uint16_t* hp, unsigned int* ovf) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void k_ln_gelu(float* h, const float* gamma, c
     const f16x4 m1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4v), f16x4);
     *reinterpret_cast<f16x4*>(q0) = h0; *reinterpret_cast<f16x4*>(q1) = h1;
     *reinterpret_cast<f16x4*>(q0 + 16) = m0; *reinterpret_cast<f16x4*>(q1 + 16) = m1;
+    float amax = 0.f;
+    ovf_track(amax, v0.x, v0.y); ovf_track(amax, v0.z, v0.w); ovf_track(amax, v1.x, v1.y); ovf_track(amax, v1.z, v1.w);
+    ovf_commit(ovf, amax);
     return;
   }
   *reinterpret_cast<float4*>(p + lane * 4) = v0;
@@ -228,8 +231,8 @@ void launch_prep(const PrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_extent, dim3(a.B * 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_prep, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
 }
-void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s, uint16_t* hp) {
-  hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows, hp);
+void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s, uint16_t* hp, unsigned int* ovf) {
+  hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows, hp, ovf);
 }
 void launch_matchability(const float* x, const float* w, const float* b, float* ls, int rows, hipStream_t s) {
   hipLaunchKernelGGL(k_matchability, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, ls, rows);

@@ -862,7 +862,12 @@ __global__ __launch_bounds__(256) void k_sift_rank(const SiftKeypoint* kp, long 
   if (wave == 0 && i < n) sorted[s_rank[0][lane] + s_rank[1][lane] + s_rank[2][lane] + s_rank[3][lane]] = me;
 }
 
-// removeDuplicatedSorted + first-octave rescale + the output arrays, one workgroup over the sorted list
+// removeDuplicatedSorted + first-octave rescale + the output arrays, one workgroup over the sorted list.
+// More distinct keypoints than the caller's buffers hold (max_out): the call degrades like cv2's `nfeatures` cap
+// (KeyPointsFilter::retainBest) instead of failing -- the max_out keypoints of largest response survive (equal responses: the
+// earlier one in KeyPoint_LessThan order), still listed in that order; counters[4b + 3] reports how many there were.  The
+// response threshold is found by a 4 x 8-bit radix select over the responses' bit patterns (responses are |contrast| >= 0, so
+// unsigned order = float order).
 __global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp, SiftKeypoint* out, long long kp_stride, int* counters, int max_raw,
                                                             int max_out, float* kpt_xysa, float* response, int32_t* octave, long long out_stride) {
   const int b = blockIdx.x;
@@ -871,20 +876,72 @@ __global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp
   if (response) response += (long long)b * out_stride;
   if (octave) octave += (long long)b * out_stride;
   const int* n_raw_p = counters + 4 * b + 1; int* n_out = counters + 4 * b + 2;
-  __shared__ int s_wcount[16];
-  __shared__ int s_base;
+  __shared__ int s_wcount[16], s_wcount_eq[16];
+  __shared__ int s_base, s_base_eq, s_total, s_need;
+  __shared__ unsigned int s_prefix;
+  __shared__ int s_hist[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = min(*n_raw_p, max_raw);
-  if (tid == 0) s_base = 0;
+  auto keep_at = [&](int i, SiftKeypoint& q) -> bool {
+    if (i >= n) return false;
+    q = kp[i];
+    if (i == 0) return true;
+    const SiftKeypoint p = kp[i - 1];
+    return !(p.x == q.x && p.y == q.y && p.size == q.size && p.angle == q.angle);
+  };
+  // ---- how many distinct keypoints are there?
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  {
+    int mine = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) { SiftKeypoint q; mine += keep_at(i0 + tid, q) ? 1 : 0; }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0 && mine) atomicAdd(&s_total, mine);
+  }
+  __syncthreads();
+  const int total = s_total;
+  const bool overflow = total > max_out;
+  if (overflow) {   // radix select: bit pattern of the max_out-th largest response, and how many keypoints of exactly that response fit
+    if (tid == 0) { s_prefix = 0u; s_need = max_out; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) s_hist[tid] = 0;
+      __syncthreads();
+      const unsigned int prefix = s_prefix;
+      for (int i0 = 0; i0 < n; i0 += 1024) {
+        SiftKeypoint q;
+        if (keep_at(i0 + tid, q)) {
+          const unsigned int bits = __float_as_uint(q.response);
+          if (shift == 24 || ((bits ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(bits >> shift) & 255u], 1);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int need = s_need, bin = 255;
+        for (; bin > 0; --bin) { if (s_hist[bin] >= need) break; need -= s_hist[bin]; }
+        s_need = need; s_prefix = prefix | ((unsigned int)bin << shift);
+      }
+      __syncthreads();
+    }
+  }
+  const unsigned int tbits = overflow ? s_prefix : 0u;
+  const int eq_budget = overflow ? s_need : 0;
+  if (tid == 0) { s_base = 0; s_base_eq = 0; }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += 1024) {
     const int i = i0 + tid;
-    bool keep = false;
     SiftKeypoint q;
-    if (i < n) {
-      q = kp[i];
-      keep = true;
-      if (i > 0) { const SiftKeypoint p = kp[i - 1]; keep = !(p.x == q.x && p.y == q.y && p.size == q.size && p.angle == q.angle); }
+    bool keep = keep_at(i, q);
+    if (overflow) {   // uniform branch: the barriers inside are reached by every thread
+      const unsigned int bits = keep ? __float_as_uint(q.response) : 0u;
+      const bool eq = keep && bits == tbits;
+      const unsigned long long bal_eq = __ballot(eq);
+      if (lane == 0) s_wcount_eq[wave] = __popcll(bal_eq);
+      __syncthreads();
+      int eq_pos = s_base_eq + __popcll(bal_eq & ((1ull << lane) - 1ull));
+      for (int wv = 0; wv < wave; ++wv) eq_pos += s_wcount_eq[wv];
+      keep = keep && (bits > tbits || (eq && eq_pos < eq_budget));
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int wv = 0; wv < 16; ++wv) t += s_wcount_eq[wv]; s_base_eq += t; }
     }
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) s_wcount[wave] = __popcll(bal);
@@ -903,7 +960,7 @@ __global__ __launch_bounds__(1024) void k_sift_dedup_emit(const SiftKeypoint* kp
     if (tid == 0) { int t = 0; for (int wv = 0; wv < 16; ++wv) t += s_wcount[wv]; s_base += t; }
     __syncthreads();
   }
-  if (tid == 0) *n_out = s_base;
+  if (tid == 0) { *n_out = min(s_base, max_out); counters[4 * b + 3] = total; }
 }
 
 }  // namespace

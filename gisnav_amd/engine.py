@@ -44,20 +44,29 @@ class PoseEngine:
 
     def __init__(self, device: int = 0, max_batch: int = 32, max_kpts: int = 1024,
                  precision: str = "f32", state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 n_layers: int = 9, filter_threshold: float = FILTER_THRESHOLD):
+                 n_layers: int = 9, filter_threshold: float = FILTER_THRESHOLD, guard: str = "flag"):
         if not torch.cuda.is_available():
             raise _lib.GnError("PoseEngine needs a HIP device; the product path has no CPU fallback")
         self.lib = _lib.load()
         self.device = torch.device("cuda", device)
         self.max_batch, self.precision = max_batch, precision
+        self._n_layers, self._filter_threshold, self._state_dict = n_layers, filter_threshold, None
+        self._guard = {"off": 0, "flag": 1, "sync": 2}[guard]
         ctx = C.c_void_p()
         _lib.check(None, self.lib.gn_create(device, max_batch, max_kpts, _PRECISIONS[precision], C.byref(ctx)), "gn_create")
         self.ctx = ctx
         self.kmax = self.lib.gn_kmax(ctx)
         _lib.check(ctx, self.lib.gn_set_num_layers(ctx, n_layers), "gn_set_num_layers")
         _lib.check(ctx, self.lib.gn_set_filter_threshold(ctx, filter_threshold), "gn_set_filter_threshold")
+        _lib.check(ctx, self.lib.gn_set_guard(ctx, self._guard), "gn_set_guard")
         if state_dict is not None:
             self.load_state_dict(state_dict)
+
+    def guard_status(self):
+        """(last matcher call left the fp16 range of the f16x2 mode, number of such calls so far) -- synchronises the stream."""
+        last, total = C.c_int32(0), C.c_int64(0)
+        _lib.check(self.ctx, self.lib.gn_get_guard_status(self.ctx, self._stream(), C.byref(last), C.byref(total)), "gn_get_guard_status")
+        return bool(last.value), int(total.value)
 
     def __del__(self):
         ctx, self.ctx = getattr(self, "ctx", None), None
@@ -65,7 +74,25 @@ class PoseEngine:
             self.lib.gn_destroy(ctx)
 
     # ------------------------------------------------------------------ weights
+    def grow(self, max_kpts: int) -> None:
+        """Re-create the context for more keypoints per side (weights re-loaded).  The reference accepts any keypoint count
+        (cv2.SIFT_create() is unbounded, pose_node.py:122); the mirrors call this instead of failing on a larger cloud."""
+        if max_kpts <= self.kmax:
+            return
+        ctx = C.c_void_p()
+        _lib.check(None, self.lib.gn_create(self.device.index or 0, self.max_batch, int(max_kpts), _PRECISIONS[self.precision], C.byref(ctx)), "gn_create")
+        old, self.ctx = self.ctx, ctx
+        self.lib.gn_destroy(old)
+        self.kmax = self.lib.gn_kmax(ctx)
+        self._sift = None
+        _lib.check(ctx, self.lib.gn_set_num_layers(ctx, self._n_layers), "gn_set_num_layers")
+        _lib.check(ctx, self.lib.gn_set_filter_threshold(ctx, self._filter_threshold), "gn_set_filter_threshold")
+        _lib.check(ctx, self.lib.gn_set_guard(ctx, self._guard), "gn_set_guard")
+        if self._state_dict is not None:
+            self.load_state_dict(self._state_dict)
+
     def load_state_dict(self, sd) -> None:
+        self._state_dict = sd
         for name, arr in canonical_state_dict(sd).items():
             arr = np.ascontiguousarray(arr, dtype=np.float32)
             shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
@@ -76,6 +103,7 @@ class PoseEngine:
             raise _lib.GnError(f"{missing} required LightGlue tensors missing from the state dict")
 
     def set_num_layers(self, n: int) -> None:
+        self._n_layers = n
         _lib.check(self.ctx, self.lib.gn_set_num_layers(self.ctx, n), "gn_set_num_layers")
 
     # ------------------------------------------------------------------ helpers
@@ -152,9 +180,11 @@ class PoseEngine:
         before reading R / t / n_inliers / ok."""
         _lib.check(self.ctx, self.lib.gn_set_overlap(self.ctx, int(enable)), "gn_set_overlap")
 
-    def set_substreams(self, n: int) -> None:
-        """Throughput option: every estimate() call runs its pairs as n out-of-phase groups on internal streams (gn_set_substreams)."""
+    def set_substreams(self, n: int, deferred_join: bool = False) -> None:
+        """Throughput option: every estimate() call runs its pairs as n groups on internal streams (gn_set_substreams).  With
+        deferred_join the groups are only joined by flush(): keep the input tensors of a call alive until then."""
         _lib.check(self.ctx, self.lib.gn_set_substreams(self.ctx, int(n)), "gn_set_substreams")
+        _lib.check(self.ctx, self.lib.gn_set_deferred_join(self.ctx, int(bool(deferred_join))), "gn_set_deferred_join")
 
     def set_active_kpts(self, max_kpts_per_side: int) -> int:
         """Padded keypoint count the following match()/estimate() calls run at (gn_set_active_kpts): pass the largest keypoint
@@ -200,11 +230,16 @@ class PoseEngine:
         B = int(f.shape[0])
         kpt, _, _, desc, n = sift.detect_and_compute_batch_device(torch.cat([f, t], 0))
         nd = torch.as_tensor(n, device=self.device)
-        self.set_active_kpts(max(int(n.max()), 1))
         if dem is None:
             dem = torch.zeros((B, int(f.shape[1]), int(f.shape[2])), dtype=torch.uint8, device=self.device)
         inputs = dict(desc_q=desc[:B], kpt_q=kpt[:B], n_q=nd[:B], desc_r=desc[B:], kpt_r=kpt[B:], n_r=nd[B:], dem=to_dev(dem), kpt_format=_lib.GN_KPT_XYSA)
-        return self.estimate(inputs, K, min_matches, out=out), n
+        self.set_active_kpts(max(int(n.max()), 1))
+        try:
+            res = self.estimate(inputs, K, min_matches, out=out)
+            self.flush()                                       # sub-stream groups read the temporaries above: join before they are released
+        finally:
+            self.set_active_kpts(self.kmax)                    # the active size is sticky context state: do not leak it to later calls
+        return res, n
 
     # ------------------------------------------------------------------ visual-odometry path (TwistNode)
     def vo_match(self, desc_q, n_q, desc_r, n_r, ratio: float = 0.7, want_knn: bool = False):

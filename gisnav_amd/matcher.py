@@ -43,7 +43,7 @@ class LightGlueMatcher:
             raise _lib.GnError("gisnav_amd.LightGlueMatcher runs on an MI355X only (no CPU path)")
         self._engine = PoseEngine(device.index or 0, max_batch=1, max_kpts=self._max_kpts, precision=self._precision,
                                   state_dict=self._state_dict, n_layers=self.params["n_layers"],
-                                  filter_threshold=self.params["filter_threshold"])
+                                  filter_threshold=self.params["filter_threshold"], guard="sync")
         return self
 
     def eval(self):
@@ -66,6 +66,8 @@ class LightGlueMatcher:
             return torch.zeros((0, 1), dtype=desc1.dtype, device=desc1.device), torch.zeros((0, 2), dtype=torch.int64, device=desc1.device)
         f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         d1, d2 = f(desc1).reshape(1, -1, 128), f(desc2).reshape(1, -1, 128)
+        if max(d1.shape[1], d2.shape[1]) > self._engine.kmax:      # kornia's matcher takes any number of keypoints
+            self._engine.grow(((max(d1.shape[1], d2.shape[1]) + 1023) // 1024) * 1024)
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
         n1 = torch.tensor([d1.shape[1]], dtype=torch.int32, device=dev)
         n2 = torch.tensor([d2.shape[1]], dtype=torch.int32, device=dev)

@@ -29,7 +29,7 @@ class PoseNode:
 
     def __init__(self, state_dict, extractor: Optional[Callable] = None, device: int = 0, max_kpts: int = 4096, precision: str = "f32"):
         self._engine = PoseEngine(device, max_batch=1, max_kpts=max_kpts, precision=precision, state_dict=state_dict,
-                                  n_layers=9, filter_threshold=self.CONFIDENCE_THRESHOLD)
+                                  n_layers=9, filter_threshold=self.CONFIDENCE_THRESHOLD, guard="sync")
         if extractor is None:
             from .sift import SIFT
             extractor = SIFT(engine=self._engine, max_keypoints=max_kpts).as_extractor()
@@ -71,8 +71,13 @@ class PoseNode:
                       desc_r=desc_r_t, kpt_r=kpt_r_t, n_r=n_r_t,
                       dem=torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev),
                       kpt_format=_lib.GN_KPT_XYSA)
+        if max(n, self._cached_n_r) > eng.kmax:             # the reference accepts any keypoint count (pose_node.py:122,207): grow, never fail
+            eng.grow(((max(n, self._cached_n_r) + 1023) // 1024) * 1024)
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)
-        out = eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES)
+        try:
+            out = eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES)
+        finally:
+            eng.set_active_kpts(eng.kmax)                   # sticky context state: restore
         self.last_num_matches = int(out["n_match"].cpu()[0])
         if self.last_num_matches < self.MIN_MATCHES:        # pose_node.py:299-303
             return None

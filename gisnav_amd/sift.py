@@ -66,6 +66,13 @@ class SIFT:
         _lib.check(eng.ctx, rc, "gn_sift_detect_and_compute_batch")
         return kpt, resp, octv, desc, np.frombuffer(n, dtype=np.int32).copy()
 
+    def last_totals(self, B: int = 1) -> np.ndarray:
+        """Distinct keypoints per image found by the last call BEFORE the max_keypoints cap (the cap keeps the strongest by
+        response, like cv2's nfeatures); a caller that wants them all re-creates SIFT with a larger max_keypoints."""
+        n = (C.c_int32 * B)()
+        _lib.check(self._eng.ctx, self._eng.lib.gn_sift_last_totals(self._eng.ctx, B, C.cast(n, C.POINTER(C.c_int32))), "gn_sift_last_totals")
+        return np.frombuffer(n, dtype=np.int32).copy()
+
     def detectAndCompute(self, image, mask=None):
         if mask is not None:
             raise ValueError("masks are not supported (GISNav passes None)")
@@ -78,6 +85,10 @@ class SIFT:
         """The `extractor(ref_u8) -> (kp, desc, size, angle)` callable `gisnav_amd.pose_node.PoseNode` takes."""
         def extractor(ref_u8):
             kpt, _, _, desc = self.detect_and_compute_device(ref_u8)
+            total = int(self.last_totals(1)[0])
+            if total > self._max:                      # cv2.SIFT_create() is unbounded (pose_node.py:122): enlarge the buffers, extract again
+                self._max = ((total + 1023) // 1024) * 1024
+                kpt, _, _, desc = self.detect_and_compute_device(ref_u8)
             k = kpt.cpu().numpy()
             return k[:, :2], desc.cpu().numpy(), k[:, 2], k[:, 3]
         return extractor

@@ -65,8 +65,12 @@ enum gn_precision {
   GN_PREC_F16X2_BF16_ATTN = 3 /* as 2 at half the matrix-pipe work: every f32 operand is split into two fp16
                             terms (round to nearest, 22 significant bits, subnormals honoured by the gfx950
                             matrix pipe) and three partial products are accumulated in f32; weight planes are
-                            pre-scaled by a power of two.  Requires |activation| < 65504.  Error vs fp64 at the
-                            level of an f32 accumulation (see tests) */
+                            pre-scaled by a power of two.  Domain |activation| < 65504 (the reference's fp32
+                            nn.Linear has no such limit): GUARDED -- every kernel that writes an activation in
+                            this format raises a context word when a value leaves the range, a tripped call
+                            reports ZERO matches instead of inf / NaN, and gn_set_guard(ctx, 2) re-runs it in
+                            mode 2 (see gn_set_guard).  Error vs fp64 at the level of an f32 accumulation
+                            (see tests) */
 };
 
 enum gn_kpt_format {
@@ -84,6 +88,19 @@ enum gn_kpt_format {
 const char* gn_version(void);
 /* Human-readable text for the last failure on this context (or global if ctx is NULL). */
 const char* gn_last_error(const gn_ctx* ctx);
+
+/* The fp16-range guard of GN_PREC_F16X2_BF16_ATTN (no effect in the other modes):
+ *   0  off (no checks; an out-of-range activation silently becomes inf / NaN -- for kernel experiments only);
+ *   1  (default) flag: stream-ordered, no host sync.  A call in which any activation reached |x| >= 65504 returns
+ *      n_match = 0 for every pair (and therefore ok = 0 from gn_estimate); gn_get_guard_status tells the host;
+ *   2  flag + fallback: gn_match / gn_estimate synchronise the stream once after the matcher, and a tripped call is
+ *      re-run transparently with every operand split exactly into three bf16 terms (the arithmetic of mode
+ *      GN_PREC_F32X3_BF16_ATTN: f32 range and accuracy, ~1.5x slower) before the call returns.  The Python mirrors of
+ *      the reference's objects (LightGlueMatcher, PoseNode) use this: they synchronise after the matcher anyway. */
+int gn_set_guard(gn_ctx* ctx, int mode);
+/* Synchronises `stream`; *last_call_tripped = 1 if the most recent matcher run on this context left the fp16 range,
+ * *trips_total = number of tripped calls observed so far (either pointer may be NULL). */
+int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, int64_t* trips_total);
 
 /* Create a context on HIP device `device` sized for batches of up to max_batch pairs with up
  * to max_kpts keypoints per side (rounded up to a multiple of 128 internally). */
@@ -146,16 +163,23 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
 int gn_set_overlap(gn_ctx* ctx, int enable);
 /* Throughput option for back-to-back calls: split the B pairs of every gn_estimate call into n groups (1..8) that run
  * the whole path on n internal streams, forked from the caller's stream; consecutive calls pipeline inside each
- * group's stream, the groups drift out of phase, and one group's memory-bound kernels overlap another's matrix-bound
- * ones.  ALL outputs of a call (n_match included) are complete only after gn_flush(ctx, stream).
- * Measured on the 32-pair bench: +1..3 % with n = 2, slower with n >= 4 (smaller GEMMs); off (n = 1) by default. */
+ * group's stream and one group's memory-bound kernels overlap another's matrix-bound ones.  By default the caller's stream
+ * is made to wait for every group before gn_estimate returns: inputs and outputs obey plain stream order, as without the
+ * option.  Measured on the 32-pair bench: +1..3 % with n = 2, slower with n >= 4 (smaller GEMMs); off (n = 1) by default. */
 int gn_set_substreams(gn_ctx* ctx, int n);
+/* Opt-in companion of gn_set_substreams: leave the join to gn_flush, so that the groups of consecutive calls drift out of
+ * phase.  Then ALL outputs of a call (n_match included) are complete only after gn_flush(ctx, stream), and the caller must
+ * keep the INPUT buffers of a call alive (and unmodified) until it has flushed -- they are read off the caller's stream.
+ * A call whose B or active padded size differs from the previous unflushed call joins first, by itself. */
+int gn_set_deferred_join(gn_ctx* ctx, int enable);
 /* The matcher pads every image to a multiple of 128 keypoints; by default that is max_kpts of gn_create.  When the caller
  * knows an upper bound of the keypoint counts of the coming calls (the SIFT entry points return them), this sets the padded
  * size those calls run at -- attention cost falls with its square, the GEMMs linearly.  Keypoints beyond it are ignored.
  * Results do not depend on the padded size (padding is masked out exactly).  Returns the padded size now in effect
  * (min(round_up(max_kpts_per_side, 128), padded max_kpts of the context)) or a negative status.  Output strides (gn_kmax)
- * do not change.  Host-side state: takes effect for calls issued after it. */
+ * do not change.  Host-side, STICKY state: it stays in effect for every later gn_match / gn_estimate on this context until
+ * it is set again -- a caller that shrinks it for one batch restores it afterwards (gn_set_active_kpts(ctx, max_kpts));
+ * the Python mirrors (PoseEngine.estimate_images, PoseNode.estimate) do. */
 int gn_set_active_kpts(gn_ctx* ctx, int max_kpts_per_side);
 int gn_flush(gn_ctx* ctx, void* stream);
 
@@ -210,6 +234,10 @@ int gn_pose_to_earth(const double* R9, const double* t3, const double* affine12,
  *   GN_KPT_XYSA keypoint format of gn_match / gn_estimate; response [max_kpts] f32 and octave [max_kpts] int32
  *   (packed as cv2.KeyPoint.octave) may be NULL; desc [max_kpts][128] f32 (integer-valued 0..255, as cv2 emits).
  *   n_out_host: HOST int32, number of keypoints, in OpenCV's order (sorted by x, y, size desc, angle, ...).
+ *   More than max_kpts distinct keypoints: the call does NOT fail -- like cv2's `nfeatures` cap (KeyPointsFilter::retainBest,
+ *   pose_node.py:108) the max_kpts keypoints of largest response are kept (equal responses: the earlier one in the order
+ *   above), still listed in that order (cv2 itself leaves them in nth_element order and keeps every tie of the last
+ *   response); gn_sift_last_totals reports how many there were, so the caller can grow its buffers.
  * Everything -- scale space, extrema, refinement, the sort / duplicate removal, descriptors -- runs on the device in
  * stream order; the call synchronises `stream` once, at the end, to hand the keypoint count to the host. */
 int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, int max_kpts,
@@ -220,6 +248,9 @@ int gn_sift_detect_and_compute(gn_ctx* ctx, const uint8_t* gray, int H, int W, i
  * (gn_estimate) already takes batches of pairs in this keypoint format. */
 int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, int H, int W, int max_kpts,
                                      float* kpt_xysa, float* response, int32_t* octave, float* desc, int32_t* n_out_host, void* stream);
+
+/* Distinct keypoints each image of the LAST gn_sift_detect_and_compute(_batch) call had before the max_kpts cap (HOST int32 [B]). */
+int gn_sift_last_totals(gn_ctx* ctx, int B, int32_t* totals_host);
 
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.

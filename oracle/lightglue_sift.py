@@ -279,7 +279,7 @@ def pose_node_match(
     sd: Dict[str, Tensor],
     kp_q: Tensor, desc_q: Tensor, size_q: Tensor, angle_q: Tensor,
     kp_r: Tensor, desc_r: Tensor, size_r: Tensor, angle_r: Tensor,
-    taps: Optional[dict] = None,
+    taps: Optional[dict] = None, filter_threshold: float = FILTER_THRESHOLD,
 ):
     """pose_node.py:246-297 with torch-CPU tensors: LAF build, RootSIFT, matcher, gather.
 
@@ -289,7 +289,7 @@ def pose_node_match(
         laf_q = laf_from_center_scale_ori(kp_q.unsqueeze(0), size_q[None, :, None, None], angle_q[None, :, None])
         laf_r = laf_from_center_scale_ori(kp_r.unsqueeze(0), size_r[None, :, None, None], angle_r[None, :, None])
         dq, dr = rootsift(desc_q), rootsift(desc_r)
-        scores, idx = lightglue_matcher_forward(sd, dq, dr, laf_q, laf_r, taps=taps)
+        scores, idx = lightglue_matcher_forward(sd, dq, dr, laf_q, laf_r, filter_threshold=filter_threshold, taps=taps)
         kq = get_laf_center(laf_q).squeeze(0)
         kr = get_laf_center(laf_r).squeeze(0)
         return kq[idx[:, 0]], kr[idx[:, 1]], scores, idx

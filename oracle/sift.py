@@ -417,3 +417,15 @@ def detect_and_compute(gray_u8: np.ndarray):
     desc = compute(pyr[0], kpts)
     g = lambda name, dt: np.array([k[name] for k in kpts], dt)  # noqa: E731
     return np.stack([g("x", F), g("y", F)], 1) if kpts else np.zeros((0, 2), F), g("size", F), g("angle", F), g("response", F), g("octave", np.int32), desc
+
+
+def retain_best(kp, size, angle, response, octave, desc, n: int):
+    """The keypoint cap of gn_sift_detect_and_compute (include/gisnav_amd.h): the n keypoints of largest response, ties to the
+    earlier one in KeyPoint_LessThan order, listed in that order.  cv2's own cap (`SIFT_create(nfeatures)` ->
+    KeyPointsFilter::retainBest, pose_node.py:108) selects by the same criterion but leaves the survivors in std::nth_element
+    order and keeps EVERY keypoint that ties with the n-th response -- a documented difference in order / tie handling."""
+    if len(kp) <= n:
+        return kp, size, angle, response, octave, desc
+    order = np.lexsort((np.arange(len(kp)), -response.astype(np.float64)))[:n]
+    keep = np.sort(order)
+    return kp[keep], size[keep], angle[keep], response[keep], octave[keep], desc[keep]

@@ -24,9 +24,9 @@ def state_dict_t(state_dict_np):
     return {k: torch.from_numpy(v) for k, v in state_dict_np.items()}
 
 
-def oracle_match(sd_t, p, taps=None):
+def oracle_match(sd_t, p, taps=None, filter_threshold=0.5):
     import torch
     from oracle import lightglue_sift as lg
     tq = torch.from_numpy
     return lg.pose_node_match(sd_t, tq(p.kp_q), tq(p.desc_q), tq(p.size_q), tq(p.angle_q),
-                              tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r), taps=taps)
+                              tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r), taps=taps, filter_threshold=filter_threshold)

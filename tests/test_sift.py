@@ -75,9 +75,10 @@ def sift_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,shape", [(0, (240, 320)), (1, (200, 333)), (2, (96, 128))])
+@pytest.mark.parametrize("seed,shape", [(0, (240, 320)), (1, (200, 333)), (2, (96, 128)), (5, (480, 640)), (6, (480, 640))])
 def test_sift_keypoints_and_descriptors_bit_exact(sift_gpu, seed, shape):
-    img = blob_image(seed, *shape)
+    # (480, 640) is the BASELINE frame size: k_sift_tail takes octaves 4-8 there and the fused-blur tile table differs
+    img = blob_image(seed, *shape, n=500 if shape[0] >= 480 else 150)
     okp, osize, oang, oresp, ooct, odesc = osift.detect_and_compute(img)
     kpt, resp, octv, desc = sift_gpu.detect_and_compute_device(img)
     k = kpt.cpu().numpy()
@@ -136,9 +137,28 @@ def test_sift_edge_cases_flat_tiny_and_overflow(sift_gpu):
         assert np.array_equal(k[:, :2], okp) and np.array_equal(k[:, 2], osize) and np.array_equal(k[:, 3], oang)
         assert np.array_equal(octv.cpu().numpy(), ooct) and np.array_equal(desc.cpu().numpy(), odesc)
     assert total >= 15
-    small = SIFT(engine=sift_gpu._eng, max_keypoints=16)
-    with pytest.raises(RuntimeError, match="max_kpts"):
-        small.detect_and_compute_device(blob_image(0, 240, 320))
+    # more keypoints than the caller's buffers: the strongest max_keypoints by response survive, in OpenCV's order
+    # (cv2 nfeatures / retainBest semantics) -- no error, and the true count is reported
+    img = blob_image(0, 240, 320)
+    full = osift.detect_and_compute(img)
+    for cap in (16, 100):
+        small = SIFT(engine=sift_gpu._eng, max_keypoints=cap)
+        kpt, resp, octv, desc = small.detect_and_compute_device(img)
+        okp, osize, oang, oresp, ooct, odesc = osift.retain_best(*full, cap)
+        assert len(kpt) == cap == len(okp) and int(small.last_totals(1)[0]) == len(full[0]) > cap
+        k = kpt.cpu().numpy()
+        assert np.array_equal(k[:, :2], okp) and np.array_equal(k[:, 2], osize) and np.array_equal(k[:, 3], oang)
+        assert np.array_equal(resp.cpu().numpy(), oresp) and np.array_equal(octv.cpu().numpy(), ooct)
+        assert np.array_equal(desc.cpu().numpy(), odesc)
+    imgs = np.stack([blob_image(s_, 200, 264, n=150 + 40 * s_) for s_ in range(3)])      # a batch where only some images overflow
+    small = SIFT(engine=sift_gpu._eng, max_keypoints=120)
+    kb, rb, ob, db, nb = small.detect_and_compute_batch_device(imgs)
+    tot = small.last_totals(3)
+    for b in range(3):
+        fb = osift.detect_and_compute(imgs[b])
+        okp, _, _, oresp, _, odesc = osift.retain_best(*fb, 120)
+        assert tot[b] == len(fb[0]) and nb[b] == min(120, tot[b])
+        assert np.array_equal(kb[b, : nb[b], :2].cpu().numpy(), okp) and np.array_equal(db[b, : nb[b]].cpu().numpy(), odesc)
     kpt, _, _, _ = sift_gpu.detect_and_compute_device(blob_image(0, 240, 320))          # the context is usable afterwards
     assert len(kpt) > 20
 
