@@ -26,7 +26,7 @@ from gisnav_amd.weights import synthetic_state_dict
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOW_MARGIN = dict(ffn_out_std=4.8e-3, final_scale=4.0, matchability_bias=0.0, matchability_std=0.05)
-MID_MARGIN = dict(ffn_out_std=1.2e-3, final_scale=8.0, matchability_bias=1.0, matchability_std=0.05)
+MID_MARGIN = dict(ffn_out_std=1.2e-3, final_scale=12.0, matchability_bias=2.0, matchability_std=0.05)
 MODES = ["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"]
 
 
@@ -75,9 +75,10 @@ def _mismatches(idx_gpu, k_gpu, oidx):
     return len(a ^ b), len(b)
 
 
-@pytest.mark.parametrize("name,kw,th", [("low_margin", LOW_MARGIN, 0.02), ("mid_margin", MID_MARGIN, 0.1)])
+@pytest.mark.parametrize("name,kw,th", [("low_margin", LOW_MARGIN, 0.0), ("mid_margin", MID_MARGIN, 0.01)])
 def test_low_margin_weights_index_mismatch_counts_per_precision(name, kw, th, dev):
-    """Near-tie regime.  f32 mode must reproduce the oracle's correspondences exactly; for the reduced-precision modes the
+    """Near-tie regime (low_margin: every block rewrites the residual stream several times over, scores ~1e-5, threshold 0 = pure
+    mutual nearest neighbour; mid_margin: scores straddle the 0.01 threshold).  f32 mode must reproduce the oracle's correspondences exactly; for the reduced-precision modes the
     symmetric difference of the match sets is counted, reported, and bounded (5 % of the oracle's matches)."""
     from gisnav_amd.engine import PoseEngine
     sd = synthetic_state_dict(0, **kw)
