@@ -13,7 +13,8 @@ namespace {
 
 thread_local std::string g_err;
 
-struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; float acc_scale = 1.f; };
+struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; float acc_scale = 1.f;
+                uint16_t* wf = nullptr; int frag_order = -1; };   // frag_order: -1 none, 0 natural k, 1 permuted k (see build_weight_fragments)   // wf: the scaled fp16 pair in MFMA fragment order (gn_ffn.hip), same scale as wp
 // wp: pre-split planes, [3][out][in] bf16 (f32x3) or [2][out][in] fp16 of w / acc_scale (f16x2; acc_scale a power of two)
 
 struct Block {       // one SelfBlock or CrossBlock
@@ -31,7 +32,8 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
-  int ffn_fused = 1;       // f16x2 mode: ffn.0 + LayerNorm + GELU in one launch (k_gemm_p2ln); 0 = separate k_ln_gelu (developer knob 10)
+  int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
+                           // (k_gemm_p2ln) when the grid fills the chip, 2 = always; 0 = separate k_ln_gelu (developer knob 10)
   // f16x2 domain guard (gn_set_guard): device word raised by any hm16 writer whose value does not fit fp16
   unsigned int* ovf = nullptr; unsigned int* ovf_host = nullptr;   // device word, pinned host mirror
   int guard = 1;           // 0 off, 1 flag (a tripped call reports zero matches), 2 flag + synchronous re-run in the f32x3 mode
@@ -246,6 +248,12 @@ int build_planes(gn_ctx* ctx, Linear& L) {
     const float scale = ldexpf(1.0f, e);
     L.acc_scale = ldexpf(1.0f, -e);
     if (ctx->planes_mode) launch_split_hm16(L.w, L.wp, L.out, L.in, scale, 0);   // hm16 rows for k_gemm_p2
+    if (ctx->planes_mode && L.frag_order >= 0 && L.out % 32 == 0 && L.in % 16 == 0) {   // fragment order for the fused block tail
+      std::vector<uint16_t> frag(2 * n);
+      build_weight_fragments(host.data(), L.out, L.in, scale, L.frag_order, frag.data());
+      if (!L.wf) { int rc = dalloc(ctx, &L.wf, 2 * n); if (rc != GN_OK) return rc; }
+      GN_HIP(hipMemcpy(L.wf, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     else launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);                   // [2][out][in] planes for k_gemm_f16x2
   } else {
     L.acc_scale = 1.f;
@@ -287,6 +295,25 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
 
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
+  if (c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && blk.ffn0.wf && blk.ffn3.wf && T % 64 == 0) {   // the whole tail in one launch
+    FfnArgs f;
+    f.xp = c->x_p; f.mp = c->msg_p; f.w1s = blk.ffn0.wf; f.w1_scale = blk.ffn0.acc_scale; f.b1 = blk.ffn0.b; f.ln_g = blk.ln_g; f.ln_b = blk.ln_b;
+    f.w2s = blk.ffn3.wf; f.w2_scale = blk.ffn3.acc_scale; f.b2 = blk.ffn3.b; f.yp = c->x_p; f.y = keep_f32 ? c->x : nullptr; f.T = T;
+    f.ovf = c->guard ? c->ovf : nullptr;
+    ++c->launch_count;
+    if (c->stop_after && c->launch_count > c->stop_after) return;
+    const bool rec = c->ktiming && c->kused < c->kflops.size();
+    if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+    launch_ffn_fused(f, s);
+    if (rec) {
+      hipEventRecord(c->kev[2 * c->kused + 1], s);
+      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0);
+      c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
+      c->kclass[c->kused] = 0;
+      ++c->kused;
+    }
+    return;
+  }
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
   // LayerNorm + GELU in the GEMM's epilogue (the hidden tensor leaves once, as hm16) when there are enough 128-row tiles to fill the chip:
@@ -616,8 +643,8 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
     else if (cross && leaf == "to_qk") rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim);
     else if (cross && leaf == "to_v") rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim);
     else if (cross && leaf == "to_out") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
-    else if (leaf == "ffn.0") rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim);
-    else if (leaf == "ffn.3") rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim);
+    else if (leaf == "ffn.0") { blk.ffn0.frag_order = 0; rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim); }
+    else if (leaf == "ffn.3") { blk.ffn3.frag_order = 1; rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim); }
     else if (leaf == "ffn.1") {
       if (d0 != 2 * kDim || d1 != 1) return shape_err();
       rc = upload(is_w ? &blk.ln_g : &blk.ln_b, host, 2 * kDim);

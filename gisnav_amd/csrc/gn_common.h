@@ -94,6 +94,22 @@ void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, i
 extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking
 extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 kernel when the shape allows
 
+// ---- fused block tail (gn_ffn.hip): x <- x + ffn.3(GELU(LayerNorm(ffn.0([x | msg])))) for hm16 rows ----------
+struct FfnArgs {
+  const uint16_t* xp;                      // [T][256] hm16 residual stream: k < 256 of ffn.0's input and the residual rows
+  const uint16_t* mp;                      // [T][256] hm16 message: k >= 256 of ffn.0's input
+  const uint16_t* w1s; float w1_scale;     // ffn.0 weight [512][512] in MFMA fragment order (build_weight_fragments, natural k), accumulator scale
+  const float* b1; const float* ln_g; const float* ln_b;
+  const uint16_t* w2s; float w2_scale;     // ffn.3 weight [256][512] in fragment order with the permuted k of a register-fed operand
+  const float* b2;
+  uint16_t* yp;                            // [T][256] hm16 output rows (may be xp: a workgroup only touches its own 64 rows)
+  float* y;                                // optional f32 copy of the output, or nullptr
+  int T;                                   // tokens, a multiple of 64
+  unsigned int* ovf;                       // f16x2 domain guard word, or nullptr
+};
+void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
+void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
+
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {
   const uint16_t* qb; int ldqb;   // bf16 variants of q / k (row-major) and V^T ([BS][4][64][npad])
