@@ -248,13 +248,13 @@ int build_planes(gn_ctx* ctx, Linear& L) {
     const float scale = ldexpf(1.0f, e);
     L.acc_scale = ldexpf(1.0f, -e);
     if (ctx->planes_mode) launch_split_hm16(L.w, L.wp, L.out, L.in, scale, 0);   // hm16 rows for k_gemm_p2
+    else launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);                   // [2][out][in] planes for k_gemm_f16x2
     if (ctx->planes_mode && L.frag_order >= 0 && L.out % 32 == 0 && L.in % 16 == 0) {   // fragment order for the fused block tail
       std::vector<uint16_t> frag(2 * n);
       build_weight_fragments(host.data(), L.out, L.in, scale, L.frag_order, frag.data());
       if (!L.wf) { int rc = dalloc(ctx, &L.wf, 2 * n); if (rc != GN_OK) return rc; }
       GN_HIP(hipMemcpy(L.wf, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    else launch_split2_f16(L.w, L.wp, (long long)n, scale, 0);                   // [2][out][in] planes for k_gemm_f16x2
   } else {
     L.acc_scale = 1.f;
     launch_split3_bf16(L.w, L.wp, (long long)n, 0);
@@ -1165,6 +1165,7 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
       {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
       {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)},
+      {"x_p", ctx->x_p, ctx->x_p ? T * kDim : 0}, {"msg_p", ctx->msg_p, ctx->msg_p ? T * kDim : 0},   // hm16 rows, raw (4 bytes per value)
       {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
   for (const Ent& e : tab)
     if (strcmp(e.n, name) == 0) {
