@@ -14,7 +14,8 @@ namespace {
 thread_local std::string g_err;
 
 struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; float acc_scale = 1.f;
-                uint16_t* wf = nullptr; int frag_order = -1; };   // frag_order: -1 none, 0 natural k, 1 permuted k (see build_weight_fragments)   // wf: the scaled fp16 pair in MFMA fragment order (gn_ffn.hip), same scale as wp
+                uint16_t* wf = nullptr; int frag_order = -1;       // frag_order: -1 none, else the k order of build_weight_fragments
+                uint16_t* wf2 = nullptr; };                         // ffn.0 only: order 2 (message half permuted) for the folded out_proj   // wf: the scaled fp16 pair in MFMA fragment order (gn_ffn.hip), same scale as wp
 // wp: pre-split planes, [3][out][in] bf16 (f32x3) or [2][out][in] fp16 of w / acc_scale (f16x2; acc_scale a power of two)
 
 struct Block {       // one SelfBlock or CrossBlock
@@ -32,6 +33,7 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
+  int ffn_fold = 1;        // with ffn_fused == 3: out_proj / to_out folded into the block-tail kernel (developer knob 13; 0 = separate GEMM launch)
   int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
                            // (k_gemm_p2ln) when the grid fills the chip, 2 = always; 0 = separate k_ln_gelu (developer knob 10)
   // f16x2 domain guard (gn_set_guard): device word raised by any hm16 writer whose value does not fit fp16
@@ -254,6 +256,11 @@ int build_planes(gn_ctx* ctx, Linear& L) {
       build_weight_fragments(host.data(), L.out, L.in, scale, L.frag_order, frag.data());
       if (!L.wf) { int rc = dalloc(ctx, &L.wf, 2 * n); if (rc != GN_OK) return rc; }
       GN_HIP(hipMemcpy(L.wf, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      if (L.out == 2 * kDim && L.in == 2 * kDim) {   // ffn.0: also the variant whose message half is fed from registers
+        build_weight_fragments(host.data(), L.out, L.in, scale, 2, frag.data());
+        if (!L.wf2) { int rc = dalloc(ctx, &L.wf2, 2 * n); if (rc != GN_OK) return rc; }
+        GN_HIP(hipMemcpy(L.wf2, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
     }
   } else {
     L.acc_scale = 1.f;
@@ -293,13 +300,22 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
   }
 }
 
+// true when the block-tail kernel also computes msg = out_proj(ctx): the schedule then skips the out_proj GEMM launch
+bool tail_folds_out_proj(const gn_ctx* c, const Block& blk, int T) {
+  return c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && c->ffn_fold && blk.ffn0.wf && blk.ffn0.wf2 && blk.ffn3.wf && blk.proj_out.wf &&
+         T % 64 == 0 && c->precision != GN_PREC_F32 && c->attn_variant >= 1;   // needs the attention kernel's hm16 output rows (ctx_p)
+}
+
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
   if (c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && blk.ffn0.wf && blk.ffn3.wf && T % 64 == 0) {   // the whole tail in one launch
     FfnArgs f;
-    f.xp = c->x_p; f.mp = c->msg_p; f.w1s = blk.ffn0.wf; f.w1_scale = blk.ffn0.acc_scale; f.b1 = blk.ffn0.b; f.ln_g = blk.ln_g; f.ln_b = blk.ln_b;
+    const bool fold = tail_folds_out_proj(c, blk, T);                     // out_proj computed inside the kernel from the attention output
+    f.cp = fold ? c->ctx_p : nullptr; f.wos = blk.proj_out.wf; f.wo_scale = blk.proj_out.acc_scale; f.bo = blk.proj_out.b;
+    f.xp = c->x_p; f.mp = c->msg_p; f.w1s = fold ? blk.ffn0.wf2 : blk.ffn0.wf; f.w1_scale = blk.ffn0.acc_scale; f.b1 = blk.ffn0.b; f.ln_g = blk.ln_g; f.ln_b = blk.ln_b;
     f.w2s = blk.ffn3.wf; f.w2_scale = blk.ffn3.acc_scale; f.b2 = blk.ffn3.b; f.yp = c->x_p; f.y = keep_f32 ? c->x : nullptr; f.T = T;
     f.ovf = c->guard ? c->ovf : nullptr;
+    f.dbg_ts = (gn::g_ffn_ablate == 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
     if (c->stop_after && c->launch_count > c->stop_after) return;
     const bool rec = c->ktiming && c->kused < c->kflops.size();
@@ -307,7 +323,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     launch_ffn_fused(f, s);
     if (rec) {
       hipEventRecord(c->kev[2 * c->kused + 1], s);
-      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0);
+      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + (fold ? 256.0 * 256.0 : 0.0));
       c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
       c->kclass[c->kused] = 0;
       ++c->kused;
@@ -382,7 +398,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
-      {
+      if (!tail_folds_out_proj(c, blk, T)) {
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
@@ -413,7 +429,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
-      {
+      if (!tail_folds_out_proj(c, blk, T)) {
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
@@ -639,10 +655,10 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
       if (is_w) { rc = upload(&L.w, tmp.data(), tmp.size()); } else { rc = upload(&L.b, tmp.data(), tmp.size()); }
       L.out = 3 * kDim; L.in = kDim;
       if (is_w && rc == GN_OK) rc = build_planes(ctx, L);
-    } else if (self && leaf == "out_proj") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
+    } else if (self && leaf == "out_proj") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
     else if (cross && leaf == "to_qk") rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim);
     else if (cross && leaf == "to_v") rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim);
-    else if (cross && leaf == "to_out") rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim);
+    else if (cross && leaf == "to_out") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
     else if (leaf == "ffn.0") { blk.ffn0.frag_order = 0; rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim); }
     else if (leaf == "ffn.3") { blk.ffn3.frag_order = 1; rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim); }
     else if (leaf == "ffn.1") {
@@ -1258,6 +1274,8 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 11) ctx->x_planes_only = value;
   else if (which == 8) gn::g_p2_wide = value;
   else if (which == 9) ctx->dbg_vt_skip = value;
+  else if (which == 12) gn::g_ffn_ablate = value;
+  else if (which == 13) ctx->ffn_fold = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -97,8 +97,10 @@ extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 ke
 // ---- fused block tail (gn_ffn.hip): x <- x + ffn.3(GELU(LayerNorm(ffn.0([x | msg])))) for hm16 rows ----------
 struct FfnArgs {
   const uint16_t* xp;                      // [T][256] hm16 residual stream: k < 256 of ffn.0's input and the residual rows
-  const uint16_t* mp;                      // [T][256] hm16 message: k >= 256 of ffn.0's input
-  const uint16_t* w1s; float w1_scale;     // ffn.0 weight [512][512] in MFMA fragment order (build_weight_fragments, natural k), accumulator scale
+  const uint16_t* mp;                      // [T][256] hm16 message: k >= 256 of ffn.0's input (used when cp == nullptr)
+  const uint16_t* cp;                      // [T][256] hm16 attention output: when set, message = out_proj(cp) is computed in the kernel ...
+  const uint16_t* wos; float wo_scale; const float* bo;   // ... with the out_proj / to_out weight [256][256] in fragment order (natural k) and its bias
+  const uint16_t* w1s; float w1_scale;     // ffn.0 weight [512][512] in MFMA fragment order (build_weight_fragments: natural k, or order 2 when cp is set), accumulator scale
   const float* b1; const float* ln_g; const float* ln_b;
   const uint16_t* w2s; float w2_scale;     // ffn.3 weight [256][512] in fragment order with the permuted k of a register-fed operand
   const float* b2;
@@ -106,8 +108,10 @@ struct FfnArgs {
   float* y;                                // optional f32 copy of the output, or nullptr
   int T;                                   // tokens, a multiple of 64
   unsigned int* ovf;                       // f16x2 domain guard word, or nullptr
+  long long* dbg_ts;                       // developer: [blocks][8 waves][8] s_memtime stamps (ablation 8), or nullptr
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
+extern int g_ffn_ablate;
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
 
 // ---- attention --------------------------------------------------------------------------------

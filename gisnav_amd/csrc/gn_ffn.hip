@@ -58,45 +58,136 @@ __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m) {
   m = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 }
 
+// FOLD: the message is not read from memory but computed here, msg = out_proj(ctx) (kornia `self.out_proj` / `self.to_out`), from
+// the attention output rows -- the out_proj GEMM launch and the msg round trip through HBM disappear.
+template <int ABL = 0, bool FOLD = true>   // ABL, timing-only ablations: 1 no weight loads inside the loops, 2 no second GEMM, 4 no GELU; 8 = s_memtime stamps per phase into a.dbg_ts
 __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
   const int bm = blockIdx.x * TM;
+  long long ts[8];
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (ABL & 8) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
+  stamp(0);
 
-  // ---------------------------------------------------------------- GEMM 1 (transposed): H^T[512][64] = W1[512][512] . [x | msg]^T
-  // token-tile staging: thread -> (row, 16-byte chunk) of the k-tile; k < 256 comes from x, k >= 256 from msg (both hm16, 1 KB rows)
+  // LDS: 16 slots of one k-tile each (64 token rows x 128 B, chunk c of row r at position c ^ swz(r)).  Slots 0..7 hold, in turn, the
+  // attention-output tile (operand of the folded out_proj) and the x tile; slots 8..15 the message tile; all 16 the hidden tile.
+  // token-tile staging: thread -> (row, 16-byte chunk) of a k-tile; all sources are hm16 rows of 256 values (1 KB)
   const int srow = tid >> 3, schunk = tid & 7;
-  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a.xp) + (size_t)(bm + srow) * 1024 + schunk * 16;
-  const unsigned char* msrc = reinterpret_cast<const unsigned char*>(a.mp) + (size_t)(bm + srow) * 1024 + schunk * 16;
+  const size_t soff = (size_t)(bm + srow) * 1024 + schunk * 16;
+  const unsigned char* const xsrc = reinterpret_cast<const unsigned char*>(a.xp) + soff;
+  const unsigned char* const msrc = reinterpret_cast<const unsigned char*>(FOLD ? a.cp : a.mp) + soff;   // ctx rows (FOLD) or msg rows
   const int sdst = srow * 128 + ((schunk ^ swz(srow)) * 16);
-  auto load_x = [&](int t) -> uint4 {
-    const int k0 = t * 32;
-    return *reinterpret_cast<const uint4*>(k0 < 256 ? xsrc + k0 * 4 : msrc + (k0 - 256) * 4);
-  };
-  // weight fragments: block ((tile * 32 + kstep) * 2 + term) of 64 uint4
-  const uint4* w1f = reinterpret_cast<const uint4*>(a.w1s) + lane;
-  f16x8 fa[2][2][2];   // [buffer][hidden tile][term]
-  auto load_a = [&](int buf, int kk) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        fa[buf][i][pl] = __builtin_bit_cast(f16x8, w1f[(size_t)(((2 * wave + i) * 32 + kk) * 2 + pl) * 64]);
-  };
-  // token fragments of k-step ks of a stage: lane (row 32 j + ql, hh), term pl -> chunk 4 ks + 2 pl + hh
+  // token fragments of k-step ks of a slot: lane (row 32 j + ql, hh), term pl -> chunk 4 ks + 2 pl + hh
   int brow[2], bsw[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) { brow[j] = (32 * j + ql) * 128; bsw[j] = swz(32 * j + ql); }
-  f16x8 fb[2][2];      // [token tile][term]
-  auto read_b = [&](const unsigned char* base, int ks) __attribute__((always_inline)) {
+  f16x8 fb[2][2][2];   // [buffer][token tile][term]: the fragments of k-step kk + 1 are read while k-step kk is on the matrix pipe
+  auto read_b = [&](int buf, const unsigned char* base, int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        fb[j][pl] = *reinterpret_cast<const f16x8*>(base + brow[j] + (((4 * ks + 2 * pl + hh) ^ bsw[j]) * 16));
+        fb[buf][j][pl] = *reinterpret_cast<const f16x8*>(base + brow[j] + (((4 * ks + 2 * pl + hh) ^ bsw[j]) * 16));
+  };
+  // a lane's accumulator registers 8 ks' .. 8 ks' + 7 of tile (., j) ARE one 16-byte B-operand fragment of a following transposed
+  // GEMM (whose weight columns are permuted to this order in the re-layout): publishing costs two ds_write_b128 per fragment
+  float amax = 0.f;
+  auto publish = [&](const f32x16& v, int slot, int j, float scale, const float* bias) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ksp = 0; ksp < 2; ++ksp) {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v8[e] = bias ? v[8 * ksp + e] * scale + bias[8 * ksp + e] : v[8 * ksp + e];
+        amax = fmaxf(amax, fabsf(v8[e]));
+      }
+      uint4 h4, m4;
+      split8(v8, h4, m4);
+      unsigned char* const base = smem + slot * KT + brow[j];
+      *reinterpret_cast<uint4*>(base + (((4 * ksp + hh) ^ bsw[j]) * 16)) = h4;
+      *reinterpret_cast<uint4*>(base + (((4 * ksp + 2 + hh) ^ bsw[j]) * 16)) = m4;
+    }
   };
 
+  // ---------------------------------------------------------------- prologue: the message side of the token tile
+  uint4 xr[3];
+  {
+    uint4 mt[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mt[q] = *reinterpret_cast<const uint4*>(msrc + q * 128);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) xr[q] = *reinterpret_cast<const uint4*>(xsrc + q * 128);      // first x k-tiles, written after the message phase
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(smem + ((FOLD ? 0 : 8) + q) * KT + sdst) = mt[q];
+  }
+  // weight fragments travel L2 -> registers with ~1-2 us of latency under load: rings of k-steps keep 16-24 KB per wave in flight;
+  // the slot of k-step kk is refilled as soon as its MFMAs are issued.  Every loop is fully unrolled and branch-free, so each
+  // s_waitcnt the compiler places is an exact count.
+  const uint4* w1f = reinterpret_cast<const uint4*>(a.w1s) + lane;
+  constexpr int RA = 6;
+  f16x8 fa[RA][2][2];   // [ring slot = k-step % RA][hidden tile][term]
+  // GEMM 1 visits the k-tiles in the order 8..15, 0..7 (message first: it is in LDS already): iteration n -> slot (n + 8) & 15
+  auto load_a = [&](int slot, int n2) __attribute__((always_inline)) {      // n2 = 2 * iteration + k-step
+    const int kk = (n2 + 16) & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        fa[slot][i][pl] = __builtin_bit_cast(f16x8, w1f[(size_t)(((2 * wave + i) * 32 + kk) * 2 + pl) * 64]);
+  };
+  if (FOLD) {
+    // ------------------------------------------------------------ GEMM 0 (transposed): Msg^T[256][64] = Wo[256][256] . Ctx^T; wave w: features 32 w ..
+    const uint4* wof = reinterpret_cast<const uint4*>(a.wos) + lane + (size_t)wave * 16 * 2 * 64;
+    constexpr int RO = 8;
+    f16x8 go[RO][2];
+#pragma unroll
+    for (int q = 0; q < RO; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) go[q][pl] = __builtin_bit_cast(f16x8, wof[(q * 2 + pl) * 64]);
+    f32x16 acc0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[j][r] = 0.f;
+    __syncthreads();
+    stamp(1);
+    read_b(0, smem, 0);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int cb = kk & 1;
+      if (kk + 1 < 16) read_b(cb ^ 1, smem + ((kk + 1) >> 1) * KT, (kk + 1) & 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(go[kk % RO][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc0[j], 0, 0, 0);
+      if (!(ABL & 1) && kk + RO < 16) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) go[kk % RO][pl] = __builtin_bit_cast(f16x8, wof[((kk + RO) * 2 + pl) * 64]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < RA; ++q) load_a(q, q);
+    // message = acc0 * scale + bias: feature 32 w + 8 g + 4 hh + c in register 4 g + c -> slot 8 + w
+    float bo[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + 32 * wave + 8 * g + 4 * hh);
+      bo[4 * g] = b4.x; bo[4 * g + 1] = b4.y; bo[4 * g + 2] = b4.z; bo[4 * g + 3] = b4.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) publish(acc0[j], 8 + wave, j, a.wo_scale, bo);
+    __syncthreads();     // message tile complete; every wave is done with the attention-output tile in slots 0..7
+  } else {
+#pragma unroll
+    for (int q = 0; q < RA; ++q) load_a(q, q);
+    __syncthreads();
+    stamp(1);
+  }
+
+  // ---------------------------------------------------------------- GEMM 1 (transposed): H^T[512][64] = W1[512][512] . [x | msg]^T
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -104,23 +195,19 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  constexpr int NT = 16;   // k-tiles of 32 (K = 512)
-  uint4 xr = load_x(0);
-  *reinterpret_cast<uint4*>(smem + sdst) = xr;
-  xr = load_x(1);
-  load_a(0, 0);
-  __syncthreads();
-#pragma unroll 1
-  for (int t = 0; t < NT; ++t) {
-    unsigned char* const cur = smem + (t & 1) * KT;
-    if (t + 1 < NT) *reinterpret_cast<uint4*>(smem + ((t + 1) & 1) * KT + sdst) = xr;   // tile t+1 (its stage was last read in iteration t-1)
-    if (t + 2 < NT) xr = load_x(t + 2);
+  // iterations 0..7 consume the message slots and, on the side, stage x k-tile n into slot n (loaded three iterations earlier);
+  // ONE barrier before iteration 8 makes the x slots readable
+  read_b(0, smem + 8 * KT, 0);
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    if (n < 8) {
+      *reinterpret_cast<uint4*>(smem + n * KT + sdst) = xr[n % 3];
+      if (n + 3 < 8) xr[n % 3] = *reinterpret_cast<const uint4*>(xsrc + (n + 3) * 128);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int kk = 2 * t + ks;
-      if (kk + 1 < 2 * NT) load_a((ks + 1) & 1, kk + 1);
-      read_b(cur, ks);
+      const int n2 = 2 * n + ks, slot = n2 % RA, cb = n2 & 1;
+      if (n2 + 1 < 32 && n2 + 1 != 16) read_b(cb ^ 1, smem + ((((n2 + 1) >> 1) + 8) & 15) * KT, (n2 + 1) & 1);
       // products: W_m X_h, W_h X_m, W_h X_h (small terms first); the four accumulators are visited round-robin
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -128,10 +215,14 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[slot][i][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+      if (!(ABL & 1) && n2 + RA < 32) load_a(slot, n2 + RA);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (n == 7) { __syncthreads(); read_b(0, smem, 0); }     // x tile complete (n2 + 1 == 16 is the one fragment set that could not be prefetched)
   }
+  __syncthreads();   // every wave is done with the token tile: its space is reused below
+  stamp(2);
 
   // ---------------------------------------------------------------- bias, LayerNorm(512) (two-pass, eps 1e-5), erf GELU -- in the accumulators
   // lane (ql, hh) holds, for tokens 32 j + ql, the hidden units  64 w + 32 i + 8 g + 4 hh + c   (register r = 4 g + c)
@@ -191,7 +282,6 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     for (int w8 = 0; w8 < 8; ++w8) t_ += stat2[w8 * TM + 32 * j + ql];
     rstd[j] = 1.0f / sqrtf(t_ * (1.0f / 512.0f) + 1e-5f);
   }
-  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -202,32 +292,22 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float y = gelu_erf(acc[i][j][4 * g + c] * rstd[j] * gm[c] + bt[c]);
+          const float yn = acc[i][j][4 * g + c] * rstd[j] * gm[c] + bt[c];
+          const float y = (ABL & 4) ? yn : gelu_erf(yn);
           acc[i][j][4 * g + c] = y;
-          amax = fmaxf(amax, fabsf(y));
         }
     }
-  ovf_commit(a.ovf, amax);
+  stamp(3);
 
-  // ---------------------------------------------------------------- publish the hidden tile: k-tile 2 w + i, rows = tokens, the lane's 8 values of
-  // k-step ks' (registers 8 ks' .. 8 ks' + 7) are one fragment (W2's columns are permuted to this order in the re-layout).
-  // (the token stages of GEMM 1 alias this region: every wave has passed the two barriers above, so nobody reads them any more)
+  // ---------------------------------------------------------------- publish the hidden tile: wave w's units 64 w + 32 i .. -> slot 2 w + i
+  // (the token tile of GEMM 1 occupied this region: every wave has passed the barriers above, so nobody reads it any more)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ksp = 0; ksp < 2; ++ksp) {
-        float v8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = acc[i][j][8 * ksp + e];
-        uint4 h4, m4;
-        split8(v8, h4, m4);
-        unsigned char* const base = smem + (2 * wave + i) * KT + brow[j];
-        *reinterpret_cast<uint4*>(base + (((4 * ksp + hh) ^ bsw[j]) * 16)) = h4;
-        *reinterpret_cast<uint4*>(base + (((4 * ksp + 2 + hh) ^ bsw[j]) * 16)) = m4;
-      }
+    for (int j = 0; j < 2; ++j) publish(acc[i][j], 2 * wave + i, j, 1.f, nullptr);
+  ovf_commit(a.ovf, amax);
   __syncthreads();
+  stamp(4);
 
   // ---------------------------------------------------------------- GEMM 2 (transposed): Y^T[256][64] = W2[256][512] . H^T;  wave w: output features 32 w ..
   const uint4* w2f = reinterpret_cast<const uint4*>(a.w2s) + lane + (size_t)wave * 32 * 2 * 64;
@@ -236,23 +316,33 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-  f16x8 ga[3][2];   // weight fragments, fetched two k-steps ahead
+  constexpr int RG = 8;
+  f16x8 ga[RG][2];   // weight fragments: a ring of eight k-steps (this loop has 6 MFMAs per k-step, so the same cover in cycles)
 #pragma unroll
-  for (int pl = 0; pl < 2; ++pl) { ga[0][pl] = __builtin_bit_cast(f16x8, w2f[(0 * 2 + pl) * 64]); ga[1][pl] = __builtin_bit_cast(f16x8, w2f[(1 * 2 + pl) * 64]); }
+  for (int q = 0; q < RG; ++q)
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) {
-    if (kk + 2 < 32) {
+    for (int pl = 0; pl < 2; ++pl) ga[q][pl] = __builtin_bit_cast(f16x8, w2f[(q * 2 + pl) * 64]);
+  if (!(ABL & 2)) {
+    read_b(0, smem, 0);
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) ga[(kk + 2) % 3][pl] = __builtin_bit_cast(f16x8, w2f[((kk + 2) * 2 + pl) * 64]);
+    for (int kk = 0; kk < 32; ++kk) {
+      const int cb = kk & 1;
+      if (kk + 1 < 32) read_b(cb ^ 1, smem + ((kk + 1) >> 1) * KT, (kk + 1) & 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[kk % RG][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc2[j], 0, 0, 0);
+      if (!(ABL & 1) && kk + RG < 32) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) ga[kk % RG][pl] = __builtin_bit_cast(f16x8, w2f[((kk + RG) * 2 + pl) * 64]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    read_b(smem + (kk >> 1) * KT, kk & 1);
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[kk % 3][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc2[j], 0, 0, 0);
   }
+  stamp(5);
   __syncthreads();   // the hidden tile is dead: its space becomes the [64 tokens][256 features] f32 tile of the row-wise epilogue
+  stamp(6);
 
   // ---------------------------------------------------------------- epilogue: + bias + residual x, hm16 (and optionally f32) rows
   float* const yt = reinterpret_cast<float*>(smem);
@@ -289,19 +379,40 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     ovf_track(amax2, v.x, v.y); ovf_track(amax2, v.z, v.w);
   }
   ovf_commit(a.ovf, amax2);
+  if (ABL & 8) {
+    stamp(7);
+    if (a.dbg_ts != nullptr && lane == 0)
+      for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * 8 + wave) * 8 + k] = ts[k];
+  }
 }
 }  // namespace
 
+int g_ffn_ablate = 0;   // developer knob 12: timing-only ablations of k_ffn_fused (wrong results)
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_ffn_fused, dim3(a.T / TM), dim3(512), 0, s, a);
+  const dim3 grid(a.T / TM), block(512);
+  if (a.cp == nullptr) {   // message rows from memory (separate out_proj launch)
+    hipLaunchKernelGGL((k_ffn_fused<0, false>), grid, block, 0, s, a);
+    return;
+  }
+  switch (g_ffn_ablate) {
+    case 1: hipLaunchKernelGGL((k_ffn_fused<1, true>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_ffn_fused<2, true>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_ffn_fused<3, true>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_ffn_fused<4, true>), grid, block, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((k_ffn_fused<7, true>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_ffn_fused<8, true>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_ffn_fused<0, true>), grid, block, 0, s, a); break;
+  }
 }
 
 // Weight re-layout into MFMA fragment order (host side, once per tensor at load time).
 //   w [N][K] f32 (row = output feature), scale = power of two applied before the fp16 split (the kernels multiply the
 //   accumulator by its inverse).  Block ((tile * (K / 16) + kstep) * 2 + term) holds, for lane l = (n = l & 31, hh = l >> 5),
 //   the 8 halfs  term( w[32 tile + n][16 kstep + kperm(hh, e)] ), e = 0..7:
-//     permute_k = 0: kperm = 8 hh + e                      (B operand read from an hm16 k-tile: natural order)
-//     permute_k = 1: kperm = (e & 3) + 4 hh + 8 (e >> 2)   (B operand = the accumulator registers of a preceding transposed GEMM)
+//     natural : kperm = 8 hh + e                      (B operand read from an hm16 k-tile as the producer kernel stored it)
+//     permuted: kperm = (e & 3) + 4 hh + 8 (e >> 2)   (B operand = the accumulator registers of a preceding transposed GEMM)
+//   permute_k = 0: natural everywhere; 1: permuted everywhere; 2: natural for k < K / 2, permuted for k >= K / 2 (ffn.0 with the
+//   message half produced in-kernel)
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out) {
   const int ksteps = K / 16;
   for (int tile = 0; tile < N / 32; ++tile)
@@ -309,7 +420,8 @@ void build_weight_fragments(const float* w, int N, int K, float scale, int permu
       for (int l = 0; l < 64; ++l) {
         const int n = l & 31, hh = l >> 5;
         for (int e = 0; e < 8; ++e) {
-          const int kp = permute_k ? (e & 3) + 4 * hh + 8 * (e >> 2) : 8 * hh + e;
+          const bool perm = permute_k == 1 || (permute_k == 2 && 16 * ks >= K / 2);
+          const int kp = perm ? (e & 3) + 4 * hh + 8 * (e >> 2) : 8 * hh + e;
           const float x = w[(size_t)(32 * tile + n) * K + 16 * ks + kp] * scale;
           const _Float16 h = (_Float16)x;
           const _Float16 m = (_Float16)(x - (float)h);

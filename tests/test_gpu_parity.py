@@ -573,8 +573,12 @@ def test_fused_ffn_launch_matches_the_two_launch_form(state_dict_np, state_dict_
         eng.lib.gn_debug_set_variant(eng.ctx, 10, mode)
         idx, score, n = (v.cpu().numpy().copy() for v in eng.match(*args))
         res[mode] = (idx, score, n, eng.debug_read("x", T * 256).copy())
-    eng.lib.gn_debug_set_variant(eng.ctx, 10, 3)
+    eng.lib.gn_debug_set_variant(eng.ctx, 13, 0)          # knob 13: the same kernel with out_proj as a separate GEMM launch (message rows from memory)
+    idx, score, n = (v.cpu().numpy().copy() for v in eng.match(*args))
+    i4, s4, n4, x4 = idx, score, n, eng.debug_read("x", T * 256).copy()
+    eng.lib.gn_debug_set_variant(eng.ctx, 13, 1)
     (i0, s0, n0, x0), (i2, s2, n2, x2), (i3, s3, n3, x3) = res[0], res[2], res[3]
+    assert np.array_equal(n0, n4) and _rel(x4, x0) < 3e-5 and all(np.array_equal(i0[b, : n0[b]], i4[b, : n4[b]]) for b in range(4))
     assert np.array_equal(n0, n2) and np.array_equal(n0, n3) and (n0 > 100).all()
     for b in range(4):
         assert np.array_equal(i0[b, : n0[b]], i2[b, : n2[b]]) and np.array_equal(i0[b, : n0[b]], i3[b, : n3[b]])
