@@ -224,6 +224,15 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   __syncthreads();   // every wave is done with the token tile: its space is reused below
   stamp(2);
 
+  // the second GEMM's first weight fragments are requested now, so that their latency hides behind LayerNorm + GELU
+  const uint4* w2f = reinterpret_cast<const uint4*>(a.w2s) + lane + (size_t)wave * 32 * 2 * 64;
+  constexpr int RG = 8;
+  f16x8 ga[RG][2];   // weight fragments: a ring of eight k-steps (that loop has 6 MFMAs per k-step, so the same cover in cycles)
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) ga[q][pl] = __builtin_bit_cast(f16x8, w2f[(q * 2 + pl) * 64]);
+
   // ---------------------------------------------------------------- bias, LayerNorm(512) (two-pass, eps 1e-5), erf GELU -- in the accumulators
   // lane (ql, hh) holds, for tokens 32 j + ql, the hidden units  64 w + 32 i + 8 g + 4 hh + c   (register r = 4 g + c)
   float* const stat1 = reinterpret_cast<float*>(smem + STAT);
@@ -310,18 +319,11 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   stamp(4);
 
   // ---------------------------------------------------------------- GEMM 2 (transposed): Y^T[256][64] = W2[256][512] . H^T;  wave w: output features 32 w ..
-  const uint4* w2f = reinterpret_cast<const uint4*>(a.w2s) + lane + (size_t)wave * 32 * 2 * 64;
   f32x16 acc2[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-  constexpr int RG = 8;
-  f16x8 ga[RG][2];   // weight fragments: a ring of eight k-steps (this loop has 6 MFMAs per k-step, so the same cover in cycles)
-#pragma unroll
-  for (int q = 0; q < RG; ++q)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) ga[q][pl] = __builtin_bit_cast(f16x8, w2f[(q * 2 + pl) * 64]);
   if (!(ABL & 2)) {
     read_b(0, smem, 0);
 #pragma unroll

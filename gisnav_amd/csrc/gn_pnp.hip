@@ -368,9 +368,10 @@ __device__ inline void epnp_Ab(const Shared& sh, const double be[4], double A[6]
   }
 }
 
-// min ||A x - b|| for a 6 x K system by Householder QR (no pivoting, like epnp.cpp's qr_solve; the
-// condition number is NOT squared as it would be with normal equations).  A vanishing column norm
-// zeroes that unknown.  Fully unrolled, wave-uniform.
+// epnp.cpp's own qr_solve (gauss_newton): Householder QR of a 6 x K system WITHOUT pivoting and without a rank test -- a
+// nearly dependent column gives a huge step, exactly as in OpenCV (the candidate then loses on reprojection error).  A column
+// that is exactly zero makes OpenCV's routine return early with X untouched: x keeps the caller's previous step.  Fully
+// unrolled, wave-uniform.
 template <int K>
 __device__ inline void lsq6(const double Ain[6][K], const double bin[6], double x[K]) {
   double A[6][K], b[6], rd[K];
@@ -380,18 +381,15 @@ __device__ inline void lsq6(const double Ain[6][K], const double bin[6], double 
 #pragma unroll
     for (int j = 0; j < K; ++j) A[i][j] = Ain[i][j];
   }
-  double scale = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < K; ++j) scale = fmax(scale, fabs(A[i][j]));
+  bool singular = false;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    double sigma = 0.0;
+    double sigma = 0.0, eta = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      if (i >= k) sigma += A[i][k] * A[i][k];
-    if (!(sigma > 1e-30 * scale * scale)) { rd[k] = 0.0; continue; }
+      if (i >= k) { sigma += A[i][k] * A[i][k]; if (i < 5 || k == 5) eta = fmax(eta, fabs(A[i][k])); }   // OpenCV's scan skips the last row
+    if (eta == 0.0) singular = true;
+    if (singular) { rd[k] = 1.0; continue; }
     const double akk = A[k][k];
     const double alpha = akk > 0 ? -sqrt(sigma) : sqrt(sigma);
     const double beta = 1.0 / (sigma - akk * alpha);
@@ -420,13 +418,75 @@ __device__ inline void lsq6(const double Ain[6][K], const double bin[6], double 
     }
     rd[k] = alpha;
   }
+  if (singular) return;
 #pragma unroll
   for (int k = K - 1; k >= 0; --k) {
     double v = b[k];
 #pragma unroll
     for (int j = 0; j < K; ++j)
       if (j > k) v -= A[k][j] * x[j];
-    x[k] = (rd[k] != 0.0) ? v / rd[k] : 0.0;
+    x[k] = v / rd[k];
+  }
+}
+
+// cvSolve(A, b, x, CV_SVD) for a 6 x K system, as find_betas_approx_{1,2,3} call it: minimum-norm least squares through the
+// SVD, singular values <= 2 DBL_EPSILON sum(w) treated as zero (cv::SVD::backSubst).  One-sided (Hestenes) Jacobi: the columns
+// of A are rotated pairwise until orthogonal, A V = U diag(w).  Fully unrolled per sweep, wave-uniform.
+template <int K>
+__device__ inline void svd_solve6(const double Ain[6][K], const double bin[6], double x[K]) {
+  double U[6][K], V[K][K];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) U[i][j] = Ain[i][j];
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < K - 1; ++p)
+#pragma unroll
+      for (int q = p + 1; q < K; ++q) {
+        double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { al += U[i][p] * U[i][p]; be += U[i][q] * U[i][q]; ga += U[i][p] * U[i][q]; }
+        if (fabs(ga) > 1e-16 * sqrt(al * be) && fabs(ga) > 1e-300) {
+          rotated = true;
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { const double up = U[i][p], uq = U[i][q]; U[i][p] = c * up - sn * uq; U[i][q] = sn * up + c * uq; }
+#pragma unroll
+          for (int i = 0; i < K; ++i) { const double vp = V[i][p], vq = V[i][q]; V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq; }
+        }
+      }
+    if (!rotated) break;
+  }
+  double w[K], wsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) n2 += U[i][k] * U[i][k];
+    w[k] = sqrt(n2); wsum += w[k];
+  }
+  const double thr = 2.0 * 2.220446049250313e-16 * wsum;
+#pragma unroll
+  for (int j = 0; j < K; ++j) x[j] = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (w[k] > thr) {
+      double ub = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ub += U[i][k] * bin[i];
+      const double f = ub / (w[k] * w[k]);
+#pragma unroll
+      for (int j = 0; j < K; ++j) x[j] += V[j][k] * f;
+    }
   }
 }
 
@@ -625,14 +685,14 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
       double A4[6][4], b4[4];
 #pragma unroll
       for (int i = 0; i < 6; ++i) { A4[i][0] = sh.L[i * 10 + 0]; A4[i][1] = sh.L[i * 10 + 1]; A4[i][2] = sh.L[i * 10 + 3]; A4[i][3] = sh.L[i * 10 + 6]; }
-      lsq6<4>(A4, rho, b4);
+      svd_solve6<4>(A4, rho, b4);
       if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
       else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
     } else if (cand == 1) {  // [B11 B12 B22]
       double A3[6][3], b3[3];
 #pragma unroll
       for (int i = 0; i < 6; ++i) { A3[i][0] = sh.L[i * 10 + 0]; A3[i][1] = sh.L[i * 10 + 1]; A3[i][2] = sh.L[i * 10 + 2]; }
-      lsq6<3>(A3, rho, b3);
+      svd_solve6<3>(A3, rho, b3);
       if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = b3[2] < 0 ? sqrt(-b3[2]) : 0.0; }
       else { be[0] = sqrt(b3[0]); be[1] = b3[2] > 0 ? sqrt(b3[2]) : 0.0; }
       if (b3[1] < 0) be[0] = -be[0];
@@ -642,15 +702,16 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int k = 0; k < 5; ++k) A5[i][k] = sh.L[i * 10 + k];
-      lsq6<5>(A5, rho, b5);
+      svd_solve6<5>(A5, rho, b5);
       if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = b5[2] < 0 ? sqrt(-b5[2]) : 0.0; }
       else { be[0] = sqrt(b5[0]); be[1] = b5[2] > 0 ? sqrt(b5[2]) : 0.0; }
       if (b5[1] < 0) be[0] = -be[0];
       be[2] = b5[3] / be[0];
     }
+    double x[4] = {0, 0, 0, 0};      // the step persists across iterations (qr_solve leaves X untouched on an exactly singular system)
 #pragma unroll 1
     for (int it = 0; it < 5; ++it) {  // gauss_newton
-      double A[6][4], b[6], x[4];
+      double A[6][4], b[6];
       epnp_Ab(sh, be, A, b);
       lsq6<4>(A, b, x);
 #pragma unroll

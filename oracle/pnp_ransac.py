@@ -200,8 +200,54 @@ def canonical_axis_signs(u: np.ndarray) -> np.ndarray:
     return u
 
 
-def _lstsq(A, b):
-    return np.linalg.lstsq(A, b, rcond=None)[0]
+def _svd_solve(A, b):
+    """cvSolve(A, b, x, CV_SVD) as epnp.cpp's find_betas_approx_{1,2,3} call it: minimum-norm least squares through the SVD,
+    singular values <= 2 * DBL_EPSILON * sum(w) treated as zero (cv::SVD::backSubst)."""
+    U, w, Vt = np.linalg.svd(A, full_matrices=False)
+    thr = 2.0 * DBL_EPSILON * float(np.sum(w))
+    x = np.zeros(A.shape[1])
+    for k in range(len(w)):
+        if abs(w[k]) > thr:
+            x += Vt[k] * (float(U[:, k] @ b) / w[k])
+    return x
+
+
+def _qr_solve(A, b, x_prev):
+    """epnp.cpp's own qr_solve (used by gauss_newton): Householder QR WITHOUT pivoting and without any rank test, columns scaled by
+    their largest entry (the scan that finds it skips the last row, as in the original).  A column that is exactly zero makes
+    the routine return early and leaves X as it was (the caller then adds the previous step again)."""
+    A = np.array(A, np.float64)
+    b = np.array(b, np.float64)
+    nr, nc = A.shape
+    A1, A2 = np.zeros(nc), np.zeros(nc)
+    for k in range(nc):
+        eta = abs(A[k, k])
+        for i in range(k + 1, nr):           # original: compares rows k .. nr-2 (the pointer is advanced after the compare)
+            eta = max(eta, abs(A[i - 1, k]))
+        if eta == 0:
+            return x_prev.copy()
+        sum2 = 0.0
+        for i in range(k, nr):
+            A[i, k] *= 1.0 / eta
+            sum2 += A[i, k] * A[i, k]
+        sigma = math.sqrt(sum2)
+        if A[k, k] < 0:
+            sigma = -sigma
+        A[k, k] += sigma
+        A1[k] = sigma * A[k, k]
+        A2[k] = -eta * sigma
+        for j in range(k + 1, nc):
+            tau = float(A[k:, k] @ A[k:, j]) / A1[k]
+            A[k:, j] -= tau * A[k:, k]
+    for j in range(nc):
+        tau = float(A[j:, j] @ b[j:]) / A1[j]
+        b[j:] -= tau * A[j:, j]
+    x = np.zeros(nc)
+    with np.errstate(all="ignore"):
+        x[nc - 1] = b[nc - 1] / A2[nc - 1]
+        for i in range(nc - 2, -1, -1):
+            x[i] = (b[i] - float(A[i, i + 1:] @ x[i + 1:])) / A2[i]
+    return x
 
 
 def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray]:
@@ -241,7 +287,7 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: O
     rho = np.array([np.sum((cws[a] - cws[b]) ** 2) for (a, b) in _PAIRS])
 
     def approx1():
-        b4 = _lstsq(L[:, [0, 1, 3, 6]], rho)
+        b4 = _svd_solve(L[:, [0, 1, 3, 6]], rho)
         if b4[0] < 0:
             b0 = math.sqrt(-b4[0])
             return np.array([b0, -b4[1] / b0, -b4[2] / b0, -b4[3] / b0])
@@ -249,7 +295,7 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: O
         return np.array([b0, b4[1] / b0, b4[2] / b0, b4[3] / b0])
 
     def approx2():
-        b3 = _lstsq(L[:, [0, 1, 2]], rho)
+        b3 = _svd_solve(L[:, [0, 1, 2]], rho)
         if b3[0] < 0:
             b0 = math.sqrt(-b3[0])
             b1 = math.sqrt(-b3[2]) if b3[2] < 0 else 0.0
@@ -261,7 +307,7 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: O
         return np.array([b0, b1, 0.0, 0.0])
 
     def approx3():
-        b5 = _lstsq(L[:, [0, 1, 2, 3, 4]], rho)
+        b5 = _svd_solve(L[:, [0, 1, 2, 3, 4]], rho)
         if b5[0] < 0:
             b0 = math.sqrt(-b5[0])
             b1 = math.sqrt(-b5[2]) if b5[2] < 0 else 0.0
@@ -274,6 +320,7 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: O
 
     def gauss_newton(betas):
         betas = betas.copy()
+        step = np.zeros(4)
         for _ in range(5):
             b0, b1, b2, b3 = betas
             A = np.column_stack([
@@ -284,7 +331,8 @@ def epnp(pws: np.ndarray, us: np.ndarray, fu=1.0, fv=1.0, uc=0.0, vc=0.0, dbg: O
             bb = rho - (L[:, 0] * b0 * b0 + L[:, 1] * b0 * b1 + L[:, 2] * b1 * b1 + L[:, 3] * b0 * b2
                         + L[:, 4] * b1 * b2 + L[:, 5] * b2 * b2 + L[:, 6] * b0 * b3 + L[:, 7] * b1 * b3
                         + L[:, 8] * b2 * b3 + L[:, 9] * b3 * b3)
-            betas = betas + _lstsq(A, bb)
+            step = _qr_solve(A, bb, step)
+            betas = betas + step
         return betas
 
     def r_and_t(betas):
