@@ -1,24 +1,40 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X PoseNode hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--kpts 1024] [--precision bf16_attn]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--kpts 1024] [--precision f16x2_bf16_attn]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the whole hot path -- RootSIFT, 9-layer LightGlue("sift") matcher, dual-softmax
-mutual-NN match head, matched-point gather + DEM lift, PnP-RANSAC + refinement -- over one batch of
-`--batch` synthetic 640x480 frame<->tile pairs (1024 SIFT keypoints per side) that are already resident
-in HBM.  Pairs are independent, so N ranks each process their own contiguous shard of N*batch pairs
-(weak scaling, no data-path collective); value = pairs all ranks processed / max-over-ranks time.
+A "step" is ONE pass of the whole hot path -- RootSIFT, 9-layer LightGlue("sift") matcher, dual-softmax mutual-NN match head,
+matched-point gather + DEM lift, PnP-RANSAC + refinement -- over one batch of `--batch` synthetic 640x480 frame<->tile pairs
+(1024 SIFT keypoints per side) that are already resident in HBM.  Pairs are independent, so N ranks each process their own
+contiguous shard of N*batch pairs (weak scaling, no data-path collective); value = pairs all ranks processed / max-over-ranks time.
 Rank 0 prints ONE JSON line.
+
+What the line reports, and where each number comes from:
+  value / ms_per_step   host clock around K steps, barrier + synchronize on both sides, max over ranks
+  end_to_end            value x 80.7 GFLOP (algorithmic work per pair, formula of SURVEY.md:405-408) against the 2.5 PF dense 16-bit MFMA peak
+  roofline              the DOMINANT kernel (largest share of the HIP-event time measured in this run, on the launch stream), by the
+                        name rocprofv3 prints for it: algorithmic flops per launch / average launch duration, against the same peak
+  kernels               the same for every timed kernel (joins row by row with profiles/*kernel_stats*.csv)
+  traffic               HBM bytes per step from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), collected by
+                        re-running this script under the profiler (N = 1 only; --no-traffic skips it), next to the compulsory bytes
+  extra_configs         further BASELINE configurations timed in the same process (batch-1 f32 = configs[1] as the survey reads it;
+                        batch-32 with exact-f32 MFMA GEMMs + bf16 attention = configs[2] without the split-fp16 GEMMs)
+  cpu_baseline          the CPU restatement of the reference on this box's host cores, bounded sample
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
 import platform
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,25 +48,143 @@ from gisnav_amd.engine import PoseEngine  # noqa: E402
 from gisnav_amd.synthetic import K_MATRIX, make_pair  # noqa: E402
 from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (the 2:1-sparsity figure is never used)
-PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
-GEMM_LAUNCHES_PER_STEP = 1 + 9 * 8 + 2  # input_proj + 9 x (4 proj + 2 x 2 ffn) + final_proj + sim
-ATTN_LAUNCHES_PER_STEP = 9 * 2           # one self + one (two-sided) cross attention launch per layer
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense (the 2:1-sparsity figure is never used)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
+MAX_TIMED_LAUNCHES_PER_STEP = 128
+
+
+def gflop_per_pair(n: int, m: int, d: int = 256, layers: int = 9, d_in: int = 128):
+    """Algorithmic work of one pair (2 x MACs), SURVEY.md:405-408; 80.7 GFLOP at n = m = 1024.  Attention part separately."""
+    macs = (n + m) * d_in * d + layers * ((n + m) * (4 * d * d + 6 * d * d) + (n + m) * (3 * d * d + 6 * d * d) + 2 * d * (n * n + m * m) + 3 * d * n * m) \
+        + (n + m) * d * d + d * n * m
+    attn = layers * (2 * d * (n * n + m * m) + 3 * d * n * m) + d * n * m
+    return 2.0 * macs / 1e9, 2.0 * attn / 1e9
+
+
+def compulsory_mb_per_pair(n: int, m: int) -> float:
+    """Compulsory HBM I/O of one pair (SURVEY.md:409-410): descriptors + keypoints in, matches / pose out; weights amortised over the batch."""
+    return ((n + m) * 128 * 4 + (n + m) * 4 * 4 + min(n, m) * (16 + 4) + 128) / 1e6
+
+
+def timed_steps(eng, inp, out, steps, warmup, dev, kernel_timing=False):
+    """W warm-up steps, then K steps bracketed by barrier + synchronize; returns (elapsed seconds max over ranks, this rank's seconds)."""
+    for _ in range(warmup):
+        eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush()
+    if kernel_timing:
+        eng.set_kernel_timing(MAX_TIMED_LAUNCHES_PER_STEP * steps)
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    gdist.barrier()
+    elapsed = time.perf_counter() - t0
+    return gdist.max_over_ranks(elapsed, dev), mine
+
+
+def kernel_rows(table, steps, precision):
+    """Per-kernel roofline rows from the HIP-event table of the run."""
+    total_ms = sum(r["ms"] for r in table) or 1.0
+    rows = []
+    for r in sorted(table, key=lambda r: -r["ms"]):
+        n = max(r["launches"], 1)
+        attn = r["name"].startswith("k_attn")
+        f32_pipe = r["name"].startswith("k_gemm_f32_v3") or r["name"].startswith("k_attn_f32")
+        peak = PEAK_F32_MFMA_TFLOPS if f32_pipe else PEAK_16BIT_MFMA_TFLOPS
+        mult = 1 if (attn or f32_pipe) else 6 if r["name"].startswith("k_gemm_f32x3") else 3   # matrix-pipe flops issued per algorithmic flop
+        tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+        rows.append({"name": r["name"], "launches_per_step": round(n / steps, 2), "avg_launch_us": round(r["ms"] * 1e3 / n, 2),
+                     "share_of_timed_kernel_time": round(r["ms"] / total_ms, 4),
+                     "algorithmic_gflop_per_launch": round(r["flops"] / n / 1e9, 3), "achieved_tflops": round(tf, 1),
+                     "peak_tflops": peak, "frac": round(tf / peak, 4),
+                     "mfma_flops_issued_per_algorithmic_flop": mult, "frac_of_issue_ceiling": round(tf * mult / peak, 4),
+                     "algorithmic_mb_per_launch": round(r["bytes"] / n / 1e6, 1)})
+    return rows
+
+
+def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
+    """HBM bytes per kernel from two rocprofv3 PMC passes over this same script (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass),
+    --kernel-trace only.  FETCH_SIZE counts 64 B per 128-B request on gfx950 for wide coalesced reads: doubled (MI355X_MICROARCH.md)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    work = tempfile.mkdtemp(prefix="gn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(steps_prof), "--warmup", str(warmup_prof), "--batch", str(args.batch), "--kpts", str(args.kpts), "--precision", args.precision,
+                   "--no-cpu-baseline", "--no-traffic", "--no-extras"]
+            for kv in args.debug_variant:
+                cmd += ["--debug-variant", kv]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+                        if "gn::" not in k:
+                            continue
+                        k = k.replace("void ", "").replace("gn::(anonymous namespace)::", "").replace("gn::", "").split("(")[0]
+                        v = float(row.get("Counter_Value") or row.get("Counter Value") or 0)
+                        e = per.setdefault(k, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                        e[counter][0] += v
+                        e[counter][1] += 1
+    except (subprocess.TimeoutExpired, OSError) as exc:
+        return None, f"rocprofv3 pass failed: {exc}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    n_steps = steps_prof + warmup_prof
+    kernels, total = {}, 0.0
+    for k, e in per.items():
+        f_kb, f_n = e["FETCH_SIZE"]
+        w_kb, w_n = e["WRITE_SIZE"]
+        n = max(f_n, w_n, 1)
+        by = (2.0 * f_kb + w_kb) * 1024.0           # counters are in KB; corrected fetch = 2 x FETCH_SIZE
+        kernels[k] = {"dispatches_per_step": round(n / n_steps, 2), "hbm_mb_per_launch": round(by / n / 1e6, 2)}
+        total += by / n_steps
+    return {"hbm_mb_per_step": round(total / 1e6, 1), "kernels": kernels,
+            "method": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {n_steps} steps of this script; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}, None
+
+
+def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev):
+    """One further configuration, timed like the main one (no per-kernel events, no collectives needed: every rank runs it)."""
+    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision=precision, state_dict=sd)
+    pairs = [make_pair(i, n_q=kpts, n_r=kpts) for i in range(batch)]
+    inp = eng.stage_inputs(pairs)
+    out = eng.alloc_outputs(batch)
+    torch.cuda.synchronize()
+    elapsed, _ = timed_steps(eng, inp, out, steps, warmup, dev)
+    ok = int(out["ok"].sum().item())
+    del eng
+    torch.cuda.empty_cache()
+    g, _ = gflop_per_pair(kpts, kpts)
+    pps = batch * steps / elapsed
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
+    return {"config": name, "batch": batch, "keypoints_per_side": kpts, "precision": precision, "steps": steps, "warmup": warmup,
+            "value": round(pps, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 4), "poses_ok_per_step": ok,
+            "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak}
 
 
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
-    """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this
-    box's host cores, on a bounded sample of the same workload."""
+    """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a
+    bounded sample of the same workload."""
     from oracle import lightglue_sift as lg
     from oracle import pnp_ransac as pr
-    # host threads actually used: the CPUs this process may run on, capped at 32 (beyond that the
-    # 1024x256-sized CPU GEMMs of one pair only lose time to synchronisation)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, 32)))
+    torch.set_num_threads(max(1, min(avail, 32)))   # beyond 32 threads the 1024x256-sized CPU GEMMs of one pair only lose time to synchronisation
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in state_dict.items()}
     tq = torch.from_numpy
     times, poses = [], 0
@@ -76,33 +210,6 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
                       f"cpu={platform.processor() or platform.machine()}"}
 
 
-def measured_gemm_traffic(precision: str):
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (bench.py cannot run under
-    the profiler itself); None if the summary is absent."""
-    name = {"f32x3_bf16_attn": "r01_pmc_hbm_traffic_f32x3.json", "f16x2_bf16_attn": "r01_pmc_hbm_traffic_f16x2.json"}.get(
-        precision, "r01_pmc_hbm_traffic.json")
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return int(d["k_gemm_f32_all_variants"]["hbm_bytes_per_launch_corrected"]), os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
-
-
-def measured_mfma_busy(precision: str):
-    """Matrix-pipe busy fraction of the dominant GEMM kernel from the committed PMC pass (call-weighted), or None."""
-    if precision != "f16x2_bf16_attn":
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy_f16x2.json")) as f:
-            ks = json.load(f)["kernels"]
-        rows = [(v["dispatches"], v["mfma_busy"]) for k, v in ks.items() if k.startswith("k_gemm")]
-        return round(sum(n * b for n, b in rows) / max(sum(n for n, _ in rows), 1), 4)
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,30 +219,35 @@ def main() -> None:
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (HBM bytes per step)")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (batch-1 f32, batch-32 exact-f32 GEMMs)")
     ap.add_argument("--overlap", action="store_true", help="run the PnP stage of step n on a second stream beside the matcher of step n+1 "
-                                                           "(gn_set_overlap; measured gain < 1 %: the 256-VGPR GEMM waves leave no room for co-resident PnP waves)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs)")
-    ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE", help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments)")
+                                                           "(gn_set_overlap; measured gain < 1 %%)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE",
+                    help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments; RECORDED in the JSON line, "
+                         "a line with a non-empty debug_variant is not a valid measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     rank, local_rank, world = gdist.init(args.backend)
     if args.share_gpu:
         local_rank = 0
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     # weights: seeded synthetic on rank 0, broadcast once over RCCL (no checkpoint is available offline)
     sd = synthetic_state_dict(0)
+    t_b = time.perf_counter()
     if world > 1:
         if rank != 0:
             sd = {k: np.zeros_like(v) for k, v in sd.items()}
         sd = gdist.broadcast_state_dict(sd, dev, src=0)
+        torch.cuda.synchronize()
+    broadcast_ms = (time.perf_counter() - t_b) * 1e3
     eng = PoseEngine(local_rank, max_batch=args.batch, max_kpts=args.kpts, precision=args.precision, state_dict=sd)
-
     for kv in args.debug_variant:
         which, value = (int(v) for v in kv.split(":"))
         eng.lib.gn_debug_set_variant(eng.ctx, which, value)
@@ -143,63 +255,49 @@ def main() -> None:
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
     shard = gdist.shard_range(args.batch * world, rank, world)
     pairs = [make_pair(i, n_q=args.kpts, n_r=args.kpts) for i in shard]
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
     inp = eng.stage_inputs(pairs)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t_h) * 1e3     # host packing + PCIe upload of one batch (pageable host memory): what a per-message caller pays
     out = eng.alloc_outputs(len(pairs))
-    torch.cuda.synchronize()
-
     if args.overlap:
-        eng.set_overlap(True)      # PnP of step n beside the matcher of step n+1 (HIP streams); flushed before the closing sync
-    for _ in range(args.warmup):
-        eng.estimate(inp, K_MATRIX, out=out)
-    eng.flush()
-    eng.set_kernel_timing((GEMM_LAUNCHES_PER_STEP + ATTN_LAUNCHES_PER_STEP) * args.steps)
-    gdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.estimate(inp, K_MATRIX, out=out)
-    eng.flush()
-    torch.cuda.synchronize()
-    gdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = gdist.max_over_ranks(elapsed, dev)
-    kstats = eng.kernel_stats(0)
-    astats = eng.kernel_stats(1)
-    eng.set_kernel_timing(0)
+        eng.set_overlap(True)
 
-    n_ok = float(out["ok"].sum().item())
-    n_ok_all = gdist.sum_over_ranks(n_ok, dev)
+    elapsed, mine = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=True)
+    table = eng.kernel_table()
+    eng.set_kernel_timing(0)
+    tripped, trips = eng.guard_status()
+
+    n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
     n_match_mean = float(out["n_match"].float().mean().item())
     rec = gdist.gather_records(gdist.pack_records(shard.start, out))  # fixed-size result records, 128 B/pair
+    per_rank_ms = gdist.gather_records(torch.tensor([[mine / args.steps * 1e3] + [0.0] * 15], dtype=torch.float64, device=dev))[:, 0].cpu().tolist()
+    del eng
+    torch.cuda.empty_cache()
+
+    extras = []
+    if not args.no_extras and not args.debug_variant:
+        extras.append(run_extra(local_rank, sd, "BASELINE configs[1] as SURVEY.md reads it: batch-1 640x480 pair, f32 everywhere (exact-f32 MFMA GEMMs and attention)",
+                                1, args.kpts, "f32", 30, 5, dev))
+        extras.append(run_extra(local_rank, sd, "BASELINE configs[2] with exact-f32 MFMA projections/FFN (no fp16 split) + bf16 MFMA attention",
+                                args.batch, args.kpts, "bf16_attn", 6, 2, dev))
+        extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
+                                1, args.kpts, args.precision, 30, 5, dev))
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps
         pairs_per_s = total_pairs / elapsed
-        ach = kstats["flops"] / (kstats["ms"] * 1e-3) / 1e12 if kstats["ms"] > 0 else 0.0
-        x3 = args.precision == "f32x3_bf16_attn"
-        h2 = args.precision == "f16x2_bf16_attn"
-        mult = 6 if x3 else 3 if h2 else 1      # matrix-pipe flops issued per algorithmic flop
-        peak = PEAK_BF16_MFMA_TFLOPS / mult if (x3 or h2) else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = measured_gemm_traffic(args.precision) if (args.batch == 32 and args.kpts == 1024) else (None, None)
-        # which roof binds these launches: arithmetic intensity (algorithmic flops per compulsory HBM byte) x 8 TB/s against the matrix pipe
-        alg_bytes = kstats["bytes"] / max(kstats["launches"], 1)
-        alg_flops = kstats["flops"] / max(kstats["launches"], 1)
-        intensity = alg_flops / max(alg_bytes, 1.0)
-        hbm_roof_tflops = intensity * PEAK_HBM_GBS * 1e9 / 1e12
-        gbs = kstats["bytes"] / (kstats["ms"] * 1e-3) / 1e9 if kstats["ms"] > 0 else 0.0
-        if hbm_roof_tflops < peak:
-            gemm_roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                         "note": (f"the GEMMs of this path are skinny (K, N in 256..768): {intensity:.0f} algorithmic flops per compulsory HBM byte puts their "
-                                  f"HBM roof at {hbm_roof_tflops:.0f} TFLOP/s, below the {peak:.0f} TFLOP/s matrix-pipe roof, so HBM is the binding roof; "
-                                  "achieved = algorithmic bytes (A, W, every output array, residual rows, rotary tables -- each once) / HIP-event time; the 18 ffn.0 launches "
-                                  "of a step also carry LayerNorm + GELU in their epilogue (k_gemm_p2ln), work that is not counted as bytes or flops"),
-                         "algorithmic_mb_per_launch": round(alg_bytes / 1e6, 1), "flops_per_byte": round(intensity, 1),
-                         "hbm_roof_tflops": round(hbm_roof_tflops, 1)}
-        else:
-            gemm_roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "note": f"matrix-pipe roof {peak:.0f} TFLOP/s is below the HBM roof ({intensity:.0f} flops per byte x 8 TB/s = {hbm_roof_tflops:.0f} TFLOP/s)",
-                         "algorithmic_mb_per_launch": round(alg_bytes / 1e6, 1), "flops_per_byte": round(intensity, 1),
-                         "hbm_roof_tflops": round(hbm_roof_tflops, 1), "achieved_gbs": round(gbs, 1)}
+        g_pair, g_attn = gflop_per_pair(args.kpts, args.kpts)
+        f32_all = args.precision == "f32"
+        e2e_peak = PEAK_F32_MFMA_TFLOPS if f32_all else PEAK_16BIT_MFMA_TFLOPS
+        e2e_tf = pairs_per_s / world * g_pair / 1e3          # per GPU
+        rows = kernel_rows(table, args.steps, args.precision)
+        dom = rows[0] if rows else None
+        traffic, traffic_err = (None, "skipped")
+        if not args.no_traffic and world == 1:
+            traffic, traffic_err = measure_traffic(args)
+        comp_mb = compulsory_mb_per_pair(args.kpts, args.kpts) * args.batch + 47.5   # + the f32 weights once per step (cache-resident in practice)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
             "value": round(pairs_per_s, 2),
@@ -217,8 +315,10 @@ def main() -> None:
                                          "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)",
                       "f16x2_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
                                          "significant bits, 3 fp16 MFMA partial products, f32 accumulate; error vs fp64 <= the f32 "
-                                         "MFMA path's) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
+                                         "MFMA path's; fp16-range guard active) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
             "data": "synthetic",
+            "inputs_resident": True,
+            "debug_variant": list(args.debug_variant),
             "config": {
                 "workload": f"BASELINE {'configs[1] (batch-1' if args.batch == 1 else 'configs[2]/[3] (batch-' + str(args.batch)} per GPU): "
                             f"640x480 pairs, {args.kpts} SIFT kpts/side, "
@@ -230,38 +330,49 @@ def main() -> None:
                 "parallelism": f"pair-sharded x{world} (no data-path collective)",
                 "pose_stage_overlap": bool(args.overlap),
                 "weights": "seeded synthetic, kornia sift_lightglue state-dict layout",
+                "same_staged_batch_every_step": True,
             },
             "poses_per_s": round(n_ok_all * args.steps / elapsed, 2),
             "poses_ok_per_step": int(n_ok_all),
             "mean_matches_per_pair": round(n_match_mean, 1),
             "result_records_gathered": int(rec.shape[0]),
-            "roofline": {
-                "kernel": ("k_gemm_f32x3 (projection/FFN/similarity GEMM: 3 x bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)"
-                           if x3 else "k_gemm_f16x2 (projection/FFN/similarity GEMM: 2 x fp16 split, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block)"
-                           if h2 else "k_gemm_f32_v3 (projection/FFN/similarity GEMM on v_mfma_f32_32x32x2_f32)"),
-                **gemm_roof,
-                "matrix_pipe": {"achieved_tflops": round(ach, 2), "peak_tflops": round(peak, 1), "frac": round(ach / peak, 4),
-                                "note": (f"algorithmic 2*M*N*K flops / HIP-event time; the kernel issues {mult} 16-bit MFMA flops per algorithmic "
-                                         f"flop, so the matrix-pipe ceiling is 2500 TF dense / {mult}"
-                                         if (x3 or h2) else "algorithmic 2*M*N*K flops / HIP-event time vs the f32 MFMA peak")},
-                "executed_mfma_tflops": round(ach * mult, 1),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "mfma_busy_pmc": measured_mfma_busy(args.precision) if (args.batch == 32 and args.kpts == 1024) else None,
-                "launches_timed": int(kstats["launches"]),
-                "avg_launch_us": round(kstats["ms"] * 1e3 / max(kstats["launches"], 1), 2),
-                "algorithmic_gflop_per_launch": round(kstats["flops"] / max(kstats["launches"], 1) / 1e9, 3),
-            },
+            "f16x2_guard": {"tripped_in_last_step": bool(tripped), "trips_observed": int(trips)},
+            "end_to_end": {"algorithmic_gflop_per_pair": round(g_pair, 2), "attention_gflop_per_pair": round(g_attn, 2),
+                           "achieved_tflops_per_gpu": round(e2e_tf, 1), "peak_tflops": e2e_peak, "frac": round(e2e_tf / e2e_peak, 4),
+                           "attention_only_frac": round(pairs_per_s / world * g_attn / 1e3 / e2e_peak, 4),
+                           "ceiling_pairs_per_s_per_gpu": round(e2e_peak * 1e3 / g_pair, 0),
+                           "note": "SURVEY.md 8(d): achieved = pairs/s x algorithmic GFLOP per pair; peak = dense 16-bit MFMA (f32 MFMA in the f32 mode)"},
+            "pcie_inclusive": {"stage_inputs_ms_per_batch": round(h2d_ms, 3),
+                               "pairs_per_s": round(args.batch * world / (elapsed / args.steps + h2d_ms * 1e-3), 2),
+                               "note": "one synchronous host-pack + H2D of the batch (1.1 MB/pair, pageable memory) added to every step: the reference's per-message "
+                                       "boundary (pose_node.py:254-265); never `value`"},
+            "multi_gpu": {"per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "weight_broadcast_ms": round(broadcast_ms, 2) if world > 1 else None},
         }
-        a_ach = astats["flops"] / (astats["ms"] * 1e-3) / 1e12 if astats["ms"] > 0 else 0.0
-        a_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
-        line["roofline_attention"] = {   # second-largest kernel; the QK^T / PV contractions north_star singles out
-            "kernel": "k_attn_f32" if args.precision == "f32" else "k_attn_bf16_v5",
-            "bound": "mfma", "achieved": round(a_ach, 2), "peak": a_peak, "unit": "TFLOP/s", "frac": round(a_ach / a_peak, 4),
-            "launches_timed": int(astats["launches"]),
-            "avg_launch_us": round(astats["ms"] * 1e3 / max(astats["launches"], 1), 2),
-            "algorithmic_gflop_per_launch": round(astats["flops"] / max(astats["launches"], 1) / 1e9, 3),
-        }
+        if dom is not None:
+            dom_traffic = None
+            if traffic is not None:
+                hit = traffic["kernels"].get(dom["name"]) or next((v for k, v in traffic["kernels"].items() if k.startswith(dom["name"].rstrip("<("))), None)
+                dom_traffic = int(hit["hbm_mb_per_launch"] * 1e6) if hit else None
+            line["roofline"] = {
+                "kernel": dom["name"], "bound": "mfma",
+                "achieved": dom["achieved_tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s", "frac": dom["frac"],
+                "traffic": dom_traffic,
+                "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
+                "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
+                "share_of_timed_kernel_time": dom["share_of_timed_kernel_time"],
+                "mfma_flops_issued_per_algorithmic_flop": dom["mfma_flops_issued_per_algorithmic_flop"],
+                "frac_of_issue_ceiling": dom["frac_of_issue_ceiling"],
+                "note": "achieved = algorithmic flops per launch (2 x M x N x K of the GEMMs inside the kernel) / average launch duration from HIP events recorded "
+                        "around every launch on the launch stream in THIS run; peak = dense 16-bit MFMA.  The split-fp16 arithmetic issues 3 MFMA flops per "
+                        "algorithmic flop, so the kernel's own issue ceiling is peak / 3 (frac_of_issue_ceiling).  `kernel` is the name rocprofv3 prints "
+                        "(profiles/*kernel_stats*.csv)."}
+        line["kernels"] = rows
+        line["traffic"] = {"compulsory_mb_per_step": round(comp_mb, 1),
+                           "measured_hbm_mb_per_step": traffic["hbm_mb_per_step"] if traffic else None,
+                           "ratio": round(traffic["hbm_mb_per_step"] / comp_mb, 1) if traffic else None,
+                           "per_kernel": traffic["kernels"] if traffic else None,
+                           "method": traffic["method"] if traffic else f"not measured: {traffic_err}"}
+        line["extra_configs"] = extras
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, args.kpts)
         print(json.dumps(line), flush=True)

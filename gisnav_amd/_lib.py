@@ -66,6 +66,7 @@ SIGNATURES = {
     "gn_set_kernel_timing": (C.c_int, [VP, C.c_int]),
     "gn_get_kernel_stats": (C.c_int, [VP, C.c_int, c_f64p]),
     "gn_get_kernel_bytes": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double)]),
+    "gn_get_kernel_table": (C.c_int, [VP, C.c_char_p, C.c_int]),
 }
 
 STAGE_NAMES = ("prep", "proj", "attn", "ffn", "head", "gather", "pnp")

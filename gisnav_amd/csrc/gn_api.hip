@@ -107,6 +107,7 @@ struct gn_ctx {
   std::vector<double> kflops;       // algorithmic flops of each recorded launch
   std::vector<double> kbytes;       // algorithmic HBM bytes of each recorded launch (operands in, results out, each once)
   std::vector<int> kclass;          // 0 = projection/FFN/similarity GEMM, 1 = attention
+  std::vector<const char*> kname;   // rocprof-style kernel name of each recorded launch (gn::g_last_kernel)
   size_t kused = 0;
 };
 
@@ -222,6 +223,7 @@ void timed_gemm(gn_ctx* c, int epi, const GemmArgs& g_in, int batch, hipStream_t
       c->kbytes[c->kused] = by;
     }
     c->kclass[c->kused] = 0;
+    c->kname[c->kused] = gn::g_last_kernel;
     ++c->kused;
   }
 }
@@ -296,6 +298,7 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
     c->kflops[c->kused] = 4.0 * a.BS * kHeads * (double)a.npad * a.npad * kHeadDim;
     c->kbytes[c->kused] = (double)a.BS * a.npad * kDim * (a.qb ? 2.0 + 2.0 + 2.0 : 12.0) + (double)a.BS * a.npad * kDim * 4.0;   // q, k, v in; context rows out
     c->kclass[c->kused] = 1;
+    c->kname[c->kused] = gn::g_last_kernel;
     ++c->kused;
   }
 }
@@ -326,6 +329,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
       c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + (fold ? 256.0 * 256.0 : 0.0));
       c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
       c->kclass[c->kused] = 0;
+      c->kname[c->kused] = gn::g_last_kernel;
       ++c->kused;
     }
     return;
@@ -1310,7 +1314,7 @@ int gn_set_kernel_timing(gn_ctx* ctx, int max_launches) {
   while ((int)ctx->kflops.size() < max_launches) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return GN_ERR_HIP;
-    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0); ctx->kbytes.push_back(0.0); ctx->kclass.push_back(0);
+    ctx->kev.push_back(a); ctx->kev.push_back(b); ctx->kflops.push_back(0.0); ctx->kbytes.push_back(0.0); ctx->kclass.push_back(0); ctx->kname.push_back("");
   }
   ctx->ktiming = max_launches > 0;
   ctx->kused = 0;
@@ -1330,6 +1334,35 @@ int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3) {
   }
   out3[0] = n; out3[1] = ms; out3[2] = fl;
   return GN_OK;
+}
+
+// Per-kernel table of the recorded launches as a JSON array (HIP-event time on the launch stream, algorithmic flops and bytes):
+// [{"name": "k_ffn_fused<0, true>", "launches": n, "ms": total, "flops": total, "bytes": total}, ...].  Names are the ones
+// rocprofv3's kernel_stats rows carry (namespace prefix and argument list stripped).  Returns the length written, or a negative status.
+int gn_get_kernel_table(gn_ctx* ctx, char* json, int capacity) {
+  if (!ctx || !json || capacity < 64) return GN_ERR_ARG;
+  hipSetDevice(ctx->device);
+  std::map<std::string, std::vector<double>> tab;   // name -> {launches, ms, flops, bytes}
+  for (size_t i = 0; i < ctx->kused; ++i) {
+    if (hipEventSynchronize(ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ctx->kev[2 * i], ctx->kev[2 * i + 1]) != hipSuccess) return GN_ERR_HIP;
+    std::vector<double>& v = tab[ctx->kname[i] ? ctx->kname[i] : "?"];
+    if (v.empty()) v.assign(4, 0.0);
+    v[0] += 1.0; v[1] += t; v[2] += ctx->kflops[i]; v[3] += ctx->kbytes[i];
+  }
+  std::string out = "[";
+  bool first = true;
+  for (const auto& kv : tab) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"launches\": %.0f, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+             kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2], kv.second[3]);
+    out += buf; first = false;
+  }
+  out += "]";
+  if ((int)out.size() + 1 > capacity) return GN_ERR_ARG;
+  memcpy(json, out.c_str(), out.size() + 1);
+  return (int)out.size();
 }
 
 int gn_get_kernel_bytes(gn_ctx* ctx, int kernel_class, double* out1) {

@@ -538,11 +538,13 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
   dim3 grid(a.npad / QB, kHeads, a.BS), block(256);
   hipLaunchKernelGGL(k_attn_f32, grid, block, 0, s, a);
+  g_last_kernel = "k_attn_f32(";
 }
 
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
   dim3 grid(a.npad / QB, kHeads, a.BS), block(256);
   hipLaunchKernelGGL(k_attn_bf16, grid, block, 0, s, a);
+  g_last_kernel = "k_attn_bf16(";
 }
 
 }  // namespace gn
@@ -550,6 +552,7 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 namespace gn {
 int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
+  g_last_kernel = "k_attn_bf16_v5<0, 4, 3>";
   if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
     dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
     switch (g_attn_variant) {

@@ -394,6 +394,7 @@ void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
   const dim3 grid(a.T / TM), block(512);
   if (a.cp == nullptr) {   // message rows from memory (separate out_proj launch)
     hipLaunchKernelGGL((k_ffn_fused<0, false>), grid, block, 0, s, a);
+    g_last_kernel = "k_ffn_fused<0, false>";
     return;
   }
   switch (g_ffn_ablate) {
@@ -405,6 +406,7 @@ void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
     case 8: hipLaunchKernelGGL((k_ffn_fused<8, true>), grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL((k_ffn_fused<0, true>), grid, block, 0, s, a); break;
   }
+  g_last_kernel = "k_ffn_fused<0, true>";
 }
 
 // Weight re-layout into MFMA fragment order (host side, once per tensor at load time).

@@ -991,6 +991,7 @@ void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s) {
 }
 
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
+  g_last_kernel = g_gemm_variant == 5 || (g_gemm_variant >= 50 && g_gemm_variant < 60) ? "k_gemm_f32x3<" : g_gemm_variant >= 6 ? "k_gemm_f16x2<" : "k_gemm_f32_v3<";
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
   if (g_gemm_variant == 4 && epi == EPI_BIAS) {
     hipLaunchKernelGGL((k_gemm_f32_v3<EPI_BIAS, false>), grid, block, 0, s, a);

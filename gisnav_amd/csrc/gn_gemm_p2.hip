@@ -700,12 +700,14 @@ __global__ __launch_bounds__(512) void k_gemm_p2ln(GemmArgs a) {
 }
 }  // namespace
 
+const char* g_last_kernel = "";
 int g_p2_wide = 1;   // developer knob: 0 = always the 128x128 kernel
 
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   if (epi == EPI_LN_GELU) {   // ffn.0 + LayerNorm + GELU (caller guarantees N == 512, M % 128 == 0, hm16 output)
     dim3 grid(1, a.M / LBM, batch), block(512);
     hipLaunchKernelGGL((k_gemm_p2ln<0>), grid, block, 0, s, a);
+    g_last_kernel = "k_gemm_p2ln<0>";
     return;
   }
   if (g_p2_wide >= 2 && epi == EPI_BIAS && a.M % WBM == 0 && a.N % WBN == 0) {   // timing-only ablations of the wide kernel
@@ -729,6 +731,8 @@ void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
       default: hipLaunchKernelGGL((k_gemm_p2w<EPI_PLAIN>), grid, block, 0, s, a); break;
     }
 #undef P2W_CASE
+    static const char* const wn[7] = {"k_gemm_p2w<0, 0>", "k_gemm_p2w<1, 0>", "k_gemm_p2w<2, 0>", "k_gemm_p2w<3, 0>", "k_gemm_p2w<4, 0>", "k_gemm_p2w<5, 0>", "k_gemm_p2w<6, 0>"};
+    g_last_kernel = wn[epi >= 0 && epi < 7 ? epi : 4];   // the names rocprofv3 prints (template arguments as integers)
     return;
   }
   dim3 grid(a.N / BN, a.M / BM, batch), block(256);
@@ -739,6 +743,8 @@ void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {
     default: hipLaunchKernelGGL((k_gemm_p2<EPI_PLAIN>), grid, block, 0, s, a); break;
   }
 #undef P2_CASE
+  static const char* const nn[7] = {"k_gemm_p2<0>", "k_gemm_p2<1>", "k_gemm_p2<2>", "k_gemm_p2<3>", "k_gemm_p2<4>", "k_gemm_p2<5>", "k_gemm_p2<6>"};
+  g_last_kernel = nn[epi >= 0 && epi < 7 ? epi : 4];
 }
 
 }  // namespace gn

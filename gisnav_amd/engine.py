@@ -322,6 +322,14 @@ class PoseEngine:
         _lib.check(self.ctx, self.lib.gn_get_kernel_bytes(self.ctx, kernel_class, C.byref(by)), "gn_get_kernel_bytes")
         return {"launches": buf[0], "ms": buf[1], "flops": buf[2], "bytes": by.value}
 
+    def kernel_table(self):
+        """[{name, launches, ms, flops, bytes}] of the launches recorded since set_kernel_timing (HIP events on the launch stream)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.gn_get_kernel_table(self.ctx, buf, len(buf))
+        _lib.check(self.ctx, n, "gn_get_kernel_table")
+        return json.loads(buf.value.decode())
+
     def debug_gemm(self, A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         M, K = A.shape
         N = W.shape[0]

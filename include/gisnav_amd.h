@@ -288,6 +288,9 @@ int gn_set_kernel_timing(gn_ctx* ctx, int max_launches);
 int gn_get_kernel_stats(gn_ctx* ctx, int kernel_class, double* out3);
 /* summed ALGORITHMIC HBM bytes of the same launches (every operand / result array once: the compulsory traffic). */
 int gn_get_kernel_bytes(gn_ctx* ctx, int kernel_class, double* out1);
+/* Per-kernel table of the launches recorded since gn_set_kernel_timing, as a JSON array in `json` (capacity bytes):
+ * [{"name", "launches", "ms", "flops", "bytes"}, ...] with rocprofv3-style kernel names; returns the length or a negative status. */
+int gn_get_kernel_table(gn_ctx* ctx, char* json, int capacity);
 
 #ifdef __cplusplus
 }
