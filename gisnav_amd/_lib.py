@@ -23,6 +23,8 @@ SIGNATURES = {
     "gn_version": (C.c_char_p, []),
     "gn_last_error": (C.c_char_p, [VP]),
     "gn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
+    "gn_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
+    "gn_set_image_size": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_float]),
     "gn_destroy": (None, [VP]),
     "gn_load_tensor": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
     "gn_missing_tensors": (C.c_int, [VP]),
@@ -75,6 +77,8 @@ GN_PREC_F32 = 0
 GN_PREC_BF16_ATTN = 1
 GN_PREC_F32X3_BF16_ATTN = 2
 GN_PREC_F16X2_BF16_ATTN = 3
+GN_FEATURE_SIFT = 0
+GN_FEATURE_SUPERPOINT = 1
 GN_KPT_LAF = 0
 GN_KPT_XYSA = 1
 

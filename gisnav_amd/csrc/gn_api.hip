@@ -40,6 +40,8 @@ struct gn_ctx {
   unsigned int* ovf = nullptr; unsigned int* ovf_host = nullptr;   // device word, pinned host mirror
   int guard = 1;           // 0 off, 1 flag (a tripped call reports zero matches), 2 flag + synchronous re-run in the f32x3 mode
   long long guard_trips = 0;   // calls that tripped (counted when observed: guard 2, or gn_get_guard_status)
+  int feature = 0;         // GN_FEATURE_SIFT / GN_FEATURE_SUPERPOINT (gn_create_ex)
+  float size_q[2] = {0.f, 0.f}, size_r[2] = {0.f, 0.f};   // gn_set_image_size: (w, h) per side for the keypoint normalisation, 0 = keypoint extent
   int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
   int n_layers = kMaxLayers;
   float threshold = 0.5f;
@@ -372,11 +374,19 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     p.desc_r = desc_r; p.kpt_r = kpt_r; p.n_r = n_r; p.stride_r = stride_r;
     p.kpt_format = kpt_format; p.B = B; p.npad = np; p.wr = c->wr;
     p.desc = c->desc; p.kxy = nullptr; p.cos_t = c->cos_t; p.sin_t = c->sin_t; p.nvalid = c->nvalid; p.extent = c->extent;
-    launch_prep(p, s);
-    if (c->planes_mode) launch_split_hm16(c->desc, c->desc_p, T, kInDim, 1.0f, s);
-    GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
-    g.drop_f32 = (c->planes_mode && c->x_planes_only && c->n_layers > 0) ? 1 : 0;
-    gemm(c, EPI_BIAS, g, s);
+    p.size_q[0] = c->size_q[0]; p.size_q[1] = c->size_q[1]; p.size_r[0] = c->size_r[0]; p.size_r[1] = c->size_r[1];
+    p.feature = c->feature; p.x = nullptr; p.xp = nullptr;
+    const bool planes_only = c->planes_mode && c->x_planes_only && c->n_layers > 0;
+    if (c->feature == 1) {   // 256-d descriptors ARE the initial residual stream (no input_proj)
+      p.x = planes_only ? nullptr : c->x; p.xp = c->planes_mode ? c->x_p : nullptr;
+      launch_prep(p, s);
+    } else {
+      launch_prep(p, s);
+      if (c->planes_mode) launch_split_hm16(c->desc, c->desc_p, T, kInDim, 1.0f, s);
+      GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
+      g.drop_f32 = planes_only ? 1 : 0;
+      gemm(c, EPI_BIAS, g, s);
+    }
   }
   for (int i = 0; i < c->n_layers; ++i) {
     {  // SelfBlock on both sides at once
@@ -483,6 +493,16 @@ const char* gn_version(void) { return "gisnav_amd 0.2.0 gfx950"; }
 const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out) {
+  return gn_create_ex(device, max_batch, max_kpts, precision, GN_FEATURE_SIFT, out);
+}
+
+int gn_set_image_size(gn_ctx* ctx, float w_q, float h_q, float w_r, float h_r) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->size_q[0] = w_q; ctx->size_q[1] = h_q; ctx->size_r[0] = w_r; ctx->size_r[1] = h_r;
+  return GN_OK;
+}
+
+int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int feature, gn_ctx** out) {
   gn_ctx* ctx = nullptr;
   if (!out || max_batch < 1 || max_kpts < 2) return fail(nullptr, GN_ERR_ARG, "bad gn_create argument");
   if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN && precision != GN_PREC_F32X3_BF16_ATTN &&
@@ -494,7 +514,8 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, GN_ERR_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   ctx = new gn_ctx();
-  ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision;
+  if (feature != GN_FEATURE_SIFT && feature != GN_FEATURE_SUPERPOINT) { delete ctx; return fail(nullptr, GN_ERR_ARG, "bad feature type"); }
+  ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision; ctx->feature = feature;
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   ctx->npad = ((max_kpts + 127) / 128) * 128;
   ctx->npad_run = ctx->npad;
@@ -527,7 +548,7 @@ int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** o
   ctx->ev_ready = true;
   // required tensor names
   auto req = [&](const std::string& n) { ctx->required.push_back(n + ".weight"); ctx->required.push_back(n + ".bias"); };
-  req("input_proj");
+  if (feature == GN_FEATURE_SIFT) req("input_proj");
   ctx->required.push_back("posenc.Wr.weight");
   for (int i = 0; i < kMaxLayers; ++i) {
     const std::string ps = "transformers." + std::to_string(i) + ".self_attn.", pc = "transformers." + std::to_string(i) + ".cross_attn.";
@@ -627,10 +648,13 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
   };
 
   int rc = GN_ERR_NAME;
-  if (base == "input_proj") rc = load_linear(ctx->input_proj, kDim, kInDim, 0, kDim);
-  else if (base == "posenc.Wr") {
-    if (!is_w || ndim != 2 || d0 != kFreq || d1 != 4) return shape_err();
-    rc = upload(&ctx->wr, host, kFreq * 4);
+  if (base == "input_proj") {
+    if (ctx->feature != GN_FEATURE_SIFT) return fail(ctx, GN_ERR_NAME, "input_proj does not exist for 256-d features (input_dim == descriptor_dim)");
+    rc = load_linear(ctx->input_proj, kDim, kInDim, 0, kDim);
+  } else if (base == "posenc.Wr") {
+    const int pin = ctx->feature == GN_FEATURE_SIFT ? 4 : 2;   // (x, y, scale, ori) or (x, y)
+    if (!is_w || ndim != 2 || d0 != kFreq || d1 != pin) return shape_err();
+    rc = upload(&ctx->wr, host, kFreq * pin);
   } else if (base.compare(0, 13, "transformers.") == 0) {
     const int i = atoi(base.c_str() + 13);
     if (i < 0 || i >= kMaxLayers) return fail(ctx, GN_ERR_NAME, "layer index out of range in " + name);
@@ -820,14 +844,15 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   ctx->sub_last_B = B; ctx->sub_last_np = ctx->npad_run;
   GN_HIP(hipEventRecord(ctx->ev_fork, s));
   const int kw = (kpt_format & 0xff) == GN_KPT_LAF ? 6 : 4;
+  const int in_dim = ctx->feature == GN_FEATURE_SIFT ? kInDim : kDim;
   int rc_all = GN_OK, b0 = 0;
   for (int g = 0; g < groups; ++g) {
     const int Bg = B / groups + (g < B % groups ? 1 : 0);
     GN_HIP(hipStreamWaitEvent(ctx->sub_s[g], ctx->ev_fork, 0));
     shift_workspaces(ctx, b0, +1);
     const int rc = estimate_impl(ctx, Bg, kpt_format,
-                                 desc_q + (size_t)b0 * stride_q * kInDim, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
-                                 desc_r + (size_t)b0 * stride_r * kInDim, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
+                                 desc_q + (size_t)b0 * stride_q * in_dim, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
+                                 desc_r + (size_t)b0 * stride_r * in_dim, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
                                  dem ? dem + (size_t)b0 * H * W : nullptr, H, W, K9, min_matches,
                                  R + (size_t)b0 * 9, t + (size_t)b0 * 3, n_match + b0, n_inliers + b0, ok + b0, ctx->sub_s[g]);
     shift_workspaces(ctx, b0, -1);

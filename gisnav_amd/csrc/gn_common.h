@@ -148,6 +148,9 @@ struct PrepArgs {
   float* cos_t; float* sin_t;  // [B*2*npad][32]
   int32_t* nvalid;          // [B*2] (n_q[b], n_r[b]) interleaved
   float* extent;            // [B*2][2] (max_x, max_y)
+  float size_q[2], size_r[2];   // image size (w, h) per side for normalize_keypoints; <= 0: the keypoint extent (hw = None in kornia's LightGlueMatcher)
+  int feature;              // 0: SIFT (128-d descriptors, RootSIFT, Wr [32][4] on (x, y, scale, ori)); 1: SuperPoint-style (256-d descriptors used as they are, Wr [32][2] on (x, y))
+  float* x; uint16_t* xp;   // feature 1: the descriptors go straight into the residual stream, f32 [T][256] and / or hm16 (either may be nullptr)
 };
 void launch_prep(const PrepArgs& a, hipStream_t s);
 void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s,

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void k_extent(PrepArgs a) {
   if ((threadIdx.x & 63) == 0) { sx[threadIdx.x >> 6] = mx; sy[threadIdx.x >> 6] = my; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.extent[bs * 2 + 0] = fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3]));
-    a.extent[bs * 2 + 1] = fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3]));
+    const float* given = side ? a.size_r : a.size_q;     // hw passed to the matcher: image size instead of the keypoint extent
+    a.extent[bs * 2 + 0] = given[0] > 0.f ? given[0] : fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3]));
+    a.extent[bs * 2 + 1] = given[1] > 0.f ? given[1] : fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3]));
     a.nvalid[bs] = n;
   }
 }
@@ -102,6 +103,45 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
     const float xn = (x - sx / 2.0f) / sc, yn = (y - sy / 2.0f) / sc;  // normalize_keypoints
     const float* wr = a.wr + lane * 4;
     const float e = wr[0] * xn + wr[1] * yn + wr[2] * scale + wr[3] * ori;
+    a.cos_t[tok * kFreq + lane] = cosf(e);
+    a.sin_t[tok * kFreq + lane] = sinf(e);
+  }
+}
+
+// LightGlue(features = "superpoint" / any 256-d extractor): descriptors are used as they are (input_proj is the identity when
+// input_dim == descriptor_dim), the positional encoding sees only the normalised (x, y).  One wave per token slot: the 256
+// descriptor values go straight into the residual stream (f32 and / or hm16 rows), cos / sin(Wr [x^, y^]) into the tables.
+__global__ __launch_bounds__(256) void k_prep_sp(PrepArgs a) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bs = blockIdx.y, b = bs >> 1, side = bs & 1;
+  const int i = blockIdx.x * 4 + wave;
+  const int n = side ? a.n_r[b] : a.n_q[b];
+  const int stride = side ? a.stride_r : a.stride_q;
+  const size_t tok = (size_t)bs * a.npad + i;
+  f32x4v d = {0.f, 0.f, 0.f, 0.f};
+  const bool valid = i < n;
+  if (valid) d = *reinterpret_cast<const f32x4v*>((side ? a.desc_r : a.desc_q) + ((size_t)b * stride + i) * kDim + lane * 4);
+  if (a.x != nullptr) *reinterpret_cast<f32x4v*>(a.x + tok * kDim + lane * 4) = d;
+  if (a.xp != nullptr) {
+    const f16x4 h = __builtin_convertvector(d, f16x4);
+    const f16x4 m = __builtin_convertvector(d - __builtin_convertvector(h, f32x4v), f16x4);
+    uint16_t* q = a.xp + hm16_off(tok, kDim, lane * 4);
+    *reinterpret_cast<f16x4*>(q) = h;
+    *reinterpret_cast<f16x4*>(q + 16) = m;
+  }
+  if (lane < kFreq) {
+    if (!valid) { a.cos_t[tok * kFreq + lane] = 1.f; a.sin_t[tok * kFreq + lane] = 0.f; return; }
+    const int fmt = a.kpt_format & 0xff;
+    const int w = fmt == GN_KPT_LAF ? 6 : 4;
+    const float* kp = (side ? a.kpt_r : a.kpt_q) + ((size_t)b * stride + i) * w;
+    const float x = kp[fmt == GN_KPT_LAF ? 2 : 0], y = kp[fmt == GN_KPT_LAF ? 5 : 1];
+    const float sx = a.extent[bs * 2], sy = a.extent[bs * 2 + 1];
+    const float sc = fmaxf(sx, sy) / 2.0f;
+    const float xn = (x - sx / 2.0f) / sc, yn = (y - sy / 2.0f) / sc;  // normalize_keypoints
+    const float* wr = a.wr + lane * 2;
+    const float e = wr[0] * xn + wr[1] * yn;
     a.cos_t[tok * kFreq + lane] = cosf(e);
     a.sin_t[tok * kFreq + lane] = sinf(e);
   }
@@ -229,7 +269,8 @@ void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStrea
 
 void launch_prep(const PrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_extent, dim3(a.B * 2), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_prep, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
+  if (a.feature == 1) hipLaunchKernelGGL(k_prep_sp, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_prep, dim3(a.npad / 4, a.B * 2), dim3(256), 0, s, a);
 }
 void launch_ln_gelu(float* h, const float* gamma, const float* beta, int rows, hipStream_t s, uint16_t* hp, unsigned int* ovf) {
   hipLaunchKernelGGL(k_ln_gelu, dim3((rows + 3) / 4), dim3(256), 0, s, h, gamma, beta, rows, hp, ovf);

@@ -44,7 +44,7 @@ class PoseEngine:
 
     def __init__(self, device: int = 0, max_batch: int = 32, max_kpts: int = 1024,
                  precision: str = "f32", state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 n_layers: int = 9, filter_threshold: float = FILTER_THRESHOLD, guard: str = "flag"):
+                 n_layers: int = 9, filter_threshold: float = FILTER_THRESHOLD, guard: str = "flag", feature: str = "sift"):
         if not torch.cuda.is_available():
             raise _lib.GnError("PoseEngine needs a HIP device; the product path has no CPU fallback")
         self.lib = _lib.load()
@@ -52,8 +52,11 @@ class PoseEngine:
         self.max_batch, self.precision = max_batch, precision
         self._n_layers, self._filter_threshold, self._state_dict = n_layers, filter_threshold, None
         self._guard = {"off": 0, "flag": 1, "sync": 2}[guard]
+        self.feature = feature
+        self._feature = {"sift": _lib.GN_FEATURE_SIFT, "superpoint": _lib.GN_FEATURE_SUPERPOINT}[feature]
+        self.desc_dim = 128 if feature == "sift" else 256
         ctx = C.c_void_p()
-        _lib.check(None, self.lib.gn_create(device, max_batch, max_kpts, _PRECISIONS[precision], C.byref(ctx)), "gn_create")
+        _lib.check(None, self.lib.gn_create_ex(device, max_batch, max_kpts, _PRECISIONS[precision], self._feature, C.byref(ctx)), "gn_create_ex")
         self.ctx = ctx
         self.kmax = self.lib.gn_kmax(ctx)
         _lib.check(ctx, self.lib.gn_set_num_layers(ctx, n_layers), "gn_set_num_layers")
@@ -80,7 +83,7 @@ class PoseEngine:
         if max_kpts <= self.kmax:
             return
         ctx = C.c_void_p()
-        _lib.check(None, self.lib.gn_create(self.device.index or 0, self.max_batch, int(max_kpts), _PRECISIONS[self.precision], C.byref(ctx)), "gn_create")
+        _lib.check(None, self.lib.gn_create_ex(self.device.index or 0, self.max_batch, int(max_kpts), _PRECISIONS[self.precision], self._feature, C.byref(ctx)), "gn_create_ex")
         old, self.ctx = self.ctx, ctx
         self.lib.gn_destroy(old)
         self.kmax = self.lib.gn_kmax(ctx)
@@ -102,6 +105,12 @@ class PoseEngine:
         if missing:
             raise _lib.GnError(f"{missing} required LightGlue tensors missing from the state dict")
 
+    def set_image_size(self, wh_q=None, wh_r=None) -> None:
+        """kornia LightGlueMatcher's hw1 / hw2 as (w, h): image sizes for the keypoint normalisation; None = keypoint extent (what
+        PoseNode gets, pose_node.py:285-287)."""
+        q, r = wh_q or (0.0, 0.0), wh_r or (0.0, 0.0)
+        _lib.check(self.ctx, self.lib.gn_set_image_size(self.ctx, float(q[0]), float(q[1]), float(r[0]), float(r[1])), "gn_set_image_size")
+
     def set_num_layers(self, n: int) -> None:
         self._n_layers = n
         _lib.check(self.ctx, self.lib.gn_set_num_layers(self.ctx, n), "gn_set_num_layers")
@@ -115,8 +124,9 @@ class PoseEngine:
         B = len(pairs)
         nq = max(len(p.kp_q) for p in pairs)
         nr = max(len(p.kp_r) for p in pairs)
-        dq = np.zeros((B, nq, 128), np.float32); kq = np.zeros((B, nq, 4), np.float32)
-        dr = np.zeros((B, nr, 128), np.float32); kr = np.zeros((B, nr, 4), np.float32)
+        D = self.desc_dim
+        dq = np.zeros((B, nq, D), np.float32); kq = np.zeros((B, nq, 4), np.float32)
+        dr = np.zeros((B, nr, D), np.float32); kr = np.zeros((B, nr, 4), np.float32)
         n_q = np.zeros(B, np.int32); n_r = np.zeros(B, np.int32)
         h, w = pairs[0].dem.shape
         dem = np.zeros((B, h, w), np.uint8)

@@ -23,8 +23,10 @@ _DEFAULTS = {"n_layers": N_LAYERS, "filter_threshold": 0.1, "depth_confidence": 
 class LightGlueMatcher:
     def __init__(self, feature_name: str = "sift", params: Optional[Dict] = None, *,
                  state_dict=None, max_kpts: int = 4096, precision: str = "f32"):
-        if feature_name != "sift":
-            raise NotImplementedError("PoseNode uses LightGlue('sift') only (pose_node.py:110)")
+        if feature_name not in ("sift", "superpoint"):
+            raise NotImplementedError("LightGlue('sift') is what PoseNode uses (pose_node.py:110); 'superpoint' (256-d descriptors, BASELINE configs[4]) "
+                                      "is the other variant built here")
+        self.feature_name = feature_name
         p = dict(_DEFAULTS)
         p.update(params or {})
         if p["depth_confidence"] > 0 or p["width_confidence"] > 0:
@@ -43,7 +45,7 @@ class LightGlueMatcher:
             raise _lib.GnError("gisnav_amd.LightGlueMatcher runs on an MI355X only (no CPU path)")
         self._engine = PoseEngine(device.index or 0, max_batch=1, max_kpts=self._max_kpts, precision=self._precision,
                                   state_dict=self._state_dict, n_layers=self.params["n_layers"],
-                                  filter_threshold=self.params["filter_threshold"], guard="sync")
+                                  filter_threshold=self.params["filter_threshold"], guard="sync", feature=self.feature_name)
         return self
 
     def eval(self):
@@ -59,19 +61,20 @@ class LightGlueMatcher:
                  hw1=None, hw2=None):
         if self._engine is None:
             raise _lib.GnError("call .to(device) first")
-        if hw1 is not None or hw2 is not None:
-            raise NotImplementedError("PoseNode passes hw1 = hw2 = None (pose_node.py:285-287)")
+        # kornia: image_size = (w, h) from hw when given, else the keypoint extent -- PoseNode passes hw1 = hw2 = None (pose_node.py:285-287)
+        self._engine.set_image_size(None if hw1 is None else (hw1[1], hw1[0]), None if hw2 is None else (hw2[1], hw2[0]))
         dev = self._engine.device
         if desc1.shape[0] < 2 or desc2.shape[0] < 2:
             return torch.zeros((0, 1), dtype=desc1.dtype, device=desc1.device), torch.zeros((0, 2), dtype=torch.int64, device=desc1.device)
         f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
-        d1, d2 = f(desc1).reshape(1, -1, 128), f(desc2).reshape(1, -1, 128)
+        D = self._engine.desc_dim
+        d1, d2 = f(desc1).reshape(1, -1, D), f(desc2).reshape(1, -1, D)
         if max(d1.shape[1], d2.shape[1]) > self._engine.kmax:      # kornia's matcher takes any number of keypoints
             self._engine.grow(((max(d1.shape[1], d2.shape[1]) + 1023) // 1024) * 1024)
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
         n1 = torch.tensor([d1.shape[1]], dtype=torch.int32, device=dev)
         n2 = torch.tensor([d2.shape[1]], dtype=torch.int32, device=dev)
-        idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, _lib.GN_KPT_LAF | 0x100)
+        idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, _lib.GN_KPT_LAF | 0x100)   # 0x100: descriptors are already normalised by the caller
         k = int(n_match.item())  # the D2H sync the reference has at pose_node.py:296-297
         return score[0, :k].reshape(-1, 1), idx[0, :k]
 

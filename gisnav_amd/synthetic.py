@@ -115,3 +115,20 @@ def make_pair(pair_index: int, n_q: int = 1024, n_r: int = 1024, h: int = IMG_H,
 
 def make_batch(first_index: int, count: int, **kw):
     return [make_pair(first_index + i, **kw) for i in range(count)]
+
+
+def make_pair_256(pair_index: int, n_q: int = 1024, n_r: int = 1024, h: int = 1080, w: int = 1920, match_fraction: float = 0.7):
+    """A frame<->tile pair for a 256-d local feature (BASELINE.json configs[4]: 1920x1080 frames, SuperPoint-style descriptors):
+    the geometry of `make_pair` scaled to (w, h), descriptors = unit-norm 256-vectors, matched ones perturbed.  Returns a Pair whose
+    desc_* are (N, 256) float32; size / angle are unused by the 256-d matcher (set to 1 / 0)."""
+    p = make_pair(pair_index, n_q=n_q, n_r=n_r, h=h, w=w, match_fraction=match_fraction)
+    rng = np.random.default_rng(99_000 + pair_index)
+    dr = rng.normal(size=(n_r, 256))
+    dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    dq = rng.normal(size=(n_q, 256))
+    m = p.gt_q2r >= 0
+    dq[m] = dr[p.gt_q2r[m]] + 0.25 * rng.normal(size=(int(m.sum()), 256)) / 16.0
+    dq /= np.linalg.norm(dq, axis=1, keepdims=True)
+    p.desc_q, p.desc_r = dq.astype(np.float32), dr.astype(np.float32)
+    p.size_q[:], p.size_r[:], p.angle_q[:], p.angle_r[:] = 1.0, 1.0, 0.0, 0.0
+    return p

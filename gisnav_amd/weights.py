@@ -47,7 +47,7 @@ def _ffn(rng, sd, p, d, ffn_out_std):
 def synthetic_state_dict(seed: int = 0, n_layers: int = N_LAYERS, qk_gain: float = 30.0,
                          ffn_out_std: float = 2.4e-4, final_scale: float = 28.0,
                          identity_blocks: bool = False, matchability_bias: float = 10.0,
-                         matchability_std: float = 0.01) -> Dict[str, np.ndarray]:
+                         matchability_std: float = 0.01, feature: str = "sift") -> Dict[str, np.ndarray]:
     """Seeded weights, kornia key layout (``transformers.{i}.self_attn.*`` ...).
 
     ``identity_blocks=True`` zeroes every ``ffn.3`` so each block is the identity on the
@@ -61,10 +61,14 @@ def synthetic_state_dict(seed: int = 0, n_layers: int = N_LAYERS, qk_gain: float
     rng = np.random.default_rng(seed)
     d = DESC_DIM
     sd: Dict[str, np.ndarray] = {}
-    sd["input_proj.weight"] = _orthogonal(rng, d)[:, :INPUT_DIM].astype(np.float32)  # (256,128), W^T W = I
-    sd["input_proj.bias"] = (0.01 * rng.normal(size=d)).astype(np.float32)
+    ip_w = _orthogonal(rng, d)[:, :INPUT_DIM].astype(np.float32)  # (256,128), W^T W = I
+    ip_b = (0.01 * rng.normal(size=d)).astype(np.float32)
     wr = rng.normal(size=(HEAD_DIM // 2, 4)) * np.array([3.0, 3.0, 0.05, 0.3])
-    sd["posenc.Wr.weight"] = wr.astype(np.float32)  # input order (x, y, scale, ori_rad)
+    if feature == "sift":
+        sd["input_proj.weight"], sd["input_proj.bias"] = ip_w, ip_b
+        sd["posenc.Wr.weight"] = wr.astype(np.float32)  # input order (x, y, scale, ori_rad)
+    else:   # kornia LightGlue(features="superpoint"): input_dim == descriptor_dim (no input_proj), add_scale_ori False: Wr on (x, y) only
+        sd["posenc.Wr.weight"] = np.ascontiguousarray(wr[:, :2]).astype(np.float32)
     b = d ** -0.5
     for i in range(n_layers):
         p = f"transformers.{i}.self_attn"
@@ -118,10 +122,11 @@ def canonical_state_dict(sd) -> Dict[str, np.ndarray]:
     return out
 
 
-def expected_shapes(n_layers: int = N_LAYERS) -> Dict[str, tuple]:
+def expected_shapes(n_layers: int = N_LAYERS, feature: str = "sift") -> Dict[str, tuple]:
     """Shape table of SURVEY.md Appendix A, used by the loader to validate a checkpoint."""
     d = DESC_DIM
-    shp = {"input_proj.weight": (d, INPUT_DIM), "input_proj.bias": (d,), "posenc.Wr.weight": (HEAD_DIM // 2, 4)}
+    shp = {"input_proj.weight": (d, INPUT_DIM), "input_proj.bias": (d,), "posenc.Wr.weight": (HEAD_DIM // 2, 4)} if feature == "sift" \
+        else {"posenc.Wr.weight": (HEAD_DIM // 2, 2)}
     for i in range(n_layers):
         for blk, lin in (("self_attn", (("Wqkv", 3 * d, d), ("out_proj", d, d))),
                          ("cross_attn", (("to_qk", d, d), ("to_v", d, d), ("to_out", d, d)))):

@@ -105,6 +105,18 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
 /* Create a context on HIP device `device` sized for batches of up to max_batch pairs with up
  * to max_kpts keypoints per side (rounded up to a multiple of 128 internally). */
 int gn_create(int device, int max_batch, int max_kpts, int precision, gn_ctx** out);
+/* The same for another local-feature type.  The reference instantiates LightGlueMatcher("sift") only (pose_node.py:109-121);
+ * BASELINE.json configs[4] names the SuperPoint + LightGlue path, i.e. kornia's LightGlue(features = "superpoint"):
+ * input_dim 256 = descriptor_dim (no input_proj), add_scale_ori False (posenc.Wr is [32][2] on the normalised (x, y)),
+ * everything else -- 9 layers, shared to_qk, match head -- as for SIFT.  With GN_FEATURE_SUPERPOINT the descriptor arguments
+ * of gn_match / gn_estimate are [B][stride][256] (used as they are: L2-normalised by the extractor), the keypoint records
+ * keep their format (size / angle fields ignored), and the state dict has no input_proj.* entries. */
+enum gn_feature { GN_FEATURE_SIFT = 0, GN_FEATURE_SUPERPOINT = 1 };
+int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int feature, gn_ctx** out);
+/* kornia's LightGlueMatcher.forward(..., hw1, hw2): image sizes (w, h) used by normalize_keypoints for the query / reference
+ * side; a non-positive value selects the keypoint extent (max_x, max_y) of that side, which is what PoseNode gets because it
+ * passes hw1 = hw2 = None (pose_node.py:285-287).  Sticky host-side state, (0, 0, 0, 0) by default. */
+int gn_set_image_size(gn_ctx* ctx, float w_q, float h_q, float w_r, float h_r);
 void gn_destroy(gn_ctx* ctx);
 
 /* Load one tensor of the kornia LightGlue("sift") state dict from HOST

@@ -154,8 +154,44 @@ def test_two_process_gloo_broadcast_gather_and_timing_reduction():
         assert mx == 1.5 and sm == 8.0
 
 
+def _worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from gisnav_amd import dist as gd
+    r, lr, w = gd.init("gloo")
+    dev = torch.device("cpu")
+    shard = gd.shard_range(256, r, w)                       # BASELINE configs[3]: 256 pairs over 8 ranks
+    B = len(shard)
+    idx = torch.arange(shard.start, shard.stop, dtype=torch.float64)
+    out = dict(R=torch.eye(3, dtype=torch.float64).repeat(B, 1, 1) * idx[:, None, None], t=idx[:, None, None].repeat(1, 3, 1),
+               ok=torch.ones(B, dtype=torch.uint8), n_match=(idx % 7).to(torch.int32), n_inliers=(idx % 5).to(torch.int32))
+    rec = gd.gather_records(gd.pack_records(shard.start, out))
+    gd.barrier()
+    q.put((r, B, shard.start, rec[:, 0].tolist(), rec[:, 13].tolist(), gd.max_over_ranks(0.1 * (r + 1), dev), gd.sum_over_ranks(float(B), dev)))
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_process_gloo_shards_of_256_pairs():
+    """World size 8 (the BASELINE node): contiguous 32-pair shards, one gather of the 256 result records, max / sum reductions."""
+    world, port = 8, 29633
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, B, start, pair_idx, t0, mx, sm in res:
+        assert B == 32 and start == 32 * r
+        assert pair_idx == [float(i) for i in range(256)] and t0 == [float(i) for i in range(256)]
+        assert abs(mx - 0.8) < 1e-12 and sm == 256.0
+
+
 def test_bench_json_contract_fields_present_in_source():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
-                '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"workload"'):
+                '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"workload"',
+                '"traffic"', '"extra_configs"', '"inputs_resident"', '"debug_variant"', '"pcie_inclusive"', '"multi_gpu"', '"end_to_end"'):
         assert key in src, key

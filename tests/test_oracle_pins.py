@@ -103,6 +103,45 @@ def test_match_assignment_equals_transformers_layer():
     assert torch.equal(m0[0], hm[0]) and torch.equal(m1[0], hm[1])
 
 
+@pytest.mark.parametrize("weights", ["margin", "low_margin"])
+def test_superpoint_lightglue_oracle_equals_transformers_full_model(weights):
+    """oracle/lightglue_superpoint.py (kornia LightGlue(features="superpoint") restated) against transformers'
+    LightGlueForKeypointMatching._match_image_pair with the same weights: 2-D positional encoding, nine layers, match head,
+    mutual filter -- identical matches, scores within 2e-5.  This variant of the oracle IS pinned to third-party code."""
+    from transformers.models.lightglue.configuration_lightglue import LightGlueConfig
+    from transformers.models.lightglue.modeling_lightglue import LightGlueForKeypointMatching
+    from gisnav_amd.synthetic import make_pair_256
+    from oracle import lightglue_superpoint as lsp
+    kw = {} if weights == "margin" else dict(ffn_out_std=4.8e-3, final_scale=4.0, matchability_bias=0.0, matchability_std=0.05)
+    sd = synthetic_state_dict(2, feature="superpoint", **kw)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cfg = LightGlueConfig(descriptor_dim=256, num_hidden_layers=9, num_attention_heads=4, depth_confidence=-1.0, width_confidence=-1.0,
+                          filter_threshold=0.0 if weights == "low_margin" else 0.1)
+    cfg._attn_implementation = "eager"
+    hf = LightGlueForKeypointMatching(cfg).eval()
+    hf.positional_encoder.projector.weight.data = tsd["posenc.Wr.weight"]
+    for i in range(9):
+        layer = _hf_layer(sd, i)
+        hf.transformer_layers[i].load_state_dict(layer.state_dict())
+        hf.match_assignment_layers[i].final_projection.weight.data = tsd[f"log_assignment.{i}.final_proj.weight"]
+        hf.match_assignment_layers[i].final_projection.bias.data = tsd[f"log_assignment.{i}.final_proj.bias"]
+        hf.match_assignment_layers[i].matchability.weight.data = tsd[f"log_assignment.{i}.matchability.weight"]
+        hf.match_assignment_layers[i].matchability.bias.data = tsd[f"log_assignment.{i}.matchability.bias"]
+    p = make_pair_256(3, n_q=300, n_r=300, h=480, w=640)
+    kq, kr = torch.from_numpy(p.kp_q), torch.from_numpy(p.kp_r)
+    dq, dr = torch.from_numpy(p.desc_q), torch.from_numpy(p.desc_r)
+    th = 0.0 if weights == "low_margin" else 0.1
+    sc, idx = lsp.match(tsd, kq, dq, kr, dr, hw0=(480, 640), hw1=(480, 640), filter_threshold=th)
+    with torch.inference_mode():
+        m, s_, _, _, _ = hf._match_image_pair(torch.stack([kq, kr])[None], torch.stack([dq, dr])[None], 480, 640, mask=torch.ones(1, 2, 300, dtype=torch.int))
+    m0, s0 = m.reshape(-1, 300)[0], s_.reshape(-1, 300)[0]          # rows: image 0 -> 1, image 1 -> 0
+    valid = m0 > -1
+    hidx = torch.stack([torch.where(valid)[0], m0[valid].long()], -1)
+    assert len(idx) > 100
+    assert torch.equal(idx, hidx)
+    assert float((sc[:, 0] - s0[valid]).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("flat", [False, True])
 def test_refined_pose_is_the_least_squares_optimum_of_its_inlier_set(flat):
     """solvePnPRansac's final solvePnP(ITERATIVE) minimises the reprojection error over the inliers; an independent

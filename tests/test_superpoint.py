@@ -1,0 +1,112 @@
+"""LightGlue(features="superpoint") -- the matcher of BASELINE.json configs[4] (256-d descriptors, 2-D positional encoding, no
+input projection).  The golden fixtures tests/golden/lightglue_sp_*.npz come from THIRD-PARTY code
+(transformers' LightGlueForKeypointMatching on CPU, tests/golden/make_superpoint_golden.py), not from the repo's oracle: the CPU
+test pins the oracle to them, the GPU tests pin the HIP path to them and to the oracle.
+
+Tolerances: correspondence indices identical; scores |d| <= 1e-5 (f32 mode) / 5e-3 (bf16-attention modes); final descriptors
+rel 2e-5 (f32 mode)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gisnav_amd.synthetic import K_MATRIX, make_pair_256
+from gisnav_amd.weights import synthetic_state_dict
+from oracle import lightglue_superpoint as lsp
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FIXTURES = ["lightglue_sp_seed0_n200_640x480", "lightglue_sp_seed0_n384_1920x1080"]
+
+
+@pytest.fixture(scope="module")
+def sd_sp():
+    return synthetic_state_dict(0, feature="superpoint")
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_reproduces_the_transformers_generated_fixture(name, sd_sp):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    tsd = {k: torch.from_numpy(v) for k, v in sd_sp.items()}
+    taps = {}
+    sc, idx = lsp.match(tsd, torch.from_numpy(g["kp_q"]), torch.from_numpy(g["desc_q"]), torch.from_numpy(g["kp_r"]), torch.from_numpy(g["desc_r"]),
+                        hw0=(int(g["h"]), int(g["w"])), hw1=(int(g["h"]), int(g["w"])), taps=taps)
+    assert np.array_equal(idx.numpy(), g["idx"])
+    assert np.abs(sc.numpy()[:, 0] - g["scores"]).max() < 2e-5
+    x = torch.cat([taps["layer8_0"], taps["layer8_1"]], 0).numpy()
+    assert np.abs(x - g["x_final"]).max() < 2e-5 * np.abs(g["x_final"]).max()
+
+
+def test_weight_layout_of_the_superpoint_variant(sd_sp):
+    from gisnav_amd.weights import expected_shapes
+    shp = expected_shapes(feature="superpoint")
+    assert "input_proj.weight" not in sd_sp and sd_sp["posenc.Wr.weight"].shape == (32, 2) == shp["posenc.Wr.weight"]
+    for k, v in shp.items():
+        assert sd_sp[k].shape == v, k
+
+
+# ------------------------------------------------------------------ HIP path (GPU)
+@pytest.fixture(scope="module")
+def engines(sd_sp):
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from gisnav_amd.engine import PoseEngine
+    return {prec: PoseEngine(0, max_batch=4, max_kpts=384, precision=prec, state_dict=sd_sp, filter_threshold=0.1, feature="superpoint")
+            for prec in ("f32", "f16x2_bf16_attn")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_superpoint_matcher_against_transformers_fixture(engines, name, prec):
+    eng = engines[prec]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    dev = eng.device
+    n = len(g["kp_q"])
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kq = np.zeros((1, n, 4), np.float32); kq[0, :, :2] = g["kp_q"]
+    kr = np.zeros((1, n, 4), np.float32); kr[0, :, :2] = g["kp_r"]
+    nn = torch.tensor([n], dtype=torch.int32, device=dev)
+    eng.set_image_size((float(g["w"]), float(g["h"])), (float(g["w"]), float(g["h"])))
+    idx, score, n_match = eng.match(f(g["desc_q"][None]), f(kq), nn, f(g["desc_r"][None]), f(kr), nn)
+    torch.cuda.synchronize()
+    k = int(n_match[0])
+    assert k == len(g["idx"]) and np.array_equal(idx[0, :k].cpu().numpy(), g["idx"])
+    assert np.abs(score[0, :k].cpu().numpy() - g["scores"]).max() < (1e-5 if prec == "f32" else 5e-3)
+    if prec == "f32":
+        x = eng.debug_read("x", 4 * 2 * 384 * 256).reshape(4, 2, 384, 256)
+        assert np.abs(x[0, :, :n] - g["x_final"]).max() < 2e-5 * np.abs(g["x_final"]).max()
+    eng.set_image_size(None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+def test_superpoint_ragged_batch_extent_sizes_and_pose(engines, sd_sp, prec):
+    """Ragged batch, image size = keypoint extent (hw None, kornia's fallback) and the pose stage behind the 256-d matcher."""
+    eng = engines[prec]
+    tsd = {k: torch.from_numpy(v) for k, v in sd_sp.items()}
+    pairs = [make_pair_256(60 + i, n_q=384 - 23 * i, n_r=370 - 11 * i, h=480, w=640) for i in range(3)]
+    inp = eng.stage_inputs(pairs)
+    idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    out = eng.estimate(inp, K_MATRIX)
+    torch.cuda.synchronize()
+    for b, p in enumerate(pairs):
+        sc, oidx = lsp.match(tsd, torch.from_numpy(p.kp_q), torch.from_numpy(p.desc_q), torch.from_numpy(p.kp_r), torch.from_numpy(p.desc_r))
+        k = int(n_match[b])
+        assert k == len(oidx) > 100 and np.array_equal(idx[b, :k].cpu().numpy(), oidx.numpy())
+        assert int(out["ok"][b]) == 1 and np.linalg.norm(out["R"][b].cpu().numpy() - p.R_gt) < 2e-2
+
+
+@pytest.mark.gpu
+def test_superpoint_matcher_object_drop_in(sd_sp):
+    """gisnav_amd.LightGlueMatcher("superpoint") with kornia's call signature, hw given."""
+    from gisnav_amd.matcher import LightGlueMatcher
+    from oracle import lightglue_sift as lg
+    tsd = {k: torch.from_numpy(v) for k, v in sd_sp.items()}
+    p = make_pair_256(70, n_q=300, n_r=280, h=1080, w=1920)
+    m = LightGlueMatcher("superpoint", params={"filter_threshold": 0.1, "depth_confidence": -1, "width_confidence": -1}, state_dict=sd_sp, max_kpts=384).to("cuda:0").eval()
+    tq = torch.from_numpy
+    laf_q = lg.laf_from_center_scale_ori(tq(p.kp_q)[None], torch.ones(1, 300, 1, 1), torch.zeros(1, 300, 1))
+    laf_r = lg.laf_from_center_scale_ori(tq(p.kp_r)[None], torch.ones(1, 280, 1, 1), torch.zeros(1, 280, 1))
+    dists, idx = m(tq(p.desc_q).cuda(), tq(p.desc_r).cuda(), laf_q.cuda(), laf_r.cuda(), hw1=(1080, 1920), hw2=(1080, 1920))
+    sc, oidx = lsp.match(tsd, tq(p.kp_q), tq(p.desc_q), tq(p.kp_r), tq(p.desc_r), hw0=(1080, 1920), hw1=(1080, 1920))
+    assert idx.dtype == torch.int64 and dists.shape == (len(oidx), 1) and torch.equal(idx.cpu(), oidx)
