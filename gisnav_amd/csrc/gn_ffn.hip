@@ -291,31 +291,30 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     for (int w8 = 0; w8 < 8; ++w8) t_ += stat2[w8 * TM + 32 * j + ql];
     rstd[j] = 1.0f / sqrtf(t_ * (1.0f / 512.0f) + 1e-5f);
   }
-  // normalise, GELU and publish tile by tile: wave w's units 64 w + 32 i .. go to slot 2 w + i, and the LDS writes of one tile
-  // overlap the GELU arithmetic of the next.  (The token tile of GEMM 1 occupied this region: every wave has passed the barriers
-  // above, so nobody reads it any more.)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    f32x4 gm[4], bt[4];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      gm[g] = *reinterpret_cast<const f32x4*>(a.ln_g + 64 * wave + 32 * i + 8 * g + 4 * hh);
-      bt[g] = *reinterpret_cast<const f32x4*>(a.ln_b + 64 * wave + 32 * i + 8 * g + 4 * hh);
-    }
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 64 * wave + 32 * i + 8 * g + 4 * hh);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 64 * wave + 32 * i + 8 * g + 4 * hh);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float yn = acc[i][j][4 * g + c] * rstd[j] * gm[g][c] + bt[g][c];
-          acc[i][j][4 * g + c] = (ABL & 4) ? yn : gelu_erf(yn);
+          const float yn = acc[i][j][4 * g + c] * rstd[j] * gm[c] + bt[c];
+          const float y = (ABL & 4) ? yn : gelu_erf(yn);
+          acc[i][j][4 * g + c] = y;
         }
-      publish(acc[i][j], 2 * wave + i, j, 1.f, nullptr);
     }
-  }
-  ovf_commit(a.ovf, amax);
   stamp(3);
+
+  // ---------------------------------------------------------------- publish the hidden tile: wave w's units 64 w + 32 i .. -> slot 2 w + i
+  // (the token tile of GEMM 1 occupied this region: every wave has passed the barriers above, so nobody reads it any more)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) publish(acc[i][j], 2 * wave + i, j, 1.f, nullptr);
+  ovf_commit(a.ovf, amax);
   __syncthreads();
   stamp(4);
 
@@ -325,17 +324,6 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-  // residual rows of the epilogue, in the accumulator layout: requested now, consumed after the loop (their latency hides behind it).
-  // In-place update is safe: a lane reads exactly the 8-byte pieces it later overwrites.
-  f16x4 rh[2][4], rm[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const uint16_t* rp = a.xp + hm16_off((size_t)(bm + 32 * j + ql), kDim, 32 * wave + 8 * g + 4 * hh);
-      rh[j][g] = *reinterpret_cast<const f16x4*>(rp);
-      rm[j][g] = *reinterpret_cast<const f16x4*>(rp + 16);
-    }
   if (!(ABL & 2)) {
     read_b(0, smem, 0);
 #pragma unroll
@@ -355,33 +343,43 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     }
   }
   stamp(5);
+  __syncthreads();   // the hidden tile is dead: its space becomes the [64 tokens][256 features] f32 tile of the row-wise epilogue
   stamp(6);
 
-  // ---------------------------------------------------------------- epilogue, straight from the accumulator layout (no barrier, no LDS round trip): a lane
-  // owns tokens 32 j + ql and, per register group g, the four adjacent features 32 w + 8 g + 4 hh ..: + bias + residual x ->
-  // hm16 (8 bytes of high terms, 8 of residual terms) and optionally f32.  The eight waves of the workgroup complete each row's
-  // 1 KB between them, so the partial lines merge in L2 before they leave it.
-  const float s2 = a.w2_scale;
-  float amax2 = 0.f;
+  // ---------------------------------------------------------------- epilogue: + bias + residual x, hm16 (and optionally f32) rows
+  float* const yt = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int col = 32 * wave + 8 * g + 4 * hh;
-      const size_t tok = (size_t)(bm + 32 * j + ql);
-      const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b2 + col);
-      f32x4 v = {acc2[j][4 * g], acc2[j][4 * g + 1], acc2[j][4 * g + 2], acc2[j][4 * g + 3]};
-      v = v * s2;
-      v += bias4;
-      v += __builtin_convertvector(rh[j][g], f32x4) + __builtin_convertvector(rm[j][g], f32x4);
-      const f16x4 hv = __builtin_convertvector(v, f16x4);
-      const f16x4 mv = __builtin_convertvector(v - __builtin_convertvector(hv, f32x4), f16x4);
-      uint16_t* yp = a.yp + hm16_off(tok, kDim, col);
-      *reinterpret_cast<f16x4*>(yp) = hv;
-      *reinterpret_cast<f16x4*>(yp + 16) = mv;
-      if (a.y != nullptr) *reinterpret_cast<f32x4*>(a.y + tok * kDim + col) = v;
-      ovf_track(amax2, v.x, v.y); ovf_track(amax2, v.z, v.w);
+      const f32x4 v = {acc2[j][4 * g], acc2[j][4 * g + 1], acc2[j][4 * g + 2], acc2[j][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(yt + (32 * j + ql) * YP + 32 * wave + 8 * g + 4 * hh) = v;
     }
+  __syncthreads();
+  const float s2 = a.w2_scale;
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
+  f16x4 rh[8], rm[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {   // residual rows requested up front: one memory latency, not eight
+    const uint16_t* rp = a.xp + hm16_off((size_t)(bm + 8 * wave + rr), kDim, 4 * lane);
+    rh[rr] = *reinterpret_cast<const f16x4*>(rp);
+    rm[rr] = *reinterpret_cast<const f16x4*>(rp + 16);
+  }
+  float amax2 = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = 8 * wave + rr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(yt + row * YP + 4 * lane) * s2;
+    v += bias4;
+    v += __builtin_convertvector(rh[rr], f32x4) + __builtin_convertvector(rm[rr], f32x4);
+    const f16x4 hv = __builtin_convertvector(v, f16x4);
+    const f16x4 mv = __builtin_convertvector(v - __builtin_convertvector(hv, f32x4), f16x4);
+    uint16_t* yp = a.yp + hm16_off((size_t)(bm + row), kDim, 4 * lane);
+    *reinterpret_cast<f16x4*>(yp) = hv;
+    *reinterpret_cast<f16x4*>(yp + 16) = mv;
+    if (a.y != nullptr) *reinterpret_cast<f32x4*>(a.y + (size_t)(bm + row) * kDim + 4 * lane) = v;
+    ovf_track(amax2, v.x, v.y); ovf_track(amax2, v.z, v.w);
+  }
   ovf_commit(a.ovf, amax2);
   if (ABL & 8) {
     stamp(7);
