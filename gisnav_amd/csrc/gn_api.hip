@@ -93,6 +93,12 @@ struct gn_ctx {
   int4* sift_cand = nullptr; int* sift_counts = nullptr; SiftKeypoint* sift_kp = nullptr;
   int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0, sift_batch = 0; long long sift_kp_stride = 0;
   std::vector<int32_t> sift_totals;   // distinct keypoints found per image by the last call (before the max_kpts cap)
+  // SuperPoint extractor (gn_sp_*): 12 convolutions in network order, workspace sized for the last (chunk, H, W) seen
+  struct SpConv { float* wf = nullptr; float* b = nullptr; int cout = 0, cin = 0, taps = 0, cout_pad = 0; bool have_w = false, have_b = false; };
+  SpConv sp[12];
+  std::vector<void*> sp_allocs; int sp_h = 0, sp_w = 0, sp_chunk = 0, sp_cap = 0, sp_max = 0;
+  float *sp_x = nullptr, *sp_y = nullptr, *sp_z = nullptr, *sp_maps[6] = {};
+  int *sp_cand = nullptr, *sp_counts = nullptr, *sp_index = nullptr;
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
@@ -569,6 +575,7 @@ void gn_destroy(gn_ctx* ctx) {
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
+  for (void* p : ctx->sp_allocs) hipFree(p);
   if (ctx->ev_fork) {
     for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); }
     hipEventDestroy(ctx->ev_fork);
@@ -1196,6 +1203,108 @@ int gn_sift_last_totals(gn_ctx* ctx, int B, int32_t* totals_host) {
   return GN_OK;
 }
 
+// ---- SuperPoint extractor -----------------------------------------------------------------------------------------------
+namespace {
+const char* const kSpNames[12] = {
+    "encoder.conv_blocks.0.conv_a", "encoder.conv_blocks.0.conv_b", "encoder.conv_blocks.1.conv_a", "encoder.conv_blocks.1.conv_b",
+    "encoder.conv_blocks.2.conv_a", "encoder.conv_blocks.2.conv_b", "encoder.conv_blocks.3.conv_a", "encoder.conv_blocks.3.conv_b",
+    "keypoint_decoder.conv_score_a", "keypoint_decoder.conv_score_b", "descriptor_decoder.conv_descriptor_a", "descriptor_decoder.conv_descriptor_b"};
+const int kSpShape[12][3] = {{64, 1, 9}, {64, 64, 9}, {64, 64, 9}, {64, 64, 9}, {128, 64, 9}, {128, 128, 9}, {128, 128, 9}, {128, 128, 9},
+                             {256, 128, 9}, {65, 256, 1}, {256, 128, 9}, {256, 256, 1}};   // Cout, Cin, taps
+}  // namespace
+
+int gn_sp_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int64_t* shape, int ndim) {
+  if (!ctx || !name_c || !host || !shape) return fail(ctx, GN_ERR_ARG, "bad gn_sp_load_tensor argument");
+  GN_HIP(hipSetDevice(ctx->device));
+  const std::string name(name_c);
+  for (int i = 0; i < 12; ++i) {
+    const std::string base(kSpNames[i]);
+    const int cout = kSpShape[i][0], cin = kSpShape[i][1], taps = kSpShape[i][2];
+    const int k = taps == 9 ? 3 : 1;
+    gn_ctx::SpConv& c = ctx->sp[i];
+    c.cout = cout; c.cin = cin; c.taps = taps; c.cout_pad = ((cout + 63) / 64) * 64;
+    if (name == base + ".weight") {
+      if (ndim != 4 || shape[0] != cout || shape[1] != cin || shape[2] != k || shape[3] != k) return fail(ctx, GN_ERR_SHAPE, "shape mismatch for " + name);
+      std::vector<float> frag;
+      const float* src = host;
+      if (i > 0) { frag.resize((size_t)c.cout_pad * taps * cin); sp_weight_fragments(host, cout, cin, taps, c.cout_pad, frag.data()); src = frag.data(); }
+      const size_t n = i > 0 ? frag.size() : (size_t)cout * 9;       // the first layer (1 input channel) keeps [64][9] for the FMA kernel
+      if (!c.wf) { void* q = nullptr; GN_HIP(hipMalloc(&q, n * sizeof(float))); ctx->sp_allocs.push_back(q); c.wf = (float*)q; }
+      GN_HIP(hipMemcpy(c.wf, src, n * sizeof(float), hipMemcpyHostToDevice));
+      c.have_w = true;
+      return GN_OK;
+    }
+    if (name == base + ".bias") {
+      if (shape[0] != cout) return fail(ctx, GN_ERR_SHAPE, "shape mismatch for " + name);
+      std::vector<float> pad((size_t)c.cout_pad, 0.f);
+      memcpy(pad.data(), host, (size_t)cout * sizeof(float));
+      if (!c.b) { void* q = nullptr; GN_HIP(hipMalloc(&q, pad.size() * sizeof(float))); ctx->sp_allocs.push_back(q); c.b = (float*)q; }
+      GN_HIP(hipMemcpy(c.b, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice));
+      c.have_b = true;
+      return GN_OK;
+    }
+  }
+  return fail(ctx, GN_ERR_NAME, "unknown SuperPoint tensor " + name);
+}
+
+int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, int W, int max_kpts,
+                              float* kpt_xysa, float* score, float* desc, int32_t* n_out_host, void* stream) {
+  if (!ctx || !gray01 || !kpt_xysa || !desc || !n_out_host || B < 1 || H < 16 || W < 16 || H % 8 || W % 8 || max_kpts < 1 || max_kpts > 2048)
+    return fail(ctx, GN_ERR_ARG, "bad gn_sp_detect_and_describe argument (H, W multiples of 8; max_kpts <= 2048)");
+  for (int i = 0; i < 12; ++i) if (!ctx->sp[i].have_w || !ctx->sp[i].have_b) return fail(ctx, GN_ERR_WEIGHTS, "SuperPoint weights not fully loaded");
+  GN_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int chunk = std::min(B, 4);                       // images per pass: the full-resolution 64-channel maps are 0.5 GB per 1080p image
+  const int h = H / 8, w = W / 8;
+  const int cap = std::max(16384, H * W / 16);            // candidates after NMS (radius 4): at most one per ~5 x 5 neighbourhood in practice
+  if (ctx->sp_h != H || ctx->sp_w != W || ctx->sp_chunk < chunk || ctx->sp_max < max_kpts) {
+    for (void* p : ctx->sp_allocs) { bool is_weight = false; for (int i = 0; i < 12; ++i) is_weight |= (p == ctx->sp[i].wf || p == ctx->sp[i].b); if (!is_weight) hipFree(p); }
+    std::vector<void*> keep;
+    for (void* p : ctx->sp_allocs) { for (int i = 0; i < 12; ++i) if (p == ctx->sp[i].wf || p == ctx->sp[i].b) { keep.push_back(p); break; } }
+    ctx->sp_allocs = keep;
+    auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; ctx->sp_allocs.push_back(p); return p; };
+    const size_t full = (size_t)chunk * H * W;
+    ctx->sp_x = (float*)alloc(full * 64 * sizeof(float));
+    ctx->sp_y = (float*)alloc(full * 64 * sizeof(float));
+    ctx->sp_z = (float*)alloc((size_t)chunk * h * w * 256 * sizeof(float));
+    bool ok = ctx->sp_x && ctx->sp_y && ctx->sp_z;
+    for (int k = 0; k < 6; ++k) { ctx->sp_maps[k] = (float*)alloc(full * sizeof(float)); ok = ok && ctx->sp_maps[k]; }
+    ctx->sp_cand = (int*)alloc((size_t)chunk * cap * sizeof(int));
+    ctx->sp_counts = (int*)alloc((size_t)chunk * 4 * sizeof(int));
+    ctx->sp_index = (int*)alloc((size_t)chunk * 2048 * sizeof(int));
+    if (!ok || !ctx->sp_cand || !ctx->sp_counts || !ctx->sp_index) return fail(ctx, GN_ERR_HIP, "SuperPoint workspace allocation failed");
+    ctx->sp_h = H; ctx->sp_w = W; ctx->sp_chunk = chunk; ctx->sp_cap = cap; ctx->sp_max = max_kpts;
+  }
+  float *X = ctx->sp_x, *Y = ctx->sp_y, *Z = ctx->sp_z;
+  auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu) {
+    sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s);
+  };
+  std::vector<int> counts((size_t)chunk * 4);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int n = std::min(chunk, B - b0);
+    sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s);
+    conv(1, X, Y, n, H, W, 1);             sp_pool(Y, X, n, H, W, 64, s);                      // block 0 -> X [H/2][W/2][64]
+    conv(2, X, Y, n, H / 2, W / 2, 1);     conv(3, Y, X, n, H / 2, W / 2, 1);   sp_pool(X, Y, n, H / 2, W / 2, 64, s);    // block 1 -> Y [H/4]
+    conv(4, Y, X, n, H / 4, W / 4, 1);     conv(5, X, Y, n, H / 4, W / 4, 1);   sp_pool(Y, X, n, H / 4, W / 4, 128, s);   // block 2 -> X [H/8][128]
+    conv(6, X, Y, n, h, w, 1);             conv(7, Y, X, n, h, w, 1);                                                    // block 3 -> X = encoder output
+    conv(8, X, Y, n, h, w, 1);             conv(9, Y, Z, n, h, w, 0);                           // detector head: Z = logits [h][w][128 (65 used)]
+    sp_scores(Z, ctx->sp[9].cout_pad, ctx->sp_maps[0], n, h, w, s);
+    sp_nms(ctx->sp_maps[0], n, H, W, 4, ctx->sp_maps[1], ctx->sp_maps[2], ctx->sp_maps[3], ctx->sp_maps[4], ctx->sp_maps[5], s);
+    sp_select(ctx->sp_maps[5], n, H, W, 0.005f, 4, ctx->sp_cand, ctx->sp_counts, ctx->sp_cap, max_kpts,
+              kpt_xysa + (size_t)b0 * max_kpts * 4, score ? score + (size_t)b0 * max_kpts : ctx->sp_maps[1], ctx->sp_index, max_kpts, s);
+    conv(10, X, Y, n, h, w, 1);            conv(11, Y, Z, n, h, w, 0);                          // descriptor head: Z = raw descriptor map [h][w][256]
+    sp_describe(Z, n, h, w, kpt_xysa + (size_t)b0 * max_kpts * 4, ctx->sp_counts, max_kpts, max_kpts, desc + (size_t)b0 * max_kpts * 256, s);
+    GN_HIP(hipMemcpyAsync(counts.data(), ctx->sp_counts, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    GN_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < n; ++b) {
+      if (counts[4 * b] > ctx->sp_cap) return fail(ctx, GN_ERR_ARG, "SuperPoint candidate buffer overflow");
+      n_out_host[b0 + b] = counts[4 * b + 1];
+    }
+  }
+  GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
 int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream) {
   if (!ctx || !name || !host_out) return GN_ERR_ARG;
   hipSetDevice(ctx->device);
@@ -1210,6 +1319,9 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
       {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
       {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)},
+      {"sp_enc", ctx->sp_x, ctx->sp_x ? (size_t)ctx->sp_chunk * (ctx->sp_h / 8) * (ctx->sp_w / 8) * 128 : 0},          // SuperPoint: encoder output of the last pass, NHWC
+      {"sp_scores", ctx->sp_maps[0], ctx->sp_maps[0] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},             // softmax + depth-to-space scores
+      {"sp_nms", ctx->sp_maps[5], ctx->sp_maps[5] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},                // after simple_nms
       {"x_p", ctx->x_p, ctx->x_p ? T * kDim : 0}, {"msg_p", ctx->msg_p, ctx->msg_p ? T * kDim : 0},   // hm16 rows, raw (4 bytes per value)
       {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
   for (const Ent& e : tab)

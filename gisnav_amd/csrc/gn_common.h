@@ -235,6 +235,17 @@ void sift_descriptors(const SiftPyramid& py, int B, const SiftKeypoint* kp_final
 void sift_sort_dedup(int B, SiftKeypoint* kp, long long kp_stride, int* counters, int max_raw, int max_out,
                      float* kpt_xysa, float* response, int32_t* octave, long long out_stride, hipStream_t s);
 
+// ---- SuperPoint extractor (gn_superpoint.hip) ------------------------------------------------------------------
+void sp_weight_fragments(const float* w, int Cout, int Cin, int taps, int Cout_pad, float* out);   // host arrays
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s);
+void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+void sp_scores(const float* logits, int cp, float* scores, int B, int h, int w, hipStream_t s);
+void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, float* tmp, float* mask, float* supp, float* aux, hipStream_t s);
+void sp_select(const float* nms, int B, int H, int W, float thr, int border, int* cand, int* counts, int cap, int k,
+               float* kpt_xysa, float* score, int* kp_index, long long out_stride, hipStream_t s);
+void sp_describe(const float* dmap, int B, int h, int w, const float* kpt_xysa, const int* counts, long long out_stride, int max_k, float* desc, hipStream_t s);
+
 // ---- bf16 helpers -------------------------------------------------------------------------------
 void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s);
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]

@@ -1,0 +1,400 @@
+// SuperPoint extractor (DeTone et al.) -- the "conv backbone" BASELINE.json's north_star / configs[4] name for the deep-matcher path
+// (the reference tree does not contain it; spec = the published architecture, pinned through
+// oracle/superpoint.py to the `transformers` port).  Every kernel is hand-written for gfx950:
+//
+//   k_sp_conv1        first layer, 1 -> 64 channels, 3x3: plain FMAs (9 taps per output, VALU)
+//   k_sp_conv<TAPS>   3x3 (TAPS = 9) or 1x1 (TAPS = 1) convolution + bias (+ ReLU), NHWC f32, as an implicit GEMM on the EXACT f32
+//                     matrix instruction v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain): weights are the A operand, fetched
+//                     from L2 straight into registers in MFMA fragment order (re-laid-out once at load time, like gn_ffn.hip);
+//                     output pixels are the B operand, read from an LDS halo tile of 18 x 34 pixels x 32 input channels
+//   k_sp_pool         2x2 max-pool
+//   k_sp_scores       65-way softmax per 8x8 cell, dustbin dropped, depth-to-space -> full-resolution score map
+//   k_sp_maxrow/col   separable (2 r + 1)^2 max-pool passes of simple_nms (restated exactly: -inf padding)
+//   k_sp_nms_step     the mask algebra of simple_nms between the pools
+//   k_sp_candidates   threshold 0.005 + border 4 -> candidate list (atomic append)
+//   k_sp_select       top-k by score: 4 x 8-bit radix select of the k-th largest score, compaction, rank sort (score descending,
+//                     raster index ascending on ties) -- one workgroup per image
+//   k_sp_describe     per keypoint: bilinear sample (align_corners) of the L2-normalised 1/8-resolution descriptor map, L2 normalise
+//
+// The convolutions are f32-exact (no reduced-precision operand anywhere), so keypoints agree with an f32 CPU run except where two
+// scores tie to the last bit.
+#include "gn_common.h"
+
+#include <cmath>
+
+namespace gn {
+
+namespace {
+constexpr int TH = 16, TW = 32;          // output tile of k_sp_conv: 16 rows x 32 columns, 64 output channels
+constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
+
+__global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
+  // thread -> (pixel, 16-channel group); image index in blockIdx.z
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int grp = (int)(idx & 3);
+  const long long pix = idx >> 2;
+  if (pix >= (long long)H * W) return;
+  const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+  const float* img = in + (long long)blockIdx.z * H * W;
+  float v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
+  }
+  float* o = out + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = grp * 16 + c4 * 4 + e;
+      float acc = bias[c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(w[c * 9 + t], v[t], acc);
+      r[e] = fmaxf(acc, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+  }
+}
+
+struct ConvArgs {
+  const float* in;  int H, W, Cin;          // NHWC f32 [B][H][W][Cin], Cin a multiple of 32
+  const float* wf;                           // weights in fragment order (sp_weight_fragments): [Cout/32][TAPS][Cin/8][64 lanes][4]
+  const float* bias;                         // [Cout_padded]
+  float* out; int Cout;                      // NHWC f32 [B][H][W][Cout], Cout a multiple of 64 (padded with zero weights)
+  int relu;
+};
+
+// grid (tiles_x, tiles_y, B * Cout/64)
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
+  __shared__ __attribute__((aligned(16))) float tile[LH * LW * CH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = a.Cout / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const float* in = a.in + (long long)img * a.H * a.W * a.Cin;
+  const int csteps = a.Cin / 8;
+  const f32x4* wf = reinterpret_cast<const f32x4*>(a.wf) + lane;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+    __syncthreads();     // the previous pass is done with the tile
+    // stage the halo tile of this 32-channel slice: thread -> (pixel, 16-byte chunk), zero outside the image
+    for (int q = tid; q < LH * LW * 8; q += 256) {
+      const int pix = q >> 3, chunk = q & 7;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.W + gx) * a.Cin + c0 + chunk * 4);
+      *reinterpret_cast<f32x4*>(tile + pix * CH + ((chunk ^ (lx & 7)) * 4)) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;    // offsets into the halo tile (already shifted by HALO)
+#pragma unroll
+      for (int s = 0; s < CH / 8; ++s) {
+        f32x4 fa[2], fb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fa[i] = wf[(size_t)(((2 * og + i) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ly = 4 * wave + j + dy, lx = ql + dx;
+          fb[j] = *reinterpret_cast<const f32x4*>(tile + (ly * LW + lx) * CH + (((2 * s + hh) ^ (lx & 7)) * 4));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane = pixel (row 4 wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c
+  float* out = a.out + (long long)img * a.H * a.W * a.Cout;
+  const int gx = x0 + ql;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gy = y0 + 4 * wave + j;
+    if (gy >= a.H || gx >= a.W) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        v += b4;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(out + ((long long)gy * a.W + gx) * a.Cout + c) = v;
+      }
+  }
+}
+
+// 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void k_sp_pool(const float* in, float* out, int H, int W, int C, long long total4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = (int)(idx % (C / 4));
+  long long p = idx / (C / 4);
+  const int Wo = W / 2, Ho = H / 2;
+  const int x = (int)(p % Wo); p /= Wo;
+  const int y = (int)(p % Ho); const long long b = p / Ho;
+  const float* s = in + ((b * H + 2 * y) * W + 2 * x) * C + c4 * 4;
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(s), v01 = *reinterpret_cast<const f32x4*>(s + C);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(s + (long long)W * C), v11 = *reinterpret_cast<const f32x4*>(s + (long long)W * C + C);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+  *reinterpret_cast<f32x4*>(out + ((b * Ho + y) * Wo + x) * C + c4 * 4) = r;
+}
+
+// softmax over the 65 logits of a cell (channel pitch cp), dustbin dropped, 8x8 depth-to-space.  One wave per cell.
+__global__ __launch_bounds__(256) void k_sp_scores(const float* logits, int cp, float* scores, int h, int w, long long cells) {
+  const int lane = threadIdx.x & 63;
+  const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= cells) return;
+  const float* l = logits + cell * cp;
+  const float v = l[lane], d = l[64];
+  float m = fmaxf(v, d);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const float e = expf(v - m);
+  float sum = e;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  sum += expf(d - m);
+  long long c = cell;
+  const int cx = (int)(c % w); c /= w;
+  const int cy = (int)(c % h); const long long b = c / h;
+  scores[(b * h * 8 + cy * 8 + (lane >> 3)) * (long long)(w * 8) + cx * 8 + (lane & 7)] = e / sum;
+}
+
+// F.max_pool2d(kernel 2 r + 1, stride 1, padding r) split into a row pass and a column pass (-inf padding = ignore)
+__global__ __launch_bounds__(256) void k_sp_maxrow(const float* in, float* out, int H, int W, int r, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const float* row = in + (idx - x);
+  float m = -INFINITY;
+  for (int d = -r; d <= r; ++d) { const int xx = x + d; if (xx >= 0 && xx < W) m = fmaxf(m, row[xx]); }
+  out[idx] = m;
+}
+__global__ __launch_bounds__(256) void k_sp_maxcol(const float* in, float* out, int H, int W, int r, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const long long p = idx / W;
+  const int y = (int)(p % H);
+  const float* col = in + (idx - (long long)y * W);
+  float m = -INFINITY;
+  for (int d = -r; d <= r; ++d) { const int yy = y + d; if (yy >= 0 && yy < H) m = fmaxf(m, col[(long long)yy * W]); }
+  out[idx] = m;
+  (void)x;
+}
+// simple_nms mask algebra.  mode 0: mask = (scores == pooled);  mode 1: supp = pooled(mask) > 0, tmp = supp ? 0 : scores (written to `aux`);
+// mode 2: mask |= (aux == pooled(aux)) & !supp  (supp recomputed as aux == 0 && ... is not exact, so it is kept in `supp`)
+__global__ __launch_bounds__(256) void k_sp_nms_step(int mode, const float* scores, const float* pooled, float* mask, float* supp, float* aux, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  if (mode == 0) mask[i] = scores[i] == pooled[i] ? 1.f : 0.f;
+  else if (mode == 1) { const float sp = pooled[i] > 0.f ? 1.f : 0.f; supp[i] = sp; aux[i] = sp != 0.f ? 0.f : scores[i]; }
+  else if (mode == 2) { if (aux[i] == pooled[i] && supp[i] == 0.f) mask[i] = 1.f; }
+  else { /* mode 3: final scores = mask ? scores : 0, in place into aux */ aux[i] = mask[i] != 0.f ? scores[i] : 0.f; }
+}
+
+// candidates: score > threshold, y >= border, x >= border (transformers tests the far borders against 8 x the map size, i.e. never)
+__global__ __launch_bounds__(256) void k_sp_candidates(const float* nms, int H, int W, float thr, int border, int* cand /*[B][cap] raster index*/, int* counts /*[B][4]*/, int cap) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.z;
+  if (i >= (long long)H * W) return;
+  const float s = nms[(long long)b * H * W + i];
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  if (s > thr && y >= border && x >= border) {
+    const int slot = atomicAdd(&counts[4 * b], 1);
+    if (slot < cap) cand[(long long)b * cap + slot] = (int)i;
+  }
+}
+
+// top-k by score, one workgroup per image: radix select of the k-th largest score over the candidates, survivors compacted into
+// LDS and rank-sorted by (score descending, raster index ascending).  Outputs GN_KPT_XYSA keypoint records and scores.
+__global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int W, const int* cand, int* counts, int cap, int k,
+                                                      float* kpt_xy, float* score_out, int* kp_index, long long out_stride) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* sc = nms + (long long)b * H * W;
+  const int* cd = cand + (long long)b * cap;
+  const int n = min(counts[4 * b], cap);
+  __shared__ int s_hist[256];
+  __shared__ unsigned int s_prefix;
+  __shared__ int s_need, s_cnt, s_eq;
+  __shared__ int s_idx[2048];
+  __shared__ float s_val[2048];
+  const int kk = min(k, 2048);
+  unsigned int tbits = 0u; int eq_budget = 0x7fffffff;
+  if (n > kk) {
+    if (tid == 0) { s_prefix = 0u; s_need = kk; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) s_hist[tid] = 0;
+      __syncthreads();
+      const unsigned int prefix = s_prefix;
+      for (int i = tid; i < n; i += 1024) {
+        const unsigned int bits = __float_as_uint(sc[cd[i]]);
+        if (shift == 24 || ((bits ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(bits >> shift) & 255u], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int need = s_need, bin = 255;
+        for (; bin > 0; --bin) { if (s_hist[bin] >= need) break; need -= s_hist[bin]; }
+        s_need = need; s_prefix = prefix | ((unsigned int)bin << shift);
+      }
+      __syncthreads();
+    }
+    tbits = s_prefix; eq_budget = s_need;
+  }
+  if (tid == 0) { s_cnt = 0; s_eq = 0; }
+  __syncthreads();
+  // survivors: score > T, plus the eq_budget candidates of score == T with the smallest raster index (found by counting)
+  for (int i = tid; i < n; i += 1024) {
+    const int ci = cd[i];
+    const unsigned int bits = __float_as_uint(sc[ci]);
+    if (bits > tbits || n <= kk) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
+  }
+  __syncthreads();
+  if (n > kk) {
+    // ties at the threshold: take them in raster order -- each tie counts the ties with a smaller index
+    for (int i = tid; i < n; i += 1024) {
+      const int ci = cd[i];
+      if (__float_as_uint(sc[ci]) != tbits) continue;
+      int before = 0;
+      for (int j = 0; j < n; ++j) { const int cj = cd[j]; if (cj < ci && __float_as_uint(sc[cj]) == tbits) ++before; }
+      if (before < eq_budget) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
+    }
+    __syncthreads();
+  }
+  const int m = min(s_cnt, min(kk, 2048));
+  for (int i = tid; i < m; i += 1024) {
+    const float v = s_val[i]; const int ci = s_idx[i];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) { const float vj = s_val[j]; if (vj > v || (vj == v && s_idx[j] < ci)) ++rank; }
+    const int y = ci / W, x = ci - y * W;
+    float* kr = kpt_xy + ((long long)b * out_stride + rank) * 4;       // GN_KPT_XYSA record: x, y, size (unused: 1), angle (unused: 0)
+    kr[0] = (float)x; kr[1] = (float)y; kr[2] = 1.f; kr[3] = 0.f;
+    score_out[(long long)b * out_stride + rank] = v;
+    kp_index[(long long)b * out_stride + rank] = ci;
+  }
+  if (tid == 0) { counts[4 * b + 1] = m; counts[4 * b + 2] = n; }
+}
+
+// descriptors: one wave per keypoint; lane -> 4 of the 256 channels.  dmap [B][h][w][256] (conv_descriptor_b output, NOT yet normalised)
+__global__ __launch_bounds__(256) void k_sp_describe(const float* dmap, int h, int w, const float* kpt_xy, const int* counts, long long out_stride, float* desc) {
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= counts[4 * b + 1]) return;
+  const float kx = kpt_xy[((long long)b * out_stride + k) * 4], ky = kpt_xy[((long long)b * out_stride + k) * 4 + 1];
+  // _sample_descriptors: kp - 4 + 0.5, / (w 8 - 4 - 0.5), * 2 - 1; grid_sample(align_corners=True): ((g + 1) / 2) (w - 1)
+  const float gx = ((kx - 4.0f + 0.5f) / ((float)(w * 8) - 4.0f - 0.5f)) * 2.0f - 1.0f;
+  const float gy = ((ky - 4.0f + 0.5f) / ((float)(h * 8) - 4.0f - 0.5f)) * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+  const float* base = dmap + (long long)b * h * w * 256;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+    const float wt = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
+    if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;     // zero padding
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long long)yy * w + xx) * 256 + lane * 4);
+    float n2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);        // F.normalize(p=2, dim=1, eps=1e-12) of the map
+    acc += v * (inv * wt);
+  }
+  float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+  const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+  *reinterpret_cast<f32x4*>(desc + ((long long)b * out_stride + k) * 256 + lane * 4) = acc * inv;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+// conv weight [Cout][Cin][kh][kw] (torch layout) -> fragment order [Cout_pad/32][TAPS][Cin/8][64 lanes][4]: lane (n = l & 31, hh = l >> 5)
+// holds W[32 tile + n][tap][8 cs + 4 hh .. + 3]; rows >= Cout are zero.
+void sp_weight_fragments(const float* w, int Cout, int Cin, int taps, int Cout_pad, float* out) {
+  const int csteps = Cin / 8;
+  for (int tile = 0; tile < Cout_pad / 32; ++tile)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int cs = 0; cs < csteps; ++cs)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 4; ++e) {
+            const int n = 32 * tile + (l & 31), c = 8 * cs + 4 * (l >> 5) + e;
+            const float v = n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.f;
+            out[((((size_t)tile * taps + tap) * csteps + cs) * 64 + l) * 4 + e] = v;
+          }
+}
+
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
+  const long long n = (long long)H * W * 4;
+  hipLaunchKernelGGL(k_sp_conv1, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
+}
+void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s) {
+  ConvArgs a; a.in = in; a.H = H; a.W = W; a.Cin = Cin; a.wf = wf; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = relu;
+  const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (Cout_pad / 64));
+  if (taps == 9) hipLaunchKernelGGL(k_sp_conv<9>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_sp_conv<1>, grid, dim3(256), 0, s, a);
+}
+void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(k_sp_pool, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out, H, W, C, total4);
+}
+void sp_scores(const float* logits, int cp, float* scores, int B, int h, int w, hipStream_t s) {
+  const long long cells = (long long)B * h * w;
+  hipLaunchKernelGGL(k_sp_scores, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, logits, cp, scores, h, w, cells);
+}
+// simple_nms(scores, r) -> `aux` (the suppressed score map); scratch: pooled, tmp, mask, supp (each B*H*W floats)
+void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, float* tmp, float* mask, float* supp, float* aux, hipStream_t s) {
+  const long long total = (long long)B * H * W;
+  const dim3 g((unsigned)((total + 255) / 256)), blk(256);
+  auto pool = [&](const float* src) {
+    hipLaunchKernelGGL(k_sp_maxrow, g, blk, 0, s, src, tmp, H, W, r, total);
+    hipLaunchKernelGGL(k_sp_maxcol, g, blk, 0, s, tmp, pooled, H, W, r, total);
+  };
+  pool(scores);
+  hipLaunchKernelGGL(k_sp_nms_step, g, blk, 0, s, 0, scores, pooled, mask, supp, aux, total);
+  for (int it = 0; it < 2; ++it) {
+    pool(mask);
+    hipLaunchKernelGGL(k_sp_nms_step, g, blk, 0, s, 1, scores, pooled, mask, supp, aux, total);
+    pool(aux);
+    hipLaunchKernelGGL(k_sp_nms_step, g, blk, 0, s, 2, scores, pooled, mask, supp, aux, total);
+  }
+  hipLaunchKernelGGL(k_sp_nms_step, g, blk, 0, s, 3, scores, pooled, mask, supp, aux, total);
+}
+void sp_select(const float* nms, int B, int H, int W, float thr, int border, int* cand, int* counts, int cap, int k,
+               float* kpt_xy, float* score, int* kp_index, long long out_stride, hipStream_t s) {
+  hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int), s);
+  hipLaunchKernelGGL(k_sp_candidates, dim3((unsigned)(((long long)H * W + 255) / 256), 1, B), dim3(256), 0, s, nms, H, W, thr, border, cand, counts, cap);
+  hipLaunchKernelGGL(k_sp_select, dim3(B), dim3(1024), 0, s, nms, H, W, cand, counts, cap, k, kpt_xy, score, kp_index, out_stride);
+}
+void sp_describe(const float* dmap, int B, int h, int w, const float* kpt_xy, const int* counts, long long out_stride, int max_k, float* desc, hipStream_t s) {
+  hipLaunchKernelGGL(k_sp_describe, dim3((max_k + 3) / 4, B), dim3(256), 0, s, dmap, h, w, kpt_xy, counts, out_stride, desc);
+}
+
+}  // namespace gn

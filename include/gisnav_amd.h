@@ -264,6 +264,20 @@ int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, in
 /* Distinct keypoints each image of the LAST gn_sift_detect_and_compute(_batch) call had before the max_kpts cap (HOST int32 [B]). */
 int gn_sift_last_totals(gn_ctx* ctx, int B, int32_t* totals_host);
 
+/* ---- SuperPoint extractor (BASELINE.json configs[4] / north_star "conv backbone"; not in the reference tree) ---------- */
+/* Load one tensor of the SuperPoint network from HOST memory, float32, torch layout ([out][in][kh][kw] for conv weights), under
+ * transformers' SuperPointForKeypointDetection key names: encoder.conv_blocks.{0..3}.conv_{a,b}.{weight,bias},
+ * keypoint_decoder.conv_score_{a,b}.*, descriptor_decoder.conv_descriptor_{a,b}.*. */
+int gn_sp_load_tensor(gn_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+/* SuperPoint on B grayscale images: gray01 [B][H][W] f32 in [0, 1] (device), H and W multiples of 8.  Outputs (device):
+ * kpt_xysa [B][max_kpts][4] = (x, y, 1, 0) keypoint records in the GN_KPT_XYSA format of gn_match / gn_estimate (for a
+ * GN_FEATURE_SUPERPOINT context), score [B][max_kpts] (may be NULL), desc [B][max_kpts][256] L2-normalised; n_out_host: HOST
+ * int32 [B] keypoints per image, sorted by descending score (raster order on equal scores).  Detector settings of the
+ * published model: threshold 0.005, NMS radius 4, border 4, top max_kpts (<= 2048).  The convolutions are exact f32
+ * (v_mfma_f32_32x32x2_f32).  Synchronises `stream` once per pass of 4 images to read the counts. */
+int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, int W, int max_kpts,
+                              float* kpt_xysa, float* score, float* desc, int32_t* n_out_host, void* stream);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"

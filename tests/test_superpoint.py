@@ -110,3 +110,95 @@ def test_superpoint_matcher_object_drop_in(sd_sp):
     dists, idx = m(tq(p.desc_q).cuda(), tq(p.desc_r).cuda(), laf_q.cuda(), laf_r.cuda(), hw1=(1080, 1920), hw2=(1080, 1920))
     sc, oidx = lsp.match(tsd, tq(p.kp_q), tq(p.desc_q), tq(p.kp_r), tq(p.desc_r), hw0=(1080, 1920), hw1=(1080, 1920))
     assert idx.dtype == torch.int64 and dists.shape == (len(oidx), 1) and torch.equal(idx.cpu(), oidx)
+
+
+# ------------------------------------------------------------------ SuperPoint extractor (conv backbone)
+def _test_image(seed, h, w):
+    rs = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = 0.45 + 0.2 * np.sin(xx / 9.0 + 0.3 * seed) * np.cos(yy / 7.0)
+    for _ in range(60):
+        cx, cy, s_, a = rs.uniform(0, w), rs.uniform(0, h), rs.uniform(2.0, 9.0), rs.uniform(-0.4, 0.4)
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s_ * s_))
+    img += 0.03 * rs.normal(size=(h, w))
+    return np.clip(img, 0, 1).astype(np.float32)
+
+
+def test_superpoint_oracle_equals_transformers_model():
+    """oracle/superpoint.py against transformers' SuperPointForKeypointDetection with the same (seeded random) weights: keypoints,
+    scores and descriptors identical -- the extractor's oracle IS pinned to third-party code."""
+    from transformers.models.superpoint.configuration_superpoint import SuperPointConfig
+    from transformers.models.superpoint.modeling_superpoint import SuperPointForKeypointDetection
+    from oracle import superpoint as osp
+    sd = osp.synthetic_state_dict(0)
+    hf = SuperPointForKeypointDetection(SuperPointConfig(max_keypoints=300)).eval()
+    hf.load_state_dict(sd, strict=True)
+    img = torch.from_numpy(_test_image(1, 120, 160))
+    kp, sc, d = osp.detect_and_describe(sd, img, 300)
+    with torch.inference_mode():
+        out = hf(img[None, None].repeat(1, 3, 1, 1))
+    n = int(out.mask[0].sum())
+    assert n == len(kp) == 300
+    assert torch.equal(kp, torch.round(out.keypoints[0, :n] * torch.tensor([160.0, 120.0])))      # the model returns relative coordinates
+    assert torch.equal(sc, out.scores[0, :n]) and float((d - out.descriptors[0, :n]).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape,k", [(2, (120, 160), 300), (3, (240, 320), 512), (4, (136, 200), 2048)])
+def test_superpoint_extractor_against_oracle(seed, shape, k):
+    """HIP SuperPoint (exact-f32 MFMA convolutions) against the oracle: encoder features and score map to f32 rounding, the keypoint
+    SET identical up to last-bit score ties (>= 99 %), descriptors of the common keypoints within 1e-4."""
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    sd = osp.synthetic_state_dict(0)
+    sp = SuperPoint(max_keypoints=k, state_dict=sd)
+    img = _test_image(seed, *shape)
+    taps = {}
+    okp, osc, od = osp.detect_and_describe(sd, torch.from_numpy(img), k, taps=taps)
+    kpt, score, desc, n = sp.detect_and_describe_device(img[None])
+    torch.cuda.synchronize()
+    h, w = shape[0] // 8, shape[1] // 8
+    enc = sp._eng.debug_read("sp_enc", h * w * 128).reshape(h, w, 128)
+    ref_enc = taps["block3"][0].permute(1, 2, 0).numpy()
+    assert np.abs(enc - ref_enc).max() < 2e-5 * np.abs(ref_enc).max()
+    smap = sp._eng.debug_read("sp_nms", shape[0] * shape[1]).reshape(shape)
+    ref_map = taps["scores"][0].numpy()
+    assert np.abs(smap - ref_map).max() < 1e-5
+    assert ((smap > 0) != (ref_map > 0)).mean() < 1e-4          # NMS decisions: identical except where two scores tie to the last bit
+    m = int(n[0])
+    assert abs(m - len(okp)) <= max(2, len(okp) // 100)
+    got = {(float(x), float(y)): i for i, (x, y) in enumerate(kpt[0, :m, :2].cpu().numpy())}
+    ref = {(float(x), float(y)): i for i, (x, y) in enumerate(okp.numpy())}
+    common = set(got) & set(ref)
+    assert len(common) >= 0.99 * len(ref)
+    gi = np.array([got[c] for c in common]); ri = np.array([ref[c] for c in common])
+    assert np.abs(score[0].cpu().numpy()[gi] - osc.numpy()[ri]).max() < 1e-5
+    assert np.abs(desc[0].cpu().numpy()[gi] - od.numpy()[ri]).max() < 1e-4
+    sc = score[0, :m].cpu().numpy()
+    assert (np.diff(sc) <= 0).all()                             # sorted by descending score
+    assert np.abs(np.linalg.norm(desc[0, :m].cpu().numpy(), axis=1) - 1).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_superpoint_plus_lightglue_pixels_to_pose(sd_sp):
+    """configs[4] end to end at reduced size: SuperPoint on a frame and on a shifted copy of it, LightGlue(superpoint) on the result
+    (identity-block weights: mutual nearest neighbours of the descriptors), matches must be the shift."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    sd_m = synthetic_state_dict(0, feature="superpoint", identity_blocks=True)
+    eng = PoseEngine(0, max_batch=1, max_kpts=512, precision="f32", state_dict=sd_m, filter_threshold=0.1, feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=512, state_dict=osp.synthetic_state_dict(0))
+    big = _test_image(9, 256, 336)
+    a, b = big[8:248, 8:328], big[16:256, 0:320]                # b(y, x) = a(y + 8, x - 8): 8-aligned shift -> identical cell phase
+    kpt, score, desc, n = sp.detect_and_describe_device(np.stack([a, b]))
+    nd = torch.as_tensor(n, device=eng.device)
+    eng.set_image_size((320.0, 240.0), (320.0, 240.0))
+    idx, sc, nm = eng.match(desc[0:1], kpt[0:1], nd[0:1], desc[1:2], kpt[1:2], nd[1:2])
+    torch.cuda.synchronize()
+    k = int(nm[0])
+    assert k > 50
+    pa = kpt[0, idx[0, :k, 0], :2].cpu().numpy(); pb = kpt[1, idx[0, :k, 1], :2].cpu().numpy()
+    d = pa - pb
+    good = (np.abs(d[:, 0] - 8) < 0.5) & (np.abs(d[:, 1] + 8) < 0.5)
+    assert good.mean() > 0.9
