@@ -175,6 +175,67 @@ def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev):
             "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak}
 
 
+def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, kpts=1024):
+    """BASELINE configs[4] on this rank's GPU: `batch` 1920x1080 frame<->tile pairs from PIXELS -- SuperPoint (exact-f32 convolutions) on
+    2 x batch images, LightGlue(features="superpoint") in the headline precision, PnP-RANSAC.  Synthetic textured frames, the tile is a
+    shifted crop of the same scene; seeded random weights (timing is what is measured; match quality is not)."""
+    from gisnav_amd.superpoint import SuperPoint
+    from gisnav_amd import _lib as glib
+    sd_m = synthetic_state_dict(0, feature="superpoint")
+    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision="f16x2_bf16_attn", state_dict=sd_m, filter_threshold=0.1, feature="superpoint")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    conv_sd = {}
+    sizes = [1, 64, 64, 128, 128]
+    def conv(name, cout, cin, k):
+        conv_sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        conv_sd[name + ".bias"] = torch.randn(cout, generator=g) * 0.05
+    for b in range(4):
+        conv(f"encoder.conv_blocks.{b}.conv_a", sizes[b + 1], sizes[b], 3)
+        conv(f"encoder.conv_blocks.{b}.conv_b", sizes[b + 1], sizes[b + 1], 3)
+    conv("keypoint_decoder.conv_score_a", 256, 128, 3); conv("keypoint_decoder.conv_score_b", 65, 256, 1)
+    conv("descriptor_decoder.conv_descriptor_a", 256, 128, 3); conv("descriptor_decoder.conv_descriptor_b", 256, 256, 1)
+    sp = SuperPoint(engine=eng, max_keypoints=kpts, state_dict=conv_sd)
+    rs = np.random.default_rng(11)
+    base = rs.uniform(0, 1, (batch, h // 8 + 3, w // 8 + 3)).astype(np.float32)
+    big = torch.nn.functional.interpolate(torch.from_numpy(base)[:, None], size=(h + 16, w + 16), mode="bicubic", align_corners=False)[:, 0].clamp(0, 1)
+    frames = big[:, 8:8 + h, 8:8 + w].contiguous().to(dev)
+    tiles = big[:, 16:16 + h, 0:w].contiguous().to(dev)
+    imgs = torch.cat([frames, tiles], 0)
+    dem = torch.zeros((batch, h, w), dtype=torch.uint8, device=dev)
+    Kc = np.array([[205.4696 * 3, 0.0, w / 2], [0.0, 205.4696 * 3, h / 2], [0.0, 0.0, 1.0]])
+    eng.set_image_size((float(w), float(h)), (float(w), float(h)))
+    out = eng.alloc_outputs(batch)
+    t_sp = 0.0
+
+    def step():
+        nonlocal t_sp
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        kpt, score, desc, n = sp.detect_and_describe_device(imgs)
+        torch.cuda.synchronize(); t_sp += time.perf_counter() - t0
+        nd = torch.as_tensor(n, device=dev)
+        inp = dict(desc_q=desc[:batch], kpt_q=kpt[:batch], n_q=nd[:batch], desc_r=desc[batch:], kpt_r=kpt[batch:], n_r=nd[batch:], dem=dem, kpt_format=glib.GN_KPT_XYSA)
+        eng.estimate(inp, Kc, out=out)
+        return n
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(); t_sp = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    res = {"config": "BASELINE configs[4] per GPU: 1920x1080 frames -> SuperPoint (exact-f32 MFMA convolutions) -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels",
+           "batch": batch, "keypoints_per_side": kpts, "precision": "f32 convolutions + f16x2_bf16_attn matcher", "steps": steps, "warmup": warmup,
+           "value": round(batch * steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "superpoint_ms_per_image": round(t_sp / steps / (2 * batch) * 1e3, 3), "superpoint_gflop_per_image": 345.0,
+           "superpoint_tflops": round(345.0 / (t_sp / steps / (2 * batch)) / 1e3, 1), "superpoint_frac_of_f32_mfma_peak": round(345.0 / (t_sp / steps / (2 * batch)) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "mean_keypoints": float(np.mean(n)), "mean_matches": float(out["n_match"].float().mean().item()), "poses_ok": int(out["ok"].sum().item()),
+           "note": "random-init networks: keypoints / matches are whatever the untrained detector yields; the model named by configs[4] is not in the reference tree"}
+    del sp, eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
     """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a
     bounded sample of the same workload."""
@@ -284,6 +345,7 @@ def main() -> None:
                                 args.batch, args.kpts, "bf16_attn", 6, 2, dev))
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
                                 1, args.kpts, args.precision, 30, 5, dev))
+        extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps
