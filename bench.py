@@ -181,8 +181,8 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
     shifted crop of the same scene; seeded random weights (timing is what is measured; match quality is not)."""
     from gisnav_amd.superpoint import SuperPoint
     from gisnav_amd import _lib as glib
-    sd_m = synthetic_state_dict(0, feature="superpoint")
-    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision="f16x2_bf16_attn", state_dict=sd_m, filter_threshold=0.1, feature="superpoint")
+    sd_m = synthetic_state_dict(0, feature="superpoint", identity_blocks=True)    # blocks = identity: the match is the mutual nearest neighbour of the descriptors
+    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision="f16x2_bf16_attn", state_dict=sd_m, filter_threshold=0.0, feature="superpoint")
     g = torch.Generator(device="cpu").manual_seed(5)
     conv_sd = {}
     sizes = [1, 64, 64, 128, 128]
