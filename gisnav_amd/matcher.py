@@ -34,15 +34,38 @@ class LightGlueMatcher:
             # always False, pose_node.py:88); only the exhaustive configuration is implemented
             raise NotImplementedError("only depth_confidence = width_confidence = -1 is supported")
         self.params = p
+        if state_dict is None:
+            state_dict = self._find_pretrained(feature_name)    # kornia loads the pretrained checkpoint in its constructor (pose_node.py:109-121 passes none)
         self._state_dict = state_dict
         self._max_kpts, self._precision = max_kpts, precision
         self._engine: Optional[PoseEngine] = None
+
+    @staticmethod
+    def _find_pretrained(feature_name: str):
+        """kornia's LightGlue constructor fetches `{feature}_lightglue` (cvg/LightGlue release v0.1_arxiv) through torch.hub into
+        <hub_dir>/checkpoints/ and loads it; this mirror looks in the same place (and in $GISNAV_AMD_LIGHTGLUE_WEIGHTS) but never
+        downloads.  Returns a state dict or None (then .to() fails loudly unless load_state_dict() was called)."""
+        import os
+        cands = [os.environ.get("GISNAV_AMD_LIGHTGLUE_WEIGHTS")]
+        try:
+            hub = os.path.join(torch.hub.get_dir(), "checkpoints")
+            cands += [os.path.join(hub, f"{feature_name}_lightglue_v0-1_arxiv-pth"), os.path.join(hub, f"{feature_name}_lightglue_v0-1_arxiv.pth"),
+                      os.path.join(hub, f"{feature_name}_lightglue.pth")]
+        except Exception:  # noqa: BLE001
+            pass
+        for c in cands:
+            if c and os.path.exists(c):
+                return torch.load(c, map_location="cpu")
+        return None
 
     # torch.nn.Module-shaped conveniences used by the call site
     def to(self, device):
         device = torch.device(device)
         if device.type != "cuda":
             raise _lib.GnError("gisnav_amd.LightGlueMatcher runs on an MI355X only (no CPU path)")
+        if self._state_dict is None:
+            raise _lib.GnError(f"no LightGlue('{self.feature_name}') weights: kornia would download {self.feature_name}_lightglue (v0.1_arxiv) here; offline, put the "
+                               "checkpoint into torch.hub's checkpoints directory, set GISNAV_AMD_LIGHTGLUE_WEIGHTS, or call load_state_dict() before .to()")
         self._engine = PoseEngine(device.index or 0, max_batch=1, max_kpts=self._max_kpts, precision=self._precision,
                                   state_dict=self._state_dict, n_layers=self.params["n_layers"],
                                   filter_threshold=self.params["filter_threshold"], guard="sync", feature=self.feature_name)

@@ -25,6 +25,15 @@ def _engine(max_pts: int) -> PoseEngine:
     return _default_engine
 
 
+def init(device: int = 0, max_points: int = 4096) -> PoseEngine:
+    """Create the module-level solver context ahead of time (otherwise the first compute_pose call pays the hipMalloc inside
+    the ROS callback)."""
+    global _default_engine
+    if _default_engine is None or _default_engine.kmax < max_points or (_default_engine.device.index or 0) != device:
+        _default_engine = PoseEngine(device, max_batch=1, max_kpts=max(max_points, 1024))
+    return _default_engine
+
+
 def compute_pose(camera_info, mkp_qry: np.ndarray, mkp_ref: np.ndarray, elevation: Optional[np.ndarray],
                  engine: Optional[PoseEngine] = None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
     def _compute_3d_points(mkp_ref, elevation):
