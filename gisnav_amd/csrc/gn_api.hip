@@ -33,6 +33,7 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
+  int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
   int ffn_fold = 1;        // with ffn_fused == 3: out_proj / to_out folded into the block-tail kernel (developer knob 13; 0 = separate GEMM launch)
   int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
                            // (k_gemm_p2ln) when the grid fills the chip, 2 = always; 0 = separate k_ln_gelu (developer knob 10)
@@ -797,6 +798,7 @@ int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const 
   a.fx = K9[0]; a.fy = K9[4]; a.cx = K9[2]; a.cy = K9[5];
   a.iterations = iterations_count; a.reproj = reproj_error_px; a.confidence = confidence; a.min_pts = min_pts;
   a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws; a.hyp = ctx->hyp_ws;
+  a.dbg_ts = ctx->pnp_stamps ? reinterpret_cast<long long*>(ctx->sim) : nullptr;   // developer knob 15: phase stamps land in the (idle) sim buffer
   StageTimer tm(ctx, (hipStream_t)stream, ST_PNP);
   launch_pnp(a, (hipStream_t)stream);
   GN_HIP(hipGetLastError());
@@ -1417,6 +1419,8 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 9) ctx->dbg_vt_skip = value;
   else if (which == 12) gn::g_ffn_ablate = value;
   else if (which == 13) ctx->ffn_fold = value;
+  else if (which == 14) gn::g_ffn_shape = value;
+  else if (which == 15) ctx->pnp_stamps = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -107,12 +107,13 @@ struct FfnArgs {
   const float* b2;
   uint16_t* yp;                            // [T][256] hm16 output rows (may be xp: a workgroup only touches its own 64 rows)
   float* y;                                // optional f32 copy of the output, or nullptr
-  int T;                                   // tokens, a multiple of 64
+  int T;                                   // tokens, a multiple of 64 (of 32 for the 4-wave shape)
   unsigned int* ovf;                       // f16x2 domain guard word, or nullptr
   long long* dbg_ts;                       // developer: [blocks][8 waves][8] s_memtime stamps (ablation 8), or nullptr
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 extern int g_ffn_ablate;
+extern int g_ffn_shape;
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
 
 // ---- attention --------------------------------------------------------------------------------
@@ -186,6 +187,7 @@ struct PnpArgs {
   double* R; double* t; int32_t* n_inliers; uint8_t* ok;
   uint8_t* mask_ws;          // [B][16][kstride] scratch: one inlier mask per concurrent hypothesis
   HypResult* hyp;            // [B][16]
+  long long* dbg_ts;         // developer: nullptr, or [B][16 + 1][16] s_memtime phase stamps (k_pnp_hyp waves, then k_pnp_refine)
 };
 void launch_pnp(const PnpArgs& a, hipStream_t s);
 void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s);

@@ -33,12 +33,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-constexpr int TM = 64;                  // tokens per workgroup
-constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 64 token rows (hm16: 128 B per row)
-constexpr int HBUF = 16 * KT;           // hidden tile: 512 units = 16 k-tiles (128 KB)
-constexpr int STAT = HBUF;              // two [8 waves][64 tokens] float arrays behind it
+// Shapes of the same kernel: NW waves x NJ token tiles of 32 per workgroup.  (8, 2) is the bulk shape (64 tokens, one workgroup per
+// CU); (8, 1) halves the tokens per workgroup for small grids (batch 1: 2048 tokens are 32 workgroups of 64 on 256 CUs).  (4, 1) --
+// two workgroups per CU, whose VALU and MFMA phases could overlap -- was measured SLOWER at every batch size (each wave then streams
+// twice the weight bytes with the same number of loads in flight) and is not instantiated.
+//   NJ            token tiles of 32 per workgroup (every wave covers all of them)
+//   NI = 16 / NW  hidden tiles of 32 per wave in GEMM 1;   NO = 8 / NW  output tiles of 32 per wave in GEMM 0 and GEMM 2
 constexpr int YP = 260;                 // float pitch of the output tile staged for the row-wise epilogue (aliases the hidden tile)
-constexpr int SMEM = HBUF + 2 * 8 * TM * 4;
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
 
@@ -60,8 +61,14 @@ __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m) {
 
 // FOLD: the message is not read from memory but computed here, msg = out_proj(ctx) (kornia `self.out_proj` / `self.to_out`), from
 // the attention output rows -- the out_proj GEMM launch and the msg round trip through HBM disappear.
-template <int ABL = 0, bool FOLD = true>   // ABL, timing-only ablations: 1 no weight loads inside the loops, 2 no second GEMM, 4 no GELU; 8 = s_memtime stamps per phase into a.dbg_ts
-__global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
+template <int ABL = 0, bool FOLD = true, int NW = 8, int NJ = 2>   // ABL, timing-only ablations: 1 no weight loads inside the loops, 2 no second GEMM, 4 no GELU; 8 = s_memtime stamps per phase into a.dbg_ts
+__global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
+  constexpr int NI = 16 / NW, NO = 8 / NW;
+  constexpr int TM = 32 * NJ;             // tokens per workgroup
+  constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of TM token rows (hm16: 128 B per row)
+  constexpr int HBUF = 16 * KT;           // hidden tile: 512 units = 16 k-tiles (128 KB / 64 KB)
+  constexpr int STAT = HBUF;              // two [NW waves][TM tokens] float arrays behind it
+  constexpr int SMEM = HBUF + 2 * NW * TM * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
@@ -73,19 +80,19 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   // LDS: 16 slots of one k-tile each (64 token rows x 128 B, chunk c of row r at position c ^ swz(r)).  Slots 0..7 hold, in turn, the
   // attention-output tile (operand of the folded out_proj) and the x tile; slots 8..15 the message tile; all 16 the hidden tile.
   // token-tile staging: thread -> (row, 16-byte chunk) of a k-tile; all sources are hm16 rows of 256 values (1 KB)
-  const int srow = tid >> 3, schunk = tid & 7;
+  const int srow = (tid >> 3) & (TM - 1), schunk = tid & 7;   // TM < 8 NW: the upper waves stage the same rows again (identical bytes, no branch)
   const size_t soff = (size_t)(bm + srow) * 1024 + schunk * 16;
   const unsigned char* const xsrc = reinterpret_cast<const unsigned char*>(a.xp) + soff;
   const unsigned char* const msrc = reinterpret_cast<const unsigned char*>(FOLD ? a.cp : a.mp) + soff;   // ctx rows (FOLD) or msg rows
   const int sdst = srow * 128 + ((schunk ^ swz(srow)) * 16);
   // token fragments of k-step ks of a slot: lane (row 32 j + ql, hh), term pl -> chunk 4 ks + 2 pl + hh
-  int brow[2], bsw[2];
+  int brow[NJ], bsw[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { brow[j] = (32 * j + ql) * 128; bsw[j] = swz(32 * j + ql); }
-  f16x8 fb[2][2][2];   // [buffer][token tile][term]: the fragments of k-step kk + 1 are read while k-step kk is on the matrix pipe
+  for (int j = 0; j < NJ; ++j) { brow[j] = (32 * j + ql) * 128; bsw[j] = swz(32 * j + ql); }
+  f16x8 fb[2][NJ][2];   // [buffer][token tile][term]: the fragments of k-step kk + 1 are read while k-step kk is on the matrix pipe
   auto read_b = [&](int buf, const unsigned char* base, int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
         fb[buf][j][pl] = *reinterpret_cast<const f16x8*>(base + brow[j] + (((4 * ks + 2 * pl + hh) ^ bsw[j]) * 16));
@@ -111,13 +118,14 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   };
 
   // ---------------------------------------------------------------- prologue: the message side of the token tile
-  uint4 xr[3];
+  uint4 xr0, xr1, xr2;   // three named registers, not an array: an array here is promoted to LDS (48 B per lane) before the unroll makes its indices constant
+  auto xr = [&](int q) __attribute__((always_inline)) -> uint4& { return q == 0 ? xr0 : (q == 1 ? xr1 : xr2); };
   {
     uint4 mt[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) mt[q] = *reinterpret_cast<const uint4*>(msrc + q * 128);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) xr[q] = *reinterpret_cast<const uint4*>(xsrc + q * 128);      // first x k-tiles, written after the message phase
+    for (int q = 0; q < 3; ++q) xr(q) = *reinterpret_cast<const uint4*>(xsrc + q * 128);      // first x k-tiles, written after the message phase
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(smem + ((FOLD ? 0 : 8) + q) * KT + sdst) = mt[q];
   }
@@ -125,31 +133,35 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   // the slot of k-step kk is refilled as soon as its MFMAs are issued.  Every loop is fully unrolled and branch-free, so each
   // s_waitcnt the compiler places is an exact count.
   const uint4* w1f = reinterpret_cast<const uint4*>(a.w1s) + lane;
-  constexpr int RA = 6;
-  f16x8 fa[RA][2][2];   // [ring slot = k-step % RA][hidden tile][term]
+  constexpr int RA = NW == 8 ? (NJ == 2 ? 6 : 8) : 4;     // k-steps in flight: NI x 4 KB per wave each
+  f16x8 fa[RA][NI][2];   // [ring slot = k-step % RA][hidden tile][term]
   // GEMM 1 visits the k-tiles in the order 8..15, 0..7 (message first: it is in LDS already): iteration n -> slot (n + 8) & 15
   auto load_a = [&](int slot, int n2) __attribute__((always_inline)) {      // n2 = 2 * iteration + k-step
     const int kk = (n2 + 16) & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        fa[slot][i][pl] = __builtin_bit_cast(f16x8, w1f[(size_t)(((2 * wave + i) * 32 + kk) * 2 + pl) * 64]);
+        fa[slot][i][pl] = __builtin_bit_cast(f16x8, w1f[(size_t)(((NI * wave + i) * 32 + kk) * 2 + pl) * 64]);
   };
   if (FOLD) {
     // ------------------------------------------------------------ GEMM 0 (transposed): Msg^T[256][64] = Wo[256][256] . Ctx^T; wave w: features 32 w ..
-    const uint4* wof = reinterpret_cast<const uint4*>(a.wos) + lane + (size_t)wave * 16 * 2 * 64;
-    constexpr int RO = 8;
-    f16x8 go[RO][2];
+    const uint4* wof = reinterpret_cast<const uint4*>(a.wos) + lane + (size_t)(NO * wave) * 16 * 2 * 64;      // output tile NO w + o: block ((tile * 16 + kstep) * 2 + term)
+    constexpr int RO = NW == 8 ? 8 : 6;
+    f16x8 go[RO][NO][2];
 #pragma unroll
     for (int q = 0; q < RO; ++q)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) go[q][pl] = __builtin_bit_cast(f16x8, wof[(q * 2 + pl) * 64]);
-    f32x16 acc0[2];
+      for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int pl = 0; pl < 2; ++pl) go[q][o][pl] = __builtin_bit_cast(f16x8, wof[((o * 16 + q) * 2 + pl) * 64]);
+    f32x16 acc0[NO][NJ];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[j][r] = 0.f;
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[o][j][r] = 0.f;
     __syncthreads();
     stamp(1);
     read_b(0, smem, 0);
@@ -160,25 +172,32 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(go[kk % RO][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc0[j], 0, 0, 0);
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc0[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(go[kk % RO][o][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc0[o][j], 0, 0, 0);
       if (!(ABL & 1) && kk + RO < 16) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) go[kk % RO][pl] = __builtin_bit_cast(f16x8, wof[((kk + RO) * 2 + pl) * 64]);
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) go[kk % RO][o][pl] = __builtin_bit_cast(f16x8, wof[((o * 16 + kk + RO) * 2 + pl) * 64]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int q = 0; q < RA; ++q) load_a(q, q);
-    // message = acc0 * scale + bias: feature 32 w + 8 g + 4 hh + c in register 4 g + c -> slot 8 + w
-    float bo[16];
+    // message = acc0 * scale + bias: feature 32 (NO w + o) + 8 g + 4 hh + c in register 4 g + c -> slot 8 + NO w + o
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + 32 * wave + 8 * g + 4 * hh);
-      bo[4 * g] = b4.x; bo[4 * g + 1] = b4.y; bo[4 * g + 2] = b4.z; bo[4 * g + 3] = b4.w;
+    for (int o = 0; o < NO; ++o) {
+      float bo[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + 32 * (NO * wave + o) + 8 * g + 4 * hh);
+        bo[4 * g] = b4.x; bo[4 * g + 1] = b4.y; bo[4 * g + 2] = b4.z; bo[4 * g + 3] = b4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) publish(acc0[o][j], 8 + NO * wave + o, j, a.wo_scale, bo);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) publish(acc0[j], 8 + wave, j, a.wo_scale, bo);
     __syncthreads();     // message tile complete; every wave is done with the attention-output tile in slots 0..7
   } else {
 #pragma unroll
@@ -188,11 +207,11 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   }
 
   // ---------------------------------------------------------------- GEMM 1 (transposed): H^T[512][64] = W1[512][512] . [x | msg]^T
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // iterations 0..7 consume the message slots and, on the side, stage x k-tile n into slot n (loaded three iterations earlier);
@@ -201,8 +220,8 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
   for (int n = 0; n < 16; ++n) {
     if (n < 8) {
-      *reinterpret_cast<uint4*>(smem + n * KT + sdst) = xr[n % 3];
-      if (n + 3 < 8) xr[n % 3] = *reinterpret_cast<const uint4*>(xsrc + (n + 3) * 128);
+      *reinterpret_cast<uint4*>(smem + n * KT + sdst) = xr(n % 3);
+      if (n + 3 < 8) xr(n % 3) = *reinterpret_cast<const uint4*>(xsrc + (n + 3) * 128);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -212,9 +231,9 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[slot][i][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
       if (!(ABL & 1) && n2 + RA < 32) load_a(slot, n2 + RA);
       __builtin_amdgcn_sched_barrier(0);
@@ -225,27 +244,31 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   stamp(2);
 
   // the second GEMM's first weight fragments are requested now, so that their latency hides behind LayerNorm + GELU
-  const uint4* w2f = reinterpret_cast<const uint4*>(a.w2s) + lane + (size_t)wave * 32 * 2 * 64;
-  constexpr int RG = 8;
-  f16x8 ga[RG][2];   // weight fragments: a ring of eight k-steps (that loop has 6 MFMAs per k-step, so the same cover in cycles)
+  const uint4* w2f = reinterpret_cast<const uint4*>(a.w2s) + lane + (size_t)(NO * wave) * 32 * 2 * 64;        // output tile NO w + o: block ((tile * 32 + kstep) * 2 + term)
+  constexpr int RG = NW == 8 ? 8 : 6;
+  f16x8 ga[RG][NO][2];   // weight fragments: a ring of k-steps (that loop has 6 MFMAs per k-step and wave in both shapes)
 #pragma unroll
   for (int q = 0; q < RG; ++q)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) ga[q][pl] = __builtin_bit_cast(f16x8, w2f[(q * 2 + pl) * 64]);
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) ga[q][o][pl] = __builtin_bit_cast(f16x8, w2f[((o * 32 + q) * 2 + pl) * 64]);
 
   // ---------------------------------------------------------------- bias, LayerNorm(512) (two-pass, eps 1e-5), erf GELU -- in the accumulators
-  // lane (ql, hh) holds, for tokens 32 j + ql, the hidden units  64 w + 32 i + 8 g + 4 hh + c   (register r = 4 g + c)
+  // lane (ql, hh) holds, for tokens 32 j + ql, the hidden units  32 (NI w + i) + 8 g + 4 hh + c   (register r = 4 g + c)
   float* const stat1 = reinterpret_cast<float*>(smem + STAT);
-  float* const stat2 = stat1 + 8 * TM;
+  float* const stat2 = stat1 + NW * TM;
   const float s1 = a.w1_scale;
-  float sum[2] = {0.f, 0.f};
+  float sum[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + 64 * wave + 32 * i + 8 * g + 4 * hh);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + 32 * (NI * wave + i) + 8 * g + 4 * hh);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float v = acc[i][j][4 * g + c] * s1 + b[c];
@@ -254,24 +277,24 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
         }
     }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     sum[j] += __shfl_xor(sum[j], 32);
     if (hh == 0) stat1[wave * TM + 32 * j + ql] = sum[j];
   }
   __syncthreads();
-  float mean[2], rstd[2];
+  float mean[NJ], rstd[NJ], sq[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     float t_ = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) t_ += stat1[w8 * TM + 32 * j + ql];
+    for (int w8 = 0; w8 < NW; ++w8) t_ += stat1[w8 * TM + 32 * j + ql];
     mean[j] = t_ * (1.0f / 512.0f);
+    sq[j] = 0.f;
   }
-  float sq[2] = {0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float d = acc[i][j][r] - mean[j];
@@ -279,26 +302,26 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
         sq[j] += d * d;
       }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     sq[j] += __shfl_xor(sq[j], 32);
     if (hh == 0) stat2[wave * TM + 32 * j + ql] = sq[j];
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     float t_ = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) t_ += stat2[w8 * TM + 32 * j + ql];
+    for (int w8 = 0; w8 < NW; ++w8) t_ += stat2[w8 * TM + 32 * j + ql];
     rstd[j] = 1.0f / sqrtf(t_ * (1.0f / 512.0f) + 1e-5f);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 64 * wave + 32 * i + 8 * g + 4 * hh);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 64 * wave + 32 * i + 8 * g + 4 * hh);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + 32 * (NI * wave + i) + 8 * g + 4 * hh);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.ln_b + 32 * (NI * wave + i) + 8 * g + 4 * hh);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float yn = acc[i][j][4 * g + c] * rstd[j] * gm[c] + bt[c];
@@ -308,22 +331,24 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     }
   stamp(3);
 
-  // ---------------------------------------------------------------- publish the hidden tile: wave w's units 64 w + 32 i .. -> slot 2 w + i
+  // ---------------------------------------------------------------- publish the hidden tile: wave w's units 32 (NI w + i) .. -> slot NI w + i
   // (the token tile of GEMM 1 occupied this region: every wave has passed the barriers above, so nobody reads it any more)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) publish(acc[i][j], 2 * wave + i, j, 1.f, nullptr);
+    for (int j = 0; j < NJ; ++j) publish(acc[i][j], NI * wave + i, j, 1.f, nullptr);
   ovf_commit(a.ovf, amax);
   __syncthreads();
   stamp(4);
 
-  // ---------------------------------------------------------------- GEMM 2 (transposed): Y^T[256][64] = W2[256][512] . H^T;  wave w: output features 32 w ..
-  f32x16 acc2[2];
+  // ---------------------------------------------------------------- GEMM 2 (transposed): Y^T[256][TM] = W2[256][512] . H^T;  wave w: output features 32 NO w ..
+  f32x16 acc2[NO][NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[o][j][r] = 0.f;
   if (!(ABL & 2)) {
     read_b(0, smem, 0);
 #pragma unroll
@@ -333,42 +358,49 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[kk % RG][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc2[j], 0, 0, 0);
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc2[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[kk % RG][o][p == 0 ? 1 : 0], fb[cb][j][p == 1 ? 1 : 0], acc2[o][j], 0, 0, 0);
       if (!(ABL & 1) && kk + RG < 32) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) ga[kk % RG][pl] = __builtin_bit_cast(f16x8, w2f[((kk + RG) * 2 + pl) * 64]);
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) ga[kk % RG][o][pl] = __builtin_bit_cast(f16x8, w2f[((o * 32 + kk + RG) * 2 + pl) * 64]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   stamp(5);
-  __syncthreads();   // the hidden tile is dead: its space becomes the [64 tokens][256 features] f32 tile of the row-wise epilogue
+  __syncthreads();   // the hidden tile is dead: its space becomes the [TM tokens][256 features] f32 tile of the row-wise epilogue
   stamp(6);
 
   // ---------------------------------------------------------------- epilogue: + bias + residual x, hm16 (and optionally f32) rows
   float* const yt = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = {acc2[j][4 * g], acc2[j][4 * g + 1], acc2[j][4 * g + 2], acc2[j][4 * g + 3]};
-      *reinterpret_cast<f32x4*>(yt + (32 * j + ql) * YP + 32 * wave + 8 * g + 4 * hh) = v;
-    }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc2[o][j][4 * g], acc2[o][j][4 * g + 1], acc2[o][j][4 * g + 2], acc2[o][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(yt + (32 * j + ql) * YP + 32 * (NO * wave + o) + 8 * g + 4 * hh) = v;
+      }
   __syncthreads();
   const float s2 = a.w2_scale;
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
-  f16x4 rh[8], rm[8];
+  constexpr int RW = TM / NW;   // token rows per wave
+  f16x4 rh[RW], rm[RW];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {   // residual rows requested up front: one memory latency, not eight
-    const uint16_t* rp = a.xp + hm16_off((size_t)(bm + 8 * wave + rr), kDim, 4 * lane);
+  for (int rr = 0; rr < RW; ++rr) {   // residual rows requested up front: one memory latency, not RW
+    const uint16_t* rp = a.xp + hm16_off((size_t)(bm + RW * wave + rr), kDim, 4 * lane);
     rh[rr] = *reinterpret_cast<const f16x4*>(rp);
     rm[rr] = *reinterpret_cast<const f16x4*>(rp + 16);
   }
   float amax2 = 0.f;
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = 8 * wave + rr;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = RW * wave + rr;
     f32x4 v = *reinterpret_cast<const f32x4*>(yt + row * YP + 4 * lane) * s2;
     v += bias4;
     v += __builtin_convertvector(rh[rr], f32x4) + __builtin_convertvector(rm[rr], f32x4);
@@ -384,29 +416,38 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   if (ABL & 8) {
     stamp(7);
     if (a.dbg_ts != nullptr && lane == 0)
-      for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * 8 + wave) * 8 + k] = ts[k];
+      for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * NW + wave) * 8 + k] = ts[k];
   }
 }
 }  // namespace
 
 int g_ffn_ablate = 0;   // developer knob 12: timing-only ablations of k_ffn_fused (wrong results)
+int g_ffn_shape = 0;    // developer knob 14: 0 = automatic, 64 / 32 = force the 64-token / 32-token workgroup shape
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
-  const dim3 grid(a.T / TM), block(512);
+  // small grids: 32-token workgroups give twice the workgroups (fewer than one 64-token workgroup per CU leaves CUs idle)
+  const bool small = g_ffn_shape == 32 || (g_ffn_shape == 0 && a.T / 64 < 256);
   if (a.cp == nullptr) {   // message rows from memory (separate out_proj launch)
-    hipLaunchKernelGGL((k_ffn_fused<0, false>), grid, block, 0, s, a);
-    g_last_kernel = "k_ffn_fused<0, false>";
+    if (small) { hipLaunchKernelGGL((k_ffn_fused<0, false, 8, 1>), dim3(a.T / 32), dim3(512), 0, s, a); g_last_kernel = "k_ffn_fused<0, false, 8, 1>"; }
+    else { hipLaunchKernelGGL((k_ffn_fused<0, false, 8, 2>), dim3(a.T / 64), dim3(512), 0, s, a); g_last_kernel = "k_ffn_fused<0, false, 8, 2>"; }
     return;
   }
-  switch (g_ffn_ablate) {
-    case 1: hipLaunchKernelGGL((k_ffn_fused<1, true>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_ffn_fused<2, true>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_ffn_fused<3, true>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_ffn_fused<4, true>), grid, block, 0, s, a); break;
-    case 7: hipLaunchKernelGGL((k_ffn_fused<7, true>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_ffn_fused<8, true>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_ffn_fused<0, true>), grid, block, 0, s, a); break;
+  if (small) {
+    if (g_ffn_ablate == 8) hipLaunchKernelGGL((k_ffn_fused<8, true, 8, 1>), dim3(a.T / 32), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_ffn_fused<0, true, 8, 1>), dim3(a.T / 32), dim3(512), 0, s, a);
+    g_last_kernel = "k_ffn_fused<0, true, 8, 1>";
+    return;
   }
-  g_last_kernel = "k_ffn_fused<0, true>";
+  const dim3 grid(a.T / 64), block(512);
+  switch (g_ffn_ablate) {
+    case 1: hipLaunchKernelGGL((k_ffn_fused<1, true, 8, 2>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_ffn_fused<2, true, 8, 2>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_ffn_fused<3, true, 8, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_ffn_fused<4, true, 8, 2>), grid, block, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((k_ffn_fused<7, true, 8, 2>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_ffn_fused<8, true, 8, 2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_ffn_fused<0, true, 8, 2>), grid, block, 0, s, a); break;
+  }
+  g_last_kernel = "k_ffn_fused<0, true, 8, 2>";
 }
 
 // Weight re-layout into MFMA fragment order (host side, once per tensor at load time).

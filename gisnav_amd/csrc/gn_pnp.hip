@@ -551,7 +551,8 @@ __device__ inline double epnp_Rt(const Shared& sh, const double be[4], double R[
   return err * 0.2;
 }
 
-__device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], double* dbg = nullptr) {
+__device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], double* dbg = nullptr, long long* ts = nullptr) {
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   // control points: centroid + PCA axes
   double c0[3] = {0, 0, 0};
 #pragma unroll
@@ -624,7 +625,9 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
     sh.A[idx] = v;
   }
   wave_sync();
+  stamp(1);
   sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+  stamp(2);
   // M is 10 x 12, so the two smallest eigenvectors span an exactly 2-D null space whose basis is an
   // artefact of the eigen-solver.  Fix it deterministically (same rule as the oracle's
   // canonical_nullspace): v0 = normalised projection of e_11 onto the null space, v1 = its in-plane
@@ -674,6 +677,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
   }
   wave_sync();
 
+  stamp(3);
   double best_err = 0; bool have = false;
   double rho[6];
 #pragma unroll
@@ -708,6 +712,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
       if (b5[1] < 0) be[0] = -be[0];
       be[2] = b5[3] / be[0];
     }
+    stamp(4 + 3 * cand);
     double x[4] = {0, 0, 0, 0};      // the step persists across iterations (qr_solve leaves X untouched on an exactly singular system)
 #pragma unroll 1
     for (int it = 0; it < 5; ++it) {  // gauss_newton
@@ -717,8 +722,10 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
 #pragma unroll
       for (int k = 0; k < 4; ++k) be[k] += x[k];
     }
+    stamp(5 + 3 * cand);
     double R[3][3], t[3];
     const double err = epnp_Rt(sh, be, R, t);
+    stamp(6 + 3 * cand);
     if (dbg && lane == 0) {
       dbg[12 + cand] = err;
 #pragma unroll
@@ -1094,7 +1101,9 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
     }
     wave_sync();
     double R[3][3], t[3];
-    const bool okm = epnp5(sh, lane, R, t);
+    long long ts[16];
+    if (a.dbg_ts) ts[0] = (long long)__builtin_amdgcn_s_memtime();
+    const bool okm = epnp5(sh, lane, R, t, nullptr, a.dbg_ts ? ts : nullptr);
     int good = 0;
     if (okm) {
       const float thr = a.reproj * a.reproj;
@@ -1115,6 +1124,10 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
         }
         good += __popcll(__ballot(inl));
       }
+    }
+    if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps of this hypothesis
+      ts[13] = (long long)__builtin_amdgcn_s_memtime();
+      for (int k = 0; k < 14; ++k) a.dbg_ts[((size_t)b * kMaxHyp + wave) * 16 + k] = ts[k];
     }
     if (lane == 0) {
       HypResult& hr = hyp[wave];
@@ -1138,6 +1151,9 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   double* Rout = a.R + (size_t)b * 9;
   double* tout = a.t + (size_t)b * 3;
   const Cam cam = {a.fx, a.fy, a.cx, a.cy};
+  long long ts[8];
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg_ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
+  stamp(0);
   if (n < a.min_pts || n < 5) {
     if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
     if (lane < 3) tout[lane] = 0.0;
@@ -1162,6 +1178,7 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
     if (lane == 0) { a.ok[b] = 0; a.n_inliers[b] = 0; }
     return;
   }
+  stamp(1);
   double bestR[3][3], bestT[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { bestT[i] = hyp[best].t[i];
@@ -1190,6 +1207,7 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   double MM[3][3] = {{mm[0], mm[1], mm[2]}, {mm[1], mm[3], mm[4]}, {mm[2], mm[4], mm[5]}};
   double W[3], Vc[3][3];
   eig3(MM, W, Vc);
+  stamp(2);
   bool init_ok = true;
   if (W[2] / W[1] < 1e-3) {
     init_ok = pnp_init_planar(sh, obj, img, mask, n, ninl, lane, cam, mc, Vc, p);
@@ -1199,9 +1217,11 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
     init_ok = false;  // < 6 non-planar inliers: OpenCV >= 4.5 falls back to the RANSAC model
   }
 
+  stamp(3);
   double Rf[3][3], dummy[3][9];
   if (init_ok) {
     levmarq_pose(obj, img, mask, n, lane, cam, p);
+    stamp(4);
     rodrigues_v2m(p, Rf, dummy, false);
   } else {
     // rvec = Rodrigues(bestR) then back, as the reference applies cv2.Rodrigues to the returned rvec
@@ -1209,6 +1229,10 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
     rodrigues_m2v(bestR, rv);
     rodrigues_v2m(rv, Rf, dummy, false);
     p[3] = bestT[0]; p[4] = bestT[1]; p[5] = bestT[2];
+  }
+  if (a.dbg_ts && lane == 0) {
+    stamp(5);
+    for (int k = 0; k < 6; ++k) a.dbg_ts[((size_t)a.B * kMaxHyp + b) * 16 + k] = ts[k];
   }
   if (lane == 0) {
 #pragma unroll
