@@ -30,12 +30,42 @@ constexpr double kDblEps = 2.220446049250313e-16;
 constexpr double kFltEps = 1.1920928955078125e-07;
 constexpr double kDblMin = 2.2250738585072014e-308;
 
+// wave-wide sum, the same value in every lane.  DPP row shifts + row broadcasts (20 VALU instructions, no LDS round trips: the
+// ds_bpermute butterfly this replaces cost six dependent LDS latencies per value).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);   // lanes without a source add +0.0
+}
 __device__ inline double wsum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of every row of 16 holds the row sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, 63), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// 1 / sqrt(x) and 1 / x for normal, well-scaled x: hardware seed + two Newton steps (no range scaling, no special cases)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);      // y (1 + e/2 + 3 e^2 / 8)
+  e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y * e, 0.5, y);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
 // Every PnP kernel runs single-wave workgroups, so a workgroup barrier is a wave barrier: it orders the
 // LDS traffic exchanged between lanes and costs next to nothing.
 __device__ inline void wave_sync() { __syncthreads(); }
@@ -276,76 +306,121 @@ __device__ inline void spd_solve(const double N[K][K], const double b[K], double
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-parallel Jacobi for an n x n symmetric matrix in LDS (n <= 12), PARALLEL ordering: a sweep is m - 1 rounds
-// (m = n rounded up to even) of m / 2 rotations on disjoint index pairs (round-robin tournament), and the
-// rotations of one round commute, so their angles are computed side by side by m / 2 lanes and applied together
-// (column phase, then row phase): 3 barriers per ROUND instead of per rotation.  On return the eigenvalues are on
-// the diagonal of A, eigenvectors are the COLUMNS of V, and ord[] lists the column indices by ASCENDING
-// eigenvalue.  Called by the whole (single-wave) block.
-__device__ void sym_eig_lds(double* A, double* V, int* ord, int n, int lane) {
-  __shared__ double rot_c[6], rot_s[6];
-  __shared__ int rot_p[6], rot_q[6];
-  const int m = (n + 1) & ~1, half = m >> 1;
-  for (int idx = lane; idx < n * n; idx += 64) V[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
-  wave_sync();
+// Register-resident Jacobi for an N x N symmetric matrix (N = 9, 12), PARALLEL ordering: a sweep is M - 1 rounds (M = N rounded
+// up to even) of M / 2 rotations on disjoint index pairs (round-robin tournament); the rotations of one round commute.
+//   lane k      (k < N) holds ROW k of A,   lane 16 + k holds ROW k of V   -- both in the same N registers `row`
+//   column phase (A <- A J, V <- V J): element pairs (k, p), (k, q) sit in ONE lane; the schedule is static, so after unrolling the
+//                rounds p and q are register names and the six (c, s) are wave-uniform (v_readlane from the pair's lane)
+//   row phase    (A <- J^T A): lane p and lane q exchange their rows through ds_bpermute; the V lanes pass through (c = 1, s = 0)
+// No LDS traffic and no barriers inside a sweep (the LDS version this replaces spent ~1800 cycles per round, this one ~600).
+// A comes from LDS and the results go back to LDS in the layout the callers read: eigenvalues on the diagonal of A, eigenvectors
+// in the COLUMNS of V, ord[] = column indices by ASCENDING eigenvalue.  Called by the whole (single-wave) block.
+__device__ __forceinline__ double bcast_lane(double v, int src_lane /* compile-time constant */) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src_lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+struct RoundRobin {   // pair i of round r over m players: 0 <= p < q < m
+  int p, q;
+  constexpr RoundRobin(int m, int r, int i) : p(0), q(0) {
+    int a_ = i == 0 ? r % (m - 1) : (r + i) % (m - 1);
+    int b_ = i == 0 ? m - 1 : (r - i + (m - 1)) % (m - 1);
+    p = a_ < b_ ? a_ : b_; q = a_ < b_ ? b_ : a_;
+  }
+};
+template <int N>
+__device__ void sym_eig_reg(double* A, double* V, int* ord, int lane) {
+  constexpr int M = (N + 1) & ~1, H = M / 2;
+  const bool isA = lane < N, isV = lane >= 16 && lane < 16 + N;
+  const int k = isA ? lane : (isV ? lane - 16 : 0);
+  double row[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) row[j] = isA ? A[k * N + j] : ((isV && j == k) ? 1.0 : 0.0);
+  // per round: the lane holding the partner row (self when idle), and whether this lane is the pair's lower index
+  int partner[M - 1];
+  unsigned lowmask = 0;
+#pragma unroll
+  for (int r = 0; r < M - 1; ++r) {
+    int pt = lane;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      constexpr int dummy = 0; (void)dummy;
+      const RoundRobin pr(M, r, i);
+      if (pr.q < N) {
+        if (lane == pr.p) { pt = pr.q; lowmask |= 1u << r; }
+        if (lane == pr.q) pt = pr.p;
+      }
+    }
+    partner[r] = pt;
+  }
+#pragma unroll 1
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0, dg = 0.0;
-    for (int idx = lane; idx < n * n; idx += 64) {
-      const double v = A[idx];
-      if (idx / n == idx % n) dg += v * v; else off += v * v;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double v2 = row[j] * row[j];
+      if (isA) { if (j == k) dg += v2; else off += v2; }
     }
     off = wsum(off); dg = wsum(dg);
     if (off <= 1e-30 * dg || off == 0.0) break;
-    for (int r = 0; r < m - 1; ++r) {
-      if (lane < half) {
-        int p = lane == 0 ? r % (m - 1) : (r + lane) % (m - 1);
-        int q = lane == 0 ? m - 1 : (r - lane + (m - 1)) % (m - 1);
-        if (p > q) { const int t_ = p; p = q; q = t_; }
-        double c = 1.0, sn = 0.0;
-        if (q < n) {
-          const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
-          if (!(fabs(apq) <= 1e-18 * sqrt(fabs(app * aqq)) || fabs(apq) < 1e-300)) {
-            const double tau = (aqq - app) / (2.0 * apq);
-            const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-            c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
-          }
-        } else {
-          q = p;                                        // dummy partner (odd n): identity
-        }
-        rot_p[lane] = p; rot_q[lane] = q; rot_c[lane] = c; rot_s[lane] = sn;
+#pragma unroll
+    for (int r = 0; r < M - 1; ++r) {
+      // the rotation of this lane's pair, computed identically by both of its lanes from lane p's copy of a_pq
+      double apq = 0.0, diag = 0.0;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const RoundRobin pr(M, r, i);
+        if (pr.q < N) apq = lane == pr.p ? row[pr.q] : apq;
       }
-      wave_sync();
-      for (int idx = lane; idx < n * half; idx += 64) {   // columns p, q of A and V
-        const int k = idx / half, i = idx - k * half;
-        const int p = rot_p[i], q = rot_q[i];
-        const double c = rot_c[i], sn = rot_s[i];
-        if (p != q && sn != 0.0) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq;
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq;
-        }
-      }
-      wave_sync();
-      for (int idx = lane; idx < n * half; idx += 64) {   // rows p, q of A
-        const int k = idx / half, i = idx - k * half;
-        const int p = rot_p[i], q = rot_q[i];
-        const double c = rot_c[i], sn = rot_s[i];
-        if (p != q && sn != 0.0) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk;
+#pragma unroll
+      for (int j = 0; j < N; ++j) diag = lane == j ? row[j] : diag;
+      const int pt = partner[r];
+      const bool low = (lowmask >> r) & 1u;
+      const double odiag = __shfl(diag, pt), oapq = __shfl(apq, pt);
+      const double app = low ? diag : odiag, aqq = low ? odiag : diag;
+      apq = low ? apq : oapq;
+      // Jacobi angle without the IEEE division / square-root expansions (6 of them, ~100 dependent instructions, were 2/3 of a
+      // round): t = sgn(tau) |o| / (|d| + sqrt(d^2 + o^2)) with d = a_qq - a_pp, o = 2 a_pq, tau = d / o;  c = 1 / sqrt(1 + t^2).
+      // v_rsq_f64 / v_rcp_f64 seeds + two Newton steps each: relative error of (c, s) a few ulp, c^2 + s^2 = 1 to ~4e-16.
+      const double d = aqq - app, o = apq + apq;
+      const double h2 = d * d + o * o;
+      const double t = ((d == 0.0 || (d < 0.0) == (o < 0.0)) ? fabs(o) : -fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
+      double c = fast_rsqrt(1.0 + t * t), sn = t * c;
+      const bool rotate = isA && pt != lane && apq * apq > 1e-36 * fabs(app * aqq) && fabs(apq) >= 1e-300;
+      c = rotate ? c : 1.0; sn = rotate ? sn : 0.0;
+      // column phase, A rows and V rows alike
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const RoundRobin pr(M, r, i);
+        if (pr.q < N) {
+          const double ci = bcast_lane(c, pr.p), si = bcast_lane(sn, pr.p);
+          const double rp = row[pr.p], rq = row[pr.q];
+          row[pr.p] = ci * rp - si * rq; row[pr.q] = si * rp + ci * rq;
         }
       }
-      wave_sync();
+      // row phase: row_p <- c row_p - s row_q, row_q <- s row_p + c row_q  (V lanes and idle lanes: c = 1, s = 0, partner = self)
+      const double sg = low ? -sn : sn;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double other = __shfl(row[j], pt);
+        row[j] = c * row[j] + sg * other;
+      }
     }
   }
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (isA && j == k) A[k * N + j] = row[j];
+    if (isV) V[k * N + j] = row[j];
+  }
+  wave_sync();
   if (lane == 0) {
-    for (int i = 0; i < n; ++i) ord[i] = i;
-    for (int i = 1; i < n; ++i) {
+    for (int i = 0; i < N; ++i) ord[i] = i;
+    for (int i = 1; i < N; ++i) {
       const int oi = ord[i];
-      const double wi = A[oi * n + oi];
+      const double wi = A[oi * N + oi];
       int j = i - 1;
-      while (j >= 0 && A[ord[j] * n + ord[j]] > wi) { ord[j + 1] = ord[j]; --j; }
+      while (j >= 0 && A[ord[j] * N + ord[j]] > wi) { ord[j + 1] = ord[j]; --j; }
       ord[j + 1] = oi;
     }
   }
@@ -431,7 +506,9 @@ __device__ inline void lsq6(const double Ain[6][K], const double bin[6], double 
 
 // cvSolve(A, b, x, CV_SVD) for a 6 x K system, as find_betas_approx_{1,2,3} call it: minimum-norm least squares through the
 // SVD, singular values <= 2 DBL_EPSILON sum(w) treated as zero (cv::SVD::backSubst).  One-sided (Hestenes) Jacobi: the columns
-// of A are rotated pairwise until orthogonal, A V = U diag(w).  Fully unrolled per sweep, wave-uniform.
+// of A are rotated pairwise until orthogonal, A V = U diag(w).  Fully unrolled per sweep.  The lanes of the wave may hold DIFFERENT
+// systems (the three EPnP candidates run side by side): all lanes sweep until none rotates, a converged lane's sweeps are no-ops.
+// Trailing all-zero columns are inert (never rotated, w = 0, x = 0): a 6 x 3 or 6 x 4 system padded to K = 5 gives bit-identical x.
 template <int K>
 __device__ inline void svd_solve6(const double Ain[6][K], const double bin[6], double x[K]) {
   double U[6][K], V[K][K];
@@ -453,18 +530,19 @@ __device__ inline void svd_solve6(const double Ain[6][K], const double bin[6], d
         double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) { al += U[i][p] * U[i][p]; be += U[i][q] * U[i][q]; ga += U[i][p] * U[i][q]; }
-        if (fabs(ga) > 1e-16 * sqrt(al * be) && fabs(ga) > 1e-300) {
-          rotated = true;
-          const double zeta = (be - al) / (2.0 * ga);
-          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        // branch-free (the lanes of a wave may hold different systems): c = 1, s = 0 leaves the columns bit-identical
+        const bool rot = ga * ga > 1e-32 * (al * be) && fabs(ga) > 1e-300;
+        rotated = rotated || rot;
+        const double d = be - al, o = ga + ga, h2 = d * d + o * o;
+        const double t = ((d == 0.0 || (d < 0.0) == (o < 0.0)) ? fabs(o) : -fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
+        double c = fast_rsqrt(1.0 + t * t), sn = c * t;
+        c = rot ? c : 1.0; sn = rot ? sn : 0.0;
 #pragma unroll
-          for (int i = 0; i < 6; ++i) { const double up = U[i][p], uq = U[i][q]; U[i][p] = c * up - sn * uq; U[i][q] = sn * up + c * uq; }
+        for (int i = 0; i < 6; ++i) { const double up = U[i][p], uq = U[i][q]; U[i][p] = c * up - sn * uq; U[i][q] = sn * up + c * uq; }
 #pragma unroll
-          for (int i = 0; i < K; ++i) { const double vp = V[i][p], vq = V[i][q]; V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq; }
-        }
+        for (int i = 0; i < K; ++i) { const double vp = V[i][p], vq = V[i][q]; V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq; }
       }
-    if (!rotated) break;
+    if (!__any(rotated)) break;
   }
   double w[K], wsum = 0.0;
 #pragma unroll
@@ -626,7 +704,7 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
   }
   wave_sync();
   stamp(1);
-  sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+  sym_eig_reg<12>(sh.A, sh.V, sh.ord, lane);
   stamp(2);
   // M is 10 x 12, so the two smallest eigenvectors span an exactly 2-D null space whose basis is an
   // artefact of the eigen-solver.  Fix it deterministically (same rule as the oracle's
@@ -678,67 +756,67 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
   wave_sync();
 
   stamp(3);
-  double best_err = 0; bool have = false;
+  // The three beta approximations (find_betas_approx_1 / _2 / _3), their Gauss-Newton refinements and the candidate poses run SIDE BY
+  // SIDE: lane 0, 1, 2 carry candidate 0, 1, 2 (lanes >= 3 repeat candidate 2), one pass through the code instead of three.
   double rho[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) rho[i] = sh.rho[i];
-#pragma unroll 1
-  for (int cand = 0; cand < 3; ++cand) {
-    double be[4] = {0, 0, 0, 0};
-    if (cand == 0) {  // betas10 -> [B11 B12 B13 B14]
-      double A4[6][4], b4[4];
+  const int cand = lane < 2 ? lane : 2;
+  double be[4] = {0, 0, 0, 0};
+  {
+    // the 6 x 4 (columns 0 1 3 6 of L), 6 x 3 (0 1 2) and 6 x 5 (0 1 2 3 4) systems, zero-padded to 6 x 5
+    double A5[6][5], b5[5];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { A4[i][0] = sh.L[i * 10 + 0]; A4[i][1] = sh.L[i * 10 + 1]; A4[i][2] = sh.L[i * 10 + 3]; A4[i][3] = sh.L[i * 10 + 6]; }
-      svd_solve6<4>(A4, rho, b4);
-      if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
-      else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
-    } else if (cand == 1) {  // [B11 B12 B22]
-      double A3[6][3], b3[3];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { A3[i][0] = sh.L[i * 10 + 0]; A3[i][1] = sh.L[i * 10 + 1]; A3[i][2] = sh.L[i * 10 + 2]; }
-      svd_solve6<3>(A3, rho, b3);
-      if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = b3[2] < 0 ? sqrt(-b3[2]) : 0.0; }
-      else { be[0] = sqrt(b3[0]); be[1] = b3[2] > 0 ? sqrt(b3[2]) : 0.0; }
-      if (b3[1] < 0) be[0] = -be[0];
-    } else {  // [B11 B12 B22 B13 B23]
-      double A5[6][5], b5[5];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) A5[i][k] = sh.L[i * 10 + k];
-      svd_solve6<5>(A5, rho, b5);
+    for (int i = 0; i < 6; ++i) {
+      const double* l = &sh.L[i * 10];
+      A5[i][0] = l[0]; A5[i][1] = l[1];
+      A5[i][2] = cand == 0 ? l[3] : l[2];
+      A5[i][3] = cand == 0 ? l[6] : (cand == 2 ? l[3] : 0.0);
+      A5[i][4] = cand == 2 ? l[4] : 0.0;
+    }
+    svd_solve6<5>(A5, rho, b5);
+    if (cand == 0) {         // betas10 -> [B11 B12 B13 B14]
+      if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = -b5[1] / be[0]; be[2] = -b5[2] / be[0]; be[3] = -b5[3] / be[0]; }
+      else { be[0] = sqrt(b5[0]); be[1] = b5[1] / be[0]; be[2] = b5[2] / be[0]; be[3] = b5[3] / be[0]; }
+    } else {                 // [B11 B12 B22] and [B11 B12 B22 B13 B23]
       if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = b5[2] < 0 ? sqrt(-b5[2]) : 0.0; }
       else { be[0] = sqrt(b5[0]); be[1] = b5[2] > 0 ? sqrt(b5[2]) : 0.0; }
       if (b5[1] < 0) be[0] = -be[0];
-      be[2] = b5[3] / be[0];
-    }
-    stamp(4 + 3 * cand);
-    double x[4] = {0, 0, 0, 0};      // the step persists across iterations (qr_solve leaves X untouched on an exactly singular system)
-#pragma unroll 1
-    for (int it = 0; it < 5; ++it) {  // gauss_newton
-      double A[6][4], b[6];
-      epnp_Ab(sh, be, A, b);
-      lsq6<4>(A, b, x);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) be[k] += x[k];
-    }
-    stamp(5 + 3 * cand);
-    double R[3][3], t[3];
-    const double err = epnp_Rt(sh, be, R, t);
-    stamp(6 + 3 * cand);
-    if (dbg && lane == 0) {
-      dbg[12 + cand] = err;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dbg[15 + 4 * cand + k] = be[k];
-    }
-    if (err == err && (!have || err < best_err)) {
-      have = true; best_err = err;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { tb[i] = t[i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Rb[i][j] = R[i][j]; }
+      if (cand == 2) be[2] = b5[3] / be[0];
     }
   }
+  stamp(4);
+  double x[4] = {0, 0, 0, 0};      // the step persists across iterations (qr_solve leaves X untouched on an exactly singular system)
+#pragma unroll 1
+  for (int it = 0; it < 5; ++it) {  // gauss_newton
+    double A[6][4], b[6];
+    epnp_Ab(sh, be, A, b);
+    lsq6<4>(A, b, x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) be[k] += x[k];
+  }
+  stamp(5);
+  double R[3][3], t[3];
+  const double err = epnp_Rt(sh, be, R, t);
+  stamp(6);
+  if (dbg && lane < 3) {
+    dbg[12 + lane] = err;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dbg[15 + 4 * lane + k] = be[k];
+  }
+  // the sequential choice `if (err < best) best = cand` over candidates 0, 1, 2 (NaN never wins)
+  int bestc = -1; double best_err = 0;
+#pragma unroll
+  for (int cnd = 0; cnd < 3; ++cnd) {
+    const double e = bcast_lane(err, cnd);
+    if (e == e && (bestc < 0 || e < best_err)) { bestc = cnd; best_err = e; }
+  }
+  const bool have = bestc >= 0;
+  const int src = have ? bestc : 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { tb[i] = __shfl(t[i], src);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rb[i][j] = __shfl(R[i][j], src); }
   bool fin = have;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { fin = fin && isfinite(tb[i]);
@@ -944,7 +1022,7 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
         sh.A[idx] = v;
       }
       wave_sync();
-      sym_eig_lds(sh.A, sh.V, sh.ord, 9, lane);
+      sym_eig_reg<9>(sh.A, sh.V, sh.ord, lane);
       double H0[3][3];
       const int c0 = sh.ord[0];
 #pragma unroll
@@ -1024,7 +1102,7 @@ __device__ __noinline__ bool pnp_init_dlt(Shared& sh, const float* obj, const fl
       sh.A[idx] = v;
     }
     wave_sync();
-    sym_eig_lds(sh.A, sh.V, sh.ord, 12, lane);
+    sym_eig_reg<12>(sh.A, sh.V, sh.ord, lane);
     const int c0 = sh.ord[0];
     double RR[3][3], tt[3];
 #pragma unroll
@@ -1101,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
     }
     wave_sync();
     double R[3][3], t[3];
-    long long ts[16];
+    long long ts[8];
     if (a.dbg_ts) ts[0] = (long long)__builtin_amdgcn_s_memtime();
     const bool okm = epnp5(sh, lane, R, t, nullptr, a.dbg_ts ? ts : nullptr);
     int good = 0;
@@ -1126,8 +1204,8 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
       }
     }
     if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps of this hypothesis
-      ts[13] = (long long)__builtin_amdgcn_s_memtime();
-      for (int k = 0; k < 14; ++k) a.dbg_ts[((size_t)b * kMaxHyp + wave) * 16 + k] = ts[k];
+      ts[7] = (long long)__builtin_amdgcn_s_memtime();
+      for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)b * kMaxHyp + wave) * 16 + k] = ts[k];
     }
     if (lane == 0) {
       HypResult& hr = hyp[wave];
