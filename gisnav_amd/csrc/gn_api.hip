@@ -33,6 +33,8 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
+  int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
+  int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
   int ffn_fold = 1;        // with ffn_fused == 3: out_proj / to_out folded into the block-tail kernel (developer knob 13; 0 = separate GEMM launch)
   int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
@@ -78,6 +80,10 @@ struct gn_ctx {
   int gemm_variant = -1;   // -1: library default (f32 MFMA, LDS-DMA); 5: f32x3 (GN_PREC_F32X3_BF16_ATTN)
   float *rowmax = nullptr, *rowlog = nullptr, *colmax = nullptr, *collog = nullptr, *max0 = nullptr;
   int32_t *m0 = nullptr, *m1 = nullptr;
+  float *cpart_m = nullptr, *cpart_s = nullptr;   // fused head: column partials [B][2 npad / 64][npad]
+  int32_t* cpart_i = nullptr;
+  float *rpart_a = nullptr, *rpart_b = nullptr;   // fused head: row partials [B][8][npad]
+  unsigned int* tickets = nullptr;                // fused head: [B][2] arrival counters, zero between calls
   // pipeline scratch for gn_estimate
   int64_t* e_idx = nullptr; float* e_score = nullptr; float* e_mkp = nullptr; float* e_obj = nullptr;
   // sub-batch streams (gn_set_substreams): the pairs of one call are split into groups that run the whole path on
@@ -148,6 +154,13 @@ int dalloc(gn_ctx* ctx, T** p, size_t count) {
   ctx->allocs.push_back(q);
   *p = reinterpret_cast<T*>(q);
   return GN_OK;
+}
+
+// The [B][npad][npad] similarity buffer is no longer part of the matcher (fused match head): it exists only for TwistNode's
+// brute-force matcher, the unfused developer path and the phase-stamp tools, and is allocated on their first use.
+int ensure_sim(gn_ctx* ctx) {
+  if (ctx->sim) return GN_OK;
+  return dalloc(ctx, &ctx->sim, (size_t)ctx->max_batch * ctx->npad * ctx->npad);
 }
 
 std::string canonical(const std::string& k) {
@@ -465,18 +478,26 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     g.scale = 0.25f; g.scale_cols = kDim;  // / d ** 0.25
     gemm(c, EPI_SCALE_COLS, g, s);
     launch_matchability(c->x, c->matchability[li].w, c->matchability[li].b, c->ls, T, s);
-    GemmArgs gs;
-    memset(&gs, 0, sizeof gs);
-    gs.A = c->md; gs.lda = kDim; gs.K1 = kDim; gs.W = c->md + (size_t)np * kDim; gs.ldw = kDim;
-    gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim; gs.acc_scale = 1.f;
-    gs.strideA = gs.strideW = 2LL * np * kDim; gs.strideY = (long long)np * np;
-    timed_gemm(c, EPI_PLAIN, gs, B, s);
     HeadArgs hd;
     hd.sim = c->sim; hd.ls = c->ls; hd.nvalid = c->nvalid; hd.B = B; hd.npad = np; hd.threshold = c->threshold;
     hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
     hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
     hd.ovf = (c->planes_mode && c->guard) ? c->ovf : nullptr;
     hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = c->npad;   // output stride: gn_kmax(), whatever the active size
+    hd.md = c->planes_mode ? (const void*)c->md_p : (const void*)c->md; hd.md_f32 = c->planes_mode ? 0 : 1;
+    hd.cpart_m = c->cpart_m; hd.cpart_s = c->cpart_s; hd.cpart_i = c->cpart_i; hd.rpart_a = c->rpart_a; hd.rpart_b = c->rpart_b; hd.tickets = c->tickets;
+    hd.dbg_ts = (c->head_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 17
+    if (c->head_fused || !c->sim) {
+      ++c->launch_count;
+      if (!(c->stop_after && c->launch_count > c->stop_after)) launch_match_head_fused(hd, s);
+      return GN_OK;
+    }
+    GemmArgs gs;
+    memset(&gs, 0, sizeof gs);
+    gs.A = c->md; gs.lda = kDim; gs.K1 = kDim; gs.W = c->md + (size_t)np * kDim; gs.ldw = kDim;
+    gs.Y = c->sim; gs.ldy = np; gs.M = np; gs.N = np; gs.K = kDim; gs.acc_scale = 1.f;
+    gs.strideA = gs.strideW = 2LL * np * kDim; gs.strideY = (long long)np * np;
+    timed_gemm(c, EPI_PLAIN, gs, B, s);
     launch_match_head(hd, s);
   }
   return GN_OK;
@@ -539,10 +560,10 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
     GN_ALLOC(desc_p, 2 * T * kInDim); GN_ALLOC(x_p, 2 * T * kDim); GN_ALLOC(ctx_p, 2 * T * kDim);
     GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
   }
-  GN_ALLOC(sim, B * np * np);
   if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
+  GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
   GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
   GN_ALLOC(mask_ws, B * np * 16);
@@ -818,6 +839,7 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   mv(c->h_p, 2 * T2 * 2 * kDim); mv(c->md_p, 2 * T2 * kDim);
   mv(c->qkb, T2 * 2 * kDim); mv(c->vtb, T2 * kDim);
   mv(c->rowmax, np); mv(c->rowlog, np); mv(c->colmax, np); mv(c->collog, np); mv(c->max0, np); mv(c->m0, np); mv(c->m1, np);
+  mv(c->cpart_m, (np / 32) * np); mv(c->cpart_s, (np / 32) * np); mv(c->cpart_i, (np / 32) * np); mv(c->rpart_a, 8 * np); mv(c->rpart_b, 8 * np); mv(c->tickets, 2);
   // match lists and the PnP masks are strided by the context's padded maximum (gn_kmax), whatever the active size
   const long long km = c->npad;
   mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
@@ -983,6 +1005,7 @@ int gn_vo_match(gn_ctx* ctx, int B, const float* desc_q, const int32_t* n_q, int
     return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
   if (!desc_q || !n_q || !desc_r || !n_r || !idx || !dist || !n_good) return fail(ctx, GN_ERR_ARG, "null argument");
   GN_HIP(hipSetDevice(ctx->device));
+  { const int rc = ensure_sim(ctx); if (rc != GN_OK) return rc; }   // q . r panel of the brute-force matcher (first call allocates it)
   hipStream_t s = (hipStream_t)stream;
   const int np = ctx->npad;
   VoArgs v;
@@ -1315,7 +1338,7 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
   const Ent tab[] = {
       {"desc", ctx->desc, T * kInDim}, {"cos", ctx->cos_t, T * kFreq}, {"sin", ctx->sin_t, T * kFreq},
       {"x", ctx->x, T * kDim}, {"qkv", ctx->qkv, T * 3 * kDim}, {"ctx", ctx->ctx, T * kDim}, {"msg", ctx->msg, T * kDim},
-      {"h", ctx->h, T * 2 * kDim}, {"md", ctx->md, T * kDim}, {"ls", ctx->ls, T}, {"sim", ctx->sim, B * np * np},
+      {"h", ctx->h, T * 2 * kDim}, {"md", ctx->md, T * kDim}, {"ls", ctx->ls, T}, {"sim", ctx->sim, ctx->sim ? B * np * np : 0},
       {"rowmax", ctx->rowmax, B * np}, {"rowlog", ctx->rowlog, B * np}, {"colmax", ctx->colmax, B * np},
       {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
@@ -1405,6 +1428,10 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
 
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
+  if ((which == 12 && value == 8) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value)) {   // these developer paths use the similarity buffer
+    GN_HIP(hipSetDevice(ctx->device));
+    const int rc = ensure_sim(ctx); if (rc != GN_OK) return rc;
+  }
   if (which == 0) { gn::g_gemm_variant = value; ctx->gemm_variant = value; }
   else if (which == 1) ctx->attn_variant = value;
   else if (which == 2) ctx->dbg_planes = value;
@@ -1421,6 +1448,9 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 13) ctx->ffn_fold = value;
   else if (which == 14) gn::g_ffn_shape = value;
   else if (which == 15) ctx->pnp_stamps = value;
+  else if (which == 16) ctx->head_fused = value;
+  else if (which == 17) ctx->head_stamps = value;
+  else if (which == 18) gn::g_head_ablate = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -114,6 +114,7 @@ struct FfnArgs {
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 extern int g_ffn_ablate;
 extern int g_ffn_shape;
+extern int g_head_ablate;
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
 
 // ---- attention --------------------------------------------------------------------------------
@@ -167,8 +168,16 @@ struct HeadArgs {
   int32_t* m0; float* max0; int32_t* m1;                        // [B][npad]
   int64_t* idx; float* score; int32_t* n_match; int kmax;       // outputs
   const unsigned int* ovf;  // f16x2 domain guard word: non-zero -> the call reports zero matches
+  // fused head (launch_match_head_fused): the similarity matrix is recomputed tile by tile from the projected descriptors
+  const void* md;           // [B*2*npad] rows of 256 values, 1 KB each: f32 (md_f32) or hm16
+  int md_f32;
+  float* cpart_m; float* cpart_s; int32_t* cpart_i;   // [B][npad / 32][npad] column partials: max / sum of exponentials (sweep 1), best score / row (sweep 2)
+  float* rpart_a; float* rpart_b;                      // [B][8][npad] row partials per column split: (max, sum) or (best score, column as int bits)
+  unsigned int* tickets;    // [B][2] arrival counters of the two sweeps, zero between calls
+  long long* dbg_ts;        // developer: nullptr, or [2][B][npad / 128][8 splits][8] s_memtime phase stamps
 };
 void launch_match_head(const HeadArgs& a, hipStream_t s);
+void launch_match_head_fused(const HeadArgs& a, hipStream_t s);
 
 struct GatherArgs {
   const float* kpt_q; int stride_q; const float* kpt_r; int stride_r; int kpt_format;

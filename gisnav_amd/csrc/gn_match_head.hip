@@ -14,6 +14,8 @@
 //
 // The similarity matrix S comes from the MFMA GEMM (gn_gemm.hip) and stays L2/Infinity-Cache
 // resident (4 MB per pair at 1024 keypoints); the passes here are coalesced row/column sweeps.
+#include <type_traits>
+
 #include "gn_common.h"
 
 namespace gn {
@@ -178,6 +180,448 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
   if (tid == 0) a.n_match[b] = base_s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused match head: the similarity matrix is never written.  Two sweeps over S = md0 . md1^T, each recomputing the tiles on the
+// matrix cores (the GEMM is 0.5 GFLOP per pair; writing + four times re-reading 4 MB per pair cost more than computing it twice):
+//   k_head_fused<., 1>  row and column soft-max statistics (running max / sum of exponentials), finished per pair by the LAST workgroup
+//   k_head_fused<., 2>  score_at() in the reference's association order, row and column arg-max partials; the last workgroup of a
+//                       pair reduces them, does the mutual check, the threshold and the ordered compaction.
+// grid (npad / 128, B, S), 4 waves: a workgroup owns 128 rows of image 0 (wave w: rows 32 w ..) and a contiguous 1 / S of the
+// 64-column tiles of image 1 (S > 1 only for small batches, to occupy the chip).  What bounds these sweeps is the rate at which a CU
+// can pull column tiles out of L2 (measured ~13 B / clk / CU whether by LDS-DMA or by loads), so the shape maximises the rows
+// served by one tile: the row operand lives in registers for the whole sweep (32 x 16-byte fragments per lane, no copies between
+// waves), every wave multiplies it with BOTH 32-column halves of the tile.  Column tiles (64 rows x 1 KB) are double-buffered in
+// LDS, staged by LDS-DMA while the previous tile is on the matrix pipe, and the VALU work of tile t - 1 (one accumulator register
+// per k-step and half) is interleaved with the MFMAs of tile t.
+// F32 = false: hm16 rows, three v_mfma_f32_32x32x16_f16 per k-step (the f16x2 mode);  F32 = true: f32 rows, v_mfma_f32_32x32x2_f32.
+// Both row formats are 1 KB per keypoint and use the same 16-byte fragment addressing.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int kHeadKT = 64 * 128;        // bytes of one 32-wide k-slot of a 64-row column tile
+constexpr int kHeadTile = 8 * kHeadKT;   // 64 KB
+constexpr int kHeadRows = 128;           // rows of image 0 per workgroup
+constexpr int kHeadMaxSplit = 8;         // column splits (grid.z) the partial buffers are sized for
+constexpr float kLog2e = 1.4426950408889634f;
+#ifndef GN_HEAD_SCHED
+#define GN_HEAD_SCHED 0
+#endif
+constexpr bool kHeadSchedGroups = GN_HEAD_SCHED;
+__device__ __forceinline__ int hswz(int row) { return (row ^ (row >> 3)) & 7; }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+// (m, s) <- (m, s) (+) (om, os): running maximum and sum of exp(. - maximum); -inf maxima are empty sets
+__device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os) {
+  const float mn = fmaxf(m, om);
+  const float ref = mn == -INFINITY ? 0.f : mn;
+  s = s * ex2((m - ref) * kLog2e) + os * ex2((om - ref) * kLog2e);
+  m = mn;
+}
+// (m, s) <- (m, s) (+) {v}: one element joins.  One exponential: of the two factors exp(m - max) and exp(v - max) one is exactly 1.
+// Empty sets carry m = kLseEmpty (a large negative FINITE number), masked elements arrive as v = -inf: neither makes a NaN
+// (m - v = +inf -> e = 0 -> s + 0), so there is no validity select in the chain.
+constexpr float kLseEmpty = -1.0e30f;
+__device__ __forceinline__ void lse_push(float& m, float& s, float v) {
+  const float e = ex2(-fabsf(m - v) * kLog2e);
+  s = v > m ? __builtin_fmaf(s, e, 1.f) : s + e;
+  m = fmaxf(m, v);
+}
+// Results that ANOTHER workgroup of the same launch reads (the last workgroup of a pair): device-coherent stores / loads
+// (sc1: written through / read past the per-XCD L2).  A __threadfence() would write back and invalidate the whole L2 of the XCD
+// under every other workgroup's feet (measured: 36 k cycles per workgroup at batch 32).
+template <typename T> __device__ __forceinline__ void st_dev(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T ld_dev(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool arg_better(float ov, int oi, float v, int i) {   // (ov, oi) beats (v, i): larger value, lower index on ties
+  return oi != 0x7fffffff && (i == 0x7fffffff || ov > v || (ov == v && oi < i));
+}
+
+// One k-step of one 32 x 32 tile on two INDEPENDENT accumulation chains (a dependent MFMA waits for the whole latency of the one
+// before it): hm16: chain 0 = A_m B_h + A_h B_m (the small terms), chain 1 = A_h B_h;  f32: the eight MFMAs alternate.
+struct Acc2 { f32x16 c[2]; };
+template <bool F32, bool FIRST, int PART>   // FIRST: the chains start from zero (inline-constant C operand);  PART 0 / 1: first / second half of the step
+__device__ __forceinline__ void head_mma(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, Acc2& acc) {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (F32) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, PART == 0 ? a0 : a1), fb = __builtin_bit_cast(f32x4, PART == 0 ? b0 : b1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc.c[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], (FIRST && PART == 0 && e < 2) ? z : acc.c[e & 1], 0, 0, 0);
+  } else {   // a0 / b0: high terms, a1 / b1: residual terms
+    if constexpr (PART == 0) {
+      acc.c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), FIRST ? z : acc.c[0], 0, 0, 0);
+      acc.c[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), FIRST ? z : acc.c[1], 0, 0, 0);
+    } else {
+      acc.c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc.c[0], 0, 0, 0);
+    }
+  }
+}
+
+template <bool F32, int SWEEP, int ABL = 0>   // ABL, timing-only ablations (wrong results): 1 no DMA in the loop, 2 no VALU work, 4 no MFMA, 8 no LDS fragment reads
+__global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kHeadTile];
+  __shared__ int s_last;
+  __shared__ float xch[2][2][4][64];   // [tile parity][value][wave][column of the tile]: column partials of the four waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the row blocks and
+  // column splits of ONE pair -- which all stream the same 1 MB of image-1 descriptors -- are renumbered to share an XCD.
+  const int S = gridDim.z, np = a.npad;
+  int b, rb, sp;
+  {
+    const int per = gridDim.x * S, nwg = per * gridDim.y;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.z + S * blockIdx.y);
+    int v = L;
+    if ((nwg & 7) == 0) v = (L & 7) * (nwg >> 3) + (L >> 3);
+    b = v / per; const int w_ = v - b * per; sp = w_ / gridDim.x; rb = w_ - sp * gridDim.x;
+  }
+  const int n0 = a.nvalid[2 * b], n1 = a.nvalid[2 * b + 1];
+  const bool nomatch = n0 < 2 || n1 < 2;                 // kornia LightGlueMatcher._no_match
+  const int nact = nomatch ? 1 : (n0 + kHeadRows - 1) / kHeadRows;   // row blocks of this pair that hold valid rows (block 0 always reports)
+  if (rb >= nact) return;
+  const int i0 = rb * kHeadRows;
+  const int ntile_all = nomatch ? 0 : (n1 + 63) / 64;
+  const int tbeg = ntile_all * sp / S, tend = ntile_all * (sp + 1) / S, ntile = tend - tbeg;   // this workgroup's column tiles
+  const size_t ro = (size_t)b * np;
+  const int npart = np / kHeadRows;                      // column partials per pair: one per row block
+  const unsigned char* const A0 = reinterpret_cast<const unsigned char*>(a.md) + ((size_t)(2 * b) * np + i0) * 1024;
+  const unsigned char* const B0 = reinterpret_cast<const unsigned char*>(a.md) + ((size_t)(2 * b + 1) * np + 64 * tbeg) * 1024;
+  long long* const ts = a.dbg_ts ? a.dbg_ts + ((((size_t)(SWEEP - 1) * a.B + b) * (np / kHeadRows) + rb) * kHeadMaxSplit + sp) * 8 : nullptr;   // developer: phase stamps
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (ts && tid == 0) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // row operand: 32 fragments of 16 bytes (unit u = 32 bytes of the row: lane half hh takes bytes 16 hh ..)
+  uint4 af[32];
+  {
+    const unsigned char* ap = A0 + (size_t)(32 * wave + ql) * 1024 + hh * 16;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) af[u] = *reinterpret_cast<const uint4*>(ap + u * 32);
+  }
+  // column-tile staging by LDS-DMA (global_load_lds_dwordx4: one instruction moves 1 KB = 8 rows x 128 B straight into LDS, no
+  // registers, nothing to wait for until the end of the tile).  Instruction q = 0..15 of wave w fills slot q >> 1, row group
+  // 2 w + (q & 1); lane L lands at position L & 7 of row 8 group + (L >> 3), so it fetches the chunk that belongs there.
+  const unsigned char* ssrc[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = 8 * (2 * wave + e) + (lane >> 3);
+    ssrc[e] = B0 + (size_t)row * 1024 + (((lane & 7) ^ hswz(row)) * 16);
+  }
+  // The DMA is issued through inline assembly ON PURPOSE: hipcc's wait-count pass makes every ds_read that follows a
+  // __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot prove that the tile being read is not the tile being filled), which
+  // puts the full DMA latency in front of every k-step.  The waits that matter are written by hand: vmcnt(0) + barrier at the end
+  // of every tile.  (The compiler's own vmcnt accounting only ever over-waits because of the in-flight operations it does not see.)
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  auto stage = [&](int bufi, int t, int q) __attribute__((always_inline)) {
+    const unsigned char* g = ssrc[q & 1] + (size_t)t * 65536 + (q >> 1) * 128;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + bufi * kHeadTile + (q >> 1) * kHeadKT + (2 * wave + (q & 1)) * 1024);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+  };
+  // column fragments of step st (16 per tile), half c: slot st >> 1, chunks 4 (st & 1) + hh and 4 (st & 1) + 2 + hh of row 32 c + ql
+  int brow[2], bsw[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { brow[c] = (32 * c + ql) * 128; bsw[c] = hswz(32 * c + ql); }
+  uint4 fb[2][2][2];   // [buffer][half][term]
+  auto read_b = [&](int buf, const unsigned char* tile, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned char* base = tile + (st >> 1) * kHeadKT + brow[c];
+      fb[buf][c][0] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + hh) ^ bsw[c]) * 16));
+      fb[buf][c][1] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + 2 + hh) ^ bsw[c]) * 16));
+    }
+  };
+
+  // rows of this lane: register r of a tile <-> row i0 + 32 wave + (r & 3) + 8 (r >> 2) + 4 hh
+  const int irow0 = i0 + 32 * wave + 4 * hh;
+  unsigned rvalid = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rvalid |= (irow0 + (r & 3) + 8 * (r >> 2) < n0 ? 1u : 0u) << r;
+  float ra[16], rbv[16];        // SWEEP 1: running row max / sum;  SWEEP 2: row best score (ra) / best column (rj)
+  int rj[16];
+  float rm[16], rl[16], li[16]; // SWEEP 2: row constants of score_at
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ra[r] = SWEEP == 1 ? kLseEmpty : -INFINITY; rbv[r] = 0.f; rj[r] = 0x7fffffff;
+    if (SWEEP == 2) {
+      const int i = irow0 + (r & 3) + 8 * (r >> 2);
+      rm[r] = a.rowmax[ro + i]; rl[r] = a.rowlog[ro + i]; li[r] = a.ls[(size_t)(2 * b) * np + i];
+    }
+  }
+  if (ntile > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) stage(0, 0, q);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stamp(1);
+
+  Acc2 acc[2][2];     // [parity of the tile][column half]
+  float cmj[2] = {0.f, 0.f}, clj[2] = {0.f, 0.f}, ljj[2] = {0.f, 0.f};      // SWEEP 2: column constants of the tile whose VALU work is in flight
+  // iteration t: MFMAs of tile t (MMA) interleaved with the VALU work of tile t - 1 (EPI).  The first iteration has no EPI, the
+  // last no MMA: both are compile-time variants, so the k-step loop is branch-free.
+  auto tile_iter = [&](auto par, auto mma_c, auto epi_c, int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool MMA = decltype(mma_c)::value, EPI = decltype(epi_c)::value;
+    const int tn = min(t + 1, ntile - 1);               // tile staged during this iteration (the last iteration re-stages its own: harmless)
+    const int jp0 = 64 * (tbeg + t - 1) + ql;           // this lane's columns of tile t - 1: jp0 + 32 c
+    bool cvalid[2]; float c0[2], c1[2]; int ci[2];      // column running (max, sum) or (best, row) over this lane's 16 rows
+    float ncm[2] = {0.f, 0.f}, ncl[2] = {0.f, 0.f}, nlj[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cvalid[c] = EPI && jp0 + 32 * c < n1; c0[c] = SWEEP == 1 ? kLseEmpty : -INFINITY; c1[c] = 0.f; ci[c] = 0x7fffffff;
+      if (SWEEP == 2 && MMA) {   // next tile's column constants, requested one tile ahead
+        const int jn = 64 * (tbeg + t) + 32 * c + ql;
+        ncm[c] = a.colmax[ro + jn]; ncl[c] = a.collog[ro + jn]; nlj[c] = a.ls[(size_t)(2 * b + 1) * np + jn];
+      }
+    }
+    const unsigned char* const cur = smem + P * kHeadTile;
+    if (MMA) {   // the whole next tile is requested up front: the DMA has the full tile time to land (the wait is at the end of the tile)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (!(ABL & 1)) stage(P ^ 1, tn, q);
+      read_b(0, cur, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      if (MMA) {
+        if (st + 1 < 16 && !(ABL & 8)) read_b((st + 1) & 1, cur, st + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (ABL & 4) continue;
+          if (st == 0) head_mma<F32, true, 0>(af[0], af[1], fb[0][c][0], fb[0][c][1], acc[P][c]);
+          else head_mma<F32, false, 0>(af[2 * st], af[2 * st + 1], fb[st & 1][c][0], fb[st & 1][c][1], acc[P][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) if (!(ABL & 4)) head_mma<F32, false, 1>(af[2 * st], af[2 * st + 1], fb[st & 1][c][0], fb[st & 1][c][1], acc[P][c]);
+      }
+      if (EPI && !(ABL & 2)) {   // element r = st of both halves of the previous tile
+        const int r = st;
+        const bool rv = (rvalid >> r) & 1u;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float v = acc[P ^ 1][c].c[0][r] + acc[P ^ 1][c].c[1][r];   // small terms + main term
+          if (SWEEP == 1) {
+            const float vr = cvalid[c] ? v : -INFINITY;
+            lse_push(ra[r], rbv[r], vr);
+            lse_push(c0[c], c1[c], rv ? vr : -INFINITY);
+          } else {
+            const float p = score_at(v, rm[r], rl[r], cmj[c], clj[c], li[r], ljj[c]);
+            const bool take = cvalid[c] & ((p > ra[r]) | (rj[r] == 0x7fffffff));      // c = 0 before c = 1: columns in increasing order
+            ra[r] = take ? p : ra[r]; rj[r] = take ? jp0 + 32 * c : rj[r];
+            const bool takec = cvalid[c] & rv & ((p > c0[c]) | (ci[c] == 0x7fffffff));
+            c0[c] = takec ? p : c0[c]; ci[c] = takec ? irow0 + (r & 3) + 8 * (r >> 2) : ci[c];
+          }
+        }
+      }
+      if (MMA && EPI && kHeadSchedGroups) {   // issue order inside the k-step: the LDS reads first, then each MFMA followed by a share of the VALU work
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int g = 0; g < (F32 ? 16 : 6); ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, F32 ? 3 : 8, 0);
+        }
+      }
+      if (kHeadSchedGroups) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EPI) {   // this lane's columns of tile t - 1: merge the two row halves of the wave; the four waves meet in LDS (next iteration)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (SWEEP == 1) {
+          const float om = __shfl_xor(c0[c], 32), os = __shfl_xor(c1[c], 32);
+          lse_merge(c0[c], c1[c], om, os);
+          if (hh == 0) { xch[P ^ 1][0][wave][32 * c + ql] = c0[c]; xch[P ^ 1][1][wave][32 * c + ql] = c1[c]; }
+        } else {
+          const float ov = __shfl_xor(c0[c], 32); const int oi = __shfl_xor(ci[c], 32);
+          if (arg_better(ov, oi, c0[c], ci[c])) { c0[c] = ov; ci[c] = oi; }
+          if (hh == 0) { xch[P ^ 1][0][wave][32 * c + ql] = c0[c]; xch[P ^ 1][1][wave][32 * c + ql] = __int_as_float(ci[c]); }
+        }
+      }
+    }
+    if (SWEEP == 2) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { cmj[c] = ncm[c]; clj[c] = ncl[c]; ljj[c] = nlj[c]; }
+    }
+    if (MMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();    // tile t + 1 is staged; every wave is done reading tile t
+    }
+  };
+  // one partial per (row block, column): wave 0 merges the four waves' values of tile tt (waves in increasing row order)
+  auto flush_cols = [&](int tt) __attribute__((always_inline)) {
+    if (wave != 0) return;
+    const int par = tt & 1, j = 64 * (tbeg + tt) + lane;
+    const size_t po = ((size_t)b * npart + rb) * np + j;
+    if (SWEEP == 1) {
+      float m = xch[par][0][0][lane], sm = xch[par][1][0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) lse_merge(m, sm, xch[par][0][w][lane], xch[par][1][w][lane]);
+      if (j < np) { st_dev(a.cpart_m + po, m); st_dev(a.cpart_s + po, sm); }
+    } else {
+      float bv = xch[par][0][0][lane]; int bi = __float_as_int(xch[par][1][0][lane]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float ov = xch[par][0][w][lane]; const int oi = __float_as_int(xch[par][1][w][lane]);
+        if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+      }
+      if (j < np) { st_dev(a.cpart_m + po, bv); st_dev(a.cpart_i + po, bi); }
+    }
+  };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type; using No = std::false_type;
+  if (ntile > 0) {
+    tile_iter(C0{}, Yes{}, No{}, 0);
+    for (int t = 1; t < ntile; t += 2) {
+      tile_iter(C1{}, Yes{}, Yes{}, t);          // (ends with a barrier: the partials of tile t - 1 are in xch[(t - 1) & 1])
+      flush_cols(t - 1);
+      if (t + 1 < ntile) { tile_iter(C0{}, Yes{}, Yes{}, t + 1); flush_cols(t); }
+    }
+    if (ntile & 1) tile_iter(C1{}, No{}, Yes{}, ntile); else tile_iter(C0{}, No{}, Yes{}, ntile);
+    __syncthreads();
+    flush_cols(ntile - 1);
+  }
+  stamp(2);
+
+  // ---- rows of this workgroup over its column range: merge the 32 per-lane partials of every row through LDS, one partial per
+  // (row, column split) -- rpart_a / rpart_b [B][kHeadMaxSplit][npad]
+  __syncthreads();
+  float* const red0 = reinterpret_cast<float*>(smem);                 // [128 rows][33]
+  float* const red1 = red0 + kHeadRows * 33;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * wave + 4 * hh + (r & 3) + 8 * (r >> 2);
+    red0[row * 33 + ql] = ra[r];
+    red1[row * 33 + ql] = SWEEP == 1 ? rbv[r] : __int_as_float(rj[r]);
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 1, part = tid & 1, i = i0 + row;
+    const size_t pr = ((size_t)b * kHeadMaxSplit + sp) * np + i;
+    if (SWEEP == 1) {
+      float m = -INFINITY, sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lse_merge(m, sm, red0[row * 33 + 16 * part + k], red1[row * 33 + 16 * part + k]);
+      { const float om = __shfl_xor(m, 1), os = __shfl_xor(sm, 1); lse_merge(m, sm, om, os); }
+      if (part == 0 && i < np) {
+        if (S == 1) { if (i < n0) { a.rowmax[ro + i] = m; a.rowlog[ro + i] = logf(sm); } }    // single column split: the row is complete
+        else { st_dev(a.rpart_a + pr, m); st_dev(a.rpart_b + pr, sm); }
+      }
+    } else {
+      float bv = -INFINITY; int bj = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float ov = red0[row * 33 + 16 * part + k]; const int oj = __float_as_int(red1[row * 33 + 16 * part + k]);
+        if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; }
+      }
+      { const float ov = __shfl_xor(bv, 1); const int oj = __shfl_xor(bj, 1); if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; } }
+      if (part == 0 && i < np) {
+        if (S == 1) { if (i < n0) { st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv); } }
+        else { st_dev(a.rpart_a + pr, bv); st_dev(a.rpart_b + pr, __int_as_float(bj)); }
+      }
+    }
+  }
+  stamp(3);
+
+  // ---- the last workgroup of the pair finishes the rows and the columns (and, in sweep 2, the matches)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's coherent stores have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = atomicAdd(&a.tickets[2 * b + (SWEEP - 1)], 1u);
+    s_last = prev == (unsigned)(nact * S) - 1u;
+    if (s_last) a.tickets[2 * b + (SWEEP - 1)] = 0u;   // ready for the next call on this stream
+  }
+  __syncthreads();
+  stamp(4);
+  if (!s_last) return;
+  const int nparts = nact;
+  // one thread per row / column; the partials are requested up to 32 at a time (independent loads: one memory latency per batch)
+  // and merged in increasing (column split / row) order
+  int* const m1s = reinterpret_cast<int*>(smem) + 64;     // sweep 2: the column arg-max of the pair stays in LDS for the mutual check
+  for (int i = tid; S > 1 && i < n0; i += 256) {
+    float pa[kHeadMaxSplit], pb[kHeadMaxSplit];
+#pragma unroll
+    for (int e = 0; e < kHeadMaxSplit; ++e) {
+      const size_t pr = ((size_t)b * kHeadMaxSplit + min(e, S - 1)) * np + i;
+      pa[e] = ld_dev(a.rpart_a + pr); pb[e] = ld_dev(a.rpart_b + pr);
+    }
+    if (SWEEP == 1) {
+      float m = -INFINITY, sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < kHeadMaxSplit; ++e) if (e < S) lse_merge(m, sm, pa[e], pb[e]);
+      a.rowmax[ro + i] = m; a.rowlog[ro + i] = logf(sm);
+    } else {
+      float bv = -INFINITY; int bj = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < kHeadMaxSplit; ++e) if (e < S && arg_better(pa[e], __float_as_int(pb[e]), bv, bj)) { bv = pa[e]; bj = __float_as_int(pb[e]); }
+      st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv);
+    }
+  }
+  if (SWEEP == 1) {
+    for (int j = tid; j < n1; j += 256) {
+      float m = -INFINITY, sm = 0.f;
+      for (int p0 = 0; p0 < nparts; p0 += 32) {
+        float pm[32], ps[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          const size_t po = ((size_t)b * npart + min(p0 + e, nparts - 1)) * np + j;
+          pm[e] = ld_dev(a.cpart_m + po); ps[e] = ld_dev(a.cpart_s + po);
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+          if (p0 + e < nparts) lse_merge(m, sm, pm[e], ps[e]);
+      }
+      a.colmax[ro + j] = m; a.collog[ro + j] = logf(sm);
+    }
+    stamp(5);
+    return;
+  }
+  for (int j = tid; j < n1; j += 256) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int p0 = 0; p0 < nparts; p0 += 32) {     // partials in increasing row order: a strict comparison keeps the lowest row on ties
+      float pv[32]; int pi[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const size_t po = ((size_t)b * npart + min(p0 + e, nparts - 1)) * np + j;
+        pv[e] = ld_dev(a.cpart_m + po); pi[e] = ld_dev(a.cpart_i + po);
+      }
+#pragma unroll
+      for (int e = 0; e < 32; ++e)
+        if (p0 + e < nparts && arg_better(pv[e], pi[e], bv, bi)) { bv = pv[e]; bi = pi[e]; }
+    }
+    a.m1[ro + j] = bi; m1s[j] = bi;
+  }
+  stamp(5);
+  __syncthreads();
+  // mutual check + threshold + order-preserving compaction (k_compact); m0 / max0 were written by this workgroup's own threads
+  int* const wcount = reinterpret_cast<int*>(smem);     // (the tile buffers are idle: 64 ints of scratch, then m1s[npad])
+  int* const base_s = wcount + 4;
+  if (tid == 0) *base_s = 0;
+  __syncthreads();
+  if (nomatch || (a.ovf != nullptr && *a.ovf != 0u)) {
+    if (tid == 0) a.n_match[b] = 0;
+    return;
+  }
+  for (int ib = 0; ib < n0; ib += 256) {
+    const int i = ib + tid;
+    bool valid = false; int j = 0; float sc = 0.f;
+    if (i < n0) {
+      j = ld_dev(a.m0 + ro + i);
+      sc = expf(ld_dev(a.max0 + ro + i));
+      valid = (m1s[j] == i) && (sc > a.threshold);
+    }
+    const unsigned long long bal = __ballot(valid);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = *base_s;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (valid) {
+      const size_t k = (size_t)b * a.kmax + off + before;
+      a.idx[2 * k] = i; a.idx[2 * k + 1] = j;
+      a.score[k] = sc;
+    }
+    __syncthreads();
+    if (tid == 0) *base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  if (tid == 0) a.n_match[b] = *base_s;
+  stamp(6);
+}
+
 // grid (kmax/256, B)
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
@@ -199,6 +643,34 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   a.obj[3 * o] = xr; a.obj[3 * o + 1] = yr; a.obj[3 * o + 2] = z;
 }
 }  // namespace
+
+int g_head_ablate = 0;   // developer knob 18: timing-only ablations of the first sweep (wrong results)
+void launch_match_head_fused(const HeadArgs& a, hipStream_t s) {
+  // small batches: split the column tiles of a pair over S workgroups per row block until the grid covers the chip
+  const int nrb = a.npad / kHeadRows, ntile = a.npad / 64;
+  int S = 1;
+  while (S < kHeadMaxSplit && 2 * S <= ntile && nrb * a.B * S < 256) S *= 2;
+  const dim3 grid(nrb, a.B, S), block(256);
+  if (a.md_f32) {
+    hipLaunchKernelGGL((k_head_fused<true, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((k_head_fused<true, 2>), grid, block, 0, s, a);
+    g_last_kernel = "k_head_fused<true, 2>";
+  } else if (g_head_ablate) {
+    switch (g_head_ablate) {
+      case 1: hipLaunchKernelGGL((k_head_fused<false, 1, 1>), grid, block, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((k_head_fused<false, 1, 2>), grid, block, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((k_head_fused<false, 1, 4>), grid, block, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((k_head_fused<false, 1, 8>), grid, block, 0, s, a); break;
+      case 6: hipLaunchKernelGGL((k_head_fused<false, 1, 6>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_head_fused<false, 1, 14>), grid, block, 0, s, a); break;
+    }
+    hipLaunchKernelGGL((k_head_fused<false, 2>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_head_fused<false, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((k_head_fused<false, 2>), grid, block, 0, s, a);
+    g_last_kernel = "k_head_fused<false, 2>";
+  }
+}
 
 void launch_match_head(const HeadArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_row_stats, dim3(a.npad / 4, a.B), dim3(256), 0, s, a);

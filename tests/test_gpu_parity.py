@@ -154,7 +154,23 @@ def test_matcher_matches_oracle_per_layer_and_bit_exact_indices(eng256, state_di
             assert _rel(x[b, 1, :nr], taps[b][f"layer{nl - 1}_1"][0].numpy()) < 2e-5
     desc = eng256.debug_read("desc", T * 128).reshape(4, 2, npad, 128)
     cos = eng256.debug_read("cos", T * 32).reshape(4, 2, npad, 32)
+    # the fused match head never writes the similarity matrix: the unfused developer path (knob 16 = 0: sim GEMM + five passes) does,
+    # and both heads must return the same matches
+    fused = (idx.clone(), score.clone(), n_match.clone())
+    stats_f = {k: eng256.debug_read(k, 4 * npad) for k in ("rowmax", "rowlog", "colmax", "collog")}
+    eng256.lib.gn_debug_set_variant(eng256.ctx, 16, 0)
+    idx, score, n_match = eng256.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    torch.cuda.synchronize()
+    eng256.lib.gn_debug_set_variant(eng256.ctx, 16, 1)
     sim = eng256.debug_read("sim", 4 * npad * npad).reshape(4, npad, npad)
+    assert torch.equal(fused[2], n_match)
+    for b, p in enumerate(pairs):
+        k = int(n_match[b]); nq, nr = len(p.kp_q), len(p.kp_r)
+        assert torch.equal(fused[0][b, :k], idx[b, :k])
+        assert (fused[1][b, :k] - score[b, :k]).abs().max().item() < 1e-5
+        for name, n in (("rowmax", nq), ("rowlog", nq), ("colmax", nr), ("collog", nr)):
+            u = eng256.debug_read(name, 4 * npad).reshape(4, npad)[b, :n]
+            assert np.abs(u - stats_f[name].reshape(4, npad)[b, :n]).max() < 1e-4, name   # different summation orders of the 256 products
     from oracle import lightglue_sift as lg
     for b, p in enumerate(pairs):
         nq, nr = len(p.kp_q), len(p.kp_r)
