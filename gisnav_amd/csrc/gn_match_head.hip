@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
 //   k_head_fused<., 1>  row and column soft-max statistics (running max / sum of exponentials), finished per pair by the LAST workgroup
 //   k_head_fused<., 2>  score_at() in the reference's association order, row and column arg-max partials; the last workgroup of a
 //                       pair reduces them, does the mutual check, the threshold and the ordered compaction.
-// grid (npad / 128, B, S), 4 waves: a workgroup owns 128 rows of image 0 (wave w: rows 32 w ..) and a contiguous 1 / S of the
+// grid (npad / 128, B, S), 8 waves: a workgroup owns 128 rows of image 0 (wave (wq, wc): rows 32 wq .., columns 32 wc .. of every
+// tile) and a contiguous 1 / S of the
 // 64-column tiles of image 1 (S > 1 only for small batches, to occupy the chip).  What bounds these sweeps is the rate at which a CU
 // can pull column tiles out of L2 (measured ~13 B / clk / CU whether by LDS-DMA or by loads), so the shape maximises the rows
 // served by one tile: the row operand lives in registers for the whole sweep (32 x 16-byte fragments per lane, no copies between
@@ -255,11 +256,13 @@ __device__ __forceinline__ void head_mma(const uint4& a0, const uint4& a1, const
 }
 
 template <bool F32, int SWEEP, int ABL = 0>   // ABL, timing-only ablations (wrong results): 1 no DMA in the loop, 2 no VALU work, 4 no MFMA, 8 no LDS fragment reads
-__global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
+__global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kHeadTile];
   __shared__ int s_last;
-  __shared__ float xch[2][2][4][64];   // [tile parity][value][wave][column of the tile]: column partials of the four waves
+  __shared__ float xch[3][2][4][64];   // [tile % 3][value][row quarter][column of the tile]: column partials of the four row quarters
+  __shared__ f32x4 rowc[kHeadRows];    // SWEEP 2: (rowmax, rowlog, logsigmoid matchability, -) of the workgroup's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, wc = wave >> 2;       // row quarter (32 rows), column half (32 columns of every tile)
   const int hh = lane >> 5, ql = lane & 31;
   // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the row blocks and
   // column splits of ONE pair -- which all stream the same 1 MB of image-1 descriptors -- are renumbered to share an XCD.
@@ -290,161 +293,119 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
   // row operand: 32 fragments of 16 bytes (unit u = 32 bytes of the row: lane half hh takes bytes 16 hh ..)
   uint4 af[32];
   {
-    const unsigned char* ap = A0 + (size_t)(32 * wave + ql) * 1024 + hh * 16;
+    const unsigned char* ap = A0 + (size_t)(32 * wq + ql) * 1024 + hh * 16;
 #pragma unroll
     for (int u = 0; u < 32; ++u) af[u] = *reinterpret_cast<const uint4*>(ap + u * 32);
   }
+  if (SWEEP == 2 && tid < kHeadRows) {
+    const int i = i0 + tid;
+    const f32x4 rc = {a.rowmax[ro + i], a.rowlog[ro + i], a.ls[(size_t)(2 * b) * np + i], 0.f};
+    rowc[tid] = rc;
+  }
   // column-tile staging by LDS-DMA (global_load_lds_dwordx4: one instruction moves 1 KB = 8 rows x 128 B straight into LDS, no
-  // registers, nothing to wait for until the end of the tile).  Instruction q = 0..15 of wave w fills slot q >> 1, row group
-  // 2 w + (q & 1); lane L lands at position L & 7 of row 8 group + (L >> 3), so it fetches the chunk that belongs there.
-  const unsigned char* ssrc[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int row = 8 * (2 * wave + e) + (lane >> 3);
-    ssrc[e] = B0 + (size_t)row * 1024 + (((lane & 7) ^ hswz(row)) * 16);
+  // registers, nothing to wait for until the end of the tile).  Instruction q = 0..7 of wave w fills slot q, row group w; lane L
+  // lands at position L & 7 of row 8 w + (L >> 3), so it fetches the chunk that belongs there.
+  const unsigned char* ssrc;
+  {
+    const int row = 8 * wave + (lane >> 3);
+    ssrc = B0 + (size_t)row * 1024 + (((lane & 7) ^ hswz(row)) * 16);
   }
   // The DMA is issued through inline assembly ON PURPOSE: hipcc's wait-count pass makes every ds_read that follows a
   // __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot prove that the tile being read is not the tile being filled), which
   // puts the full DMA latency in front of every k-step.  The waits that matter are written by hand: vmcnt(0) + barrier at the end
   // of every tile.  (The compiler's own vmcnt accounting only ever over-waits because of the in-flight operations it does not see.)
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-  auto stage = [&](int bufi, int t, int q) __attribute__((always_inline)) {
-    const unsigned char* g = ssrc[q & 1] + (size_t)t * 65536 + (q >> 1) * 128;
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + bufi * kHeadTile + (q >> 1) * kHeadKT + (2 * wave + (q & 1)) * 1024);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
-  };
-  // column fragments of step st (16 per tile), half c: slot st >> 1, chunks 4 (st & 1) + hh and 4 (st & 1) + 2 + hh of row 32 c + ql
-  int brow[2], bsw[2];
+  auto stage_tile = [&](int t) __attribute__((always_inline)) {
+    const unsigned lb = __builtin_amdgcn_readfirstlane(lds0 + (t & 1) * kHeadTile + wave * 1024);
 #pragma unroll
-  for (int c = 0; c < 2; ++c) { brow[c] = (32 * c + ql) * 128; bsw[c] = hswz(32 * c + ql); }
-  uint4 fb[2][2][2];   // [buffer][half][term]
-  auto read_b = [&](int buf, const unsigned char* tile, int st) __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const unsigned char* base = tile + (st >> 1) * kHeadKT + brow[c];
-      fb[buf][c][0] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + hh) ^ bsw[c]) * 16));
-      fb[buf][c][1] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + 2 + hh) ^ bsw[c]) * 16));
+    for (int q = 0; q < 8; ++q) {
+      const unsigned char* g = ssrc + (size_t)t * 65536 + q * 128;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lb + q * kHeadKT), "v"(g) : "memory");
     }
   };
+  // column fragments of step st (16 per tile): slot st >> 1, chunks 4 (st & 1) + hh and 4 (st & 1) + 2 + hh of row 32 wc + ql
+  const int brow = (32 * wc + ql) * 128, bsw = hswz(32 * wc + ql);
+  uint4 fb[2][2];   // [buffer][term]
+  auto read_b = [&](int buf, const unsigned char* tile, int st) __attribute__((always_inline)) {
+    const unsigned char* base = tile + (st >> 1) * kHeadKT + brow;
+    fb[buf][0] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + hh) ^ bsw) * 16));
+    fb[buf][1] = *reinterpret_cast<const uint4*>(base + (((4 * (st & 1) + 2 + hh) ^ bsw) * 16));
+  };
 
-  // rows of this lane: register r of a tile <-> row i0 + 32 wave + (r & 3) + 8 (r >> 2) + 4 hh
-  const int irow0 = i0 + 32 * wave + 4 * hh;
+  // rows of this lane: register r of a tile <-> local row 32 wq + 4 hh + (r & 3) + 8 (r >> 2)
+  const int lrow0 = 32 * wq + 4 * hh, irow0 = i0 + lrow0;
   unsigned rvalid = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) rvalid |= (irow0 + (r & 3) + 8 * (r >> 2) < n0 ? 1u : 0u) << r;
   float ra[16], rbv[16];        // SWEEP 1: running row max / sum;  SWEEP 2: row best score (ra) / best column (rj)
   int rj[16];
-  float rm[16], rl[16], li[16]; // SWEEP 2: row constants of score_at
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    ra[r] = SWEEP == 1 ? kLseEmpty : -INFINITY; rbv[r] = 0.f; rj[r] = 0x7fffffff;
-    if (SWEEP == 2) {
-      const int i = irow0 + (r & 3) + 8 * (r >> 2);
-      rm[r] = a.rowmax[ro + i]; rl[r] = a.rowlog[ro + i]; li[r] = a.ls[(size_t)(2 * b) * np + i];
-    }
-  }
-  if (ntile > 0) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) stage(0, 0, q);
-  }
+  for (int r = 0; r < 16; ++r) { ra[r] = SWEEP == 1 ? kLseEmpty : -INFINITY; rbv[r] = 0.f; rj[r] = 0x7fffffff; }
+  if (ntile > 0) stage_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   stamp(1);
 
-  Acc2 acc[2][2];     // [parity of the tile][column half]
-  float cmj[2] = {0.f, 0.f}, clj[2] = {0.f, 0.f}, ljj[2] = {0.f, 0.f};      // SWEEP 2: column constants of the tile whose VALU work is in flight
-  // iteration t: MFMAs of tile t (MMA) interleaved with the VALU work of tile t - 1 (EPI).  The first iteration has no EPI, the
-  // last no MMA: both are compile-time variants, so the k-step loop is branch-free.
-  auto tile_iter = [&](auto par, auto mma_c, auto epi_c, int t) __attribute__((always_inline)) {
-    constexpr int P = decltype(par)::value;
-    constexpr bool MMA = decltype(mma_c)::value, EPI = decltype(epi_c)::value;
-    const int tn = min(t + 1, ntile - 1);               // tile staged during this iteration (the last iteration re-stages its own: harmless)
-    const int jp0 = 64 * (tbeg + t - 1) + ql;           // this lane's columns of tile t - 1: jp0 + 32 c
-    bool cvalid[2]; float c0[2], c1[2]; int ci[2];      // column running (max, sum) or (best, row) over this lane's 16 rows
-    float ncm[2] = {0.f, 0.f}, ncl[2] = {0.f, 0.f}, nlj[2] = {0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      cvalid[c] = EPI && jp0 + 32 * c < n1; c0[c] = SWEEP == 1 ? kLseEmpty : -INFINITY; c1[c] = 0.f; ci[c] = 0x7fffffff;
-      if (SWEEP == 2 && MMA) {   // next tile's column constants, requested one tile ahead
-        const int jn = 64 * (tbeg + t) + 32 * c + ql;
-        ncm[c] = a.colmax[ro + jn]; ncl[c] = a.collog[ro + jn]; nlj[c] = a.ls[(size_t)(2 * b + 1) * np + jn];
-      }
-    }
-    const unsigned char* const cur = smem + P * kHeadTile;
-    if (MMA) {   // the whole next tile is requested up front: the DMA has the full tile time to land (the wait is at the end of the tile)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) if (!(ABL & 1)) stage(P ^ 1, tn, q);
-      read_b(0, cur, 0);
-    }
+  Acc2 acc;
+  // the MFMAs of tile t
+  auto mma_tile = [&](int t) __attribute__((always_inline)) {
+    if (ABL & 4) return;
+    const unsigned char* const cur = smem + (t & 1) * kHeadTile;
+    read_b(0, cur, 0);
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
-      if (MMA) {
-        if (st + 1 < 16 && !(ABL & 8)) read_b((st + 1) & 1, cur, st + 1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (ABL & 4) continue;
-          if (st == 0) head_mma<F32, true, 0>(af[0], af[1], fb[0][c][0], fb[0][c][1], acc[P][c]);
-          else head_mma<F32, false, 0>(af[2 * st], af[2 * st + 1], fb[st & 1][c][0], fb[st & 1][c][1], acc[P][c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) if (!(ABL & 4)) head_mma<F32, false, 1>(af[2 * st], af[2 * st + 1], fb[st & 1][c][0], fb[st & 1][c][1], acc[P][c]);
-      }
-      if (EPI && !(ABL & 2)) {   // element r = st of both halves of the previous tile
-        const int r = st;
-        const bool rv = (rvalid >> r) & 1u;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float v = acc[P ^ 1][c].c[0][r] + acc[P ^ 1][c].c[1][r];   // small terms + main term
-          if (SWEEP == 1) {
-            const float vr = cvalid[c] ? v : -INFINITY;
-            lse_push(ra[r], rbv[r], vr);
-            lse_push(c0[c], c1[c], rv ? vr : -INFINITY);
-          } else {
-            const float p = score_at(v, rm[r], rl[r], cmj[c], clj[c], li[r], ljj[c]);
-            const bool take = cvalid[c] & ((p > ra[r]) | (rj[r] == 0x7fffffff));      // c = 0 before c = 1: columns in increasing order
-            ra[r] = take ? p : ra[r]; rj[r] = take ? jp0 + 32 * c : rj[r];
-            const bool takec = cvalid[c] & rv & ((p > c0[c]) | (ci[c] == 0x7fffffff));
-            c0[c] = takec ? p : c0[c]; ci[c] = takec ? irow0 + (r & 3) + 8 * (r >> 2) : ci[c];
-          }
-        }
-      }
-      if (MMA && EPI && kHeadSchedGroups) {   // issue order inside the k-step: the LDS reads first, then each MFMA followed by a share of the VALU work
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int g = 0; g < (F32 ? 16 : 6); ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, F32 ? 3 : 8, 0);
-        }
-      }
-      if (kHeadSchedGroups) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (EPI) {   // this lane's columns of tile t - 1: merge the two row halves of the wave; the four waves meet in LDS (next iteration)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (SWEEP == 1) {
-          const float om = __shfl_xor(c0[c], 32), os = __shfl_xor(c1[c], 32);
-          lse_merge(c0[c], c1[c], om, os);
-          if (hh == 0) { xch[P ^ 1][0][wave][32 * c + ql] = c0[c]; xch[P ^ 1][1][wave][32 * c + ql] = c1[c]; }
-        } else {
-          const float ov = __shfl_xor(c0[c], 32); const int oi = __shfl_xor(ci[c], 32);
-          if (arg_better(ov, oi, c0[c], ci[c])) { c0[c] = ov; ci[c] = oi; }
-          if (hh == 0) { xch[P ^ 1][0][wave][32 * c + ql] = c0[c]; xch[P ^ 1][1][wave][32 * c + ql] = __int_as_float(ci[c]); }
-        }
-      }
-    }
-    if (SWEEP == 2) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) { cmj[c] = ncm[c]; clj[c] = ncl[c]; ljj[c] = nlj[c]; }
-    }
-    if (MMA) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();    // tile t + 1 is staged; every wave is done reading tile t
+      if (st + 1 < 16 && !(ABL & 8)) read_b((st + 1) & 1, cur, st + 1);
+      if (st == 0) head_mma<F32, true, 0>(af[0], af[1], fb[0][0], fb[0][1], acc);
+      else head_mma<F32, false, 0>(af[2 * st], af[2 * st + 1], fb[st & 1][0], fb[st & 1][1], acc);
+      head_mma<F32, false, 1>(af[2 * st], af[2 * st + 1], fb[st & 1][0], fb[st & 1][1], acc);
     }
   };
-  // one partial per (row block, column): wave 0 merges the four waves' values of tile tt (waves in increasing row order)
+  // the VALU work of tile t on the accumulators: row statistics / arg-max in registers, the column's over this lane's 16 rows
+  auto epi_tile = [&](int t) __attribute__((always_inline)) {
+    if (ABL & 2) return;
+    const int j = 64 * (tbeg + t) + 32 * wc + ql;        // this lane's column
+    const bool cvalid = j < n1;
+    float cm = 0.f, cl = 0.f, lj = 0.f;
+    if (SWEEP == 2) { cm = a.colmax[ro + j]; cl = a.collog[ro + j]; lj = a.ls[(size_t)(2 * b + 1) * np + j]; }
+    float c0[2], c1[2]; int ci[2];                        // two interleaved column chains (even / odd registers)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { c0[e] = SWEEP == 1 ? kLseEmpty : -INFINITY; c1[e] = 0.f; ci[e] = 0x7fffffff; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc.c[0][r] + acc.c[1][r];           // small terms + main term
+      const bool rv = (rvalid >> r) & 1u;
+      if (SWEEP == 1) {
+        const float vr = cvalid ? v : -INFINITY;
+        lse_push(ra[r], rbv[r], vr);
+        lse_push(c0[r & 1], c1[r & 1], rv ? vr : -INFINITY);
+      } else {
+        const f32x4 rc = rowc[lrow0 + (r & 3) + 8 * (r >> 2)];
+        const float p = score_at(v, rc[0], rc[1], cm, cl, rc[2], lj);
+        const bool take = cvalid & ((p > ra[r]) | (rj[r] == 0x7fffffff));
+        ra[r] = take ? p : ra[r]; rj[r] = take ? j : rj[r];
+        const bool takec = cvalid & rv & ((p > c0[r & 1]) | (ci[r & 1] == 0x7fffffff));
+        c0[r & 1] = takec ? p : c0[r & 1]; ci[r & 1] = takec ? irow0 + (r & 3) + 8 * (r >> 2) : ci[r & 1];
+      }
+    }
+    // merge the two chains, the two row halves of the wave; the four row quarters meet in LDS
+    float* const xm = &xch[t % 3][0][wq][32 * wc + ql];
+    float* const xs = &xch[t % 3][1][wq][32 * wc + ql];
+    if (SWEEP == 1) {
+      lse_merge(c0[0], c1[0], c0[1], c1[1]);
+      const float om = __shfl_xor(c0[0], 32), os = __shfl_xor(c1[0], 32);
+      lse_merge(c0[0], c1[0], om, os);
+      if (hh == 0) { *xm = c0[0]; *xs = c1[0]; }
+    } else {
+      if (arg_better(c0[1], ci[1], c0[0], ci[0])) { c0[0] = c0[1]; ci[0] = ci[1]; }
+      const float ov = __shfl_xor(c0[0], 32); const int oi = __shfl_xor(ci[0], 32);
+      if (arg_better(ov, oi, c0[0], ci[0])) { c0[0] = ov; ci[0] = oi; }
+      if (hh == 0) { *xm = c0[0]; *xs = __int_as_float(ci[0]); }
+    }
+  };
+  // one partial per (row block, column): wave 0 merges the four row quarters' values of tile tt (in increasing row order)
   auto flush_cols = [&](int tt) __attribute__((always_inline)) {
-    if (wave != 0) return;
-    const int par = tt & 1, j = 64 * (tbeg + tt) + lane;
+    if (wave != 0 || tt < 0) return;
+    const int par = tt % 3, j = 64 * (tbeg + tt) + lane;
     const size_t po = ((size_t)b * npart + rb) * np + j;
     if (SWEEP == 1) {
       float m = xch[par][0][0][lane], sm = xch[par][1][0][lane];
@@ -461,41 +422,45 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
       if (j < np) { st_dev(a.cpart_m + po, bv); st_dev(a.cpart_i + po, bi); }
     }
   };
-  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
-  using Yes = std::true_type; using No = std::false_type;
+  // The two waves of a SIMD (w and w + 4: the two column halves) run in OPPOSITE phases -- one is on the matrix pipe while the
+  // other does its VALU work: column half 0 does MFMA(t) then VALU(t), column half 1 does VALU(t - 1) then MFMA(t).
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile && !(ABL & 1)) stage_tile(t + 1);
+    flush_cols(t - 2);                // complete since the barrier that ended iteration t - 1
+    if (wc == 0) { mma_tile(t); epi_tile(t); }
+    else { if (t > 0) epi_tile(t - 1); mma_tile(t); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // tile t + 1 is staged; every wave is done reading tile t
+  }
   if (ntile > 0) {
-    tile_iter(C0{}, Yes{}, No{}, 0);
-    for (int t = 1; t < ntile; t += 2) {
-      tile_iter(C1{}, Yes{}, Yes{}, t);          // (ends with a barrier: the partials of tile t - 1 are in xch[(t - 1) & 1])
-      flush_cols(t - 1);
-      if (t + 1 < ntile) { tile_iter(C0{}, Yes{}, Yes{}, t + 1); flush_cols(t); }
-    }
-    if (ntile & 1) tile_iter(C1{}, No{}, Yes{}, ntile); else tile_iter(C0{}, No{}, Yes{}, ntile);
+    flush_cols(ntile - 2);
+    if (wc == 1) epi_tile(ntile - 1);
     __syncthreads();
     flush_cols(ntile - 1);
   }
   stamp(2);
 
-  // ---- rows of this workgroup over its column range: merge the 32 per-lane partials of every row through LDS, one partial per
-  // (row, column split) -- rpart_a / rpart_b [B][kHeadMaxSplit][npad]
+  // ---- rows of this workgroup over its column range: merge the 64 per-lane partials of every row (32 lanes x 2 column halves)
+  // through LDS, one partial per (row, column split) -- rpart_a / rpart_b [B][kHeadMaxSplit][npad]
   __syncthreads();
-  float* const red0 = reinterpret_cast<float*>(smem);                 // [128 rows][33]
-  float* const red1 = red0 + kHeadRows * 33;
+  float* const red0 = reinterpret_cast<float*>(smem);                 // [128 rows][65]
+  float* const red1 = red0 + kHeadRows * 65;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = 32 * wave + 4 * hh + (r & 3) + 8 * (r >> 2);
-    red0[row * 33 + ql] = ra[r];
-    red1[row * 33 + ql] = SWEEP == 1 ? rbv[r] : __int_as_float(rj[r]);
+    const int row = lrow0 + (r & 3) + 8 * (r >> 2), slot = 32 * wc + ql;
+    red0[row * 65 + slot] = ra[r];
+    red1[row * 65 + slot] = SWEEP == 1 ? rbv[r] : __int_as_float(rj[r]);
   }
   __syncthreads();
   {
-    const int row = tid >> 1, part = tid & 1, i = i0 + row;
+    const int row = tid >> 2, part = tid & 3, i = i0 + row;
     const size_t pr = ((size_t)b * kHeadMaxSplit + sp) * np + i;
     if (SWEEP == 1) {
       float m = -INFINITY, sm = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) lse_merge(m, sm, red0[row * 33 + 16 * part + k], red1[row * 33 + 16 * part + k]);
-      { const float om = __shfl_xor(m, 1), os = __shfl_xor(sm, 1); lse_merge(m, sm, om, os); }
+      for (int k = 0; k < 16; ++k) lse_merge(m, sm, red0[row * 65 + 16 * part + k], red1[row * 65 + 16 * part + k]);
+#pragma unroll
+      for (int o = 1; o < 4; o <<= 1) { const float om = __shfl_xor(m, o), os = __shfl_xor(sm, o); lse_merge(m, sm, om, os); }
       if (part == 0 && i < np) {
         if (S == 1) { if (i < n0) { a.rowmax[ro + i] = m; a.rowlog[ro + i] = logf(sm); } }    // single column split: the row is complete
         else { st_dev(a.rpart_a + pr, m); st_dev(a.rpart_b + pr, sm); }
@@ -504,10 +469,14 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
       float bv = -INFINITY; int bj = 0x7fffffff;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const float ov = red0[row * 33 + 16 * part + k]; const int oj = __float_as_int(red1[row * 33 + 16 * part + k]);
+        const float ov = red0[row * 65 + 16 * part + k]; const int oj = __float_as_int(red1[row * 65 + 16 * part + k]);
         if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; }
       }
-      { const float ov = __shfl_xor(bv, 1); const int oj = __shfl_xor(bj, 1); if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; } }
+#pragma unroll
+      for (int o = 1; o < 4; o <<= 1) {
+        const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o);
+        if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; }
+      }
       if (part == 0 && i < np) {
         if (S == 1) { if (i < n0) { st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv); } }
         else { st_dev(a.rpart_a + pr, bv); st_dev(a.rpart_b + pr, __int_as_float(bj)); }
@@ -528,10 +497,10 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
   stamp(4);
   if (!s_last) return;
   const int nparts = nact;
-  // one thread per row / column; the partials are requested up to 32 at a time (independent loads: one memory latency per batch)
-  // and merged in increasing (column split / row) order
+  // one thread per row / column; the partials are requested together (independent loads: one memory latency per batch) and merged
+  // in increasing (column split / row) order
   int* const m1s = reinterpret_cast<int*>(smem) + 64;     // sweep 2: the column arg-max of the pair stays in LDS for the mutual check
-  for (int i = tid; S > 1 && i < n0; i += 256) {
+  for (int i = tid; S > 1 && i < n0; i += 512) {
     float pa[kHeadMaxSplit], pb[kHeadMaxSplit];
 #pragma unroll
     for (int e = 0; e < kHeadMaxSplit; ++e) {
@@ -550,52 +519,40 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
       st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv);
     }
   }
-  if (SWEEP == 1) {
-    for (int j = tid; j < n1; j += 256) {
-      float m = -INFINITY, sm = 0.f;
-      for (int p0 = 0; p0 < nparts; p0 += 32) {
-        float pm[32], ps[32];
+  for (int j = tid; j < n1; j += 512) {
+    float m = -INFINITY, sm = 0.f; int bi = 0x7fffffff;
+    for (int p0 = 0; p0 < nparts; p0 += 16) {     // partials in increasing row order: a strict comparison keeps the lowest row on ties
+      float pm[16], ps[16];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-          const size_t po = ((size_t)b * npart + min(p0 + e, nparts - 1)) * np + j;
-          pm[e] = ld_dev(a.cpart_m + po); ps[e] = ld_dev(a.cpart_s + po);
-        }
-#pragma unroll
-        for (int e = 0; e < 32; ++e)
-          if (p0 + e < nparts) lse_merge(m, sm, pm[e], ps[e]);
-      }
-      a.colmax[ro + j] = m; a.collog[ro + j] = logf(sm);
-    }
-    stamp(5);
-    return;
-  }
-  for (int j = tid; j < n1; j += 256) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int p0 = 0; p0 < nparts; p0 += 32) {     // partials in increasing row order: a strict comparison keeps the lowest row on ties
-      float pv[32]; int pi[32];
-#pragma unroll
-      for (int e = 0; e < 32; ++e) {
+      for (int e = 0; e < 16; ++e) {
         const size_t po = ((size_t)b * npart + min(p0 + e, nparts - 1)) * np + j;
-        pv[e] = ld_dev(a.cpart_m + po); pi[e] = ld_dev(a.cpart_i + po);
+        pm[e] = ld_dev(a.cpart_m + po);
+        ps[e] = SWEEP == 1 ? ld_dev(a.cpart_s + po) : __int_as_float(ld_dev(a.cpart_i + po));
       }
 #pragma unroll
-      for (int e = 0; e < 32; ++e)
-        if (p0 + e < nparts && arg_better(pv[e], pi[e], bv, bi)) { bv = pv[e]; bi = pi[e]; }
+      for (int e = 0; e < 16; ++e) {
+        if (p0 + e >= nparts) continue;
+        if (SWEEP == 1) lse_merge(m, sm, pm[e], ps[e]);
+        else if (arg_better(pm[e], __float_as_int(ps[e]), m, bi)) { m = pm[e]; bi = __float_as_int(ps[e]); }
+      }
     }
-    a.m1[ro + j] = bi; m1s[j] = bi;
+    if (SWEEP == 1) { a.colmax[ro + j] = m; a.collog[ro + j] = logf(sm); }
+    else { a.m1[ro + j] = bi; m1s[j] = bi; }
   }
   stamp(5);
+  if (SWEEP == 1) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // mutual check + threshold + order-preserving compaction (k_compact); m0 / max0 were written by this workgroup's own threads
+  // mutual check + threshold + order-preserving compaction (k_compact)
   int* const wcount = reinterpret_cast<int*>(smem);     // (the tile buffers are idle: 64 ints of scratch, then m1s[npad])
-  int* const base_s = wcount + 4;
+  int* const base_s = wcount + 8;
   if (tid == 0) *base_s = 0;
   __syncthreads();
   if (nomatch || (a.ovf != nullptr && *a.ovf != 0u)) {
     if (tid == 0) a.n_match[b] = 0;
     return;
   }
-  for (int ib = 0; ib < n0; ib += 256) {
+  for (int ib = 0; ib < n0; ib += 512) {
     const int i = ib + tid;
     bool valid = false; int j = 0; float sc = 0.f;
     if (i < n0) {
@@ -615,7 +572,7 @@ __global__ __launch_bounds__(256) void k_head_fused(HeadArgs a) {
       a.score[k] = sc;
     }
     __syncthreads();
-    if (tid == 0) *base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (tid == 0) { int tot = 0; for (int w = 0; w < 8; ++w) tot += wcount[w]; *base_s += tot; }
     __syncthreads();
   }
   if (tid == 0) a.n_match[b] = *base_s;
@@ -650,7 +607,7 @@ void launch_match_head_fused(const HeadArgs& a, hipStream_t s) {
   const int nrb = a.npad / kHeadRows, ntile = a.npad / 64;
   int S = 1;
   while (S < kHeadMaxSplit && 2 * S <= ntile && nrb * a.B * S < 256) S *= 2;
-  const dim3 grid(nrb, a.B, S), block(256);
+  const dim3 grid(nrb, a.B, S), block(512);
   if (a.md_f32) {
     hipLaunchKernelGGL((k_head_fused<true, 1>), grid, block, 0, s, a);
     hipLaunchKernelGGL((k_head_fused<true, 2>), grid, block, 0, s, a);
