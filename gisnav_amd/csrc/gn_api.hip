@@ -33,6 +33,8 @@ enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, 
 struct gn_ctx {
   int device = 0, max_batch = 0, npad = 0, precision = 0;
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
+  int qkv_stamps = 0;      // developer knob 20: k_qkv writes s_memtime phase stamps into the sim buffer
+  int qkv_fused = 1;       // attention input projections by k_qkv (gn_qkv.hip) instead of the LDS-staged GEMM (developer knob 19)
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
@@ -82,6 +84,7 @@ struct gn_ctx {
   int32_t *m0 = nullptr, *m1 = nullptr;
   float *cpart_m = nullptr, *cpart_s = nullptr;   // fused head: column partials [B][2 npad / 64][npad]
   int32_t* cpart_i = nullptr;
+  float* rot4 = nullptr;                          // [16][T] float4 rotary table for k_qkv (re-laid-out after every prep)
   float *rpart_a = nullptr, *rpart_b = nullptr;   // fused head: row partials [B][8][npad]
   unsigned int* tickets = nullptr;                // fused head: [B][2] arrival counters, zero between calls
   // pipeline scratch for gn_estimate
@@ -325,6 +328,34 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
   }
 }
 
+// q | k | v (or qk | v) projection of one block straight into the attention kernel's bf16 layouts; false when the shape / mode
+// needs the general GEMM
+bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
+  // (small batches keep the tiled GEMM: T / 128 workgroups would leave most of the chip idle)
+  if (!(c->planes_mode && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && T % 128 == 0 && np % 128 == 0 && (vt_perm & 1) &&
+        (T / 128 >= 128 || c->qkv_fused == 2))) return false;
+  QkvArgs q;
+  q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
+  q.rot4 = c->rot4; q.rot_stride = (long long)c->Tmax; q.qkb = c->qkb; q.ldyb = cross ? kDim : 2 * kDim; q.vt = c->vtb; q.npad = np;
+  q.qscale = 0.125f; q.scale = 0.35355339059327373f; q.vt_perm = vt_perm; q.T = T;
+  q.dbg_ts = (c->qkv_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 20
+  ++c->launch_count;
+  if (c->stop_after && c->launch_count > c->stop_after) return true;
+  const bool rec = c->ktiming && c->kused < c->kflops.size();
+  if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+  launch_qkv(q, cross, s);
+  if (rec) {
+    const double N = cross ? 2.0 * kDim : 3.0 * kDim;
+    hipEventRecord(c->kev[2 * c->kused + 1], s);
+    c->kflops[c->kused] = 2.0 * T * N * kDim;
+    c->kbytes[c->kused] = 4.0 * T * kDim + 2.0 * T * N + 4.0 * N * kDim + (cross ? 0.0 : 2.0 * 4.0 * T * kFreq);   // x in (hm16), bf16 out, weights once, rotary tables
+    c->kclass[c->kused] = 0;
+    c->kname[c->kused] = gn::g_last_kernel;
+    ++c->kused;
+  }
+  return true;
+}
+
 // true when the block-tail kernel also computes msg = out_proj(ctx): the schedule then skips the out_proj GEMM launch
 bool tail_folds_out_proj(const gn_ctx* c, const Block& blk, int T) {
   return c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && c->ffn_fold && blk.ffn0.wf && blk.ffn0.wf2 && blk.ffn3.wf && blk.proj_out.wf &&
@@ -400,8 +431,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     if (c->feature == 1) {   // 256-d descriptors ARE the initial residual stream (no input_proj)
       p.x = planes_only ? nullptr : c->x; p.xp = c->planes_mode ? c->x_p : nullptr;
       launch_prep(p, s);
+      if (c->rot4 && c->qkv_fused) launch_rot_table(c->cos_t, c->sin_t, c->rot4, T, (long long)c->Tmax, s);
     } else {
       launch_prep(p, s);
+      if (c->rot4 && c->qkv_fused) launch_rot_table(c->cos_t, c->sin_t, c->rot4, T, (long long)c->Tmax, s);
       if (c->planes_mode) launch_split_hm16(c->desc, c->desc_p, T, kInDim, 1.0f, s);
       GemmArgs g = gemm_args(c->desc, kInDim, c->input_proj, c->x, kDim, T);
       g.drop_f32 = planes_only ? 1 : 0;
@@ -415,7 +448,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 3 * kDim, T);
         g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
-        if (bf16v2) {
+        if (bf16v2 && qkv_projection(c, blk, false, T, np, vt_perm, s)) {
+        } else if (bf16v2) {
           g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np; g.vt_perm = vt_perm;
           gemm(c, EPI_ROTARY_BF16, g, s);
         } else {
@@ -446,7 +480,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 2 * kDim, T);
         g.scale = 0.35355339059327373f;  // (dim_head ** -0.5) ** 0.5 applied to both qk sides
         g.scale_cols = kDim;
-        if (bf16v2) {
+        if (bf16v2 && qkv_projection(c, blk, true, T, np, vt_perm, s)) {
+        } else if (bf16v2) {
           g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np; g.vt_perm = vt_perm;
           gemm(c, EPI_SCALE_BF16, g, s);
         } else {
@@ -559,6 +594,7 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
     ctx->planes_mode = 1;
     GN_ALLOC(desc_p, 2 * T * kInDim); GN_ALLOC(x_p, 2 * T * kDim); GN_ALLOC(ctx_p, 2 * T * kDim);
     GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
+    GN_ALLOC(rot4, T * 2 * kFreq);
   }
   if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
@@ -709,12 +745,13 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
             memcpy(&tmp[(size_t)dst * in], host + (size_t)src * in, in * sizeof(float));
           }
       Linear& L = blk.proj_in;
+      L.frag_order = 0;
       if (is_w) { rc = upload(&L.w, tmp.data(), tmp.size()); } else { rc = upload(&L.b, tmp.data(), tmp.size()); }
       L.out = 3 * kDim; L.in = kDim;
       if (is_w && rc == GN_OK) rc = build_planes(ctx, L);
     } else if (self && leaf == "out_proj") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
-    else if (cross && leaf == "to_qk") rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim);
-    else if (cross && leaf == "to_v") rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim);
+    else if (cross && leaf == "to_qk") { blk.proj_in.frag_order = 0; rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim); }
+    else if (cross && leaf == "to_v") { blk.proj_in.frag_order = 0; rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim); }
     else if (cross && leaf == "to_out") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
     else if (leaf == "ffn.0") { blk.ffn0.frag_order = 0; rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim); }
     else if (leaf == "ffn.3") { blk.ffn3.frag_order = 1; rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim); }
@@ -832,7 +869,7 @@ namespace {
 void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   const long long d = sign * b0, np = c->npad_run, T2 = 2 * np;
   auto mv = [&](auto*& p, long long per_pair) { if (p) p += d * per_pair; };
-  mv(c->desc, T2 * kInDim); mv(c->cos_t, T2 * kFreq); mv(c->sin_t, T2 * kFreq); mv(c->extent, 4); mv(c->nvalid, 2);
+  mv(c->desc, T2 * kInDim); mv(c->cos_t, T2 * kFreq); mv(c->sin_t, T2 * kFreq); mv(c->rot4, T2 * 4); mv(c->extent, 4); mv(c->nvalid, 2);
   mv(c->x, T2 * kDim); mv(c->qkv, T2 * 3 * kDim); mv(c->ctx, T2 * kDim); mv(c->msg, T2 * kDim); mv(c->h, T2 * 2 * kDim);
   mv(c->md, T2 * kDim); mv(c->ls, T2); mv(c->sim, np * np);
   mv(c->desc_p, 2 * T2 * kInDim); mv(c->x_p, 2 * T2 * kDim); mv(c->ctx_p, 2 * T2 * kDim); mv(c->msg_p, 2 * T2 * kDim);
@@ -1428,7 +1465,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
 
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
-  if ((which == 12 && value == 8) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value)) {   // these developer paths use the similarity buffer
+  if ((which == 12 && value == 8) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value) || (which == 20 && value)) {   // these developer paths use the similarity buffer
     GN_HIP(hipSetDevice(ctx->device));
     const int rc = ensure_sim(ctx); if (rc != GN_OK) return rc;
   }
@@ -1451,6 +1488,8 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 16) ctx->head_fused = value;
   else if (which == 17) ctx->head_stamps = value;
   else if (which == 18) gn::g_head_ablate = value;
+  else if (which == 19) ctx->qkv_fused = value;
+  else if (which == 20) ctx->qkv_stamps = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

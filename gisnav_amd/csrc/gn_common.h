@@ -117,6 +117,21 @@ extern int g_ffn_shape;
 extern int g_head_ablate;
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
 
+// ---- attention input projections of the f16x2 mode (gn_qkv.hip): hm16 rows in, bf16 q | k rows and bf16 V^T panels out -------
+struct QkvArgs {
+  const uint16_t* xp;                 // [T][256] hm16 rows
+  const uint16_t* wf; float acc_scale; const float* bias;   // Wqkv re-ordered to [q | k | v] (768 x 256) or [to_qk ; to_v] (512 x 256), fragment order (natural k)
+  const float* rot4; long long rot_stride;                  // [16][rot_stride] float4 rotary table (launch_rot_table) (self block)
+  uint16_t* qkb; int ldyb;            // bf16 rows: q | k (ldyb = 512) or qk (ldyb = 256)
+  uint16_t* vt; int npad;             // V^T bf16 [slot][4][64][npad]
+  float qscale;                       // self: multiplied into q after the rotation (dim_head^-0.5)
+  float scale;                        // cross: multiplied into qk (dim_head^-0.25)
+  int vt_perm;                        // bit 0: keys permuted inside 16-groups (k_attn_bf16_v5); bit 1: timing probe, skip the V^T stores
+  int T;                              // tokens, a multiple of 128
+  long long* dbg_ts;                  // developer: nullptr, or [blocks][8 waves][8] s_memtime stamps
+};
+void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
+
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {
   const uint16_t* qb; int ldqb;   // bf16 variants of q / k (row-major) and V^T ([BS][4][64][npad])
@@ -262,5 +277,6 @@ void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s
 void launch_split3_bf16(const float* in, uint16_t* planes, long long n, hipStream_t s);  // planes[3][n]
 void launch_split2_f16(const float* in, uint16_t* planes, long long n, float scale, hipStream_t s);  // planes[2][n] = fp16 split of in * scale
 void launch_split_hm16(const float* in, uint16_t* out, long long rows, int cols, float scale, hipStream_t s);  // hm16 rows of in * scale
+void launch_rot_table(const float* cos_t, const float* sin_t, float* rot4, int T, long long stride, hipStream_t s);   // [16][stride] float4 (cos, cos, sin, sin) for k_qkv
 
 }  // namespace gn

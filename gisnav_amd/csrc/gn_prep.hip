@@ -253,7 +253,24 @@ __global__ void k_split_hm16(const float* in, uint16_t* out, long long rows, int
     *reinterpret_cast<f16x4*>(q + 16) = m;
   }
 }
+// rotary tables re-laid-out for k_qkv (gn_qkv.hip): rot4[fg][t] = (cos[t][2 fg], cos[t][2 fg + 1], sin[t][2 fg], sin[t][2 fg + 1]),
+// fg = 0..15, rows `stride` tokens apart -- the lanes of a wave are consecutive tokens, so one 16-byte load per lane is a fully coalesced wave load
+__global__ void k_rot_table(const float* cos_t, const float* sin_t, f32x4* rot4, int T, long long stride) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+#pragma unroll
+  for (int fg = 0; fg < kFreq / 2; ++fg) {
+    const float2 c = *reinterpret_cast<const float2*>(cos_t + (size_t)t * kFreq + 2 * fg);
+    const float2 s_ = *reinterpret_cast<const float2*>(sin_t + (size_t)t * kFreq + 2 * fg);
+    const f32x4 v = {c.x, c.y, s_.x, s_.y};
+    rot4[(size_t)fg * stride + t] = v;
+  }
+}
 }  // namespace
+
+void launch_rot_table(const float* cos_t, const float* sin_t, float* rot4, int T, long long stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_rot_table, dim3((T + 255) / 256), dim3(256), 0, s, cos_t, sin_t, reinterpret_cast<f32x4*>(rot4), T, stride);
+}
 
 void launch_split_hm16(const float* in, uint16_t* out, long long rows, int cols, float scale, hipStream_t s) {
   hipLaunchKernelGGL(k_split_hm16, dim3(2048), dim3(256), 0, s, in, out, rows, cols, scale);
