@@ -524,7 +524,18 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     hd.dbg_ts = (c->head_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 17
     if (c->head_fused || !c->sim) {
       ++c->launch_count;
-      if (!(c->stop_after && c->launch_count > c->stop_after)) launch_match_head_fused(hd, s);
+      if (c->stop_after && c->launch_count > c->stop_after) return GN_OK;
+      const bool rec = c->ktiming && c->kused < c->kflops.size();
+      if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+      launch_match_head_fused(hd, s);
+      if (rec) {   // both sweeps as one entry
+        hipEventRecord(c->kev[2 * c->kused + 1], s);
+        c->kflops[c->kused] = 2.0 * 2.0 * B * (double)np * np * kDim;                                   // the similarity tiles are computed twice
+        c->kbytes[c->kused] = 2.0 * (4.0 * T * kDim) + 4.0 * T * 4.0 + 8.0 * B * np * 3.0;               // descriptors once per sweep, per-row / per-column statistics, matches
+        c->kclass[c->kused] = 0;
+        c->kname[c->kused] = "k_head_fused (2 sweeps)";
+        ++c->kused;
+      }
       return GN_OK;
     }
     GemmArgs gs;
