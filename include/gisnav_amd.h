@@ -282,7 +282,8 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"
  * "colmax" "collog" "m0" "m1" (ints are returned bit-cast in float slots). Returns the element
- * count copied, or a negative status. */
+ * count copied, or a negative status.  "sim" exists only after the unfused match head (developer knob 16 = 0), gn_vo_match or a
+ * phase-stamp knob allocated it: the matcher itself never materialises the similarity matrix (it returns 0 elements before that). */
 int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream);
 /* Stand-alone kernels for unit tests: Y[M,N] = A[M,K] W[N,K]^T + bias (f32 MFMA path). */
 int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float* W, const float* bias,
@@ -298,7 +299,11 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * stream: enable with room for max_launches launches (0 disables), then read
  * out3 = {launches recorded, total milliseconds, total algorithmic flops (2 M N K)}. */
 /* Developer knobs: select a kernel variant (which = 0: GEMM) for A/B benchmarking; run a pure
- * v_mfma_f32_32x32x2_f32 issue-rate probe (blocks x 256 threads x iters x 8 MFMAs per wave). */
+ * v_mfma_f32_32x32x2_f32 issue-rate probe (blocks x 256 threads x iters x 8 MFMAs per wave).
+ * Knobs added in round 2 (value 0 restores the round-1 path unless noted): 10 block-tail fusion level, 12 k_ffn_fused ablations /
+ * phase stamps, 13 out_proj folded into the tail, 14 k_ffn_fused workgroup shape (64 / 32 tokens), 15 PnP phase stamps,
+ * 16 fused match head (0 = similarity GEMM + five passes), 17 / 18 k_head_fused phase stamps / ablations, 19 k_qkv projections
+ * (0 = tiled GEMM, 2 = force at any batch size), 20 k_qkv phase stamps.  A bench line run with any knob set records it in `debug_variant`. */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream);
 /* LDS-DMA addressing probe (80 KB of LDS per block filled by global_load_lds, verified by ds_read):
