@@ -10,7 +10,7 @@ from gisnav_amd.engine import PoseEngine  # noqa: E402
 from gisnav_amd.synthetic import make_pair  # noqa: E402
 from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
-B = 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
 inp = eng.stage_inputs([make_pair(i) for i in range(B)])
 args = (inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
@@ -19,7 +19,8 @@ eng.lib.gn_debug_set_variant(eng.ctx, 12, 8)
 eng.lib.gn_debug_set_variant(eng.ctx, 4, 5)       # stop after the first FFN launch: the stamps in `sim` are not overwritten by the head
 eng.match(*args)
 torch.cuda.synchronize()
-nb = B * 2 * 1024 // 64
+TOK = 64 if B * 2 * 1024 // 64 >= 256 else 32          # the launcher's shape rule (gn_ffn.hip)
+nb = B * 2 * 1024 // TOK
 ts = eng.debug_read("sim", nb * 8 * 8 * 2, np.uint32).view(np.int64).reshape(nb, 8, 8)
 d = np.diff(ts, axis=2).astype(np.float64)
 names = ["prologue", "gemm1", "ln+gelu", "publish", "gemm2", "barrier", "epilogue"]
