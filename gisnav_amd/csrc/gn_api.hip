@@ -35,6 +35,8 @@ struct gn_ctx {
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
   int qkv_stamps = 0;      // developer knob 20: k_qkv writes s_memtime phase stamps into the sim buffer
   int qkv_fused = 1;       // attention input projections by k_qkv (gn_qkv.hip) instead of the LDS-staged GEMM (developer knob 19)
+  int sp_split = 1;        // SuperPoint convolutions on split-fp16 operands in contexts of the f16x2 mode (developer knob 21; 0 = exact f32)
+  long long sp_split_trips = 0;
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
@@ -104,7 +106,8 @@ struct gn_ctx {
   int sift_max_cand = 0, sift_max_kp = 0, sift_raw_cap = 0, sift_batch = 0; long long sift_kp_stride = 0;
   std::vector<int32_t> sift_totals;   // distinct keypoints found per image by the last call (before the max_kpts cap)
   // SuperPoint extractor (gn_sp_*): 12 convolutions in network order, workspace sized for the last (chunk, H, W) seen
-  struct SpConv { float* wf = nullptr; float* b = nullptr; int cout = 0, cin = 0, taps = 0, cout_pad = 0; bool have_w = false, have_b = false; };
+  struct SpConv { float* wf = nullptr; float* b = nullptr; int cout = 0, cin = 0, taps = 0, cout_pad = 0; bool have_w = false, have_b = false;
+                  uint16_t* wfh = nullptr; float acc_scale = 1.f; };   // wfh: fp16 pairs in fragment order (contexts of the f16x2 mode)
   SpConv sp[12];
   std::vector<void*> sp_allocs; int sp_h = 0, sp_w = 0, sp_chunk = 0, sp_cap = 0, sp_max = 0;
   float *sp_x = nullptr, *sp_y = nullptr, *sp_z = nullptr, *sp_maps[6] = {};
@@ -1304,6 +1307,18 @@ int gn_sp_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const 
       const size_t n = i > 0 ? frag.size() : (size_t)cout * 9;       // the first layer (1 input channel) keeps [64][9] for the FMA kernel
       if (!c.wf) { void* q = nullptr; GN_HIP(hipMalloc(&q, n * sizeof(float))); ctx->sp_allocs.push_back(q); c.wf = (float*)q; }
       GN_HIP(hipMemcpy(c.wf, src, n * sizeof(float), hipMemcpyHostToDevice));
+      if (i > 0 && ctx->precision == GN_PREC_F16X2_BF16_ATTN && cin % 16 == 0) {   // the split-fp16 convolution of this precision mode
+        float mx = 0.f;
+        for (size_t q = 0; q < (size_t)cout * cin * taps; ++q) mx = std::max(mx, fabsf(host[q]));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) { frexpf(mx, &e); e = 13 - e; }      // max |w| * 2^e in [2^12, 2^13), as for the matcher's weights (build_planes)
+        e = std::max(-60, std::min(60, e));
+        std::vector<uint16_t> fh((size_t)2 * c.cout_pad * taps * cin);
+        sp_weight_fragments_hm16(host, cout, cin, taps, c.cout_pad, ldexpf(1.0f, e), fh.data());
+        if (!c.wfh) { void* q = nullptr; GN_HIP(hipMalloc(&q, fh.size() * sizeof(uint16_t))); ctx->sp_allocs.push_back(q); c.wfh = (uint16_t*)q; }
+        GN_HIP(hipMemcpy(c.wfh, fh.data(), fh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        c.acc_scale = ldexpf(1.0f, -e);
+      }
       c.have_w = true;
       return GN_OK;
     }
@@ -1331,9 +1346,9 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
   const int h = H / 8, w = W / 8;
   const int cap = std::max(16384, H * W / 16);            // candidates after NMS (radius 4): at most one per ~5 x 5 neighbourhood in practice
   if (ctx->sp_h != H || ctx->sp_w != W || ctx->sp_chunk < chunk || ctx->sp_max < max_kpts) {
-    for (void* p : ctx->sp_allocs) { bool is_weight = false; for (int i = 0; i < 12; ++i) is_weight |= (p == ctx->sp[i].wf || p == ctx->sp[i].b); if (!is_weight) hipFree(p); }
+    for (void* p : ctx->sp_allocs) { bool is_weight = false; for (int i = 0; i < 12; ++i) is_weight |= (p == ctx->sp[i].wf || p == ctx->sp[i].b || p == ctx->sp[i].wfh); if (!is_weight) hipFree(p); }
     std::vector<void*> keep;
-    for (void* p : ctx->sp_allocs) { for (int i = 0; i < 12; ++i) if (p == ctx->sp[i].wf || p == ctx->sp[i].b) { keep.push_back(p); break; } }
+    for (void* p : ctx->sp_allocs) { for (int i = 0; i < 12; ++i) if (p == ctx->sp[i].wf || p == ctx->sp[i].b || p == ctx->sp[i].wfh) { keep.push_back(p); break; } }
     ctx->sp_allocs = keep;
     auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; ctx->sp_allocs.push_back(p); return p; };
     const size_t full = (size_t)chunk * H * W;
@@ -1349,12 +1364,18 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     ctx->sp_h = H; ctx->sp_w = W; ctx->sp_chunk = chunk; ctx->sp_cap = cap; ctx->sp_max = max_kpts;
   }
   float *X = ctx->sp_x, *Y = ctx->sp_y, *Z = ctx->sp_z;
+  // contexts of the f16x2 mode run the convolutions on split-fp16 operands (5 x the matrix-pipe rate of the exact f32 instruction,
+  // the same accuracy class); an activation that does not fit fp16 raises ovf[1] and the pass is repeated on the exact path
+  bool split = ctx->sp_split && ctx->sp[1].wfh != nullptr;
   auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu) {
-    sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s);
+    const bool hm = split && ctx->sp[i].wfh != nullptr;
+    sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
+            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1);
   };
   std::vector<int> counts((size_t)chunk * 4);
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
+    if (split) GN_HIP(hipMemsetAsync(ctx->ovf + 1, 0, sizeof(unsigned int), s));
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s);
     conv(1, X, Y, n, H, W, 1);             sp_pool(Y, X, n, H, W, 64, s);                      // block 0 -> X [H/2][W/2][64]
     conv(2, X, Y, n, H / 2, W / 2, 1);     conv(3, Y, X, n, H / 2, W / 2, 1);   sp_pool(X, Y, n, H / 2, W / 2, 64, s);    // block 1 -> Y [H/4]
@@ -1368,7 +1389,10 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     conv(10, X, Y, n, h, w, 1);            conv(11, Y, Z, n, h, w, 0);                          // descriptor head: Z = raw descriptor map [h][w][256]
     sp_describe(Z, n, h, w, kpt_xysa + (size_t)b0 * max_kpts * 4, ctx->sp_counts, max_kpts, max_kpts, desc + (size_t)b0 * max_kpts * 256, s);
     GN_HIP(hipMemcpyAsync(counts.data(), ctx->sp_counts, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    unsigned int tripped = 0;
+    if (split) GN_HIP(hipMemcpyAsync(&tripped, ctx->ovf + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     GN_HIP(hipStreamSynchronize(s));
+    if (split && tripped) { split = false; ++ctx->sp_split_trips; b0 -= chunk; continue; }   // repeat this pass with exact f32 convolutions
     for (int b = 0; b < n; ++b) {
       if (counts[4 * b] > ctx->sp_cap) return fail(ctx, GN_ERR_ARG, "SuperPoint candidate buffer overflow");
       n_out_host[b0 + b] = counts[4 * b + 1];
@@ -1501,6 +1525,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 18) gn::g_head_ablate = value;
   else if (which == 19) ctx->qkv_fused = value;
   else if (which == 20) ctx->qkv_stamps = value;
+  else if (which == 21) ctx->sp_split = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

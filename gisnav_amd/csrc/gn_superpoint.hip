@@ -29,6 +29,11 @@ constexpr int TH = 16, TW = 32;          // output tile of k_sp_conv: 16 rows x 
 constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
 
 __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
+  // the 576 weights + 64 biases sit in LDS: a lane's channel group differs from its neighbours', so reading them from memory was
+  // 144 vector loads per thread (the layer ran at 1.5 TB/s of output instead of the HBM rate)
+  __shared__ float ws[64 * 9 + 64];
+  for (int q = threadIdx.x; q < 64 * 9 + 64; q += 256) ws[q] = q < 576 ? w[q] : bias[q - 576];
+  __syncthreads();
   // thread -> (pixel, 16-channel group); image index in blockIdx.z
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int grp = (int)(idx & 3);
@@ -49,9 +54,9 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = grp * 16 + c4 * 4 + e;
-      float acc = bias[c];
+      float acc = ws[576 + c];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc = fmaf(w[c * 9 + t], v[t], acc);
+      for (int t = 0; t < 9; ++t) acc = fmaf(ws[c * 9 + t], v[t], acc);
       r[e] = fmaxf(acc, 0.f);
     }
     *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
@@ -64,10 +69,22 @@ struct ConvArgs {
   const float* bias;                         // [Cout_padded]
   float* out; int Cout;                      // NHWC f32 [B][H][W][Cout], Cout a multiple of 64 (padded with zero weights)
   int relu;
+  const uint16_t* wfh; float acc_scale;      // HM variant: weights as fp16 pairs in fragment order (sp_weight_fragments_hm16), scaled by 1 / acc_scale
+  unsigned int* ovf;                         // HM variant: raised when an input activation does not fit fp16 (the caller re-runs the exact path)
 };
 
 // grid (tiles_x, tiles_y, B * Cout/64)
-template <int TAPS>
+// HM = false: exact f32 (v_mfma_f32_32x32x2_f32, 64 flops / clk / SIMD).  HM = true (contexts of the f16x2 precision mode): every f32
+// operand as two fp16 terms, three v_mfma_f32_32x32x16_f16 per 16 input channels, f32 accumulation -- the arithmetic of the matcher's
+// GEMMs (gn_gemm_p2.hip: error <= the f32 pipe's) at 5 x the matrix-pipe rate.  The activations stay f32 in memory: the halo tile is
+// split while it is staged (hm16 row format: 16 high terms, 16 residual terms per 16 channels -- the same 128 bytes per pixel).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+// 16-byte chunk c of halo pixel (ly, lx) sits at position c ^ psw(lx): pixels lx, lx + 8, lx + 16, lx + 24 of a wave's fragment read
+// must not share a chunk position (a plain lx & 7 made every ds_read_b128 a 4-way bank conflict: the LDS port, not the matrix
+// pipe, set the pace of the full-resolution layers)
+__device__ __forceinline__ int psw(int lx) { return (lx ^ (lx >> 3)) & 7; }
+template <int TAPS, bool HM>
 __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
@@ -80,6 +97,8 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   const float* in = a.in + (long long)img * a.H * a.W * a.Cin;
   const int csteps = a.Cin / 8;
   const f32x4* wf = reinterpret_cast<const f32x4*>(a.wf) + lane;
+  const uint4* wfh = reinterpret_cast<const uint4*>(a.wfh) + lane;
+  unsigned char* const tb = reinterpret_cast<unsigned char*>(tile);
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -88,46 +107,110 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float amax = 0.f;
 
   for (int c0 = 0; c0 < a.Cin; c0 += CH) {
     __syncthreads();     // the previous pass is done with the tile
-    // stage the halo tile of this 32-channel slice: thread -> (pixel, 16-byte chunk), zero outside the image
-    for (int q = tid; q < LH * LW * 8; q += 256) {
-      const int pix = q >> 3, chunk = q & 7;
-      const int ly = pix / LW, lx = pix - ly * LW;
-      const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.W + gx) * a.Cin + c0 + chunk * 4);
-      *reinterpret_cast<f32x4*>(tile + pix * CH + ((chunk ^ (lx & 7)) * 4)) = v;
+    // stage the halo tile of this 32-channel slice: thread -> (pixel, 16-byte chunk), zero outside the image.  The loads are issued in
+    // batches of SB independent requests (one memory latency per batch; a load-convert-write loop paid one per ITEM: 19 latencies
+    // per slice, twice the time of the slice's MFMAs)
+    constexpr int NQ = (LH * LW * 8 + 255) / 256, SB = 10;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += SB) {
+      f32x4 v[SB];
+#pragma unroll
+      for (int e = 0; e < SB; ++e) {
+        const int q = (q0 + e) * 256 + tid;
+        const int pix = q >> 3, chunk = q & 7;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[e] = z;
+        if (q0 + e < NQ && q < LH * LW * 8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          v[e] = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.W + gx) * a.Cin + c0 + chunk * 4);
+      }
+#pragma unroll
+      for (int e = 0; e < SB; ++e) {
+        const int q = (q0 + e) * 256 + tid;
+        if (q0 + e >= NQ || q >= LH * LW * 8) continue;
+        const int pix = q >> 3, chunk = q & 7;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        if (HM) {
+          // channels 4 chunk .. 4 chunk + 3 of the slice: k-step chunk >> 2, 16-byte piece 4 (chunk >> 2) + 2 term + ((chunk & 3) >> 1), half (chunk & 1)
+          const h16x4 h4 = __builtin_convertvector(v[e], h16x4);
+          const h16x4 m4 = __builtin_convertvector(v[e] - __builtin_convertvector(h4, f32x4), h16x4);
+          ovf_track(amax, v[e].x, v[e].y); ovf_track(amax, v[e].z, v[e].w);
+          const int piece = 4 * (chunk >> 2) + ((chunk & 3) >> 1), sub = (chunk & 1) * 8;
+          *reinterpret_cast<h16x4*>(tb + pix * 128 + ((piece ^ psw(lx)) * 16) + sub) = h4;
+          *reinterpret_cast<h16x4*>(tb + pix * 128 + (((piece + 2) ^ psw(lx)) * 16) + sub) = m4;
+        } else {
+          *reinterpret_cast<f32x4*>(tile + pix * CH + ((chunk ^ psw(lx)) * 4)) = v[e];
+        }
+      }
     }
     __syncthreads();
+    if (HM) {
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;    // offsets into the halo tile (already shifted by HALO)
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;    // offsets into the halo tile (already shifted by HALO)
 #pragma unroll
-      for (int s = 0; s < CH / 8; ++s) {
-        f32x4 fa[2], fb[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          fa[i] = wf[(size_t)(((2 * og + i) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ly = 4 * wave + j + dy, lx = ql + dx;
-          fb[j] = *reinterpret_cast<const f32x4*>(tile + (ly * LW + lx) * CH + (((2 * s + hh) ^ (lx & 7)) * 4));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int s = 0; s < CH / 16; ++s) {
+          h16x8 fa[2][2], fb[4][2];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            for (int pl = 0; pl < 2; ++pl)
+              fa[i][pl] = __builtin_bit_cast(h16x8, wfh[(size_t)((((2 * og + i) * TAPS + tap) * (a.Cin / 16) + (c0 / 16 + s)) * 2 + pl) * 64]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ly = 4 * wave + j + dy, lx = ql + dx;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+              fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + (ly * LW + lx) * 128 + (((4 * s + 2 * pl + hh) ^ psw(lx)) * 16));
+          }
+          // products: W_m X_h, W_h X_m, W_h X_h (small terms first)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;    // offsets into the halo tile (already shifted by HALO)
+      {
+#pragma unroll
+        for (int s = 0; s < CH / 8; ++s) {
+          f32x4 fa[2], fb[4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            fa[i] = wf[(size_t)(((2 * og + i) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ly = 4 * wave + j + dy, lx = ql + dx;
+            fb[j] = *reinterpret_cast<const f32x4*>(tile + (ly * LW + lx) * CH + (((2 * s + hh) ^ psw(lx)) * 4));
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
       }
     }
+    }
   }
+  if (HM) ovf_commit(a.ovf, amax);
   // epilogue: lane = pixel (row 4 wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c
   float* out = a.out + (long long)img * a.H * a.W * a.Cout;
   const int gx = x0 + ql;
+  const float ascale = HM ? a.acc_scale : 1.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int gy = y0 + 4 * wave + j;
@@ -139,6 +222,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
         const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (HM) v = v * ascale;
         v += b4;
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<f32x4*>(out + ((long long)gy * a.W + gx) * a.Cout + c) = v;
@@ -266,26 +350,40 @@ __global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int
     }
     tbits = s_prefix; eq_budget = s_need;
   }
+  // ties at the threshold are taken in raster order: a second radix select, over the raster index of the candidates whose score
+  // equals T, finds the eq_budget-th SMALLEST index (a flat score map -- untrained weights -- makes almost every candidate a tie;
+  // counting, for each tie, the ties before it was O(ties x candidates): 3.7 ms per 1080p call)
+  unsigned int ithr = 0xffffffffu;
+  if (n > kk) {
+    if (tid == 0) { s_prefix = 0u; s_need = eq_budget; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) s_hist[tid] = 0;
+      __syncthreads();
+      const unsigned int prefix = s_prefix;
+      for (int i = tid; i < n; i += 1024) {
+        const unsigned int ci = (unsigned int)cd[i];
+        if (__float_as_uint(sc[ci]) != tbits) continue;
+        if (shift == 24 || ((ci ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(ci >> shift) & 255u], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int need = s_need, bin = 0;
+        for (; bin < 255; ++bin) { if (s_hist[bin] >= need) break; need -= s_hist[bin]; }
+        s_need = need; s_prefix = prefix | ((unsigned int)bin << shift);
+      }
+      __syncthreads();
+    }
+    ithr = s_prefix;
+  }
   if (tid == 0) { s_cnt = 0; s_eq = 0; }
   __syncthreads();
-  // survivors: score > T, plus the eq_budget candidates of score == T with the smallest raster index (found by counting)
+  // survivors: score > T, plus the ties with a raster index up to the one found above
   for (int i = tid; i < n; i += 1024) {
     const int ci = cd[i];
     const unsigned int bits = __float_as_uint(sc[ci]);
-    if (bits > tbits || n <= kk) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
+    if (n <= kk || bits > tbits || (bits == tbits && (unsigned int)ci <= ithr)) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
   }
   __syncthreads();
-  if (n > kk) {
-    // ties at the threshold: take them in raster order -- each tie counts the ties with a smaller index
-    for (int i = tid; i < n; i += 1024) {
-      const int ci = cd[i];
-      if (__float_as_uint(sc[ci]) != tbits) continue;
-      int before = 0;
-      for (int j = 0; j < n; ++j) { const int cj = cd[j]; if (cj < ci && __float_as_uint(sc[cj]) == tbits) ++before; }
-      if (before < eq_budget) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
-    }
-    __syncthreads();
-  }
   const int m = min(s_cnt, min(kk, 2048));
   for (int i = tid; i < m; i += 1024) {
     const float v = s_val[i]; const int ci = s_idx[i];
@@ -351,15 +449,41 @@ void sp_weight_fragments(const float* w, int Cout, int Cin, int taps, int Cout_p
           }
 }
 
+// fp16 pairs (w * scale = h + m) in the fragment order of v_mfma_f32_32x32x16_f16: block (((tile * taps + tap) * (Cin / 16) + kstep) * 2 + term)
+// of 1 KB, lane l -> output channel 32 tile + (l & 31), input channels 16 kstep + 8 (l >> 5) + e
+void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int Cout_pad, float scale, uint16_t* out) {
+  const int ksteps = Cin / 16;
+  for (int tile = 0; tile < Cout_pad / 32; ++tile)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int ks = 0; ks < ksteps; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const int n = 32 * tile + (l & 31), c = 16 * ks + 8 * (l >> 5) + e;
+            const float x = (n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.f) * scale;
+            const _Float16 h = (_Float16)x;
+            const _Float16 m = (_Float16)(x - (float)h);
+            const size_t blk = (((size_t)tile * taps + tap) * ksteps + ks) * 2;
+            out[(blk + 0) * 512 + l * 8 + e] = __builtin_bit_cast(uint16_t, h);
+            out[(blk + 1) * 512 + l * 8 + e] = __builtin_bit_cast(uint16_t, m);
+          }
+}
+
 void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
   const long long n = (long long)H * W * 4;
   hipLaunchKernelGGL(k_sp_conv1, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
 }
-void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s) {
+void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,
+             const uint16_t* wfh, float acc_scale, unsigned int* ovf) {
   ConvArgs a; a.in = in; a.H = H; a.W = W; a.Cin = Cin; a.wf = wf; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = relu;
+  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf;
   const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (Cout_pad / 64));
-  if (taps == 9) hipLaunchKernelGGL(k_sp_conv<9>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_sp_conv<1>, grid, dim3(256), 0, s, a);
+  if (wfh != nullptr) {
+    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<1, true>), grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sp_conv<1, false>), grid, dim3(256), 0, s, a);
 }
 void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);

@@ -144,14 +144,18 @@ def test_superpoint_oracle_equals_transformers_model():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
 @pytest.mark.parametrize("seed,shape,k", [(2, (120, 160), 300), (3, (240, 320), 512), (4, (136, 200), 2048)])
-def test_superpoint_extractor_against_oracle(seed, shape, k):
-    """HIP SuperPoint (exact-f32 MFMA convolutions) against the oracle: encoder features and score map to f32 rounding, the keypoint
-    SET identical up to last-bit score ties (>= 99 %), descriptors of the common keypoints within 1e-4."""
+def test_superpoint_extractor_against_oracle(seed, shape, k, prec):
+    """HIP SuperPoint against the oracle: encoder features and score map to f32 rounding, the keypoint SET identical up to last-bit
+    score ties (>= 99 %), descriptors of the common keypoints within 1e-4 -- with the exact-f32 MFMA convolutions of an f32 context
+    and with the split-fp16 convolutions (each operand as two fp16 terms, three products, f32 accumulation) of an f16x2 context."""
+    from gisnav_amd.engine import PoseEngine
     from gisnav_amd.superpoint import SuperPoint
     from oracle import superpoint as osp
     sd = osp.synthetic_state_dict(0)
-    sp = SuperPoint(max_keypoints=k, state_dict=sd)
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision=prec, feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=k, state_dict=sd)
     img = _test_image(seed, *shape)
     taps = {}
     okp, osc, od = osp.detect_and_describe(sd, torch.from_numpy(img), k, taps=taps)
