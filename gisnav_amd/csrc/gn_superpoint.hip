@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float tile[LH * LW * CH];
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[HM ? 2 * 8192 : 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
   const int ogroups = a.Cout / 64;
@@ -150,9 +151,23 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
     }
     __syncthreads();
     if (HM) {
+      // The weight fragments of one tap of this slice (2 channel tiles x 2 k-steps x 2 terms = 8 KB) are fetched ONCE per workgroup into
+      // LDS (two buffers, the next tap's in flight during this tap's MFMAs) and read from there by the four waves: fetched per wave
+      // they were 590 KB of L2 -> CU traffic per workgroup, 4 x what the layer's input is, and the per-CU ingest rate set the pace.
+      auto wsrc = [&](int tap, int e) __attribute__((always_inline)) {    // thread's e-th 16-byte piece: block 4 e + (tid >> 6) = ((i * 2 + s) * 2 + pl)
+        const int blk = 4 * e + (tid >> 6), i = blk >> 2, ks = (blk >> 1) & 1, pl = blk & 1;
+        return wfh[(size_t)((((2 * og + i) * TAPS + tap) * (a.Cin / 16) + (c0 / 16 + ks)) * 2 + pl) * 64];
+      };
+      uint4 wnext[2];
+      wnext[0] = wsrc(0, 0); wnext[1] = wsrc(0, 1);
 #pragma unroll 1
       for (int tap = 0; tap < TAPS; ++tap) {
         const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;    // offsets into the halo tile (already shifted by HALO)
+        unsigned char* const wb = wbuf + (tap & 1) * 8192;
+        *reinterpret_cast<uint4*>(wb + (tid >> 6) * 1024 + lane * 16) = wnext[0];
+        *reinterpret_cast<uint4*>(wb + (4 + (tid >> 6)) * 1024 + lane * 16) = wnext[1];
+        if (tap + 1 < TAPS) { wnext[0] = wsrc(tap + 1, 0); wnext[1] = wsrc(tap + 1, 1); }
+        __syncthreads();     // this tap's weights are in LDS (the buffer written two taps ago is no longer read: one barrier per tap in between)
 #pragma unroll
         for (int s = 0; s < CH / 16; ++s) {
           h16x8 fa[2][2], fb[4][2];
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-              fa[i][pl] = __builtin_bit_cast(h16x8, wfh[(size_t)((((2 * og + i) * TAPS + tap) * (a.Cin / 16) + (c0 / 16 + s)) * 2 + pl) * 64]);
+              fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + ((i * 2 + s) * 2 + pl) * 1024 + lane * 16);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int ly = 4 * wave + j + dy, lx = ql + dx;
