@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
     const int r = (IPW * wave + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = (lane & 7) ^ ((r ^ (r >> 3)) & 7);
     ksrc[j] = a.kb + ((size_t)kvs * a.npad + r) * a.ldkb + h * 64 + c * 8;
     vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + c * 8;
     if (ABL & 2) {   // timing probe: the same bytes fetched as contiguous 8 KB tiles (wrong data)
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
 #pragma unroll
   for (int i2 = 0; i2 < 2; ++i2) {
     const int row = i2 * 32 + ql;
-    fsw[i2] = (row >> 1) & 7;
+    fsw[i2] = (row ^ (row >> 3)) & 7;
     ro[i2] = row * 64;
   }
 
