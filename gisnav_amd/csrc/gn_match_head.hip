@@ -422,22 +422,18 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
       if (j < np) { st_dev(a.cpart_m + po, bv); st_dev(a.cpart_i + po, bi); }
     }
   };
-  // The two waves of a SIMD (w and w + 4: the two column halves) run in OPPOSITE phases -- one is on the matrix pipe while the
-  // other does its VALU work: column half 0 does MFMA(t) then VALU(t), column half 1 does VALU(t - 1) then MFMA(t).
+  // Both waves of a SIMD run the SAME phase at the same time (MFMAs of tile t, then its VALU work): tools/probes/overlap.hip measures
+  // that an MFMA wave and a VALU wave sharing a SIMD take LONGER than one after the other (500 vs 317 cycles per probe body), while
+  // two MFMA waves or two VALU waves share it well -- the opposite-phase arrangement tried first was the worst choice available.
   for (int t = 0; t < ntile; ++t) {
     if (t + 1 < ntile && !(ABL & 1)) stage_tile(t + 1);
-    flush_cols(t - 2);                // complete since the barrier that ended iteration t - 1
-    if (wc == 0) { mma_tile(t); epi_tile(t); }
-    else { if (t > 0) epi_tile(t - 1); mma_tile(t); }
+    flush_cols(t - 1);                // complete since the barrier that ended iteration t - 1
+    mma_tile(t);
+    epi_tile(t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                  // tile t + 1 is staged; every wave is done reading tile t
   }
-  if (ntile > 0) {
-    flush_cols(ntile - 2);
-    if (wc == 1) epi_tile(ntile - 1);
-    __syncthreads();
-    flush_cols(ntile - 1);
-  }
+  if (ntile > 0) flush_cols(ntile - 1);
   stamp(2);
 
   // ---- rows of this workgroup over its column range: merge the 64 per-lane partials of every row (32 lanes x 2 column halves)
