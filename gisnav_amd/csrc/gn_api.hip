@@ -1447,6 +1447,7 @@ int gn_debug_gemm(gn_ctx* ctx, int M, int N, int K, const float* A, const float*
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = K; g.K1 = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = K;
   g.acc_scale = 1.f;
+  if (ctx->gemm_variant >= 0) gn::g_gemm_variant = ctx->gemm_variant;   // the kernel family of THIS context (the selector is a process-wide developer knob: another context's last launch may have left its own)
   if (ctx->gemm_variant == 7) {   // k_gemm_p2: both operands as fp16 planes (W scaled by 2^(dbg_planes - 1) if dbg_planes > 0)
     
     const size_t na = (size_t)M * K, nw = (size_t)N * K;

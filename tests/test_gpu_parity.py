@@ -103,7 +103,10 @@ def test_gemm_f16x2_split_is_f32_accurate(eng256_h2, eng256, dev, M, N, K, plane
     y2 = eng256_h2.debug_gemm(A, W, b)
     eng256_h2.lib.gn_debug_set_variant(eng256_h2.ctx, 2, 0)
     eh2 = _rel(y.cpu().numpy(), ref)
-    assert eh2 < 2e-6 and eh2 < 2 * e32 + 1e-7, (eh2, e32)
+    # activations below ~2^-4 have fp16-SUBNORMAL residual terms (absolute resolution 2^-25): the split is then good to ~2e-6 of the
+    # result, not to the f32 pipe's error (until round 2 this case silently ran whatever kernel family the last launch of ANOTHER
+    # context had selected -- gn_debug_gemm now selects its own context's)
+    assert eh2 < 2e-6 and (astd < 0.1 or eh2 < 2 * e32 + 1e-7), (eh2, e32)
     assert torch.equal(y, y2)                                  # bitwise repeatable
 
 
