@@ -207,3 +207,27 @@ def test_superpoint_plus_lightglue_pixels_to_pose(sd_sp):
     d = pa - pb
     good = (np.abs(d[:, 0] + 8) < 0.5) & (np.abs(d[:, 1] - 8) < 0.5)            # (x, y) of a minus (x, y) of b
     assert good.mean() > 0.8, (k, good.mean())
+
+
+@pytest.mark.gpu
+def test_superpoint_split_convolutions_fall_back_when_activations_leave_fp16_range():
+    """f16x2 contexts run the convolutions on split-fp16 operands; an activation >= 65504 raises the guard word and the pass is
+    repeated with the exact-f32 instruction: the result must be what an f32 context computes, not inf / NaN."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)).copy() for k, v in osp.synthetic_state_dict(0).items()}
+    first = sorted(k for k in sd if k.endswith(".weight") and sd[k].ndim == 4 and sd[k].shape[1] == 1)[0]      # the 1 -> 64 layer
+    sd[first] = sd[first] * 3.0e6                                                                                 # its ReLU outputs overflow fp16
+    sd[first.replace(".weight", ".bias")] = sd[first.replace(".weight", ".bias")] * 3.0e6
+    img = _test_image(5, 120, 160)
+    res = {}
+    for prec in ("f32", "f16x2_bf16_attn"):
+        eng = PoseEngine(0, max_batch=1, max_kpts=128, precision=prec, feature="superpoint")
+        sp = SuperPoint(engine=eng, max_keypoints=256, state_dict=sd)
+        kpt, score, desc, n = sp.detect_and_describe_device(img[None])
+        torch.cuda.synchronize()
+        res[prec] = (kpt[0, :int(n[0])].cpu().numpy(), score[0, :int(n[0])].cpu().numpy(), desc[0, :int(n[0])].cpu().numpy(), int(n[0]))
+    a, b = res["f32"], res["f16x2_bf16_attn"]
+    assert a[3] == b[3] > 0 and np.isfinite(b[2]).all()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])               # the SAME exact-f32 kernels ran
