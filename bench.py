@@ -51,7 +51,7 @@ from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense (the 2:1-sparsity figure is never used)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
-MAX_TIMED_LAUNCHES_PER_STEP = 128
+MAX_TIMED_LAUNCHES_PER_STEP = 320
 
 
 def gflop_per_pair(n: int, m: int, d: int = 256, layers: int = 9, d_in: int = 128):
@@ -121,7 +121,7 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
             out_dir = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(steps_prof), "--warmup", str(warmup_prof), "--batch", str(args.batch), "--kpts", str(args.kpts), "--precision", args.precision,
-                   "--no-cpu-baseline", "--no-traffic", "--no-extras"]
+                   "--no-cpu-baseline", "--no-traffic", "--no-extras", "--substreams", "1"]     # one pass, full-batch launches: the configuration of the kernel table
             for kv in args.debug_variant:
                 cmd += ["--debug-variant", kv]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
@@ -286,6 +286,9 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (batch-1 f32, batch-32 exact-f32 GEMMs)")
     ap.add_argument("--overlap", action="store_true", help="run the PnP stage of step n on a second stream beside the matcher of step n+1 "
                                                            "(gn_set_overlap; measured gain < 1 %%)")
+    ap.add_argument("--substreams", type=int, default=-1, help="sub-batch streams inside one gn_estimate call (gn_set_substreams): the batch is cut into that many "
+                                                               "groups whose matcher / PnP stages overlap on internal streams, joined before the call returns; "
+                                                               "default 2 for batches >= 16 pairs (measured -3 %% step time), else 1")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE",
                     help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments; RECORDED in the JSON line, "
@@ -326,10 +329,19 @@ def main() -> None:
     out = eng.alloc_outputs(len(pairs))
     if args.overlap:
         eng.set_overlap(True)
-
-    elapsed, mine = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=True)
+    nsub = args.substreams if args.substreams > 0 else (2 if args.batch >= 16 else 1)
+    # Per-kernel figures (roofline, kernel table) come from a pass with ONE stream: with sub-batch streams the launches of two groups
+    # run concurrently and a launch's HIP-event duration stops being that kernel's own time.  `value` is timed afterwards, in its own
+    # K steps, with the sub-batch streams on.
+    eng.set_substreams(1)
+    elapsed1, _ = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=True)   # (_ = this rank's own seconds)
     table = eng.kernel_table()
     eng.set_kernel_timing(0)
+    if nsub > 1:
+        eng.set_substreams(nsub)
+        elapsed, mine = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=False)
+    else:
+        elapsed, mine = elapsed1, _
     tripped, trips = eng.guard_status()
 
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
@@ -393,6 +405,8 @@ def main() -> None:
                 "precision": args.precision,
                 "parallelism": f"pair-sharded x{world} (no data-path collective)",
                 "pose_stage_overlap": bool(args.overlap),
+                "sub_batch_streams": nsub,
+                "single_stream_ms_per_step": round(elapsed1 / args.steps * 1e3, 4),
                 "weights": "seeded synthetic, kornia sift_lightglue state-dict layout",
                 "same_staged_batch_every_step": True,
             },
@@ -429,7 +443,9 @@ def main() -> None:
                 "note": "achieved = algorithmic flops per launch (2 x M x N x K of the GEMMs inside the kernel) / average launch duration from HIP events recorded "
                         "around every launch on the launch stream in THIS run; peak = dense 16-bit MFMA.  The split-fp16 arithmetic issues 3 MFMA flops per "
                         "algorithmic flop, so the kernel's own issue ceiling is peak / 3 (frac_of_issue_ceiling).  `kernel` is the name rocprofv3 prints "
-                        "(profiles/*kernel_stats*.csv)."}
+                        "(profiles/*kernel_stats*.csv).  Measured in this run's single-stream pass (config.single_stream_ms_per_step): with sub-batch "
+                        "streams two groups' launches run concurrently and a launch's elapsed time is no longer its own (tools/collect_profiles.sh "
+                        "profiles the same single-stream configuration: --substreams 1)."}
         line["kernels"] = rows
         line["traffic"] = {"compulsory_mb_per_step": round(comp_mb, 1),
                            "measured_hbm_mb_per_step": traffic["hbm_mb_per_step"] if traffic else None,
