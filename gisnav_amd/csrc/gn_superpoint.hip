@@ -25,7 +25,9 @@
 namespace gn {
 
 namespace {
-constexpr int TH = 16, TW = 32;          // output tile of k_sp_conv: 16 rows x 32 columns, 64 output channels
+constexpr int RPW = 3;                   // output rows per wave
+constexpr int TH = 4 * RPW, TW = 32;     // output tile of k_sp_conv: 12 rows x 32 columns, 64 output channels (halo tile 61 KB + 16 KB of weights:
+                                         // two workgroups per CU -- one stages its tile while the other is on the matrix pipe)
 constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
 
 __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   const uint4* wfh = reinterpret_cast<const uint4*>(a.wfh) + lane;
   unsigned char* const tb = reinterpret_cast<unsigned char*>(tile);
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][RPW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < RPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float amax = 0.f;
@@ -170,15 +172,15 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
         __syncthreads();     // this tap's weights are in LDS (the buffer written two taps ago is no longer read: one barrier per tap in between)
 #pragma unroll
         for (int s = 0; s < CH / 16; ++s) {
-          h16x8 fa[2][2], fb[4][2];
+          h16x8 fa[2][2], fb[RPW][2];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
               fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + ((i * 2 + s) * 2 + pl) * 1024 + lane * 16);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ly = 4 * wave + j + dy, lx = ql + dx;
+          for (int j = 0; j < RPW; ++j) {
+            const int ly = RPW * wave + j + dy, lx = ql + dx;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
               fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + (ly * LW + lx) * 128 + (((4 * s + 2 * pl + hh) ^ psw(lx)) * 16));
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
+              for (int j = 0; j < RPW; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
         }
       }
@@ -200,13 +202,13 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
       {
 #pragma unroll
         for (int s = 0; s < CH / 8; ++s) {
-          f32x4 fa[2], fb[4];
+          f32x4 fa[2], fb[RPW];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             fa[i] = wf[(size_t)(((2 * og + i) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ly = 4 * wave + j + dy, lx = ql + dx;
+          for (int j = 0; j < RPW; ++j) {
+            const int ly = RPW * wave + j + dy, lx = ql + dx;
             fb[j] = *reinterpret_cast<const f32x4*>(tile + (ly * LW + lx) * CH + (((2 * s + hh) ^ psw(lx)) * 4));
           }
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
+              for (int j = 0; j < RPW; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
       }
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   const int gx = x0 + ql;
   const float ascale = HM ? a.acc_scale : 1.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gy = y0 + 4 * wave + j;
+  for (int j = 0; j < RPW; ++j) {
+    const int gy = y0 + RPW * wave + j;
     if (gy >= a.H || gx >= a.W) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
