@@ -1367,26 +1367,28 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
   // contexts of the f16x2 mode run the convolutions on split-fp16 operands (5 x the matrix-pipe rate of the exact f32 instruction,
   // the same accuracy class); an activation that does not fit fp16 raises ovf[1] and the pass is repeated on the exact path
   bool split = ctx->sp_split && ctx->sp[1].wfh != nullptr;
-  auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu) {
+  auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu, int pool = 0) {
     const bool hm = split && ctx->sp[i].wfh != nullptr;
     sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
-            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1);
+            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1, pool);
   };
   std::vector<int> counts((size_t)chunk * 4);
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
     if (split) GN_HIP(hipMemsetAsync(ctx->ovf + 1, 0, sizeof(unsigned int), s));
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s);
-    conv(1, X, Y, n, H, W, 1);             sp_pool(Y, X, n, H, W, 64, s);                      // block 0 -> X [H/2][W/2][64]
-    conv(2, X, Y, n, H / 2, W / 2, 1);     conv(3, Y, X, n, H / 2, W / 2, 1);   sp_pool(X, Y, n, H / 2, W / 2, 64, s);    // block 1 -> Y [H/4]
-    conv(4, Y, X, n, H / 4, W / 4, 1);     conv(5, X, Y, n, H / 4, W / 4, 1);   sp_pool(Y, X, n, H / 4, W / 4, 128, s);   // block 2 -> X [H/8][128]
-    conv(6, X, Y, n, h, w, 1);             conv(7, Y, X, n, h, w, 1);                                                    // block 3 -> X = encoder output
-    conv(8, X, Y, n, h, w, 1);             conv(9, Y, Z, n, h, w, 0);                           // detector head: Z = logits [h][w][128 (65 used)]
+    // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
+    // block 0 alone is 0.5 GB per 1080p image: writing it and reading it back was a quarter of the extractor's HBM traffic)
+    conv(1, X, Y, n, H, W, 1, 1);                                                                   // block 0 -> Y [H/2][W/2][64]
+    conv(2, Y, X, n, H / 2, W / 2, 1);     conv(3, X, Y, n, H / 2, W / 2, 1, 1);                    // block 1 -> Y [H/4][W/4][64]
+    conv(4, Y, X, n, H / 4, W / 4, 1);     conv(5, X, Y, n, H / 4, W / 4, 1, 1);                    // block 2 -> Y [H/8][W/8][128]
+    conv(6, Y, X, n, h, w, 1);             conv(7, X, Y, n, h, w, 1);                               // block 3 -> Y = encoder output
+    conv(8, Y, X, n, h, w, 1);             conv(9, X, Z, n, h, w, 0);                               // detector head: Z = logits [h][w][128 (65 used)]
     sp_scores(Z, ctx->sp[9].cout_pad, ctx->sp_maps[0], n, h, w, s);
     sp_nms(ctx->sp_maps[0], n, H, W, 4, ctx->sp_maps[1], ctx->sp_maps[2], ctx->sp_maps[3], ctx->sp_maps[4], ctx->sp_maps[5], s);
     sp_select(ctx->sp_maps[5], n, H, W, 0.005f, 4, ctx->sp_cand, ctx->sp_counts, ctx->sp_cap, max_kpts,
               kpt_xysa + (size_t)b0 * max_kpts * 4, score ? score + (size_t)b0 * max_kpts : ctx->sp_maps[1], ctx->sp_index, max_kpts, s);
-    conv(10, X, Y, n, h, w, 1);            conv(11, Y, Z, n, h, w, 0);                          // descriptor head: Z = raw descriptor map [h][w][256]
+    conv(10, Y, X, n, h, w, 1);            conv(11, X, Z, n, h, w, 0);                          // descriptor head: Z = raw descriptor map [h][w][256]
     sp_describe(Z, n, h, w, kpt_xysa + (size_t)b0 * max_kpts * 4, ctx->sp_counts, max_kpts, max_kpts, desc + (size_t)b0 * max_kpts * 256, s);
     GN_HIP(hipMemcpyAsync(counts.data(), ctx->sp_counts, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     unsigned int tripped = 0;
@@ -1416,7 +1418,7 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
       {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
       {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)},
-      {"sp_enc", ctx->sp_x, ctx->sp_x ? (size_t)ctx->sp_chunk * (ctx->sp_h / 8) * (ctx->sp_w / 8) * 128 : 0},          // SuperPoint: encoder output of the last pass, NHWC
+      {"sp_enc", ctx->sp_y, ctx->sp_y ? (size_t)ctx->sp_chunk * (ctx->sp_h / 8) * (ctx->sp_w / 8) * 128 : 0},          // SuperPoint: encoder output of the last pass, NHWC
       {"sp_scores", ctx->sp_maps[0], ctx->sp_maps[0] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},             // softmax + depth-to-space scores
       {"sp_nms", ctx->sp_maps[5], ctx->sp_maps[5] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},                // after simple_nms
       {"x_p", ctx->x_p, ctx->x_p ? T * kDim : 0}, {"msg_p", ctx->msg_p, ctx->msg_p ? T * kDim : 0},   // hm16 rows, raw (4 bytes per value)

@@ -25,9 +25,9 @@
 namespace gn {
 
 namespace {
-constexpr int RPW = 3;                   // output rows per wave
-constexpr int TH = 4 * RPW, TW = 32;     // output tile of k_sp_conv: 12 rows x 32 columns, 64 output channels (halo tile 61 KB + 16 KB of weights:
-                                         // two workgroups per CU -- one stages its tile while the other is on the matrix pipe)
+constexpr int TW = 32;                   // output tile of k_sp_conv: (4 RPW) rows x 32 columns, 64 output channels.  RPW = 3 rows per wave: halo tile
+                                         // 61 KB + 16 KB of weights = two workgroups per CU (one stages its tile while the other is on the matrix
+                                         // pipe); RPW = 2 for the layers whose 2 x 2 max-pool is fused into the epilogue (row pairs in one lane)
 constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
 
 __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
@@ -86,8 +86,9 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // must not share a chunk position (a plain lx & 7 made every ds_read_b128 a 4-way bank conflict: the LDS port, not the matrix
 // pipe, set the pace of the full-resolution layers)
 __device__ __forceinline__ int psw(int lx) { return (lx ^ (lx >> 3)) & 7; }
-template <int TAPS, bool HM>
+template <int TAPS, bool HM, int RPW, bool POOL>
 __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
+  constexpr int TH = 4 * RPW;
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float tile[LH * LW * CH];
@@ -224,10 +225,38 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
     }
   }
   if (HM) ovf_commit(a.ovf, amax);
-  // epilogue: lane = pixel (row 4 wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c
-  float* out = a.out + (long long)img * a.H * a.W * a.Cout;
+  // epilogue: lane = pixel (row RPW wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c
   const int gx = x0 + ql;
   const float ascale = HM ? a.acc_scale : 1.f;
+  if (POOL) {
+    // fused 2 x 2 max-pool (RPW = 2: the two rows of a wave are one pooling row pair; the column pair is lanes ql, ql ^ 1):
+    // the full-resolution map is never written -- out is [H / 2][W / 2][Cout]
+    static_assert(!POOL || RPW == 2, "the fused pool pairs the two rows of a wave");
+    float* out = a.out + (long long)img * (a.H / 2) * (a.W / 2) * a.Cout;
+    const int gy = y0 + RPW * wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0 = acc[i][0][4 * g + e], v1 = acc[i][RPW - 1][4 * g + e];
+          if (HM) { v0 = v0 * ascale; v1 = v1 * ascale; }
+          v0 += b4[e]; v1 += b4[e];
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          float mv = fmaxf(v0, v1);
+          mv = fmaxf(mv, __shfl_xor(mv, 1));
+          m[e] = mv;
+        }
+        if (!(ql & 1) && gy + 1 < a.H && gx + 1 < a.W)
+          *reinterpret_cast<f32x4*>(out + ((long long)(gy >> 1) * (a.W / 2) + (gx >> 1)) * a.Cout + c) = m;
+      }
+    return;
+  }
+  float* out = a.out + (long long)img * a.H * a.W * a.Cout;
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
     const int gy = y0 + RPW * wave + j;
@@ -490,17 +519,24 @@ void sp_conv1(const float* in, const float* w, const float* bias, float* out, in
   hipLaunchKernelGGL(k_sp_conv1, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
 }
 void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,
-             const uint16_t* wfh, float acc_scale, unsigned int* ovf) {
+             const uint16_t* wfh, float acc_scale, unsigned int* ovf, int pool) {
   ConvArgs a; a.in = in; a.H = H; a.W = W; a.Cin = Cin; a.wf = wf; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = relu;
   a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf;
-  const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (Cout_pad / 64));
-  if (wfh != nullptr) {
-    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_sp_conv<1, true>), grid, dim3(256), 0, s, a);
+  const int th = pool ? 8 : 12;
+  const dim3 grid((W + TW - 1) / TW, (H + th - 1) / th, B * (Cout_pad / 64));
+  const bool hm = wfh != nullptr;
+  if (pool) {   // 3 x 3 layers only (the SuperPoint blocks that end in a max-pool)
+    if (hm) hipLaunchKernelGGL((k_sp_conv<9, true, 2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<9, false, 2, true>), grid, dim3(256), 0, s, a);
     return;
   }
-  if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, false>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_sp_conv<1, false>), grid, dim3(256), 0, s, a);
+  if (hm) {
+    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, true, 3, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<1, true, 3, false>), grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, false, 3, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sp_conv<1, false, 3, false>), grid, dim3(256), 0, s, a);
 }
 void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
