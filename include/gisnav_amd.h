@@ -177,7 +177,8 @@ int gn_set_overlap(gn_ctx* ctx, int enable);
  * the whole path on n internal streams, forked from the caller's stream; consecutive calls pipeline inside each
  * group's stream and one group's memory-bound kernels overlap another's matrix-bound ones.  By default the caller's stream
  * is made to wait for every group before gn_estimate returns: inputs and outputs obey plain stream order, as without the
- * option.  Measured on the 32-pair bench: +1..3 % with n = 2, slower with n >= 4 (smaller GEMMs); off (n = 1) by default. */
+ * option.  Measured on the 32-pair bench with the round-2 kernels: +7..10 % with n = 2 (bench.py times `value` that way), slower with
+ * n >= 3 (smaller launches); off (n = 1) by default. */
 int gn_set_substreams(gn_ctx* ctx, int n);
 /* Opt-in companion of gn_set_substreams: leave the join to gn_flush, so that the groups of consecutive calls drift out of
  * phase.  Then ALL outputs of a call (n_match included) are complete only after gn_flush(ctx, stream), and the caller must
