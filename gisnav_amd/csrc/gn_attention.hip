@@ -460,7 +460,9 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     const float mneg = -m_run * kLog2e;
 
     // scores of the next tile on the matrix pipe while this tile's probabilities are computed on the VALU
+    if (ABL & 4) __builtin_amdgcn_s_setprio(1);
     qk_tile(SN, s1);
+    if (ABL & 4) __builtin_amdgcn_s_setprio(0);
 
     bf16x8 pf[2][2];
 #pragma unroll
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
         pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
       }
     const unsigned short* Vs = smem + (ND + s0) * kRing;
+    if (ABL & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
         }
       }
+    if (ABL & 4) __builtin_amdgcn_s_setprio(0);
     const int s_ = s0; s0 = s1; s1 = s2;
     if (ND == 4) { s2 = s3; s3 = s_; } else { s2 = s_; }
   };
@@ -565,6 +569,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 43: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 4>), grid, block, 0, s, a); break;  // 4-deep rings
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
+    case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
   }
 }

@@ -16,3 +16,10 @@ for nsub in (1, 2, 4, 1):
     for _ in range(20): eng.estimate(inp, K_MATRIX, out=out)
     eng.flush(); torch.cuda.synchronize()
     print("substreams", nsub, "ms/step", (time.perf_counter() - t0) / 20 * 1e3, "ok", int(out["ok"].sum()))
+for nsub, dj in ((2, True), (2, False)):
+    eng.set_substreams(nsub, deferred_join=dj)
+    for _ in range(3): eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): eng.estimate(inp, K_MATRIX, out=out)
+    eng.flush(); torch.cuda.synchronize()
+    print("substreams", nsub, "deferred join", dj, "ms/step", (time.perf_counter() - t0) / 20 * 1e3, "ok", int(out["ok"].sum()))
