@@ -1174,8 +1174,9 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) if (i == lane) id = idx[i];
       sh.pws[lane * 3 + 0] = obj[3 * id]; sh.pws[lane * 3 + 1] = obj[3 * id + 1]; sh.pws[lane * 3 + 2] = obj[3 * id + 2];
-      sh.us[2 * lane] = ((double)img[2 * id] - cam.cx) / cam.fx;
-      sh.us[2 * lane + 1] = ((double)img[2 * id + 1] - cam.cy) / cam.fy;
+      // cv::undistortPoints output takes the input's depth (float32): computed in double, stored as float (oracle: solve_pnp_ransac)
+      sh.us[2 * lane] = (double)(float)(((double)img[2 * id] - cam.cx) / cam.fx);
+      sh.us[2 * lane + 1] = (double)(float)(((double)img[2 * id + 1] - cam.cy) / cam.fy);
     }
     wave_sync();
     double R[3][3], t[3];

@@ -589,7 +589,9 @@ def solve_pnp_ransac(obj: np.ndarray, img: np.ndarray, A: np.ndarray, iterations
         return False, None, None, None
     A = np.asarray(A, np.float64).reshape(3, 3)
     obj64, img64 = obj.astype(np.float64), img.astype(np.float64)
-    und = np.column_stack([(img64[:, 0] - A[0, 2]) / A[0, 0], (img64[:, 1] - A[1, 2]) / A[1, 1]])
+    # solvePnP(SOLVEPNP_EPNP) runs cv::undistortPoints on the subset; its output Mat takes the INPUT's depth, so for the float32 image
+    # points PoseNode passes, epnp reads normalised coordinates that were computed in double and stored as float32
+    und = np.column_stack([(img64[:, 0] - A[0, 2]) / A[0, 0], (img64[:, 1] - A[1, 2]) / A[1, 1]]).astype(np.float32).astype(np.float64)
     rng = CvRNG(0xFFFFFFFFFFFFFFFF)
     niters = iterations_count
     max_good = 0
