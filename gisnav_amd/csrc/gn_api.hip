@@ -1190,7 +1190,7 @@ int sift_prepare(gn_ctx* ctx, int B, int H, int W, int max_kp) {
   const double sigma = 1.6;
   std::vector<double> sig(6);
   ctx->sift_kernels.assign(6, {});
-  sift_gaussian_kernel(std::sqrt(std::max(sigma * sigma - 0.5 * 0.5 * 4, 0.01)), ctx->sift_kernels[0]);
+  { const float sf = (float)sigma; sift_gaussian_kernel((double)sqrtf(std::max(sf * sf - 0.5f * 0.5f * 4, 0.01f)), ctx->sift_kernels[0]); }   // createInitialImage: float arithmetic
   const double k = std::pow(2.0, 1.0 / 3.0);
   for (int i = 1; i < 6; ++i) {
     const double sp = std::pow(k, (double)(i - 1)) * sigma, st = sp * k;

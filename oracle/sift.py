@@ -103,7 +103,9 @@ def resize_linear_2x(img: np.ndarray) -> np.ndarray:
 def build_pyramids(gray_u8: np.ndarray, n_layers: int = 3, sigma: float = 1.6):
     """createInitialImage (doubled) + buildGaussianPyramid + buildDoGPyramid.  Returns (gauss[o][0..n+2], dog[o][0..n+1])."""
     base = resize_linear_2x(gray_u8.astype(F))
-    sig_diff = math.sqrt(max(sigma * sigma - SIFT_INIT_SIGMA * SIFT_INIT_SIGMA * 4, 0.01))
+    # createInitialImage takes `float sigma` and evaluates this line in float: sqrtf(max(sigma * sigma - SIFT_INIT_SIGMA^2 * 4, 0.01f))
+    sf, s0 = F(sigma), F(SIFT_INIT_SIGMA)
+    sig_diff = float(np.sqrt(np.maximum(F(sf * sf) - F(F(s0 * s0) * F(4)), F(0.01))).astype(F))
     base = gaussian_blur(base, sig_diff)
     n_octaves = int(np.rint(math.log(min(base.shape)) / math.log(2.0) - 2)) + 1
     sig = [sigma]
