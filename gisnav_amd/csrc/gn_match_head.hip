@@ -186,14 +186,13 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
 //   k_head_fused<., 1>  row and column soft-max statistics (running max / sum of exponentials), finished per pair by the LAST workgroup
 //   k_head_fused<., 2>  score_at() in the reference's association order, row and column arg-max partials; the last workgroup of a
 //                       pair reduces them, does the mutual check, the threshold and the ordered compaction.
-// grid (npad / 128, B, S), 8 waves: a workgroup owns 128 rows of image 0 (wave (wq, wc): rows 32 wq .., columns 32 wc .. of every
-// tile) and a contiguous 1 / S of the
-// 64-column tiles of image 1 (S > 1 only for small batches, to occupy the chip).  What bounds these sweeps is the rate at which a CU
-// can pull column tiles out of L2 (measured ~13 B / clk / CU whether by LDS-DMA or by loads), so the shape maximises the rows
-// served by one tile: the row operand lives in registers for the whole sweep (32 x 16-byte fragments per lane, no copies between
-// waves), every wave multiplies it with BOTH 32-column halves of the tile.  Column tiles (64 rows x 1 KB) are double-buffered in
-// LDS, staged by LDS-DMA while the previous tile is on the matrix pipe, and the VALU work of tile t - 1 (one accumulator register
-// per k-step and half) is interleaved with the MFMAs of tile t.
+// grid (npad / 128, B, S), 8 waves: a workgroup owns 128 rows of image 0 and a contiguous 1 / S of the 64-column tiles of image 1
+// (S > 1 only for small batches, to occupy the chip); wave (wq, wc) owns rows 32 wq .. and columns 32 wc .. of every tile.  The row
+// operand lives in registers for the whole sweep (32 x 16-byte fragments per lane); column tiles (64 rows x 1 KB) are double-buffered
+// in LDS, staged by LDS-DMA while the previous tile is being worked on.  Per tile a wave issues its MFMAs, then does the VALU work on
+// the accumulators; the two waves of a SIMD run the SAME phase at the same time (tools/probes/overlap.hip: an MFMA wave and a VALU
+// wave sharing a SIMD slow each other down; two waves per SIMD still hide each other's latencies).  The sweeps are VALU-bound
+// (~45 operations per score element); measured history in DESIGN.md section 4.
 // F32 = false: hm16 rows, three v_mfma_f32_32x32x16_f16 per k-step (the f16x2 mode);  F32 = true: f32 rows, v_mfma_f32_32x32x2_f32.
 // Both row formats are 1 KB per keypoint and use the same 16-byte fragment addressing.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
