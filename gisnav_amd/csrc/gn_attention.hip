@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // tiles for both), one barrier per tile.  The running maximum is updated lazily: the output is rescaled only when
 // some query's maximum grew by more than 2^8 (probabilities then stay <= 256, exact in f32 / harmless in bf16),
 // which removes the per-tile rescale after the first tiles.
-template <int ABL, int NW, int ND = 3>   // NW waves (of 32 queries) share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster)
+template <int ABL, int NW, int ND = 3, int NQ = 1>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
+                                                     // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
 __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys]
@@ -342,23 +343,28 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
   }
   const int kvs = a.cross ? (bs ^ 1) : bs;
   const int nkv = a.nvalid[kvs];
-  const int q0 = qblk * (NW * 32) + wave * 32;
+  const int q0 = qblk * (NW * 32 * NQ) + wave * 32 * NQ;
   const int ntiles = (nkv + KT - 1) / KT;
 
-  bf16x8 qf[4];
-  {
-    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
+  bf16x8 qf[NQ][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+  for (int qi = 0; qi < NQ; ++qi) {
+    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + 32 * qi + ql) * a.ldqb + h * 64 + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[qi][c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
   }
 
-  f32x16 o[2], ol;
+  f32x16 o[NQ][2], ol[NQ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
+  for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[qi][0][r] = 0.f; o[qi][1][r] = 0.f; ol[qi][r] = 0.f; }
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
-  float m_run = -INFINITY;
+  float m_run[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) m_run[qi] = -INFINITY;
 
   // LDS-DMA addressing as in variant 4 (source-side swizzle f(row) = (row >> 1) & 7)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -392,21 +398,24 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     ro[i2] = row * 64;
   }
 
-  auto qk_tile = [&](f32x16 (&S)[2], int stage) __attribute__((always_inline)) {
+  auto qk_tile = [&](f32x16 (&S)[NQ][2], int stage) __attribute__((always_inline)) {
     const unsigned short* Ks = smem + stage * kRing;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+      for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[qi][kt][r] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[ro[kt] + (((2 * c + hh) ^ fsw[kt]) << 3)]);
-        S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], S[kt], 0, 0, 0);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) S[qi][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][c], S[qi][kt], 0, 0, 0);
       }
     }
   };
 
-  f32x16 sa[2], sb[2];
+  f32x16 sa[NQ][2], sb[NQ][2];
   int s0 = 0, s1 = 1, s2 = 2, s3 = 3;  // ring stages of tiles t, t+1, t+2 (, t+3) modulo ND
   if (ntiles > 0) {
     GN_DMA_K(0, 0);
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     qk_tile(sa, 0);
   }
 
-  auto tile = [&](f32x16 (&ST)[2], f32x16 (&SN)[2], int t) __attribute__((always_inline)) {
+  auto tile = [&](f32x16 (&ST)[NQ][2], f32x16 (&SN)[NQ][2], int t) __attribute__((always_inline)) {
     // K(t+1) and V^T(t) have landed once everything but the ND - 2 newest DMA groups ({K(t+2), V^T(t+1)}, ...) is complete;
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
     constexpr int G = 2 * (8 / NW);                       // DMA instructions per wave per group (K tile + V^T tile)
@@ -436,60 +445,78 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     }
     if (t * KT + KT > nkv) {
 #pragma unroll
+      for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= nkv) ST[qi][kt][r] = -INFINITY;
+          }
+    }
+    float mloc[NQ];
+    bool grow = false;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float m = fmaxf(ST[qi][0][0], ST[qi][1][0]);
+#pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= nkv) ST[kt][r] = -INFINITY;
-        }
+        for (int r = 1; r < 16; r += 2) m = fmaxf(fmaxf(m, ST[qi][kt][r]), ST[qi][kt][(r + 1) & 15]);   // v_max3_f32
+      m = fmaxf(m, __shfl_xor(m, 32));
+      mloc[qi] = m;
+      grow = grow || (m - m_run[qi]) * kLog2e > 8.0f;
     }
-    float mloc = fmaxf(ST[0][0], ST[1][0]);
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 1; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, ST[kt][r]), ST[kt][(r + 1) & 15]);   // v_max3_f32
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8
-    if (__builtin_amdgcn_ballot_w64((mloc - m_run) * kLog2e > 8.0f) != 0) {
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
-      m_run = m_new;
+      for (int qi = 0; qi < NQ; ++qi) {
+        const float m_new = fmaxf(m_run[qi], mloc[qi]);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * kLog2e);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[qi][0][r] *= alpha; o[qi][1][r] *= alpha; ol[qi][r] *= alpha; }
+        m_run[qi] = m_new;
+      }
     }
-    const float mneg = -m_run * kLog2e;
+    float mneg[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) mneg[qi] = -m_run[qi] * kLog2e;
 
     // scores of the next tile on the matrix pipe while this tile's probabilities are computed on the VALU
     if (ABL & 4) __builtin_amdgcn_s_setprio(1);
     qk_tile(SN, s1);
     if (ABL & 4) __builtin_amdgcn_s_setprio(0);
 
-    bf16x8 pf[2][2];
+    bf16x8 pf[NQ][2][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        u32x4 pw;
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x2 p;
-          p[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[kt][8 * u + 2 * e], kLog2e, mneg));
-          p[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[kt][8 * u + 2 * e + 1], kLog2e, mneg));
-          pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
+        for (int u = 0; u < 2; ++u) {
+          u32x4 pw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f32x2 p;
+            p[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[qi][kt][8 * u + 2 * e], kLog2e, mneg[qi]));
+            p[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[qi][kt][8 * u + 2 * e + 1], kLog2e, mneg[qi]));
+            pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
+          }
+          pf[qi][kt][u] = __builtin_bit_cast(bf16x8, pw);
         }
-        pf[kt][u] = __builtin_bit_cast(bf16x8, pw);
-      }
     const unsigned short* Vs = smem + (ND + s0) * kRing;
     if (ABL & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][u], ol, 0, 0, 0);   // softmax denominator (rounded p)
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) ol[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[qi][kt][u], ol[qi], 0, 0, 0);   // softmax denominator (rounded p)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[ro[d] + (((4 * kt + 2 * u + hh) ^ fsw[d]) << 3)]);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][u], o[d], 0, 0, 0);
+#pragma unroll
+          for (int qi = 0; qi < NQ; ++qi) o[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kt][u], o[qi][d], 0, 0, 0);
         }
       }
     if (ABL & 4) __builtin_amdgcn_s_setprio(0);
@@ -504,18 +531,20 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
 #undef GN_DMA_K
 #undef GN_DMA_V
 
-  const float l = ol[0];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+  const float l = ol[qi][0];
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   if (a.outp != nullptr) {   // hm16 rows (x = xh + xm) for the f16x2 out-projection GEMM
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4v __attribute__((ext_vector_type(4)));
-    const size_t row = (size_t)bs * a.npad + q0 + ql;
+    const size_t row = (size_t)bs * a.npad + q0 + 32 * qi + ql;
     float amax = 0.f;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4v w = {o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+        const f32x4v w = {o[qi][d][4 * g + 0] * inv, o[qi][d][4 * g + 1] * inv, o[qi][d][4 * g + 2] * inv, o[qi][d][4 * g + 3] * inv};
         ovf_track(amax, w.x, w.y); ovf_track(amax, w.z, w.w);
         const f16x4 hv = __builtin_convertvector(w, f16x4);
         const f16x4 mv = __builtin_convertvector(w - __builtin_convertvector(hv, f32x4v), f16x4);
@@ -524,18 +553,19 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
         *reinterpret_cast<f16x4*>(pp + 16) = mv;
       }
     ovf_commit(a.ovf, amax);
-    return;
+    continue;
   }
-  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh;
+  float* op = a.out + ((size_t)bs * a.npad + q0 + 32 * qi + ql) * a.ldo + h * 64 + 4 * hh;
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 w;
-      w.x = o[d][4 * g + 0] * inv; w.y = o[d][4 * g + 1] * inv;
-      w.z = o[d][4 * g + 2] * inv; w.w = o[d][4 * g + 3] * inv;
+      w.x = o[qi][d][4 * g + 0] * inv; w.y = o[qi][d][4 * g + 1] * inv;
+      w.z = o[qi][d][4 * g + 2] * inv; w.w = o[qi][d][4 * g + 3] * inv;
       *reinterpret_cast<float4*>(op + d * 32 + 8 * g) = w;
     }
+  }
 }
 }  // namespace
 
@@ -556,7 +586,7 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 namespace gn {
 int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
-  g_last_kernel = "k_attn_bf16_v5<0, 4, 3>";
+  g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1>";   // the name rocprofv3 prints (the profiles up to r02g predate the NQ parameter: "<0, 4, 3>")
   if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
     dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
     switch (g_attn_variant) {
@@ -569,7 +599,9 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 43: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 4>), grid, block, 0, s, a); break;  // 4-deep rings
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
-    case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
+    case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;
+    case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
+             hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
   }
 }
