@@ -329,7 +329,7 @@ struct RoundRobin {   // pair i of round r over m players: 0 <= p < q < m
   }
 };
 template <int N>
-__device__ void sym_eig_reg(double* A, double* V, int* ord, int lane) {
+__device__ int sym_eig_reg(double* A, double* V, int* ord, int lane) {   // returns the number of sweeps run
   constexpr int M = (N + 1) & ~1, H = M / 2;
   const bool isA = lane < N, isV = lane >= 16 && lane < 16 + N;
   const int k = isA ? lane : (isV ? lane - 16 : 0);
@@ -353,8 +353,10 @@ __device__ void sym_eig_reg(double* A, double* V, int* ord, int lane) {
     }
     partner[r] = pt;
   }
+  double prev_off = 1.7e308;
+  int sweep = 0;
 #pragma unroll 1
-  for (int sweep = 0; sweep < 40; ++sweep) {
+  for (; sweep < 40; ++sweep) {
     double off = 0.0, dg = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -362,7 +364,10 @@ __device__ void sym_eig_reg(double* A, double* V, int* ord, int lane) {
       if (isA) { if (j == k) dg += v2; else off += v2; }
     }
     off = wsum(off); dg = wsum(dg);
-    if (off <= 1e-30 * dg || off == 0.0) break;
+    // converged, or at the round-off floor: M^T M of a minimal sample is rank deficient, its null-space block keeps rotating
+    // noise (off ~ 1e-30 dg) for a dozen sweeps that change nothing; once off is tiny a sweep that fails to halve it is the last
+    if (off <= 1e-30 * dg || off == 0.0 || (off <= 1e-20 * dg && off > 0.5 * prev_off)) break;
+    prev_off = off;
 #pragma unroll
     for (int r = 0; r < M - 1; ++r) {
       // the rotation of this lane's pair, computed identically by both of its lanes from lane p's copy of a_pq
@@ -425,6 +430,7 @@ __device__ void sym_eig_reg(double* A, double* V, int* ord, int lane) {
     }
   }
   wave_sync();
+  return sweep;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,7 +537,8 @@ __device__ inline void svd_solve6(const double Ain[6][K], const double bin[6], d
 #pragma unroll
         for (int i = 0; i < 6; ++i) { al += U[i][p] * U[i][p]; be += U[i][q] * U[i][q]; ga += U[i][p] * U[i][q]; }
         // branch-free (the lanes of a wave may hold different systems): c = 1, s = 0 leaves the columns bit-identical
-        const bool rot = ga * ga > 1e-32 * (al * be) && fabs(ga) > 1e-300;
+        // |ga| <= 10 DBL_EPSILON sqrt(al be): the orthogonality test of cv::JacobiSVDImpl_ (a tighter one spins on round-off)
+        const bool rot = ga * ga > 4.93e-30 * (al * be) && fabs(ga) > 1e-300;
         rotated = rotated || rot;
         const double d = be - al, o = ga + ga, h2 = d * d + o * o;
         const double t = ((d == 0.0 || (d < 0.0) == (o < 0.0)) ? fabs(o) : -fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
@@ -704,8 +711,9 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
   }
   wave_sync();
   stamp(1);
-  sym_eig_reg<12>(sh.A, sh.V, sh.ord, lane);
+  const int eig_sweeps = sym_eig_reg<12>(sh.A, sh.V, sh.ord, lane);
   stamp(2);
+  if (ts) ts[8] = eig_sweeps;
   // M is 10 x 12, so the two smallest eigenvectors span an exactly 2-D null space whose basis is an
   // artefact of the eigen-solver.  Fix it deterministically (same rule as the oracle's
   // canonical_nullspace): v0 = normalised projection of e_11 onto the null space, v1 = its in-plane
@@ -1180,7 +1188,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
     }
     wave_sync();
     double R[3][3], t[3];
-    long long ts[8];
+    long long ts[9];
     if (a.dbg_ts) ts[0] = (long long)__builtin_amdgcn_s_memtime();
     const bool okm = epnp5(sh, lane, R, t, nullptr, a.dbg_ts ? ts : nullptr);
     int good = 0;
@@ -1206,7 +1214,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
     }
     if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps of this hypothesis
       ts[7] = (long long)__builtin_amdgcn_s_memtime();
-      for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)b * kMaxHyp + wave) * 16 + k] = ts[k];
+      for (int k = 0; k < 9; ++k) a.dbg_ts[((size_t)b * kMaxHyp + wave) * 16 + k] = ts[k];
     }
     if (lane == 0) {
       HypResult& hr = hyp[wave];

@@ -19,6 +19,7 @@ eng.lib.gn_debug_set_variant(eng.ctx, 15, 1)
 eng.estimate(inp, K_MATRIX, out=out)
 torch.cuda.synchronize()
 ts = eng.debug_read("sim", (B * 16 + B) * 16 * 2, np.uint32).view(np.int64).reshape(-1, 16)
+sweeps = ts[: B * 16].reshape(B, 16, 16)[:, :10, 8]
 hyp = ts[: B * 16].reshape(B, 16, 16)[:, :10, :8].astype(np.float64) / 1000.0     # s_memtime ticks at the shader clock here: kilo-cycles
 names = ["setup+MtM", "sym_eig 12x12", "null space + L", "3 x svd (lockstep)", "3 x gauss-newton", "3 x R,t", "choose + score all points"]
 d = np.diff(hyp, axis=2)
@@ -26,6 +27,7 @@ print(f"k_pnp_hyp phases, kilo-cycles: median / max over {B * 10} hypothesis wav
 for k, n in enumerate(names):
     print(f"  {n:20s} {np.median(d[:, :, k]):8.2f} {d[:, :, k].max():8.2f}")
 print(f"  {'total':20s} {np.median(hyp[:, :, 7] - hyp[:, :, 0]):8.2f} {(hyp[:, :, 7] - hyp[:, :, 0]).max():8.2f}")
+print(f"  sym_eig sweeps: median {np.median(sweeps):.0f}, max {sweeps.max()}")
 ref = ts[B * 16: B * 16 + B, :6].astype(np.float64) / 1000.0
 d = np.diff(ref, axis=1)
 print("k_pnp_refine phases, kilo-cycles: median / max over pairs")
