@@ -43,6 +43,30 @@ constexpr int YP = 260;                 // float pitch of the output tile staged
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
 
+// Two-wide f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 work on an aligned register pair at the rate of a single
+// v_fma_f32: the VALU phases between the GEMMs are issue-bound with two waves per SIMD).  Written out by hand: this file is built
+// without the SLP vectoriser.  Per element the operations and their order are those of gelu_erf (gn_common.h): same bits.
+__device__ __forceinline__ f32x2v pair(const f32x16& v, int r) { return (f32x2v){v[r], v[r + 1]}; }
+__device__ __forceinline__ void set_pair(f32x16& v, int r, f32x2v p) { v[r] = p[0]; v[r + 1] = p[1]; }
+__device__ __forceinline__ f32x2v splat2(float c) { return (f32x2v){c, c}; }
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v y) {
+  const f32x2v ys = y * splat2(0.70710678118654752440f);
+  const f32x2v t = {fminf(fabsf(ys[0]), 4.0f), fminf(fabsf(ys[1]), 4.0f)};
+  f32x2v q = splat2(4.6081331674940884e-05f);
+  q = q * t + splat2(-0.00045161080197431147f);
+  q = q * t + splat2(0.0015096671413630247f);
+  q = q * t + splat2(0.0007409505778923631f);
+  q = q * t + splat2(-0.028223754838109016f);
+  q = q * t + splat2(0.1484677642583847f);
+  q = q * t + splat2(0.918419361114502f);
+  q = q * t + splat2(1.6279083490371704f);
+  const f32x2v qt = q * t;
+  const f32x2v ex = {__builtin_amdgcn_exp2f(-qt[0]), __builtin_amdgcn_exp2f(-qt[1])};
+  const f32x2v e = splat2(1.0f) - ex;
+  const f32x2v cs = {copysignf(e[0], y[0]), copysignf(e[1], y[1])};
+  return (splat2(0.5f) * y) * (splat2(1.0f) + cs);
+}
+
 // 8 f32 -> 8 fp16 high terms and the 8 fp16 residual terms (round to nearest), as two 16-byte fragments
 __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m) {
   unsigned int hw[4], mw[4];
@@ -50,7 +74,7 @@ __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m) {
   for (int e = 0; e < 4; ++e) {
     const f32x2v x = {v[2 * e], v[2 * e + 1]};
     const f16x2v hv = __builtin_convertvector(x, f16x2v);
-    const f32x2v r = {x[0] - (float)hv[0], x[1] - (float)hv[1]};
+    const f32x2v r = x - __builtin_convertvector(hv, f32x2v);
     const f16x2v mv = __builtin_convertvector(r, f16x2v);
     hw[e] = __builtin_bit_cast(unsigned int, hv);
     mw[e] = __builtin_bit_cast(unsigned int, mv);
@@ -259,9 +283,9 @@ __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
   float* const stat1 = reinterpret_cast<float*>(smem + STAT);
   float* const stat2 = stat1 + NW * TM;
   const float s1 = a.w1_scale;
-  float sum[NJ];
+  f32x2v sum2[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
+  for (int j = 0; j < NJ; ++j) sum2[j] = splat2(0.f);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -270,39 +294,43 @@ __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float v = acc[i][j][4 * g + c] * s1 + b[c];
-          acc[i][j][4 * g + c] = v;
-          sum[j] += v;
+        for (int c = 0; c < 4; c += 2) {
+          const f32x2v v = pair(acc[i][j], 4 * g + c) * splat2(s1) + (f32x2v){b[c], b[c + 1]};
+          set_pair(acc[i][j], 4 * g + c, v);
+          sum2[j] += v;
         }
     }
+  float sum[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
+    sum[j] = sum2[j][0] + sum2[j][1];
     sum[j] += __shfl_xor(sum[j], 32);
     if (hh == 0) stat1[wave * TM + 32 * j + ql] = sum[j];
   }
   __syncthreads();
   float mean[NJ], rstd[NJ], sq[NJ];
+  f32x2v sq2[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     float t_ = 0.f;
 #pragma unroll
     for (int w8 = 0; w8 < NW; ++w8) t_ += stat1[w8 * TM + 32 * j + ql];
     mean[j] = t_ * (1.0f / 512.0f);
-    sq[j] = 0.f;
+    sq2[j] = splat2(0.f);
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d = acc[i][j][r] - mean[j];
-        acc[i][j][r] = d;
-        sq[j] += d * d;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2v d = pair(acc[i][j], r) - splat2(mean[j]);
+        set_pair(acc[i][j], r, d);
+        sq2[j] += d * d;
       }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
+    sq[j] = sq2[j][0] + sq2[j][1];
     sq[j] += __shfl_xor(sq[j], 32);
     if (hh == 0) stat2[wave * TM + 32 * j + ql] = sq[j];
   }
@@ -323,10 +351,9 @@ __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float yn = acc[i][j][4 * g + c] * rstd[j] * gm[c] + bt[c];
-          const float y = (ABL & 4) ? yn : gelu_erf(yn);
-          acc[i][j][4 * g + c] = y;
+        for (int c = 0; c < 4; c += 2) {
+          const f32x2v yn = pair(acc[i][j], 4 * g + c) * splat2(rstd[j]) * (f32x2v){gm[c], gm[c + 1]} + (f32x2v){bt[c], bt[c + 1]};
+          set_pair(acc[i][j], 4 * g + c, (ABL & 4) ? yn : gelu_erf2(yn));
         }
     }
   stamp(3);
