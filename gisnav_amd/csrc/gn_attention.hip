@@ -497,9 +497,16 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
           u32x4 pw;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            f32x2 x2;
+            if (ABL & 8) {   // developer variant 46: one v_pk_fma_f32 for the pair -- measured 5 % SLOWER (114.3 vs 109.1 us on one box)
+              x2 = __builtin_elementwise_fma((f32x2){ST[qi][kt][8 * u + 2 * e], ST[qi][kt][8 * u + 2 * e + 1]}, (f32x2){kLog2e, kLog2e}, (f32x2){mneg[qi], mneg[qi]});
+            } else {
+              x2[0] = __builtin_fmaf(ST[qi][kt][8 * u + 2 * e], kLog2e, mneg[qi]);
+              x2[1] = __builtin_fmaf(ST[qi][kt][8 * u + 2 * e + 1], kLog2e, mneg[qi]);
+            }
             f32x2 p;
-            p[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[qi][kt][8 * u + 2 * e], kLog2e, mneg[qi]));
-            p[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(ST[qi][kt][8 * u + 2 * e + 1], kLog2e, mneg[qi]));
+            p[0] = __builtin_amdgcn_exp2f(x2[0]);
+            p[1] = __builtin_amdgcn_exp2f(x2[1]);
             pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
           }
           pf[qi][kt][u] = __builtin_bit_cast(bf16x8, pw);
@@ -600,6 +607,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
     case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;
+    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;   // packed fmas in front of the exponentials (slower)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
