@@ -21,10 +21,11 @@ namespace gn {
 namespace {
 constexpr int BM = 128, BN = 128, BK = 32;
 
-__device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
-  unsigned int u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// two f32 -> one dword of two bf16, round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 constexpr int ES = 68;  // epilogue slab row stride (floats): each wave parks its 64x64 accumulator block in LDS and re-reads it row-wise
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] + bias;
         const float hi = slab[(t0 + 1) * ES + lane] + bias;
-        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+        w[e] = pack_bf16(lo, hi);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      pk.x = pack_bf16(v.x, v.y);
+      pk.y = pack_bf16(v.z, v.w);
       *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
     } else {
       *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] + bias;
         const float hi = slab[(t0 + 1) * ES + lane] + bias;
-        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+        w[e] = pack_bf16(lo, hi);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      pk.x = pack_bf16(v.x, v.y);
+      pk.y = pack_bf16(v.z, v.w);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] * a.acc_scale + bias;
         const float hi = slab[(t0 + 1) * ES + lane] * a.acc_scale + bias;
-        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+        w[e] = pack_bf16(lo, hi);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -898,8 +899,8 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      pk.x = pack_bf16(v.x, v.y);
+      pk.y = pack_bf16(v.z, v.w);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;

@@ -37,10 +37,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
-  unsigned int u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// two f32 -> one dword of two bf16, round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 // (x0, x1) -> packed fp16 pair h = fp16(x), and the pair of the residuals m = fp16(x - h)
@@ -80,7 +81,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
         const int t0 = (a.vt_perm & 1) ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] * ascale + bias;
         const float hi = slab[(t0 + 1) * ES + lane] * ascale + bias;
-        w[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+        w[e] = pack_bf16(lo, hi);
       }
       if (!(a.vt_perm & 2)) *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);   // bit 1: timing probe, skip the stores
     }
@@ -154,8 +155,8 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-      pk.y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+      pk.x = pack_bf16(v.x, v.y);
+      pk.y = pack_bf16(v.z, v.w);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;

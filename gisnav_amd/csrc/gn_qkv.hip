@@ -20,10 +20,12 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
-__device__ __forceinline__ unsigned short f2bf_rne(float x) {  // finite inputs
-  unsigned int u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// two f32 -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 (the integer rounding it replaces was 9 VALU
+// instructions per pair and half of the q / k epilogues' instruction count)
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2v){lo, hi}, bf16x2v));
 }
 
 constexpr int TM = 128;                 // tokens per workgroup
@@ -43,7 +45,7 @@ template <bool CROSS>
 __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   constexpr int NQK = CROSS ? kDim : 2 * kDim;      // q | k (or qk) features
   constexpr int NPASS = CROSS ? 2 : 3;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * KT];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * KT + (CROSS ? 0 : 32768)];   // token tile (128 KB) + the self block's rotary entries
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
   const int bm = blockIdx.x * TM;
@@ -87,6 +89,14 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   __syncthreads();
   stamp(1);
 
+  // (cos 2 fg, cos 2 fg + 1, sin 2 fg, sin 2 fg + 1) of this lane's tokens: rot4[fg][token], consecutive lanes = consecutive tokens.
+  // The k pass rotates the same (token, feature-in-head) positions as the q pass: the 16 table entries of a lane are fetched once and
+  // wait out the k pass's k-loop in the 32 KB of LDS the token tile leaves free -- 128 KB less to pull per workgroup, and no memory
+  // latency in front of the k epilogue (~5 k cycles).  (Requesting them under the q pass's k-loop as well was measured: the loop's
+  // in-order waits then stall on the table, 10 k -> 18 k cycles.)  Waves w, w + 2, w + 4, w + 6 hold the SAME entries (32 w mod 64): they all write the copy of
+  // set w & 1 ([set][entry][lane], 16 bytes each; identical bytes, so the race is benign) and a wave reads back what it wrote itself.
+  f32x4 rot[NJ][4];
+  f32x4* const rot_park = reinterpret_cast<f32x4*>(smem + 8 * KT) + (wave & 1) * 16 * 64 + lane;
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     const bool vpass = pass == NPASS - 1;
@@ -124,11 +134,10 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
       // register r of tile j <-> feature 32 tile + (r & 3) + 8 (r >> 2) + 4 hh, token 32 j + ql.  Every table entry and bias this lane
       // needs is requested FIRST, back to back (the weight ring and the token fragments are dead: the registers are there): the
       // pass pays one memory latency, not one per token tile (measured: 25 k -> ? cycles per pass)
-      f32x4 rot[NJ][4];     // (cos 2 fg, cos 2 fg + 1, sin 2 fg, sin 2 fg + 1) of this lane's tokens: rot4[fg][token], consecutive lanes = consecutive tokens
       f32x4 bias4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * tile + 8 * g + 4 * hh);
-      if (!CROSS) {
+      if (!CROSS && pass == 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -136,6 +145,12 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
             const int fg = ((32 * wave + 8 * g + 4 * hh) & 63) >> 2;
             rot[j][g] = *reinterpret_cast<const f32x4*>(a.rot4 + ((size_t)fg * a.rot_stride + (size_t)(bm + 32 * j + ql)) * 4);
           }
+      }
+      if (!CROSS && pass == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rot[j][g] = rot_park[(4 * j + g) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -158,8 +173,8 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
             v = o;
             if (pass == 0) v *= a.qscale;
           }
-          pk[g].x = (unsigned int)f2bf_rne(v.x) | ((unsigned int)f2bf_rne(v.y) << 16);
-          pk[g].y = (unsigned int)f2bf_rne(v.z) | ((unsigned int)f2bf_rne(v.w) << 16);
+          pk[g].x = pack_bf16(v.x, v.y);
+          pk[g].y = pack_bf16(v.z, v.w);
         }
         // the two half-waves hold interleaved groups of 4 features (hh = 0: 8 g .. 8 g + 3, hh = 1: 8 g + 4 .. 8 g + 7): they trade every
         // other group, so that a lane stores 8 consecutive features (16 bytes) -- half as many scattered stores
@@ -173,6 +188,12 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
           // hh = 0: features 16 gp + {0..3 own, 4..7 partner's group 2 gp};  hh = 1: features 16 gp + 8 + {0..3 partner's group 2 gp + 1, 4..7 own}
           *reinterpret_cast<uint4*>(a.qkb + row * a.ldyb + 32 * tile + 16 * gp + 8 * hh) = out;
         }
+      }
+      if (!CROSS && pass == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rot_park[(4 * j + g) * 64] = rot[j][g];
       }
     } else {
       // register r of tile j <-> token 32 j + (r & 3) + 8 (r >> 2) + 4 hh, feature 32 wave + ql of the V panel; registers 8 m .. 8 m + 7
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
           for (int e = 0; e < 4; ++e) {
             const float lo = acc[j][8 * m + 2 * e] * ascale + bias;
             const float hi = acc[j][8 * m + 2 * e + 1] * ascale + bias;
-            w4[e] = (unsigned int)f2bf_rne(lo) | ((unsigned int)f2bf_rne(hi) << 16);
+            w4[e] = pack_bf16(lo, hi);
           }
           if (!(a.vt_perm & 2)) *reinterpret_cast<uint4*>(dst + 32 * j + 8 * (2 * m + hh)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
