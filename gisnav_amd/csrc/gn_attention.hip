@@ -327,7 +327,7 @@ template <int ABL, int NW, int ND = 3, int NQ = 1>   // NW waves share one K / V
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
 __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys]
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, ql = lane & 31;
@@ -415,7 +415,18 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     }
   };
 
+  // Optimistic softmax reference.  The running maximum is searched in the first kSearchTiles key tiles only; after that the
+  // reference stays where it is and the tile loop has no maximum search, no cross-half shuffle and no ballot in it (they were 8 %
+  // of the launch).  Probabilities may then exceed 1: bf16 keeps the f32 exponent range and every sum is f32, so nothing is lost
+  // until a score exceeds the reference by ~100 in log2 units.  A workgroup whose denominators left the safe range (or are not
+  // finite) runs its tiles again with the maximum searched in every tile -- the exact algorithm, never a wrong result.
+  constexpr int kSearchTiles = 2;
+  int* const ovf_flag = reinterpret_cast<int*>(smem + 2 * ND * kRing);
+  if (tid == 0) *ovf_flag = 0;
   f32x16 sa[NQ][2], sb[NQ][2];
+#pragma unroll 1
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  const bool safe = attempt != 0 || (ABL & 128);
   int s0 = 0, s1 = 1, s2 = 2, s3 = 3;  // ring stages of tiles t, t+1, t+2 (, t+3) modulo ND
   if (ntiles > 0) {
     GN_DMA_K(0, 0);
@@ -432,7 +443,9 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     // K(t+1) and V^T(t) have landed once everything but the ND - 2 newest DMA groups ({K(t+2), V^T(t+1)}, ...) is complete;
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
     constexpr int G = 2 * (8 / NW);                       // DMA instructions per wave per group (K tile + V^T tile)
-    if (t + ND - 1 < ntiles) {
+    if (ABL & 32) {
+      // timing probe: no workgroup barrier per tile (races on the ring: wrong data)
+    } else if (t + ND - 1 < ntiles) {
       if (G * (ND - 2) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
       else if (G * (ND - 2) == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
@@ -454,28 +467,31 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
             if (key >= nkv) ST[qi][kt][r] = -INFINITY;
           }
     }
-    float mloc[NQ];
-    bool grow = false;
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-      float m = fmaxf(ST[qi][0][0], ST[qi][1][0]);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 1; r < 16; r += 2) m = fmaxf(fmaxf(m, ST[qi][kt][r]), ST[qi][kt][(r + 1) & 15]);   // v_max3_f32
-      m = fmaxf(m, __shfl_xor(m, 32));
-      mloc[qi] = m;
-      grow = grow || (m - m_run[qi]) * kLog2e > 8.0f;
-    }
-    // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+    if (safe || t < kSearchTiles) {   // wave-uniform
+      float mloc[NQ];
+      bool grow = false;
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        const float m_new = fmaxf(m_run[qi], mloc[qi]);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * kLog2e);
+        if (ABL & 64) { mloc[qi] = 0.f; if (t == 0) m_run[qi] = 0.f; continue; }   // timing probe: no maximum search (wrong for large scores)
+        float m = fmaxf(ST[qi][0][0], ST[qi][1][0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[qi][0][r] *= alpha; o[qi][1][r] *= alpha; ol[qi][r] *= alpha; }
-        m_run[qi] = m_new;
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 1; r < 16; r += 2) m = fmaxf(fmaxf(m, ST[qi][kt][r]), ST[qi][kt][(r + 1) & 15]);   // v_max3_f32
+        m = fmaxf(m, __shfl_xor(m, 32));
+        mloc[qi] = m;
+        grow = grow || (m - m_run[qi]) * kLog2e > 8.0f;
+      }
+      // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          const float m_new = fmaxf(m_run[qi], mloc[qi]);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * kLog2e);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[qi][0][r] *= alpha; o[qi][1][r] *= alpha; ol[qi][r] *= alpha; }
+          m_run[qi] = m_new;
+        }
       }
     }
     float mneg[NQ];
@@ -505,8 +521,12 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
               x2[1] = __builtin_fmaf(ST[qi][kt][8 * u + 2 * e + 1], kLog2e, mneg[qi]);
             }
             f32x2 p;
-            p[0] = __builtin_amdgcn_exp2f(x2[0]);
-            p[1] = __builtin_amdgcn_exp2f(x2[1]);
+            if (ABL & 16) {   // timing probe: no transcendental (wrong data)
+              p = x2;
+            } else {
+              p[0] = __builtin_amdgcn_exp2f(x2[0]);
+              p[1] = __builtin_amdgcn_exp2f(x2[1]);
+            }
             pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
           }
           pf[qi][kt][u] = __builtin_bit_cast(bf16x8, pw);
@@ -535,6 +555,21 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     tile(sa, sb, t);
     if (t + 1 < ntiles) tile(sb, sa, t + 1);
   }
+  if (safe) break;
+  // did the optimistic reference hold for every query of the workgroup?  (the K / V^T rings are shared: all waves repeat or none)
+  bool bad = false;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) bad = bad || !(ol[qi][0] < 1e30f);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *ovf_flag = 1;
+  __syncthreads();
+  if (*ovf_flag == 0) break;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[qi][0][r] = 0.f; o[qi][1][r] = 0.f; ol[qi][r] = 0.f; }
+    m_run[qi] = -INFINITY;
+  }
+  }   // attempt
 #undef GN_DMA_K
 #undef GN_DMA_V
 
@@ -607,7 +642,13 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
     case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;
-    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;   // packed fmas in front of the exponentials (slower)
+    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;
+    case 51: hipLaunchKernelGGL((k_attn_bf16_v5<16, 4>), grid, block, 0, s, a); break;    // timing probes (wrong results): no exponentials
+    case 52: hipLaunchKernelGGL((k_attn_bf16_v5<32, 4>), grid, block, 0, s, a); break;    //   no per-tile barrier
+    case 53: hipLaunchKernelGGL((k_attn_bf16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
+    case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
+    case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
+    case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)   // packed fmas in front of the exponentials (slower)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;

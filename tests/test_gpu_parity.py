@@ -136,6 +136,38 @@ def test_attention_against_fp64_with_ragged_keys(eng256, eng256_bf16, dev, prec,
         assert _rel(out[bs], o) < (3e-6 if prec == "f32" else 2e-2), (bs, prec, cross)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("boost", [1.0, 40.0, 400.0])
+def test_attention_optimistic_reference_falls_back_exactly(eng256_bf16, dev, boost):
+    """k_attn_bf16_v5 searches the softmax reference in the first two key tiles only; a workgroup whose denominators leave the safe
+    range repeats its tiles with the exact running maximum.  Keys beyond the searched tiles are boosted so that their scores exceed
+    the reference by tens (still in range) or by thousands (overflow -> fallback): the result must match fp64 either way, and must
+    equal the always-exact developer variant (knob 1 = 56) to bf16 rounding."""
+    n, BS = 256, 2
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q, k, v = (torch.randn(BS, n, 256, generator=g).to(dev) for _ in range(3))
+    k[:, 160:] *= boost                                  # scores of the late keys: ~ +-8 * boost * 0.125
+    nkv = torch.tensor([256, 231], dtype=torch.int32, device=dev)
+    out = eng256_bf16.debug_attention(q, k, v, nkv, False, 0.125).cpu().numpy()
+    eng256_bf16.lib.gn_debug_set_variant(eng256_bf16.ctx, 1, 56)
+    try:
+        exact = eng256_bf16.debug_attention(q, k, v, nkv, False, 0.125).cpu().numpy()
+    finally:
+        eng256_bf16.lib.gn_debug_set_variant(eng256_bf16.ctx, 1, 4)
+    assert np.isfinite(out).all()
+    for bs in range(BS):
+        m = int(nkv[bs])
+        # the reference sees the operands as the kernel does (bf16 q * scale, k, v): with logits this large the softmax is nearly
+        # one-hot and the rounding of the INPUTS would otherwise decide which key wins
+        qq = (q[bs] * 0.125).bfloat16().double().cpu().reshape(n, 4, 64).transpose(0, 1)
+        kk = k[bs, :m].bfloat16().double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        vv = v[bs, :m].bfloat16().double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        o = (torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(n, 256).numpy()
+        assert _rel(out[bs], o) < 2e-2, (bs, boost)
+        assert _rel(exact[bs], o) < 2e-2, (bs, boost)
+        assert _rel(out[bs], exact[bs]) < 1e-2, (bs, boost)
+
+
 # ------------------------------------------------------------------ matcher vs oracle, stage by stage
 def test_matcher_matches_oracle_per_layer_and_bit_exact_indices(eng256, state_dict_t):
     pairs = [make_pair(40 + i, n_q=256 - 13 * i, n_r=256 - 5 * i) for i in range(3)]
