@@ -389,9 +389,11 @@ __device__ int sym_eig_reg(double* A, double* V, int* ord, int lane) {   // retu
       // v_rsq_f64 / v_rcp_f64 seeds + two Newton steps each: relative error of (c, s) a few ulp, c^2 + s^2 = 1 to ~4e-16.
       const double d = aqq - app, o = apq + apq;
       const double h2 = d * d + o * o;
-      const double t = ((d == 0.0 || (d < 0.0) == (o < 0.0)) ? fabs(o) : -fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
+      // (bitwise & / | on the comparisons: the short-circuit forms compile to exec-mask branches, 17 of them per round)
+      const bool tneg = (d != 0.0) & ((d < 0.0) != (o < 0.0));
+      const double t = (tneg ? -fabs(o) : fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
       double c = fast_rsqrt(1.0 + t * t), sn = t * c;
-      const bool rotate = isA && pt != lane && apq * apq > 1e-36 * fabs(app * aqq) && fabs(apq) >= 1e-300;
+      const bool rotate = isA & (pt != lane) & (apq * apq > 1e-36 * fabs(app * aqq)) & (fabs(apq) >= 1e-300);
       c = rotate ? c : 1.0; sn = rotate ? sn : 0.0;
       // column phase, A rows and V rows alike
 #pragma unroll
@@ -404,12 +406,15 @@ __device__ int sym_eig_reg(double* A, double* V, int* ord, int lane) {   // retu
         }
       }
       // row phase: row_p <- c row_p - s row_q, row_q <- s row_p + c row_q  (V lanes and idle lanes: c = 1, s = 0, partner = self)
+      // all N exchanges are issued back to back, then consumed in order (one LDS latency per round; the compiler otherwise
+      // pairs every exchange with its own wait: ~15 exposed latencies per round, most of the ~1.9 k cycles a round took)
       const double sg = low ? -sn : sn;
+      double other[N];
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const double other = __shfl(row[j], pt);
-        row[j] = c * row[j] + sg * other;
-      }
+      for (int j = 0; j < N; ++j) other[j] = __shfl(row[j], pt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < N; ++j) row[j] = c * row[j] + sg * other[j];
     }
   }
   wave_sync();
@@ -431,6 +436,73 @@ __device__ int sym_eig_reg(double* A, double* V, int* ord, int lane) {   // retu
   }
   wave_sync();
   return sweep;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The eigenvector of the SMALLEST eigenvalue of an N x N symmetric positive semi-definite matrix (N = 9, 12) -- all that the
+// homography / DLT initial guesses of solvePnP(ITERATIVE) take from cv::eigen / cv::SVD of L^T L.  Inverse iteration on the
+// Cholesky factors of A + eps I instead of a full Jacobi diagonalisation (~8 k cycles instead of 85 - 125 k): the shift (1e-12
+// of the mean diagonal, far below lambda_2 of these data matrices) only makes the factorisation safe when round-off left
+// lambda_min <= 0; the eigenvectors of A + eps I are those of A, and each iteration shrinks the other components by
+// (lambda_min + eps) / (lambda_2 + eps).  Lane k holds row k (L overwrites it); the iterate is replicated in every lane, and every
+// element a step needs from another lane is a v_readlane with compile-time lane and register.  Result: unit vector in column 0
+// of V, ord[0] = 0 (the layout sym_eig_reg's callers read).  Called by the whole (single-wave) block.
+template <int N>
+__device__ void smallest_eigvec_reg(const double* A, double* V, int* ord, int lane) {
+  const int k = lane < N ? lane : 0;
+  double row[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) row[j] = A[k * N + j];
+  double tr = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) tr += bcast_lane(row[j], j);
+  const double eps = tr * (1e-12 / N);
+#pragma unroll
+  for (int j = 0; j < N; ++j) row[j] = lane == j ? row[j] + eps : row[j];
+  double dinv[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double pj = fmax(bcast_lane(row[j], j), eps * 1e-3);
+    const double d = fast_rsqrt(pj);            // 1 / L[j][j]
+    dinv[j] = d;
+    const double lk = row[j] * d;               // L[k][j] (lanes k >= j; lane j: L[j][j])
+    row[j] = lk;
+#pragma unroll
+    for (int m = j + 1; m < N; ++m) row[m] -= lk * bcast_lane(lk, m);
+  }
+  double x[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) x[j] = 1.0 + 0.125 * j;
+#pragma unroll 1
+  for (int it = 0; it < 5; ++it) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {                // L y = x:  L[j][m] is register m of lane j
+      double sacc = x[j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) sacc -= bcast_lane(row[m], j) * x[m];
+      x[j] = sacc * dinv[j];
+    }
+#pragma unroll
+    for (int j = N - 1; j >= 0; --j) {           // L^T z = y:  L[m][j] is register j of lane m
+      double sacc = x[j];
+#pragma unroll
+      for (int m = j + 1; m < N; ++m) sacc -= bcast_lane(row[j], m) * x[m];
+      x[j] = sacc * dinv[j];
+    }
+    double n2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) n2 += x[j] * x[j];
+    const double inv = fast_rsqrt(n2);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] *= inv;
+  }
+  wave_sync();
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) V[j * N] = x[j];
+    ord[0] = 0;
+  }
+  wave_sync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,10 +610,11 @@ __device__ inline void svd_solve6(const double Ain[6][K], const double bin[6], d
         for (int i = 0; i < 6; ++i) { al += U[i][p] * U[i][p]; be += U[i][q] * U[i][q]; ga += U[i][p] * U[i][q]; }
         // branch-free (the lanes of a wave may hold different systems): c = 1, s = 0 leaves the columns bit-identical
         // |ga| <= 10 DBL_EPSILON sqrt(al be): the orthogonality test of cv::JacobiSVDImpl_ (a tighter one spins on round-off)
-        const bool rot = ga * ga > 4.93e-30 * (al * be) && fabs(ga) > 1e-300;
-        rotated = rotated || rot;
+        const bool rot = (ga * ga > 4.93e-30 * (al * be)) & (fabs(ga) > 1e-300);
+        rotated = rotated | rot;
         const double d = be - al, o = ga + ga, h2 = d * d + o * o;
-        const double t = ((d == 0.0 || (d < 0.0) == (o < 0.0)) ? fabs(o) : -fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
+        const bool tneg = (d != 0.0) & ((d < 0.0) != (o < 0.0));
+        const double t = (tneg ? -fabs(o) : fabs(o)) * fast_rcp(fabs(d) + h2 * fast_rsqrt(h2));
         double c = fast_rsqrt(1.0 + t * t), sn = c * t;
         c = rot ? c : 1.0; sn = rot ? sn : 0.0;
 #pragma unroll
@@ -1030,7 +1103,7 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
         sh.A[idx] = v;
       }
       wave_sync();
-      sym_eig_reg<9>(sh.A, sh.V, sh.ord, lane);
+      smallest_eigvec_reg<9>(sh.A, sh.V, sh.ord, lane);
       double H0[3][3];
       const int c0 = sh.ord[0];
 #pragma unroll
@@ -1110,7 +1183,7 @@ __device__ __noinline__ bool pnp_init_dlt(Shared& sh, const float* obj, const fl
       sh.A[idx] = v;
     }
     wave_sync();
-    sym_eig_reg<12>(sh.A, sh.V, sh.ord, lane);
+    smallest_eigvec_reg<12>(sh.A, sh.V, sh.ord, lane);
     const int c0 = sh.ord[0];
     double RR[3][3], tt[3];
 #pragma unroll
