@@ -16,6 +16,8 @@
 //     rescale by exp(m_old - m_new) is lane-local as well.
 // f32 variant: v_mfma_f32_32x32x2_f32 (exact f32).  bf16 variant: v_mfma_f32_32x32x16_bf16 with f32
 // scores, softmax statistics and accumulators (GN_PREC_BF16_ATTN).
+#include <type_traits>
+
 #include "gn_common.h"
 
 namespace gn {
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // which removes the per-tile rescale after the first tiles.
 template <int ABL, int NW, int ND = 3, int NQ = 1>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
-__global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
 
@@ -439,13 +441,16 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     qk_tile(sa, 0);
   }
 
-  auto tile = [&](f32x16 (&ST)[NQ][2], f32x16 (&SN)[NQ][2], int t) __attribute__((always_inline)) {
+  // FAST: a tile in the steady state of the optimistic pass -- both rings are refilled unconditionally, no key of the tile is masked and
+  // the reference is not searched: the body has no scalar branch in it (the generic body tests six conditions per tile)
+  auto tile = [&](f32x16 (&ST)[NQ][2], f32x16 (&SN)[NQ][2], int t, auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     // K(t+1) and V^T(t) have landed once everything but the ND - 2 newest DMA groups ({K(t+2), V^T(t+1)}, ...) is complete;
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
     constexpr int G = 2 * (8 / NW);                       // DMA instructions per wave per group (K tile + V^T tile)
     if (ABL & 32) {
       // timing probe: no workgroup barrier per tile (races on the ring: wrong data)
-    } else if (t + ND - 1 < ntiles) {
+    } else if (FAST || t + ND - 1 < ntiles) {
       if (G * (ND - 2) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
       else if (G * (ND - 2) == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (!(ABL & 1)) {
-      if (t + ND < ntiles) GN_DMA_K(s0, t + ND);                          // K(t) was consumed one iteration ago
-      if (t + ND - 1 < ntiles) GN_DMA_V(ND == 4 ? s3 : s2, t + ND - 1);   // the stage V^T(t-1) was read from
+      if (FAST || t + ND < ntiles) GN_DMA_K(s0, t + ND);                          // K(t) was consumed one iteration ago
+      if (FAST || t + ND - 1 < ntiles) GN_DMA_V(ND == 4 ? s3 : s2, t + ND - 1);   // the stage V^T(t-1) was read from
     }
-    if (t * KT + KT > nkv) {
+    if (!FAST && t * KT + KT > nkv) {
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
             if (key >= nkv) ST[qi][kt][r] = -INFINITY;
           }
     }
-    if (safe || t < kSearchTiles) {   // wave-uniform
+    if (!FAST && (safe || t < kSearchTiles)) {   // wave-uniform
       float mloc[NQ];
       bool grow = false;
 #pragma unroll
@@ -551,9 +556,24 @@ __global__ __launch_bounds__(64 * NW) void k_attn_bf16_v5(AttnArgs a) {
     if (ND == 4) { s2 = s3; s3 = s_; } else { s2 = s_; }
   };
 
-  for (int t = 0; t < ntiles; t += 2) {
-    tile(sa, sb, t);
-    if (t + 1 < ntiles) tile(sb, sa, t + 1);
+  {
+    int t = 0;
+    if (!safe) {
+      for (; t < kSearchTiles && t < ntiles; t += 2) {
+        tile(sa, sb, t, std::false_type{});
+        if (t + 1 < ntiles) tile(sb, sa, t + 1, std::false_type{});
+      }
+#pragma unroll 1
+      for (; !(ABL & 256) && t + 1 + ND < ntiles; t += 2) {   // tiles t and t + 1 are both in the steady state
+        tile(sa, sb, t, std::true_type{});
+        tile(sb, sa, t + 1, std::true_type{});
+      }
+    }
+#pragma unroll 1
+    for (; t < ntiles; t += 2) {
+      tile(sa, sb, t, std::false_type{});
+      if (t + 1 < ntiles) tile(sb, sa, t + 1, std::false_type{});
+    }
   }
   if (safe) break;
   // did the optimistic reference hold for every query of the workgroup?  (the K / V^T rings are shared: all waves repeat or none)
@@ -648,6 +668,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 53: hipLaunchKernelGGL((k_attn_bf16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
     case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
     case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
+    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body
     case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)   // packed fmas in front of the exponentials (slower)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
