@@ -1496,7 +1496,16 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
   a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr;
-  attention(ctx, a, (hipStream_t)stream);
+  const long long cap = (long long)ctx->max_batch * 2 * ctx->npad;
+  if (ctx->precision != GN_PREC_F32 && ctx->attn_variant >= 1 && ctx->qkb && ctx->vtb && (long long)BS * npad <= cap) {
+    // the production kernel (k_attn_bf16_v5) on the layouts the projection epilogues would have written
+    launch_pack_attn_bf16(a, ctx->qkb, ctx->vtb, (hipStream_t)stream);
+    a.qb = ctx->qkb; a.kb = ctx->qkb + kDim; a.ldqb = a.ldkb = 2 * kDim; a.vt = ctx->vtb;
+    gn::g_attn_variant = ctx->attn_variant;
+    launch_attention_bf16_v2(a, (hipStream_t)stream);
+  } else {
+    attention(ctx, a, (hipStream_t)stream);
+  }
   GN_HIP(hipGetLastError());
   return GN_OK;
 }

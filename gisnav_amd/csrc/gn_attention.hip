@@ -329,7 +329,7 @@ template <int ABL, int NW, int ND = 3, int NQ = 1>   // NW waves share one K / V
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
 __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
-  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8];   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8 + ((ABL & 512) ? 24576 : 0)];   // ABL 512 (experiment): +48 KB so that only one workgroup fits a CU   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, ql = lane & 31;
@@ -646,6 +646,31 @@ void launch_attention_bf16(const AttnArgs& a, hipStream_t s) {
 }  // namespace gn
 
 namespace gn {
+namespace {
+// developer / test entry (gn_debug_attention): f32 q | k | v rows -> what k_attn_bf16_v5 reads (bf16 q * qscale and k rows, V^T panels
+// with the keys permuted inside 16-groups), i.e. what the projection epilogues of the matcher write
+__global__ void k_pack_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float qscale,
+                                 uint16_t* qb, uint16_t* kb, int ldb, uint16_t* vt, long long ntok, int npad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ntok * 32) return;
+  const long long tok = idx >> 5;
+  const int g8 = (int)(idx & 31), bs = (int)(tok / npad), i = (int)(tok % npad);
+  const int r = i & 15, sp = (i & ~15) + ((r & 3) | ((r & 4) << 1) | ((r & 8) >> 1));   // key r of a 16-group is stored at 0..3, 8..11, 4..7, 12..15
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int d = 8 * g8 + e;
+    const __bf16 qv = (__bf16)(q[tok * ldq + d] * qscale), kv = (__bf16)k[tok * ldk + d], vv = (__bf16)v[tok * ldv + d];
+    qb[tok * ldb + d] = __builtin_bit_cast(unsigned short, qv);
+    kb[tok * ldb + d] = __builtin_bit_cast(unsigned short, kv);
+    vt[(((size_t)bs * kHeads + (d >> 6)) * kHeadDim + (d & 63)) * npad + sp] = __builtin_bit_cast(unsigned short, vv);
+  }
+}
+}  // namespace
+void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s) {
+  const long long ntok = (long long)a.BS * a.npad;
+  hipLaunchKernelGGL(k_pack_attn_bf16, dim3((unsigned)((ntok * 32 + 255) / 256)), dim3(256), 0, s, a.q, a.ldq, a.k, a.ldk, a.v, a.ldv, a.qscale,
+                     qkb, qkb + kDim, 2 * kDim, vtb, ntok, a.npad);
+}
 int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1>";   // the name rocprofv3 prints (the profiles up to r02g predate the NQ parameter: "<0, 4, 3>")
@@ -668,6 +693,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 53: hipLaunchKernelGGL((k_attn_bf16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
     case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
     case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
+    case 58: hipLaunchKernelGGL((k_attn_bf16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
     case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body
     case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)   // packed fmas in front of the exponentials (slower)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)

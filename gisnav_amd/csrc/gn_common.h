@@ -152,6 +152,7 @@ struct AttnArgs {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
+void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s);   // f32 rows -> the bf16 layouts k_attn_bf16_v5 reads (test entry)
 extern int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
