@@ -403,18 +403,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
   auto qk_tile = [&](f32x16 (&S)[NQ][2], int stage) __attribute__((always_inline)) {
     const unsigned short* Ks = smem + stage * kRing;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[qi][kt][r] = 0.f;
+    // the two 32-key halves alternate: consecutive MFMAs never depend on each other
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[ro[kt] + (((2 * c + hh) ^ fsw[kt]) << 3)]);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) S[qi][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][c], S[qi][kt], 0, 0, 0);
       }
-    }
   };
 
   // Optimistic softmax reference.  The running maximum is searched in the first kSearchTiles key tiles only; after that the
@@ -694,7 +696,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
     case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
     case 58: hipLaunchKernelGGL((k_attn_bf16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
-    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body
+    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body: 1-1.5 % slower than the default
     case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)   // packed fmas in front of the exponentials (slower)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
