@@ -4,6 +4,7 @@
 //   mode 4: VALU only with v_exp_f32 (transcendental rate)       mode 5: as 3 but VALU waves run v_exp_f32
 //   mode 6: same wave, MFMA + 2 independent v_exp_f32 per MFMA   mode 7: VALU only, 2 v_exp_f32 per slot (the VALU half of mode 6)
 //   mode 8: same wave, MFMA + 2 v_exp_f32 + 3 v_fma_f32 per MFMA
+//   mode 9 / 10: MFMA only, the 4 MFMAs of a body on 2 / 1 accumulators (dependent distance 2 / 1 instead of 4)
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/overlap.hip -o tools/probes/overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -20,13 +21,13 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
   float v[8];
   for (int i = 0; i < 8; ++i) v[i] = 1.0f + lane * 0.001f + i;
   const float c1 = 0.999f, c2 = 0.001f;
-  const bool do_mfma = MODE == 0 || MODE == 2 || MODE == 6 || MODE == 8 || ((MODE == 3 || MODE == 5) && wave < 4);
-  const bool do_valu = MODE == 1 || MODE == 2 || MODE == 4 || MODE >= 6 || ((MODE == 3 || MODE == 5) && wave >= 4);
+  const bool do_mfma = MODE == 0 || MODE == 2 || MODE == 6 || MODE == 8 || MODE == 9 || MODE == 10 || ((MODE == 3 || MODE == 5) && wave < 4);
+  const bool do_valu = MODE == 1 || MODE == 2 || MODE == 4 || (MODE >= 6 && MODE <= 8) || ((MODE == 3 || MODE == 5) && wave >= 4);
   const bool use_exp = MODE == 4 || MODE == 5;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (do_mfma) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      if (do_mfma) { constexpr int NA = MODE == 9 ? 2 : (MODE == 10 ? 1 : 4); acc[j % NA] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j % NA], 0, 0, 0); }
       if (do_valu) {
         if (MODE >= 6) {
 #pragma unroll
@@ -80,6 +81,10 @@ int main() {
     {"mode6 same wave MFMA + 2 exp each, 1 wave/SIMD", run<6>(d, 256, 256, iters)},
     {"mode8 same wave MFMA + 2 exp + 3 fma, 1 wave/SIMD", run<8>(d, 256, 256, iters)},
     {"mode6 same wave MFMA + 2 exp each, 2 waves/SIMD", run<6>(d, 256, 512, iters)},
+    {"mode9 MFMA only, 2 accumulators, 1 wave/SIMD", run<9>(d, 256, 256, iters)},
+    {"mode10 MFMA only, 1 accumulator, 1 wave/SIMD", run<10>(d, 256, 256, iters)},
+    {"mode9 MFMA only, 2 accumulators, 2 waves/SIMD", run<9>(d, 256, 512, iters)},
+    {"mode10 MFMA only, 1 accumulator, 2 waves/SIMD", run<10>(d, 256, 512, iters)},
   };
   for (auto& x : r) printf("%-48s %8.3f ms  %7.1f cycles/body\n", x.name, x.ms, x.ms * 1e-3 * 2.4e9 / iters);
   return 0;
