@@ -70,6 +70,9 @@ struct gn_ctx {
   int planes_mode = 0;     // 1: activations travel as fp16 planes and GEMMs run k_gemm_p2 (default in f16x2 mode)
   float* sim = nullptr;
   uint16_t *qkb = nullptr, *vtb = nullptr;   // bf16 q|k rows and V^T panels (GN_PREC_BF16_ATTN)
+  float* attn_part = nullptr; unsigned int* attn_tickets = nullptr;   // split-keys attention of small batches: <= 256 partial results, their tickets
+  int attn_split = 1;      // developer knob 23: largest number of key ranges the attention of a small batch is split into (default 1 = never: the
+                           // split changes the rounding of the probabilities, and results would then depend on batch size / padding / sub-streams)
   int attn_variant = 4;    // 0: k_attn_bf16 (f32 inputs, in-kernel conversion), otherwise k_attn_bf16_v5 (4; 41 / 42 = timing ablations)
   int stop_after = 0;      // developer knob: return from run_matcher after this many GEMM/attention launches
   int launch_count = 0;
@@ -309,6 +312,15 @@ GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, 
   return g;
 }
 
+// k_attn_bf16_v5 on a grid that leaves CUs idle (one to three pairs): split the keys of every (slot, head, query block) over up to four workgroups
+static void attn_split(gn_ctx* c, AttnArgs& a) {
+  const int blocks = a.npad / 128 * kHeads * a.BS;
+  int S = 1;
+  while (S < 4 && S < c->attn_split && blocks * S * 2 <= 256 && a.npad / 64 >= 4 * S) S *= 2;
+  // (sub-batch streams would share the partial-result buffer)
+  if (c->attn_part && c->attn_tickets && c->attn_split && c->n_sub <= 1 && S > 1) { a.nsplit = S; a.part = c->attn_part; a.tickets = c->attn_tickets; }
+}
+
 void attention(gn_ctx* c, const AttnArgs& a, hipStream_t s) {
   if (c->precision != GN_PREC_F32) launch_attention_bf16(a, s); else launch_attention_f32(a, s);
 }
@@ -466,6 +478,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
         a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
+        if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
@@ -498,6 +511,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
         a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
+        if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
       }
@@ -610,7 +624,7 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
     GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
     GN_ALLOC(rot4, T * 2 * kFreq);
   }
-  if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); }
+  if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); GN_ALLOC(attn_part, (size_t)256 * 4 * 34 * 64); GN_ALLOC(attn_tickets, 256); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
   GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
   GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
@@ -1502,6 +1516,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
     launch_pack_attn_bf16(a, ctx->qkb, ctx->vtb, (hipStream_t)stream);
     a.qb = ctx->qkb; a.kb = ctx->qkb + kDim; a.ldqb = a.ldkb = 2 * kDim; a.vt = ctx->vtb;
     gn::g_attn_variant = ctx->attn_variant;
+    attn_split(ctx, a);
     launch_attention_bf16_v2(a, (hipStream_t)stream);
   } else {
     attention(ctx, a, (hipStream_t)stream);
@@ -1538,6 +1553,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 19) ctx->qkv_fused = value;
   else if (which == 20) ctx->qkv_stamps = value;
   else if (which == 21) ctx->sp_split = value;
+  else if (which == 23) ctx->attn_split = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -325,7 +325,12 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // tiles for both), one barrier per tile.  The running maximum is updated lazily: the output is rescaled only when
 // some query's maximum grew by more than 2^8 (probabilities then stay <= 256, exact in f32 / harmless in bf16),
 // which removes the per-tile rescale after the first tiles.
-template <int ABL, int NW, int ND = 3, int NQ = 1>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
+// SPLIT (small grids: one to three pairs are 64 .. 192 workgroups on 256 CUs): gridDim.x = query blocks x a.nsplit; workgroup (qblk, s)
+// attends keys [s, s + 1) * ceil(nkv / 64) / nsplit * 64 only and leaves its unnormalised output, reference and denominator in a.part;
+// the workgroup that arrives last at the (slot, head, query block)'s ticket merges the nsplit partial results and writes the rows.
+template <typename T> __device__ __forceinline__ void st_dev(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T ld_dev(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int ABL, int NW, int ND = 3, int NQ = 1, bool SPLIT = false>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
 __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
@@ -343,8 +348,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
     const int g = v / gx;
     h = g % kHeads; bs = g / kHeads;
   }
+  int split = 0, key_off = 0;
+  const int nqb = SPLIT ? (int)gridDim.x / a.nsplit : (int)gridDim.x;
+  if (SPLIT) { split = qblk / nqb; qblk -= split * nqb; }
   const int kvs = a.cross ? (bs ^ 1) : bs;
-  const int nkv = a.nvalid[kvs];
+  int nkv = a.nvalid[kvs];
+  if (SPLIT) {   // this workgroup's key tiles [t0, t1): from here on the kernel sees them as a key sequence of its own
+    const int nt = (nkv + KT - 1) / KT, t0 = split * nt / a.nsplit, t1 = (split + 1) * nt / a.nsplit;
+    key_off = t0 * KT;
+    nkv = (nkv < t1 * KT ? nkv : t1 * KT) - key_off;
+    if (nkv < 0) nkv = 0;
+  }
   const int q0 = qblk * (NW * 32 * NQ) + wave * 32 * NQ;
   const int ntiles = (nkv + KT - 1) / KT;
 
@@ -375,8 +389,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
   for (int j = 0; j < IPW; ++j) {
     const int r = (IPW * wave + j) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r ^ (r >> 3)) & 7);
-    ksrc[j] = a.kb + ((size_t)kvs * a.npad + r) * a.ldkb + h * 64 + c * 8;
-    vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + c * 8;
+    ksrc[j] = a.kb + ((size_t)kvs * a.npad + key_off + r) * a.ldkb + h * 64 + c * 8;
+    vsrc[j] = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + r) * a.npad + key_off + c * 8;
     if (ABL & 2) {   // timing probe: the same bytes fetched as contiguous 8 KB tiles (wrong data)
       ksrc[j] = a.kb + ((size_t)kvs * kHeads + h) * a.npad * 64 + (IPW * wave + j) * 512 + lane * 8;
       vsrc[j] = a.vt + ((size_t)kvs * kHeads + h) * a.npad * 64 + (IPW * wave + j) * 512 + lane * 8;
@@ -595,6 +609,57 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
 #undef GN_DMA_K
 #undef GN_DMA_V
 
+  if (SPLIT) {
+    static_assert(!SPLIT || NQ == 1, "split keys: one query tile per wave");
+    // partial result of this wave: [34][64] floats = registers o[0][0..15], o[1][0..15], reference, denominator of lane l at [.][l]
+    const int S = a.nsplit;
+    const size_t entry = (((size_t)bs * kHeads + h) * nqb + qblk) * S;
+    float* const mine = a.part + ((entry + split) * NW + wave) * (34 * 64) + lane;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st_dev(mine + (16 * d + r) * 64, o[0][d][r]);
+    st_dev(mine + 32 * 64, m_run[0]);
+    st_dev(mine + 33 * 64, ol[0][0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const last = reinterpret_cast<int*>(smem + 2 * ND * kRing) + 1;
+    if (tid == 0) {
+      const unsigned int tk = atomicAdd(a.tickets + entry / S, 1u);
+      *last = tk == (unsigned)(S - 1);
+      if (tk == (unsigned)(S - 1)) a.tickets[entry / S] = 0;   // ready for the next launch
+    }
+    __syncthreads();
+    if (!*last) return;
+    float mm[4], ll[4], M = -INFINITY;     // a.nsplit <= 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mm[i] = -INFINITY; ll[i] = 0.f;
+      if (i < S) {
+        const float* p = a.part + ((entry + i) * NW + wave) * (34 * 64) + lane;
+        mm[i] = ld_dev(p + 32 * 64); ll[i] = ld_dev(p + 33 * 64);
+        M = fmaxf(M, ll[i] > 0.f ? mm[i] : -INFINITY);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][0][r] = 0.f; o[0][1][r] = 0.f; }
+    float L = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < S && ll[i] > 0.f) {                             // (a split without keys has l = 0)
+        const float* p = a.part + ((entry + i) * NW + wave) * (34 * 64) + lane;
+        const float al = __builtin_amdgcn_exp2f((mm[i] - M) * kLog2e);
+        L += ll[i] * al;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[0][d][r] += ld_dev(p + (16 * d + r) * 64) * al;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ol[0][r] = L;
+  }
+
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
   const float l = ol[qi][0];
@@ -681,6 +746,11 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     switch (g_attn_variant) {
       default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 8>), grid, block, 0, s, a); break;
     }
+    return;
+  }
+  if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr && (g_attn_variant == 4 || g_attn_variant == 59)) {
+    hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 1, true>), dim3(a.npad / 128 * a.nsplit, kHeads, a.BS), dim3(256), 0, s, a);
+    g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1, true>";
     return;
   }
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);

@@ -148,6 +148,9 @@ struct AttnArgs {
   float qscale;              // multiplied into q before QK^T
   int BS;                    // number of (pair, side) slots
   unsigned int* ovf;         // f16x2 domain guard word for the hm16 output, or nullptr
+  int nsplit = 1;            // k_attn_bf16_v5 on small grids: key ranges per (slot, head, query block), merged by the last workgroup to finish
+  float* part = nullptr;     // [slot][head][query block][split][4 waves][34][64] partial results
+  unsigned int* tickets = nullptr;   // [slot][head][query block], zero between launches
 };
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);

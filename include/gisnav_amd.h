@@ -304,7 +304,8 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * Knobs added in round 2 (value 0 restores the round-1 path unless noted): 10 block-tail fusion level, 12 k_ffn_fused ablations /
  * phase stamps, 13 out_proj folded into the tail, 14 k_ffn_fused workgroup shape (64 / 32 tokens), 15 PnP phase stamps,
  * 16 fused match head (0 = similarity GEMM + five passes), 17 / 18 k_head_fused phase stamps / ablations, 19 k_qkv projections
- * (0 = tiled GEMM, 2 = force at any batch size), 20 k_qkv phase stamps, 21 SuperPoint split-fp16 convolutions.  Knob 1 (attention) values: 4 default,
+ * (0 = tiled GEMM, 2 = force at any batch size), 20 k_qkv phase stamps, 21 SuperPoint split-fp16 convolutions, 23 largest number of key ranges the
+ * attention of a small batch is split into (default 1 = never; 4 gives -5 % latency at batch 1 but rounds the probabilities per split).  Knob 1 (attention) values: 4 default,
  * 43 / 44 / 45 / 46 / 48 rejected variants kept for A/B timing, 51-55 timing probes with WRONG results, 56 the exact running maximum in every key
  * tile (the path a workgroup of the default kernel falls back to).  A bench line run with any knob set records it in `debug_variant`. */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);

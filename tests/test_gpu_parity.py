@@ -168,6 +168,36 @@ def test_attention_optimistic_reference_falls_back_exactly(eng256_bf16, dev, boo
         assert _rel(out[bs], exact[bs]) < 1e-2, (bs, boost)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_key_splits_equal_the_single_workgroup_result(eng256_bf16, dev, cross):
+    """Opt-in (developer knob 23 = largest split; off by default because it makes results depend on the grid): small grids split the keys
+    of every (slot, head, query block) over up to four workgroups that merge through a ticket.  Ragged key counts, incl. splits that receive no key at all: the merged rows equal the unsplit kernel's
+    to bf16 rounding noise of the probabilities, and both match fp64 on the bf16-rounded operands."""
+    n, BS = 256, 4
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q, k, v = (torch.randn(BS, n, 256, generator=g).to(dev) for _ in range(3))
+    nkv = torch.tensor([256, 70, 5, 129], dtype=torch.int32, device=dev)
+    outs = {}
+    try:
+        for split in (1, 2, 4):
+            eng256_bf16.lib.gn_debug_set_variant(eng256_bf16.ctx, 23, split)
+            outs[split] = eng256_bf16.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+    finally:
+        eng256_bf16.lib.gn_debug_set_variant(eng256_bf16.ctx, 23, 1)
+    for bs in range(BS):
+        kvs = bs ^ 1 if cross else bs
+        m = int(nkv[kvs])
+        qq = (q[bs] * 0.125).bfloat16().double().cpu().reshape(n, 4, 64).transpose(0, 1)
+        kk = k[kvs, :m].bfloat16().double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        vv = v[kvs, :m].bfloat16().double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        o = (torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(n, 256).numpy()
+        for split in (1, 2, 4):
+            assert _rel(outs[split][bs], o) < 1e-2, (bs, split, cross)
+        # (each split rounds its probabilities to bf16 relative to its OWN reference: the merged rows differ from the unsplit ones by bf16 noise)
+        assert _rel(outs[2][bs], outs[1][bs]) < 6e-3 and _rel(outs[4][bs], outs[1][bs]) < 6e-3, (bs, cross)
+
+
 # ------------------------------------------------------------------ matcher vs oracle, stage by stage
 def test_matcher_matches_oracle_per_layer_and_bit_exact_indices(eng256, state_dict_t):
     pairs = [make_pair(40 + i, n_q=256 - 13 * i, n_r=256 - 5 * i) for i in range(3)]

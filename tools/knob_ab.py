@@ -10,7 +10,7 @@ from gisnav_amd.engine import PoseEngine  # noqa: E402
 from gisnav_amd.synthetic import make_pair  # noqa: E402
 from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
-B = 32
+B = int(os.environ.get("GN_AB_BATCH", "32"))
 knob = int(sys.argv[1])
 values = [int(v) for v in sys.argv[2:]]
 eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
