@@ -740,7 +740,7 @@ void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipS
 }
 int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
-  g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1>";   // the name rocprofv3 prints (the profiles up to r02g predate the NQ parameter: "<0, 4, 3>")
+  g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1, false>";   // the name rocprofv3 prints (profiles up to r02g: "<0, 4, 3>", up to r02j: "<0, 4, 3, 1>")
   if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
     dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
     switch (g_attn_variant) {
