@@ -145,6 +145,46 @@ def test_planar_pnp_without_homography_polish_on_224_seeds(state_dict_np, dev):
     assert worst["inlier_count_diffs"] == 0 and worst["dR"] < 1e-6 and worst["dt"] < 1e-6, worst
 
 
+def test_nonplanar_pnp_dlt_start_on_96_seeds(state_dict_np, dev):
+    """DEM with relief: solvePnP(ITERATIVE) starts from the 12 x 12 DLT, whose solution the kernel takes from inverse iteration on
+    Cholesky factors (the smallest eigenvector only) where the oracle diagonalises L^T L: outliers, pixel noise and marginal
+    inliers as in the planar test -- inlier COUNT identical, pose within 1e-6 of the oracle on every seed."""
+    from gisnav_amd.engine import PoseEngine
+    from oracle import pnp_ransac as pr
+    eng = PoseEngine(0, max_batch=32, max_kpts=256, precision="f32", state_dict=state_dict_np)
+    worst = {"dR": 0.0, "dt": 0.0, "inlier_count_diffs": 0}
+    for base in range(0, 96, 32):
+        objs, imgs, refs = [], [], []
+        for s in range(32):
+            seed = 3000 + base + s
+            p = make_pair(seed, n_q=256, n_r=256, flat_dem=False)
+            q = np.nonzero(p.gt_q2r >= 0)[0]
+            mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+            rs = np.random.default_rng(seed)
+            no = int(len(q) * rs.uniform(0.0, 0.35))
+            mq[:no] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)
+            mq[no:] += rs.normal(0, rs.uniform(0.0, 1.5), (len(q) - no, 2)).astype(np.float32)
+            x, y = np.floor(mr).astype(int).T
+            obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32)
+            o = np.zeros((256, 3), np.float32); o[: len(obj)] = obj
+            m = np.zeros((256, 2), np.float32); m[: len(mq)] = mq
+            objs.append(o); imgs.append(m)
+            refs.append((len(obj), pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)))
+        n_pts = torch.tensor([r[0] for r in refs], dtype=torch.int32, device=dev)
+        R, t, ninl, ok = eng.pnp_ransac(torch.from_numpy(np.stack(objs)).to(dev), torch.from_numpy(np.stack(imgs)).to(dev), n_pts, K_MATRIX)
+        torch.cuda.synchronize()
+        for s, (_, (oko, r, tt, inl)) in enumerate(refs):
+            assert bool(oko) == bool(int(ok[s]))
+            if not oko:
+                continue
+            worst["inlier_count_diffs"] += int(int(ninl[s]) != len(inl))
+            worst["dR"] = max(worst["dR"], float(np.linalg.norm(R[s].cpu().numpy() - pr.rodrigues_vec2mat(r))))
+            worst["dt"] = max(worst["dt"], float(np.linalg.norm(t[s].cpu().numpy() - tt) / np.linalg.norm(tt)))
+    print("non-planar PnP, 96 seeds:", worst)
+    _report("nonplanar_pnp_96_seeds", worst)
+    assert worst["inlier_count_diffs"] == 0 and worst["dR"] < 1e-6 and worst["dt"] < 1e-6, worst
+
+
 def test_f16x2_domain_guard_flags_overflow_and_falls_back(state_dict_np, state_dict_t, dev):
     """One out_proj scaled so that the message leaves fp16's range (|msg| >> 65504; LayerNorm brings the stream back, so the
     f32 oracle is unimpressed).  Guard 'flag': the call reports ZERO matches (never inf / NaN garbage) and the status says so.
