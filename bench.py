@@ -175,7 +175,7 @@ def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev):
             "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak}
 
 
-def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, kpts=1024):
+def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, kpts=1024, arithmetic="split_fp16"):
     """BASELINE configs[4] on this rank's GPU: `batch` 1920x1080 frame<->tile pairs from PIXELS -- SuperPoint (exact-f32 convolutions) on
     2 x batch images, LightGlue(features="superpoint") in the headline precision, PnP-RANSAC.  Synthetic textured frames, the tile is a
     shifted crop of the same scene; seeded random weights (timing is what is measured; match quality is not)."""
@@ -194,7 +194,7 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
         conv(f"encoder.conv_blocks.{b}.conv_b", sizes[b + 1], sizes[b + 1], 3)
     conv("keypoint_decoder.conv_score_a", 256, 128, 3); conv("keypoint_decoder.conv_score_b", 65, 256, 1)
     conv("descriptor_decoder.conv_descriptor_a", 256, 128, 3); conv("descriptor_decoder.conv_descriptor_b", 256, 256, 1)
-    sp = SuperPoint(engine=eng, max_keypoints=kpts, state_dict=conv_sd)
+    sp = SuperPoint(engine=eng, max_keypoints=kpts, state_dict=conv_sd, arithmetic=arithmetic)
     rs = np.random.default_rng(11)
     base = rs.uniform(0, 1, (batch, h // 8 + 3, w // 8 + 3)).astype(np.float32)
     big = torch.nn.functional.interpolate(torch.from_numpy(base)[:, None], size=(h + 16, w + 16), mode="bicubic", align_corners=False)[:, 0].clamp(0, 1)
@@ -224,13 +224,15 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
         n = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    res = {"config": "BASELINE configs[4] per GPU: 1920x1080 frames -> SuperPoint (split-fp16 MFMA convolutions: f32 operands as 2 fp16 terms, 3 products, f32 accumulate) -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels",
-           "batch": batch, "keypoints_per_side": kpts, "precision": "f16x2 convolutions + f16x2_bf16_attn matcher", "steps": steps, "warmup": warmup,
+    fp16 = arithmetic == "fp16"
+    res = {"config": ("BASELINE configs[4] per GPU with 16-bit convolution operands (what configs[4] names; one fp16 product per block, f32 accumulate -- NOT f32-accurate: ~99 % of the exact path's keypoints): 1920x1080 frames -> SuperPoint -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels" if fp16 else
+                      "BASELINE configs[4] per GPU: 1920x1080 frames -> SuperPoint (split-fp16 MFMA convolutions: f32 operands as 2 fp16 terms, 3 products, f32 accumulate) -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels"),
+           "batch": batch, "keypoints_per_side": kpts, "precision": ("fp16 (single product) convolutions" if fp16 else "f16x2 convolutions") + " + f16x2_bf16_attn matcher", "steps": steps, "warmup": warmup,
            "value": round(batch * steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 3),
            "superpoint_ms_per_image": round(t_sp / steps / (2 * batch) * 1e3, 3), "superpoint_gflop_per_image": 345.0,
            "superpoint_tflops": round(345.0 / (t_sp / steps / (2 * batch)) / 1e3, 1),
            "superpoint_frac_of_16bit_mfma_peak": round(345.0 / (t_sp / steps / (2 * batch)) / 1e3 / PEAK_16BIT_MFMA_TFLOPS, 4),
-           "superpoint_frac_of_issue_ceiling": round(3.0 * 345.0 / (t_sp / steps / (2 * batch)) / 1e3 / PEAK_16BIT_MFMA_TFLOPS, 4),
+           "superpoint_frac_of_issue_ceiling": round((1.0 if fp16 else 3.0) * 345.0 / (t_sp / steps / (2 * batch)) / 1e3 / PEAK_16BIT_MFMA_TFLOPS, 4),
            "mean_keypoints": float(np.mean(n)), "mean_matches": float(out["n_match"].float().mean().item()), "poses_ok": int(out["ok"].sum().item()),
            "note": "random-init networks: keypoints / matches are whatever the untrained detector yields; the model named by configs[4] is not in the reference tree"}
     del sp, eng
@@ -360,6 +362,7 @@ def main() -> None:
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
                                 1, args.kpts, args.precision, 30, 5, dev))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
+        extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev, arithmetic="fp16"))
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gn_sift_last_totals": (C.c_int, [VP, C.c_int, C.POINTER(C.c_int32)]),
     "gn_sp_load_tensor": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
     "gn_sp_detect_and_describe": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.POINTER(C.c_int32), VP]),
+    "gn_sp_set_arithmetic": (C.c_int, [VP, C.c_int]),
     "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
     "gn_debug_gemm": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "gn_debug_attention": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, VP, C.c_int,

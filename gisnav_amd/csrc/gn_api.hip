@@ -35,7 +35,7 @@ struct gn_ctx {
   int x_planes_only = 1;   // f16x2 mode: between layers the residual stream x exists only as hm16 pairs (developer knob 11; 0 = also f32, residual read as f32)
   int qkv_stamps = 0;      // developer knob 20: k_qkv writes s_memtime phase stamps into the sim buffer
   int qkv_fused = 1;       // attention input projections by k_qkv (gn_qkv.hip) instead of the LDS-staged GEMM (developer knob 19)
-  int sp_split = 1;        // SuperPoint convolutions on split-fp16 operands in contexts of the f16x2 mode (developer knob 21; 0 = exact f32)
+  int sp_split = 1;        // gn_sp_set_arithmetic (developer knob 21): 0 exact f32, 1 split-fp16 operands (contexts of the f16x2 mode), 2 one fp16 product
   long long sp_split_trips = 0;
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
@@ -1381,16 +1381,20 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
   // contexts of the f16x2 mode run the convolutions on split-fp16 operands (5 x the matrix-pipe rate of the exact f32 instruction,
   // the same accuracy class); an activation that does not fit fp16 raises ovf[1] and the pass is repeated on the exact path
   bool split = ctx->sp_split && ctx->sp[1].wfh != nullptr;
+  // GN_SP_FP16: the activations of the layers above 1 / 8 resolution (layers 0 .. 6: 95 % of the extractor's bytes) travel as fp16;
+  // layer 6 writes f32 again, the 1 / 8-resolution layers and the heads read and write f32 as in the other modes
   auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu, int pool = 0) {
     const bool hm = split && ctx->sp[i].wfh != nullptr;
+    const bool half_io = hm && ctx->sp_split == 2;
     sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
-            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1, pool);
+            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1, pool, ctx->sp_split == 2,
+            half_io && i >= 1 && i <= 6, half_io && i >= 1 && i <= 5);
   };
   std::vector<int> counts((size_t)chunk * 4);
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
     if (split) GN_HIP(hipMemsetAsync(ctx->ovf + 1, 0, sizeof(unsigned int), s));
-    sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s);
+    sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s, split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr);
     // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
     // block 0 alone is 0.5 GB per 1080p image: writing it and reading it back was a quarter of the extractor's HBM traffic)
     conv(1, X, Y, n, H, W, 1, 1);                                                                   // block 0 -> Y [H/2][W/2][64]
@@ -1522,6 +1526,13 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
     attention(ctx, a, (hipStream_t)stream);
   }
   GN_HIP(hipGetLastError());
+  return GN_OK;
+}
+
+int gn_sp_set_arithmetic(gn_ctx* ctx, int mode) {
+  if (!ctx || mode < GN_SP_EXACT_F32 || mode > GN_SP_FP16) return GN_ERR_ARG;
+  if (mode != GN_SP_EXACT_F32 && ctx->precision != GN_PREC_F16X2_BF16_ATTN) return fail(ctx, GN_ERR_ARG, "the fp16 SuperPoint arithmetic needs a context of the f16x2 precision");
+  ctx->sp_split = mode;
   return GN_OK;
 }
 

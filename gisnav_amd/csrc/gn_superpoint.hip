@@ -30,6 +30,7 @@ constexpr int TW = 32;                   // output tile of k_sp_conv: (4 RPW) ro
                                          // pipe); RPW = 2 for the layers whose 2 x 2 max-pool is fused into the epilogue (row pairs in one lane)
 constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
 
+template <bool OUT_HALF>   // OUT_HALF: the 64-channel map leaves as fp16 (GN_SP_FP16)
 __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
   // the 576 weights + 64 biases sit in LDS: a lane's channel group differs from its neighbours', so reading them from memory was
   // 144 vector loads per thread (the layer ran at 1.5 TB/s of output instead of the HBM rate)
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
     v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
   }
   float* o = out + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
+  _Float16* oh = reinterpret_cast<_Float16*>(out) + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) {
     f32x4 r;
@@ -61,7 +63,12 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
       for (int t = 0; t < 9; ++t) acc = fmaf(ws[c * 9 + t], v[t], acc);
       r[e] = fmaxf(acc, 0.f);
     }
-    *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+    if (OUT_HALF) {
+      typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<h16x4_t*>(oh + c4 * 4) = __builtin_convertvector(r, h16x4_t);
+    } else {
+      *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+    }
   }
 }
 
@@ -73,6 +80,7 @@ struct ConvArgs {
   int relu;
   const uint16_t* wfh; float acc_scale;      // HM variant: weights as fp16 pairs in fragment order (sp_weight_fragments_hm16), scaled by 1 / acc_scale
   unsigned int* ovf;                         // HM variant: raised when an input activation does not fit fp16 (the caller re-runs the exact path)
+  int in_half, out_half;                     // GN_SP_FP16 only: the layer reads / writes its NHWC activations as fp16 (half the HBM traffic of the full-resolution layers)
 };
 
 // grid (tiles_x, tiles_y, B * Cout/64)
@@ -86,7 +94,7 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // must not share a chunk position (a plain lx & 7 made every ds_read_b128 a 4-way bank conflict: the LDS port, not the matrix
 // pipe, set the pace of the full-resolution layers)
 __device__ __forceinline__ int psw(int lx) { return (lx ^ (lx >> 3)) & 7; }
-template <int TAPS, bool HM, int RPW, bool POOL>
+template <int TAPS, int HM, int RPW, bool POOL>   // HM: 0 exact f32, 1 split fp16 (3 products), 2 single fp16 product (the arithmetic BASELINE configs[4] names: 16-bit operands)
 __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   constexpr int TH = 4 * RPW;
   constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -119,6 +127,34 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
     // batches of SB independent requests (one memory latency per batch; a load-convert-write loop paid one per ITEM: 19 latencies
     // per slice, twice the time of the slice's MFMAs)
     constexpr int NQ = (LH * LW * 8 + 255) / 256, SB = 10;
+    if (HM == 2 && a.in_half) {
+      // fp16 activations: a 16-byte piece is 8 channels and goes into the high-term position of the tile as it is (no conversion)
+      constexpr int NQH = (LH * LW * 4 + 255) / 256;
+      const uint16_t* inh = reinterpret_cast<const uint16_t*>(a.in) + (long long)img * a.H * a.W * a.Cin;
+#pragma unroll
+      for (int q0 = 0; q0 < NQH; q0 += SB) {
+        uint4 v[SB];
+#pragma unroll
+        for (int e = 0; e < SB; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          const int pix = q >> 2, c8 = q & 3;
+          const int ly = pix / LW, lx = pix - ly * LW;
+          const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+          v[e] = make_uint4(0u, 0u, 0u, 0u);
+          if (q0 + e < NQH && q < LH * LW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[e] = *reinterpret_cast<const uint4*>(inh + ((long long)gy * a.W + gx) * a.Cin + c0 + c8 * 8);
+        }
+#pragma unroll
+        for (int e = 0; e < SB; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          if (q0 + e >= NQH || q >= LH * LW * 4) continue;
+          const int pix = q >> 2, c8 = q & 3;
+          const int ly = pix / LW, lx = pix - ly * LW;
+          const int piece = 4 * (c8 >> 1) + (c8 & 1);
+          *reinterpret_cast<uint4*>(tb + pix * 128 + ((piece ^ psw(lx)) * 16)) = v[e];
+        }
+      }
+    } else
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += SB) {
       f32x4 v[SB];
@@ -142,11 +178,13 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
         if (HM) {
           // channels 4 chunk .. 4 chunk + 3 of the slice: k-step chunk >> 2, 16-byte piece 4 (chunk >> 2) + 2 term + ((chunk & 3) >> 1), half (chunk & 1)
           const h16x4 h4 = __builtin_convertvector(v[e], h16x4);
-          const h16x4 m4 = __builtin_convertvector(v[e] - __builtin_convertvector(h4, f32x4), h16x4);
           ovf_track(amax, v[e].x, v[e].y); ovf_track(amax, v[e].z, v[e].w);
           const int piece = 4 * (chunk >> 2) + ((chunk & 3) >> 1), sub = (chunk & 1) * 8;
           *reinterpret_cast<h16x4*>(tb + pix * 128 + ((piece ^ psw(lx)) * 16) + sub) = h4;
-          *reinterpret_cast<h16x4*>(tb + pix * 128 + (((piece + 2) ^ psw(lx)) * 16) + sub) = m4;
+          if (HM == 1) {
+            const h16x4 m4 = __builtin_convertvector(v[e] - __builtin_convertvector(h4, f32x4), h16x4);
+            *reinterpret_cast<h16x4*>(tb + pix * 128 + (((piece + 2) ^ psw(lx)) * 16) + sub) = m4;
+          }
         } else {
           *reinterpret_cast<f32x4*>(tile + pix * CH + ((chunk ^ psw(lx)) * 4)) = v[e];
         }
@@ -188,7 +226,7 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
           }
           // products: W_m X_h, W_h X_m, W_h X_h (small terms first)
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = (HM == 2 ? 2 : 0); p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -251,9 +289,15 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
           mv = fmaxf(mv, __shfl_xor(mv, 1));
           m[e] = mv;
         }
-        if (!(ql & 1) && gy + 1 < a.H && gx + 1 < a.W)
+        if (HM == 2 && a.out_half) {
+          ovf_track(amax, m.x, m.y); ovf_track(amax, m.z, m.w);
+          if (!(ql & 1) && gy + 1 < a.H && gx + 1 < a.W)
+            *reinterpret_cast<h16x4*>(reinterpret_cast<uint16_t*>(a.out) + (long long)img * (a.H / 2) * (a.W / 2) * a.Cout +
+                                      ((long long)(gy >> 1) * (a.W / 2) + (gx >> 1)) * a.Cout + c) = __builtin_convertvector(m, h16x4);
+        } else if (!(ql & 1) && gy + 1 < a.H && gx + 1 < a.W)
           *reinterpret_cast<f32x4*>(out + ((long long)(gy >> 1) * (a.W / 2) + (gx >> 1)) * a.Cout + c) = m;
       }
+    if (HM == 2 && a.out_half) ovf_commit(a.ovf, amax);
     return;
   }
   float* out = a.out + (long long)img * a.H * a.W * a.Cout;
@@ -271,9 +315,16 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
         if (HM) v = v * ascale;
         v += b4;
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(out + ((long long)gy * a.W + gx) * a.Cout + c) = v;
+        if (HM == 2 && a.out_half) {
+          ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w);
+          *reinterpret_cast<h16x4*>(reinterpret_cast<uint16_t*>(a.out) + (long long)img * a.H * a.W * a.Cout + ((long long)gy * a.W + gx) * a.Cout + c) =
+              __builtin_convertvector(v, h16x4);
+        } else {
+          *reinterpret_cast<f32x4*>(out + ((long long)gy * a.W + gx) * a.Cout + c) = v;
+        }
       }
   }
+  if (HM == 2 && a.out_half) ovf_commit(a.ovf, amax);
 }
 
 // 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
@@ -514,29 +565,37 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
           }
 }
 
-void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half) {
   const long long n = (long long)H * W * 4;
-  hipLaunchKernelGGL(k_sp_conv1, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
+  if (out_half) hipLaunchKernelGGL(k_sp_conv1<true>, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
+  else hipLaunchKernelGGL(k_sp_conv1<false>, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
 }
 void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,
-             const uint16_t* wfh, float acc_scale, unsigned int* ovf, int pool) {
+             const uint16_t* wfh, float acc_scale, unsigned int* ovf, int pool, int single_product, int in_half, int out_half) {
   ConvArgs a; a.in = in; a.H = H; a.W = W; a.Cin = Cin; a.wf = wf; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = relu;
-  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf;
+  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf; a.in_half = in_half; a.out_half = out_half;
   const int th = pool ? 8 : 12;
   const dim3 grid((W + TW - 1) / TW, (H + th - 1) / th, B * (Cout_pad / 64));
   const bool hm = wfh != nullptr;
+  const bool single = hm && single_product;
   if (pool) {   // 3 x 3 layers only (the SuperPoint blocks that end in a max-pool)
-    if (hm) hipLaunchKernelGGL((k_sp_conv<9, true, 2, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_sp_conv<9, false, 2, true>), grid, dim3(256), 0, s, a);
+    if (single) hipLaunchKernelGGL((k_sp_conv<9, 2, 2, true>), grid, dim3(256), 0, s, a);
+    else if (hm) hipLaunchKernelGGL((k_sp_conv<9, 1, 2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<9, 0, 2, true>), grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (single) {
+    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, 2, 3, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<1, 2, 3, false>), grid, dim3(256), 0, s, a);
     return;
   }
   if (hm) {
-    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, true, 3, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_sp_conv<1, true, 3, false>), grid, dim3(256), 0, s, a);
+    if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, 1, 3, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv<1, 1, 3, false>), grid, dim3(256), 0, s, a);
     return;
   }
-  if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, false, 3, false>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_sp_conv<1, false, 3, false>), grid, dim3(256), 0, s, a);
+  if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, 0, 3, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sp_conv<1, 0, 3, false>), grid, dim3(256), 0, s, a);
 }
 void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);

@@ -18,9 +18,16 @@ class SuperPoint:
     """`detect_and_describe_device(images)` -> keypoints in the GN_KPT_XYSA layout + 256-d descriptors, ready for a
     `PoseEngine(feature="superpoint")`; weights under transformers' SuperPointForKeypointDetection key names."""
 
-    def __init__(self, engine: Optional[PoseEngine] = None, device: int = 0, max_keypoints: int = 1024, state_dict: Optional[Dict] = None):
+    ARITHMETIC = {"exact_f32": 0, "split_fp16": 1, "fp16": 2}
+
+    def __init__(self, engine: Optional[PoseEngine] = None, device: int = 0, max_keypoints: int = 1024, state_dict: Optional[Dict] = None,
+                 arithmetic: Optional[str] = None):
+        """arithmetic: None keeps the context's default (split_fp16 in f16x2 contexts, exact_f32 elsewhere); "fp16" = one fp16 product per
+        block, the 16-bit-operand arithmetic BASELINE.json configs[4] names (not f32-accurate, see include/gisnav_amd.h)."""
         self._eng = engine if engine is not None else PoseEngine(device, max_batch=1, max_kpts=128, precision="f32", feature="superpoint")
         self._max = int(max_keypoints)
+        if arithmetic is not None:
+            _lib.check(self._eng.ctx, self._eng.lib.gn_sp_set_arithmetic(self._eng.ctx, self.ARITHMETIC[arithmetic]), "gn_sp_set_arithmetic")
         if state_dict is not None:
             self.load_state_dict(state_dict)
 

@@ -278,6 +278,13 @@ int gn_sp_load_tensor(gn_ctx* ctx, const char* name, const float* host, const in
  * (v_mfma_f32_32x32x2_f32).  Synchronises `stream` once per pass of 4 images to read the counts. */
 int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, int W, int max_kpts,
                               float* kpt_xysa, float* score, float* desc, int32_t* n_out_host, void* stream);
+/* Arithmetic of the SuperPoint convolutions: GN_SP_EXACT_F32 (v_mfma_f32_32x32x2_f32: every context can), GN_SP_SPLIT_FP16 (f32 operands
+ * as two fp16 terms, three products, f32 accumulate: f32-accurate, the default of f16x2 contexts, with the fp16-range guard and exact
+ * retry), GN_SP_FP16 (ONE fp16 product per block, f32 accumulate: the 16-bit-operand arithmetic BASELINE.json configs[4] names
+ * ("bf16"; fp16 keeps three more mantissa bits) -- NOT f32-accurate: ~99 % of the keypoints of the exact path on the test images;
+ * same guard and retry).  The two fp16 modes need a context of the f16x2 precision; elsewhere the call returns GN_ERR_ARG. */
+enum { GN_SP_EXACT_F32 = 0, GN_SP_SPLIT_FP16 = 1, GN_SP_FP16 = 2 };
+int gn_sp_set_arithmetic(gn_ctx* ctx, int mode);
 
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.

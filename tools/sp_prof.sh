@@ -2,6 +2,7 @@
 # Developer tool: rocprofv3 kernel table of the SuperPoint extractor on 1920x1080 frames (4 per call) in a context of the given precision.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 PREC=${1:-f16x2_bf16_attn}
+ARITH=${2:-None}      # None (the context's default) | '"fp16"' | '"split_fp16"' | '"exact_f32"'
 cat > /tmp/sp_run.py <<PY
 import sys, numpy as np, torch
 sys.path.insert(0, "$R")
@@ -9,7 +10,7 @@ from gisnav_amd.engine import PoseEngine
 from gisnav_amd.superpoint import SuperPoint
 from oracle import superpoint as osp
 eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="$PREC", feature="superpoint")
-sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0))
+sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0), arithmetic=$ARITH)
 rng = np.random.default_rng(0)
 img = torch.from_numpy(rng.random((4, 1080, 1920), dtype=np.float32)).cuda()
 for _ in range(3):
