@@ -759,7 +759,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
     case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
     case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;
-    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;
+    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;    // experiment: packed fma in front of the exponentials (5 % slower)
     case 51: hipLaunchKernelGGL((k_attn_bf16_v5<16, 4>), grid, block, 0, s, a); break;    // timing probes (wrong results): no exponentials
     case 52: hipLaunchKernelGGL((k_attn_bf16_v5<32, 4>), grid, block, 0, s, a); break;    //   no per-tile barrier
     case 53: hipLaunchKernelGGL((k_attn_bf16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
@@ -767,7 +767,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
     case 58: hipLaunchKernelGGL((k_attn_bf16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
     case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body: 1-1.5 % slower than the default
-    case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)   // packed fmas in front of the exponentials (slower)
+    case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
     default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
