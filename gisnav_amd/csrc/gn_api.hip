@@ -1564,6 +1564,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 19) ctx->qkv_fused = value;
   else if (which == 20) ctx->qkv_stamps = value;
   else if (which == 21) ctx->sp_split = value;
+  else if (which == 24) gn::g_sp_conv_h = value;
   else if (which == 23) ctx->attn_split = value;
   else return GN_ERR_ARG;
   return GN_OK;

@@ -114,6 +114,7 @@ struct FfnArgs {
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 extern int g_ffn_ablate;
 extern int g_ffn_shape;
+extern int g_sp_conv_h;
 extern int g_head_ablate;
 void build_weight_fragments(const float* w, int N, int K, float scale, int permute_k, uint16_t* out);   // host arrays; out: 2 * N * K halfs
 

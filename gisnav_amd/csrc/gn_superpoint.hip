@@ -327,6 +327,197 @@ __global__ __launch_bounds__(256) void k_sp_conv(ConvArgs a) {
   if (HM == 2 && a.out_half) ovf_commit(a.ovf, amax);
 }
 
+// GN_SP_FP16, 3 x 3 layers: the single-product arithmetic of k_sp_conv<9, 2, ...> with a tiling made for it.  With one MFMA per
+// fragment pair that kernel reads 1 KB of LDS per MFMA and the LDS port sets its pace; here a wave owns FOUR pixel rows, the taps are
+// walked column by column (dx), the three weight fragments of a kernel column stay in registers and a pixel fragment (tile row r,
+// column ql + dx) is read ONCE for the up to three taps (dy = r - j) that use it: 12 LDS reads per 24 MFMAs.  The halo tile holds high
+// terms only (64 bytes per pixel: chunk 2 s + hh of pixel (ly, lx) at position (2 s + hh) ^ ((lx >> 2) & 3), conflict-free for the lane
+// groups of ds_read_b128), 18 x 34 pixels = 38 KB, + 24 KB of weight hand-over: two workgroups per CU.
+constexpr int RPW4 = 4, TH4 = 4 * RPW4, LH4 = TH4 + 2, LW4 = TW + 2;
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void k_sp_conv_h(ConvArgs a) {   // two workgroups per CU: at most 256 registers
+  __shared__ __attribute__((aligned(16))) unsigned char tb[LH4 * LW4 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * 12288];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = a.Cout / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH4;
+  const uint4* wfh = reinterpret_cast<const uint4*>(a.wfh) + lane;
+  auto fsw = [](int lx) { return (lx >> 2) & 3; };
+
+  f32x16 acc[2][RPW4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < RPW4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float amax = 0.f;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+    __syncthreads();     // the previous slice is done with the tile
+    // stage the halo tile of this 32-channel slice: thread -> (pixel, 16-byte chunk of 8 channels); zero outside the image
+    constexpr int NQ = (LH4 * LW4 * 4 + 255) / 256, SB = 10;
+    if (a.in_half) {
+      const uint16_t* inh = reinterpret_cast<const uint16_t*>(a.in) + (long long)img * a.H * a.W * a.Cin;
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; q0 += SB) {
+        uint4 v[SB];
+#pragma unroll
+        for (int e = 0; e < SB; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          const int pix = q >> 2, c8 = q & 3;
+          const int ly = pix / LW4, lx = pix - ly * LW4;
+          const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+          v[e] = make_uint4(0u, 0u, 0u, 0u);
+          if (q0 + e < NQ && q < LH4 * LW4 * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[e] = *reinterpret_cast<const uint4*>(inh + ((long long)gy * a.W + gx) * a.Cin + c0 + c8 * 8);
+        }
+#pragma unroll
+        for (int e = 0; e < SB; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          if (q0 + e >= NQ || q >= LH4 * LW4 * 4) continue;
+          const int pix = q >> 2, c8 = q & 3;
+          const int lx = pix % LW4;
+          *reinterpret_cast<uint4*>(tb + pix * 64 + ((c8 ^ fsw(lx)) * 16)) = v[e];
+        }
+      }
+    } else {
+      const float* in = a.in + (long long)img * a.H * a.W * a.Cin;
+      constexpr int SBF = 5;
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; q0 += SBF) {
+        f32x4 v[SBF][2];
+#pragma unroll
+        for (int e = 0; e < SBF; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          const int pix = q >> 2, c8 = q & 3;
+          const int ly = pix / LW4, lx = pix - ly * LW4;
+          const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          v[e][0] = z; v[e][1] = z;
+          if (q0 + e < NQ && q < LH4 * LW4 * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const float* p = in + ((long long)gy * a.W + gx) * a.Cin + c0 + c8 * 8;
+            v[e][0] = *reinterpret_cast<const f32x4*>(p); v[e][1] = *reinterpret_cast<const f32x4*>(p + 4);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < SBF; ++e) {
+          const int q = (q0 + e) * 256 + tid;
+          if (q0 + e >= NQ || q >= LH4 * LW4 * 4) continue;
+          const int pix = q >> 2, c8 = q & 3;
+          const int lx = pix % LW4;
+          ovf_track(amax, v[e][0].x, v[e][0].y); ovf_track(amax, v[e][0].z, v[e][0].w);
+          ovf_track(amax, v[e][1].x, v[e][1].y); ovf_track(amax, v[e][1].z, v[e][1].w);
+          const h16x4 lo = __builtin_convertvector(v[e][0], h16x4), hi = __builtin_convertvector(v[e][1], h16x4);
+          *reinterpret_cast<h16x4*>(tb + pix * 64 + ((c8 ^ fsw(lx)) * 16)) = lo;
+          *reinterpret_cast<h16x4*>(tb + pix * 64 + ((c8 ^ fsw(lx)) * 16) + 8) = hi;
+        }
+      }
+    }
+    __syncthreads();
+    // weight fragments (high terms) of the three taps of kernel column dx: block tid >> 6 = i * 2 + k-step of tap dy * 3 + dx
+    auto wsrc = [&](int dy, int dx) __attribute__((always_inline)) {
+      const int b = tid >> 6, i = b >> 1, ks = b & 1;
+      return wfh[(size_t)((((2 * og + i) * 9 + (dy * 3 + dx)) * (a.Cin / 16) + (c0 / 16 + ks)) * 2) * 64];
+    };
+    uint4 wn[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) wn[dy] = wsrc(dy, 0);
+#pragma unroll 1
+    for (int dx = 0; dx < 3; ++dx) {
+      unsigned char* const wb = wbuf + (dx & 1) * 12288;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) *reinterpret_cast<uint4*>(wb + dy * 4096 + (tid >> 6) * 1024 + lane * 16) = wn[dy];
+      if (dx + 1 < 3) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wn[dy] = wsrc(dy, dx + 1);
+      }
+      __syncthreads();     // (the buffer written two columns ago is no longer read: one barrier in between)
+      const int lx = ql + dx;
+#pragma unroll
+      for (int s = 0; s < CH / 16; ++s) {
+        h16x8 fa[3][2];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[dy][i] = *reinterpret_cast<const h16x8*>(wb + dy * 4096 + (i * 2 + s) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < RPW4 + 2; ++r) {
+          const h16x8 fb = *reinterpret_cast<const h16x8*>(tb + ((RPW4 * wave + r) * LW4 + lx) * 64 + (((2 * s + hh) ^ fsw(lx)) * 16));
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int j = r - dy;
+            if (j >= 0 && j < RPW4) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[dy][i], fb, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // epilogue: lane = pixel (row RPW4 wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c
+  const int gx = x0 + ql;
+  const float ascale = a.acc_scale;
+  if (POOL) {
+#pragma unroll
+    for (int jp = 0; jp < RPW4 / 2; ++jp) {
+      const int gy = y0 + RPW4 * wave + 2 * jp;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+          f32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = acc[i][2 * jp][4 * g + e] * ascale + b4[e], v1 = acc[i][2 * jp + 1][4 * g + e] * ascale + b4[e];
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            float mv = fmaxf(v0, v1);
+            mv = fmaxf(mv, __shfl_xor(mv, 1));
+            m[e] = mv;
+          }
+          const bool wr = !(ql & 1) && gy + 1 < a.H && gx + 1 < a.W;
+          const long long o = (long long)img * (a.H / 2) * (a.W / 2) * a.Cout + ((long long)(gy >> 1) * (a.W / 2) + (gx >> 1)) * a.Cout + c;
+          if (a.out_half) {
+            ovf_track(amax, m.x, m.y); ovf_track(amax, m.z, m.w);
+            if (wr) *reinterpret_cast<h16x4*>(reinterpret_cast<uint16_t*>(a.out) + o) = __builtin_convertvector(m, h16x4);
+          } else if (wr) {
+            *reinterpret_cast<f32x4*>(a.out + o) = m;
+          }
+        }
+    }
+    ovf_commit(a.ovf, amax);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < RPW4; ++j) {
+    const int gy = y0 + RPW4 * wave + j;
+    if (gy >= a.H || gx >= a.W) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        v = v * ascale + b4;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const long long o = (long long)img * a.H * a.W * a.Cout + ((long long)gy * a.W + gx) * a.Cout + c;
+        if (a.out_half) {
+          ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w);
+          *reinterpret_cast<h16x4*>(reinterpret_cast<uint16_t*>(a.out) + o) = __builtin_convertvector(v, h16x4);
+        } else {
+          *reinterpret_cast<f32x4*>(a.out + o) = v;
+        }
+      }
+  }
+  ovf_commit(a.ovf, amax);
+}
+
 // 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
 __global__ __launch_bounds__(256) void k_sp_pool(const float* in, float* out, int H, int W, int C, long long total4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -565,6 +756,7 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
           }
 }
 
+int g_sp_conv_h = 1;   // developer knob 24: 0 = GN_SP_FP16 3 x 3 layers through k_sp_conv<9, 2, ...> (the first single-product kernel)
 void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half) {
   const long long n = (long long)H * W * 4;
   if (out_half) hipLaunchKernelGGL(k_sp_conv1<true>, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
@@ -578,6 +770,12 @@ void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, con
   const dim3 grid((W + TW - 1) / TW, (H + th - 1) / th, B * (Cout_pad / 64));
   const bool hm = wfh != nullptr;
   const bool single = hm && single_product;
+  if (single && taps == 9 && g_sp_conv_h) {
+    const dim3 grid4((W + TW - 1) / TW, (H + TH4 - 1) / TH4, B * (Cout_pad / 64));
+    if (pool) hipLaunchKernelGGL((k_sp_conv_h<true>), grid4, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv_h<false>), grid4, dim3(256), 0, s, a);
+    return;
+  }
   if (pool) {   // 3 x 3 layers only (the SuperPoint blocks that end in a max-pool)
     if (single) hipLaunchKernelGGL((k_sp_conv<9, 2, 2, true>), grid, dim3(256), 0, s, a);
     else if (hm) hipLaunchKernelGGL((k_sp_conv<9, 1, 2, true>), grid, dim3(256), 0, s, a);
