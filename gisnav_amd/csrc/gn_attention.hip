@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
   int s0 = 0, s1 = 1, s2 = 2, s3 = 3;  // ring stages of tiles t, t+1, t+2 (, t+3) modulo ND
   if (ntiles > 0) {
     GN_DMA_K(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ntiles > 1) GN_DMA_K(1, 1);
     GN_DMA_V(0, 0);
     if (ntiles > 2) GN_DMA_K(2, 2);
@@ -462,16 +462,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
   auto tile = [&](f32x16 (&ST)[NQ][2], f32x16 (&SN)[NQ][2], int t, auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     // K(t+1) and V^T(t) have landed once everything but the ND - 2 newest DMA groups ({K(t+2), V^T(t+1)}, ...) is complete;
+    // lgkmcnt(0): this wave's fragment reads of the stages refilled below (issued just in front of the barrier, consumed by MFMAs behind
+    // it) have RETURNED before any wave may start the refill -- without it an LDS-DMA that hits in cache can overtake such a read
     // the barrier publishes all waves' shares and proves the stages refilled below are no longer being read
     constexpr int G = 2 * (8 / NW);                       // DMA instructions per wave per group (K tile + V^T tile)
     if (ABL & 32) {
       // timing probe: no workgroup barrier per tile (races on the ring: wrong data)
     } else if (FAST || t + ND - 1 < ntiles) {
-      if (G * (ND - 2) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-      else if (G * (ND - 2) == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+      if (G * (ND - 2) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (G * (ND - 2) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (!(ABL & 1)) {
       if (FAST || t + ND < ntiles) GN_DMA_K(s0, t + ND);                          // K(t) was consumed one iteration ago
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
         if (t + 1 < ntiles) tile(sb, sa, t + 1, std::false_type{});
       }
 #pragma unroll 1
-      for (; !(ABL & 256) && t + 1 + ND < ntiles; t += 2) {   // tiles t and t + 1 are both in the steady state
+      for (; (ABL & 256) && t + 1 + ND < ntiles; t += 2) {   // tiles t and t + 1 are both in the steady state
         tile(sa, sb, t, std::true_type{});
         tile(sb, sa, t + 1, std::true_type{});
       }
@@ -766,7 +768,7 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
     case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
     case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
     case 58: hipLaunchKernelGGL((k_attn_bf16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
-    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // optimistic reference, but every tile through the generic (branchy) body: 1-1.5 % slower than the default
+    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // steady-state tiles through a branch-free body in a loop of their own: <= 1 % faster, not the default (it is what exposed the ring race fixed by lgkmcnt(0) in front of the barriers)
     case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)
     case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
              hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)

@@ -22,7 +22,9 @@ for r in range(runs):
     idx, score, n = eng.match(*args)
     torch.cuda.synchronize()
     x = eng.debug_read("x", B * 2 * 1024 * 256).view(np.uint32).copy()
-    cur = (x, idx.cpu().numpy().copy(), score.cpu().numpy().view(np.uint32).copy(), n.cpu().numpy().copy())
+    nn = n.cpu().numpy().copy()
+    valid = np.arange(idx.shape[1])[None, :] < nn[:, None]            # the lists are filled up to n_match only
+    cur = (x, np.where(valid[:, :, None], idx.cpu().numpy(), 0), np.where(valid, score.cpu().numpy().view(np.uint32), 0), nn)
     if ref is None:
         ref = cur
         continue
