@@ -16,8 +16,7 @@
 //   * hypothesis scoring strides the K correspondences over the 64 lanes and counts inliers with
 //     __ballot + popcount; the DLT / homography normal matrices and the Levenberg-Marquardt
 //     J^T J, J^T e, |e|^2 are per-lane partial sums combined with a butterfly of wave shuffles.
-// Deviations (documented in DESIGN.md): findHomography's 10-iteration LM polish of the planar
-// initial guess is omitted (the pose LM that follows converges to the same optimum), and where
+// Deviations (documented in DESIGN.md): where
 // OpenCV's SVD leaves a basis implementation-defined (rank-deficient 3x3 alignment) the third
 // singular pair is completed as u0 x u1, v0 x v1.
 #include "gn_common.h"
@@ -1126,6 +1125,144 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) { H[i][j] *= h22; fin = fin && isfinite(H[i][j]); }
+      if (fin && ninl > 4) {
+        // findHomography's polish: LMSolver (levmarq.cpp) on HomographyRefineCallback, 8 free parameters (h[8] = 1), at most 10
+        // iterations -- oracle/pnp_ransac.py:_homography_refine.  One pass over the inliers per iteration yields everything the
+        // solver needs at the trial point (S, J^T J, J^T r, max |r|); they are adopted when the trial is accepted.
+        //   J rows of a point, with w = 1 / (h6 X + h7 Y + 1), a = (p, q, w) = (X w, Y w, w):  [a 0 -p xi -q xi], [0 a -p yi -q yi]
+        //   sums: 0..5 a a^T (pp pq pw qq qw ww) | 6..10 (pp pq qq pw qw) xi | 11..15 the same with yi | 16..18 (pp pq qq)(xi^2 + yi^2)
+        //         19..21 a rx | 22..24 a ry | 25..26 (p q)(xi rx + yi ry) | 27 S
+        auto eval = [&](const double h[8], double sm_[28], double& rmax) {
+          double acc[28];
+#pragma unroll
+          for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+          double mx = 0.0;
+          for (int i = lane; i < n; i += 64)
+            if (mask[i]) {
+              double X, Y, x, y; plane_xy(i, X, Y, x, y);
+              double w = h[6] * X + h[7] * Y + 1.0;
+              w = fabs(w) > kDblEps ? 1.0 / w : 0.0;
+              const double xi = (h[0] * X + h[1] * Y + h[2]) * w, yi = (h[3] * X + h[4] * Y + h[5]) * w;
+              const double rx = xi - x, ry = yi - y, pp_ = X * w, qq_ = Y * w;
+              const double q5[5] = {pp_ * pp_, pp_ * qq_, qq_ * qq_, pp_ * w, qq_ * w};
+              acc[0] += q5[0]; acc[1] += q5[1]; acc[2] += q5[3]; acc[3] += q5[2]; acc[4] += q5[4]; acc[5] += w * w;
+              const double e = xi * xi + yi * yi, g = xi * rx + yi * ry;
+#pragma unroll
+              for (int k = 0; k < 5; ++k) { acc[6 + k] += q5[k] * xi; acc[11 + k] += q5[k] * yi; }
+#pragma unroll
+              for (int k = 0; k < 3; ++k) acc[16 + k] += q5[k] * e;
+              acc[19] += pp_ * rx; acc[20] += qq_ * rx; acc[21] += w * rx;
+              acc[22] += pp_ * ry; acc[23] += qq_ * ry; acc[24] += w * ry;
+              acc[25] += pp_ * g; acc[26] += qq_ * g;
+              acc[27] += rx * rx + ry * ry;
+              mx = fmax(mx, fmax(fabs(rx), fabs(ry)));
+            }
+#pragma unroll
+          for (int k = 0; k < 28; ++k) sm_[k] = wsum(acc[k]);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+          rmax = mx;
+        };
+        auto normal_eq = [&](const double sm_[28], double N8[8][8], double v8[8]) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) N8[i][j] = 0.0;
+          const double aa[3][3] = {{sm_[0], sm_[1], sm_[2]}, {sm_[1], sm_[3], sm_[4]}, {sm_[2], sm_[4], sm_[5]}};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { N8[i][j] = aa[i][j]; N8[3 + i][3 + j] = aa[i][j]; }
+          // a (p q)^T: rows p -> (pp pq), q -> (pq qq), w -> (pw qw)
+          const int ix[3][2] = {{0, 1}, {1, 2}, {3, 4}};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              N8[i][6 + j] = N8[6 + j][i] = -sm_[6 + ix[i][j]];
+              N8[3 + i][6 + j] = N8[6 + j][3 + i] = -sm_[11 + ix[i][j]];
+            }
+          N8[6][6] = sm_[16]; N8[6][7] = N8[7][6] = sm_[17]; N8[7][7] = sm_[18];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v8[k] = sm_[19 + k];
+          v8[6] = -sm_[25]; v8[7] = -sm_[26];
+        };
+        double x8[8] = {H[0][0], H[0][1], H[0][2], H[1][0], H[1][1], H[1][2], H[2][0], H[2][1]};
+        double cur[28], rmax;
+        eval(x8, cur, rmax);
+        double D8[8];
+        { double N8[8][8], v8[8]; normal_eq(cur, N8, v8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) D8[k] = N8[k][k]; }
+        double lam = 1.0, lc = 0.75;
+#pragma unroll 1
+        for (int it = 0;;) {
+          double N8[8][8], v8[8], d[8], xd[8], trial[28], rmd;
+          normal_eq(cur, N8, v8);
+          {
+            double Ap[8][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) Ap[i][j] = N8[i][j] + (i == j ? lam * D8[i] : 0.0);
+            spd_solve<8>(Ap, v8, d);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xd[k] = x8[k] - d[k];
+          eval(xd, trial, rmd);
+          const double S = cur[27], Sd = trial[27];
+          double dS = 0.0, tt = 0.0, dmax = 0.0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            double Ad = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ad += N8[i][j] * d[j];
+            dS += d[i] * (2.0 * v8[i] - Ad);
+            tt += d[i] * v8[i];
+            dmax = fmax(dmax, fabs(d[i]));
+          }
+          const double Rr = (S - Sd) / (fabs(dS) > kDblEps ? dS : 1.0);
+          if (Rr > 0.75) {
+            lam *= 0.5;
+            if (lam < lc) lam = 0.0;
+          } else if (Rr < 0.25) {
+            double nu = (Sd - S) / (fabs(tt) > kDblEps ? tt : 1.0) + 2.0;
+            nu = fmin(fmax(nu, 2.0), 10.0);
+            if (lam == 0.0) {
+              double maxval = kDblEps;     // max |diag(A^-1)|
+#pragma unroll 1
+              for (int k = 0; k < 8; ++k) {
+                double ek[8], col[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ek[i] = i == k ? 1.0 : 0.0;
+                spd_solve<8>(N8, ek, col);
+                double ckk = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ckk = i == k ? col[i] : ckk;
+                maxval = fmax(maxval, fabs(ckk));
+              }
+              lam = lc = 1.0 / maxval;
+              nu *= 0.5;
+            }
+            lam *= nu;
+          }
+          if (Sd < S) {
+#pragma unroll
+            for (int k = 0; k < 28; ++k) cur[k] = trial[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x8[k] = xd[k];
+            rmax = rmd;
+          }
+          ++it;
+          if (!(it < 10 && dmax >= kDblEps && rmax >= kDblEps)) break;
+        }
+        H[0][0] = x8[0]; H[0][1] = x8[1]; H[0][2] = x8[2]; H[1][0] = x8[3]; H[1][1] = x8[4]; H[1][2] = x8[5];
+        H[2][0] = x8[6]; H[2][1] = x8[7]; H[2][2] = 1.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) fin = fin && isfinite(H[i][j]);
+      }
       if (!fin) init_ok = false;
       else {
         const double h1n = sqrt(H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]);

@@ -12,7 +12,8 @@ from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
-inp = eng.stage_inputs([make_pair(i) for i in range(B)])
+FLAT = len(sys.argv) > 2 and sys.argv[2] == "flat"     # flat DEM: the planar (homography) start instead of the DLT
+inp = eng.stage_inputs([make_pair(i, flat_dem=FLAT) for i in range(B)])
 out = eng.alloc_outputs(B)
 eng.estimate(inp, K_MATRIX, out=out)
 eng.lib.gn_debug_set_variant(eng.ctx, 15, 1)
