@@ -1229,18 +1229,16 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
             double nu = (Sd - S) / (fabs(tt) > kDblEps ? tt : 1.0) + 2.0;
             nu = fmin(fmax(nu, 2.0), 10.0);
             if (lam == 0.0) {
-              double maxval = kDblEps;     // max |diag(A^-1)|
-#pragma unroll 1
-              for (int k = 0; k < 8; ++k) {
-                double ek[8], col[8];
+              // max |diag(A^-1)|: lane k < 8 solves A c = e_k (the same instruction stream, eight right-hand sides) and keeps c[k]
+              double ek[8], col[8], ckk = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ek[i] = i == k ? 1.0 : 0.0;
-                spd_solve<8>(N8, ek, col);
-                double ckk = 0.0;
+              for (int i = 0; i < 8; ++i) ek[i] = i == lane ? 1.0 : 0.0;
+              spd_solve<8>(N8, ek, col);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ckk = i == k ? col[i] : ckk;
-                maxval = fmax(maxval, fabs(ckk));
-              }
+              for (int i = 0; i < 8; ++i) ckk = i == lane ? fabs(col[i]) : ckk;
+#pragma unroll
+              for (int o = 4; o > 0; o >>= 1) ckk = fmax(ckk, __shfl_xor(ckk, o));
+              const double maxval = fmax(kDblEps, bcast_lane(ckk, 0));
               lam = lc = 1.0 / maxval;
               nu *= 0.5;
             }
