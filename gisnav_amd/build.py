@@ -19,6 +19,9 @@ SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_qkv.
 # v_pk_mul_f32 / v_pk_fma_f32 sequences with op_sel that produced timing-dependent wrong results on gfx950 when
 # two waves share a SIMD (one float4 component of a 16-lane group, a few elements per 10^7; found with a
 # run-to-run bitwise determinism check).  Without SLP packing every kernel is bitwise repeatable.
+# Pinned to gn_qkv.hip in round 2 (tools/qkv_var.py: word 3 of the 16-byte q / k stores, ~0.09 % of words; every other file is
+# repeatable with SLP on); tools/probes/pk_opsel.hip rules out the obvious suspect (the unwritten, op_sel-ignored half of the
+# broadcast register pair does not influence v_pk_mul_f32 / v_pk_fma_f32 results).  Root cause open; the flag stays for all files.
 FLAGS = ["--offload-arch=gfx950", "-fno-slp-vectorize", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
 # attention: keep the MFMA accumulators in VGPRs (the softmax reads the scores and rescales the output every tile;
 # with the default AGPR form each tile paid ~255 v_accvgpr_read/write moves on the VALU, the kernel's bottleneck)
