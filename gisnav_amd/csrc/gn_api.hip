@@ -118,6 +118,7 @@ struct gn_ctx {
   // visual-odometry matcher workspace (gn_vo_match)
   float* vo_norm2 = nullptr; int32_t* vo_nn_idx = nullptr; float* vo_nn_dist = nullptr; uint8_t* vo_good = nullptr;
   uint8_t* mask_ws = nullptr;
+  float* pts_ws = nullptr;
   gn::HypResult* hyp_ws = nullptr;
   std::vector<void*> allocs;
   // stage timing
@@ -631,6 +632,7 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
   GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
   GN_ALLOC(mask_ws, B * np * 16);
+  GN_ALLOC(pts_ws, B * np * 5);
   GN_ALLOC(hyp_ws, B * 16);
   GN_ALLOC(ovf, 4);
 #undef GN_ALLOC
@@ -883,7 +885,7 @@ int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const 
   a.obj = obj; a.img = img; a.n_pts = n_pts; a.kstride = kstride; a.B = B;
   a.fx = K9[0]; a.fy = K9[4]; a.cx = K9[2]; a.cy = K9[5];
   a.iterations = iterations_count; a.reproj = reproj_error_px; a.confidence = confidence; a.min_pts = min_pts;
-  a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws; a.hyp = ctx->hyp_ws;
+  a.R = R; a.t = t; a.n_inliers = n_inliers; a.ok = ok; a.mask_ws = ctx->mask_ws; a.hyp = ctx->hyp_ws; a.pts_ws = ctx->pts_ws;
   a.dbg_ts = ctx->pnp_stamps ? reinterpret_cast<long long*>(ctx->sim) : nullptr;   // developer knob 15: phase stamps land in the (idle) sim buffer
   StageTimer tm(ctx, (hipStream_t)stream, ST_PNP);
   launch_pnp(a, (hipStream_t)stream);
@@ -908,7 +910,7 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   // match lists and the PnP masks are strided by the context's padded maximum (gn_kmax), whatever the active size
   const long long km = c->npad;
   mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
-  mv(c->mask_ws, km * 16); mv(c->hyp_ws, 16);
+  mv(c->mask_ws, km * 16); mv(c->hyp_ws, 16); mv(c->pts_ws, km * 5);
 }
 
 int estimate_impl(gn_ctx* ctx, int B, int kpt_format,

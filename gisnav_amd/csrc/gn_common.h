@@ -216,6 +216,7 @@ struct PnpArgs {
   double* R; double* t; int32_t* n_inliers; uint8_t* ok;
   uint8_t* mask_ws;          // [B][16][kstride] scratch: one inlier mask per concurrent hypothesis
   HypResult* hyp;            // [B][16]
+  float* pts_ws;             // [B][kstride][5] scratch: a pair's compacted inliers when they exceed k_pnp_refine's LDS capacity (2048)
   long long* dbg_ts;         // developer: nullptr, or [B][16 + 1][16] s_memtime phase stamps (k_pnp_hyp waves, then k_pnp_refine)
 };
 void launch_pnp(const PnpArgs& a, hipStream_t s);

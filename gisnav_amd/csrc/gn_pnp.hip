@@ -908,8 +908,8 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
 // ------------------------------------------------------------------------------------------------
 struct Cam { double fx, fy, cx, cy; };
 
-// |e|^2, and optionally J^T J (upper, 21) and J^T e (6), over the masked points
-__device__ inline double lm_accumulate(const float* obj, const float* img, const uint8_t* mask, int n, int lane,
+// |e|^2, and optionally J^T J (upper, 21) and J^T e (6), over the n (compacted inlier) points
+__device__ inline double lm_accumulate(const float* obj, const float* img, int n, int lane,
                                        const Cam& cam, const double p[6], bool want_j, double JtJ[21], double Jte[6]) {
   double R[3][3], dR[3][9];
   rodrigues_v2m(p, R, dR, want_j);
@@ -917,7 +917,6 @@ __device__ inline double lm_accumulate(const float* obj, const float* img, const
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0.0;
   for (int i = lane; i < n; i += 64) {
-    if (!mask[i]) continue;
     const double M0 = obj[3 * i], M1 = obj[3 * i + 1], M2 = obj[3 * i + 2];
     const double X = R[0][0] * M0 + R[0][1] * M1 + R[0][2] * M2 + p[3];
     const double Y = R[1][0] * M0 + R[1][1] * M1 + R[1][2] * M2 + p[4];
@@ -980,11 +979,11 @@ __device__ inline void lm_step(const double JtJ[21], const double Jte[6], const 
 }
 
 // CvLevMarq(6, 2n, TermCriteria(20, FLT_EPSILON)) driven as in cvFindExtrinsicCameraParams2
-__device__ void levmarq_pose(const float* obj, const float* img, const uint8_t* mask, int n, int lane, const Cam& cam, double p[6]) {
+__device__ void levmarq_pose(const float* obj, const float* img, int n, int lane, const Cam& cam, double p[6]) {
   double prev[6], JtJ[21], Jte[6];
   int lambda_lg10 = -3, iters = 0;
   double prev_err = 0.0;
-  double e2 = lm_accumulate(obj, img, mask, n, lane, cam, p, true, JtJ, Jte);
+  double e2 = lm_accumulate(obj, img, n, lane, cam, p, true, JtJ, Jte);
   for (;;) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) prev[k] = p[k];
@@ -992,7 +991,7 @@ __device__ void levmarq_pose(const float* obj, const float* img, const uint8_t* 
     if (iters == 0) prev_err = sqrt(e2);
     double err_norm;
     for (;;) {
-      err_norm = sqrt(lm_accumulate(obj, img, mask, n, lane, cam, p, false, JtJ, Jte));
+      err_norm = sqrt(lm_accumulate(obj, img, n, lane, cam, p, false, JtJ, Jte));
       if (err_norm > prev_err) {
         if (++lambda_lg10 <= 16) { lm_step(JtJ, Jte, prev, lambda_lg10, p); continue; }
       }
@@ -1006,7 +1005,7 @@ __device__ void levmarq_pose(const float* obj, const float* img, const uint8_t* 
     const double rel = sqrt(dn) / (pn > 0 ? sqrt(pn) : 1.0);
     if (iters >= 20 || rel < kFltEps) break;
     prev_err = err_norm;
-    e2 = lm_accumulate(obj, img, mask, n, lane, cam, p, true, JtJ, Jte);
+    e2 = lm_accumulate(obj, img, n, lane, cam, p, true, JtJ, Jte);
   }
 }
 
@@ -1028,7 +1027,7 @@ constexpr int kMaxHyp = 16;   // RANSAC hypotheses evaluated concurrently, one w
 
 
 // planar-structure initial guess of cvFindExtrinsicCameraParams2 (homography from the model plane)
-__device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const float* img, const uint8_t* mask, int n, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
+__device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const float* img, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
   bool init_ok = true;
     // planar structure: homography from the model plane to the normalised image
     double Rt[3][3];  // rows = principal axes (V^T)
@@ -1060,13 +1059,13 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
       y = (double)(float)(((double)img[2 * i + 1] - cam.cy) / cam.fy);
     };
     double s4[4] = {0, 0, 0, 0};
-    for (int i = lane; i < n; i += 64)
-      if (mask[i]) { double X, Y, x, y; plane_xy(i, X, Y, x, y); s4[0] += X; s4[1] += Y; s4[2] += x; s4[3] += y; }
+    for (int i = lane; i < ninl; i += 64)
+      { double X, Y, x, y; plane_xy(i, X, Y, x, y); s4[0] += X; s4[1] += Y; s4[2] += x; s4[3] += y; }
     double cM[2], cm[2];
     cM[0] = wsum(s4[0]) / ninl; cM[1] = wsum(s4[1]) / ninl; cm[0] = wsum(s4[2]) / ninl; cm[1] = wsum(s4[3]) / ninl;
     double d4[4] = {0, 0, 0, 0};
-    for (int i = lane; i < n; i += 64)
-      if (mask[i]) { double X, Y, x, y; plane_xy(i, X, Y, x, y);
+    for (int i = lane; i < ninl; i += 64)
+      { double X, Y, x, y; plane_xy(i, X, Y, x, y);
         d4[0] += fabs(X - cM[0]); d4[1] += fabs(Y - cM[1]); d4[2] += fabs(x - cm[0]); d4[3] += fabs(y - cm[1]); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) d4[k] = wsum(d4[k]);
@@ -1078,8 +1077,8 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
       double q24[24];
 #pragma unroll
       for (int k = 0; k < 24; ++k) q24[k] = 0.0;
-      for (int i = lane; i < n; i += 64)
-        if (mask[i]) {
+      for (int i = lane; i < ninl; i += 64)
+        {
           double X, Y, x, y; plane_xy(i, X, Y, x, y);
           x = (x - cm[0]) * sm[0]; y = (y - cm[1]) * sm[1]; X = (X - cM[0]) * sM[0]; Y = (Y - cM[1]) * sM[1];
           const double qq[6] = {X * X, X * Y, X, Y * Y, Y, 1.0};
@@ -1137,8 +1136,8 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
 #pragma unroll
           for (int k = 0; k < 28; ++k) acc[k] = 0.0;
           double mx = 0.0;
-          for (int i = lane; i < n; i += 64)
-            if (mask[i]) {
+          for (int i = lane; i < ninl; i += 64)
+            {
               double X, Y, x, y; plane_xy(i, X, Y, x, y);
               double w = h[6] * X + h[7] * Y + 1.0;
               w = fabs(w) > kDblEps ? 1.0 / w : 0.0;
@@ -1289,13 +1288,13 @@ __device__ __noinline__ bool pnp_init_planar(Shared& sh, const float* obj, const
 }
 
 // non-planar initial guess of cvFindExtrinsicCameraParams2 (12 x 12 DLT)
-__device__ __noinline__ bool pnp_init_dlt(Shared& sh, const float* obj, const float* img, const uint8_t* mask, int n, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
+__device__ __noinline__ bool pnp_init_dlt(Shared& sh, const float* obj, const float* img, int ninl, int lane, const Cam& cam, const double mc[3], const double Vc[3][3], double p[6]) {
     // DLT: L^T L from 4 weighted sums of P P^T, P = [X Y Z 1]
     double s40[40];
 #pragma unroll
     for (int k = 0; k < 40; ++k) s40[k] = 0.0;
-    for (int i = lane; i < n; i += 64)
-      if (mask[i]) {
+    for (int i = lane; i < ninl; i += 64)
+      {
         const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
         const double x = -(((double)img[2 * i] - cam.cx) / cam.fx), y = -(((double)img[2 * i + 1] - cam.cy) / cam.fy);
         const double pp[10] = {X * X, X * Y, X * Z, X, Y * Y, Y * Z, Y, Z * Z, Z, 1.0};
@@ -1435,13 +1434,13 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
   }
 }
 
+constexpr int kLdsPts = 2048;   // inlier correspondences k_pnp_refine keeps in LDS (20 bytes each)
 __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   __shared__ Shared sh;
+  __shared__ float cpts[5 * kLdsPts];
   const int b = blockIdx.x, lane = threadIdx.x;
   const int nhyp = a.iterations;
   const int n = a.n_pts[b];
-  const float* obj = a.obj + (size_t)b * a.kstride * 3;
-  const float* img = a.img + (size_t)b * a.kstride * 2;
   const HypResult* hyp = a.hyp + (size_t)b * kMaxHyp;
   double* Rout = a.R + (size_t)b * 9;
   double* tout = a.t + (size_t)b * 3;
@@ -1482,18 +1481,51 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   const uint8_t* mask_best = a.mask_ws + ((size_t)b * kMaxHyp + best) * a.kstride;
 
   // ---- solvePnP(SOLVEPNP_ITERATIVE) on the inliers ---------------------------------------------
+  // The inliers are compacted once (order kept) into LDS -- object points [k][3], image points [k][2] -- and every pass below (two for
+  // the PCA, 3 + 11 for a planar start or 1 for the DLT, up to ~40 of the pose LM) strides over ninl entries: no mask test, no
+  // global-memory latency per point, ninl / 64 instead of n / 64 trips.  More than kLdsPts inliers: the same layout in a.pts_ws.
   const uint8_t* mask = mask_best;
   const int ninl = max_good;
+  const bool in_lds = ninl <= kLdsPts;
+  float* const cobj = in_lds ? cpts : a.pts_ws + (size_t)b * a.kstride * 5;
+  float* const cimg = cobj + 3 * (size_t)(in_lds ? kLdsPts : a.kstride);
+  {
+    // four chunks of 64 candidates per trip: their 24 loads are in flight together (the loop is otherwise one memory latency per chunk)
+    const float* const gobj = a.obj + (size_t)b * a.kstride * 3;
+    const float* const gimg = a.img + (size_t)b * a.kstride * 2;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      bool m[4]; float o[4][3], u[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = i0 + 64 * c + lane, ic = i < n ? i : n - 1;
+        m[c] = i < n && mask[ic] != 0;
+        o[c][0] = gobj[3 * ic]; o[c][1] = gobj[3 * ic + 1]; o[c][2] = gobj[3 * ic + 2];
+        u[c][0] = gimg[2 * ic]; u[c][1] = gimg[2 * ic + 1];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned long long bal = __ballot(m[c]);
+        if (m[c]) {
+          const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+          cobj[3 * k] = o[c][0]; cobj[3 * k + 1] = o[c][1]; cobj[3 * k + 2] = o[c][2];
+          cimg[2 * k] = u[c][0]; cimg[2 * k + 1] = u[c][1];
+        }
+        base += __popcll(bal);
+      }
+    }
+    wave_sync();
+  }
+  const float* const obj = cobj;
+  const float* const img = cimg;
   double p[6];
   // PCA of the inlier object points
   double mc[3] = {0, 0, 0};
-  for (int i = lane; i < n; i += 64)
-    if (mask[i]) { mc[0] += obj[3 * i]; mc[1] += obj[3 * i + 1]; mc[2] += obj[3 * i + 2]; }
+  for (int i = lane; i < ninl; i += 64) { mc[0] += obj[3 * i]; mc[1] += obj[3 * i + 1]; mc[2] += obj[3 * i + 2]; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) mc[k] = wsum(mc[k]) / ninl;
   double mm[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = lane; i < n; i += 64)
-    if (mask[i]) {
+  for (int i = lane; i < ninl; i += 64) {
       const double d0 = obj[3 * i] - mc[0], d1 = obj[3 * i + 1] - mc[1], d2 = obj[3 * i + 2] - mc[2];
       mm[0] += d0 * d0; mm[1] += d0 * d1; mm[2] += d0 * d2; mm[3] += d1 * d1; mm[4] += d1 * d2; mm[5] += d2 * d2;
     }
@@ -1505,9 +1537,9 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   stamp(2);
   bool init_ok = true;
   if (W[2] / W[1] < 1e-3) {
-    init_ok = pnp_init_planar(sh, obj, img, mask, n, ninl, lane, cam, mc, Vc, p);
+    init_ok = pnp_init_planar(sh, obj, img, ninl, lane, cam, mc, Vc, p);
   } else if (ninl >= 6) {
-    init_ok = pnp_init_dlt(sh, obj, img, mask, n, ninl, lane, cam, mc, Vc, p);
+    init_ok = pnp_init_dlt(sh, obj, img, ninl, lane, cam, mc, Vc, p);
   } else {
     init_ok = false;  // < 6 non-planar inliers: OpenCV >= 4.5 falls back to the RANSAC model
   }
@@ -1515,7 +1547,7 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   stamp(3);
   double Rf[3][3], dummy[3][9];
   if (init_ok) {
-    levmarq_pose(obj, img, mask, n, lane, cam, p);
+    levmarq_pose(obj, img, ninl, lane, cam, p);
     stamp(4);
     rodrigues_v2m(p, Rf, dummy, false);
   } else {

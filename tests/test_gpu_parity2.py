@@ -222,3 +222,42 @@ def test_f16x2_domain_guard_flags_overflow_and_falls_back(state_dict_np, state_d
     eng = PoseEngine(0, max_batch=2, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np, guard="sync")
     idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
     assert eng.guard_status() == (False, 0) and (n_match.cpu().numpy() > 50).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flat", [False, True], ids=["relief", "flat"])
+def test_pnp_with_more_inliers_than_the_refinement_keeps_in_lds(state_dict_np, dev, flat):
+    """k_pnp_refine compacts the inliers into LDS (2048 correspondences); a pair with more of them goes through the same passes
+    on the context's global scratch (PnpArgs.pts_ws).  ~2900 correspondences, 8 % gross outliers, against the oracle: inlier count
+    identical, pose within 1e-8."""
+    from gisnav_amd.engine import PoseEngine
+    from oracle import pnp_ransac as pr
+    K = 4096
+    eng = PoseEngine(0, max_batch=2, max_kpts=K, precision="f32", state_dict=state_dict_np)
+    objs, imgs, refs = [], [], []
+    for s in range(2):
+        seed = 7000 + s
+        p = make_pair(seed, n_q=K, n_r=K, flat_dem=flat)
+        q = np.nonzero(p.gt_q2r >= 0)[0]
+        mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+        rs = np.random.default_rng(seed)
+        no = int(len(q) * 0.08)
+        sel = rs.choice(len(q), no, replace=False)                       # outliers scattered through the list, not a prefix
+        mq[sel] = np.column_stack([rs.uniform(0, 640, no), rs.uniform(0, 480, no)]).astype(np.float32)
+        mq += rs.normal(0, 0.5, mq.shape).astype(np.float32)
+        x, y = np.floor(mr).astype(int).T
+        obj = np.hstack((mr, p.dem[y, x].reshape(-1, 1))).astype(np.float32)
+        o = np.zeros((K, 3), np.float32); o[: len(obj)] = obj
+        m = np.zeros((K, 2), np.float32); m[: len(mq)] = mq
+        objs.append(o); imgs.append(m)
+        refs.append((len(obj), pr.solve_pnp_ransac(obj, mq, K_MATRIX, 10)))
+    n_pts = torch.tensor([r[0] for r in refs], dtype=torch.int32, device=dev)
+    R, t, ninl, ok = eng.pnp_ransac(torch.from_numpy(np.stack(objs)).to(dev), torch.from_numpy(np.stack(imgs)).to(dev), n_pts, K_MATRIX)
+    torch.cuda.synchronize()
+    for s, (_, (oko, r, tt, inl)) in enumerate(refs):
+        assert oko and int(ok[s]) == 1
+        assert len(inl) > 2048, len(inl)                                 # the case under test
+        assert int(ninl[s]) == len(inl)
+        dR = float(np.linalg.norm(R[s].cpu().numpy() - pr.rodrigues_vec2mat(r)))
+        dt = float(np.linalg.norm(t[s].cpu().numpy() - tt) / np.linalg.norm(tt))
+        assert dR < 1e-8 and dt < 1e-8, (s, dR, dt)
