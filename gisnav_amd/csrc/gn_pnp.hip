@@ -1506,8 +1506,8 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned long long bal = __ballot(m[c]);
-        if (m[c]) {
-          const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+        const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (m[c] && k < ninl) {     // k < ninl always (ninl is the popcount k_pnp_hyp took of this mask); the bound keeps a corrupted count inside the buffer
           cobj[3 * k] = o[c][0]; cobj[3 * k + 1] = o[c][1]; cobj[3 * k + 2] = o[c][2];
           cimg[2 * k] = u[c][0]; cimg[2 * k + 1] = u[c][1];
         }
