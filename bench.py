@@ -67,18 +67,21 @@ def compulsory_mb_per_pair(n: int, m: int) -> float:
     return ((n + m) * 128 * 4 + (n + m) * 4 * 4 + min(n, m) * (16 + 4) + 128) / 1e6
 
 
-def timed_steps(eng, inp, out, steps, warmup, dev, kernel_timing=False):
-    """W warm-up steps, then K steps bracketed by barrier + synchronize; returns (elapsed seconds max over ranks, this rank's seconds)."""
-    for _ in range(warmup):
-        eng.estimate(inp, K_MATRIX, out=out)
+def timed_steps(eng, inps, out, steps, warmup, dev, kernel_timing=False):
+    """W warm-up steps, then K steps bracketed by barrier + synchronize; returns (elapsed seconds max over ranks, this rank's seconds).
+    `inps` is a list of DISTINCT staged batches (all resident in HBM): step i works on batch i mod len(inps)."""
+    if isinstance(inps, dict):
+        inps = [inps]
+    for i in range(warmup):
+        eng.estimate(inps[i % len(inps)], K_MATRIX, out=out)
     eng.flush()
     if kernel_timing:
         eng.set_kernel_timing(MAX_TIMED_LAUNCHES_PER_STEP * steps)
     gdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.estimate(inp, K_MATRIX, out=out)
+    for i in range(steps):
+        eng.estimate(inps[i % len(inps)], K_MATRIX, out=out)
     eng.flush()
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0
@@ -121,7 +124,7 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
             out_dir = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(steps_prof), "--warmup", str(warmup_prof), "--batch", str(args.batch), "--kpts", str(args.kpts), "--precision", args.precision,
-                   "--no-cpu-baseline", "--no-traffic", "--no-extras", "--substreams", "1"]     # one pass, full-batch launches: the configuration of the kernel table
+                   "--no-cpu-baseline", "--no-traffic", "--no-extras", "--no-stream", "--no-rccl-check", "--substreams", "1"]     # one pass, full-batch launches: the configuration of the kernel table
             for kv in args.debug_variant:
                 cmd += ["--debug-variant", kv]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
@@ -240,6 +243,65 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
     return res
 
 
+def stream_new_pairs(eng, batches_msgs, steps, warmup, dev):
+    """PCIe-INCLUSIVE rate of a stream of NEW pairs (never `value`): every step's batch arrives as host bytes -- the raw 532-byte
+    KEYPOINT_DTYPE records of OrthoStereoImage.query_sift (pose_node.py:207-213) for both sides + the DEM raster -- and is copied into
+    pinned memory and uploaded on a copy stream into one of three device slots while the GPU works on the previous batch (RecordStager);
+    k_prep reads the records as they are.  The result records (16 f64 per pair) go back to pinned host memory every step."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gisnav_amd.engine import RecordStager
+    B = len(batches_msgs[0])
+    st = RecordStager(eng, max_batch=B, max_kpts=eng.kmax, dem_hw=batches_msgs[0][0][2].shape, depth=3)
+    out = eng.alloc_outputs(B)
+    host_rec = torch.empty((B, gdist.RECORD_F64), dtype=torch.float64, pin_memory=True)
+    nb = len(batches_msgs)
+    t_stage = [0.0]
+
+    def stage(i):
+        t0 = time.perf_counter()
+        r = st.stage(batches_msgs[i % nb])
+        t_stage[0] += time.perf_counter() - t0
+        return r
+
+    def run(n_steps):
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            cur = stage(0)
+            for i in range(n_steps):
+                fut = pool.submit(stage, i + 1) if i + 1 < n_steps else None
+                st.wait(cur)
+                eng.estimate(cur, K_MATRIX, out=out)
+                st.release(cur)
+                host_rec.copy_(gdist.pack_records(0, out), non_blocking=True)
+                cur = fut.result() if fut else None
+        eng.flush()
+        torch.cuda.synchronize()
+
+    run(max(warmup, 2))
+    t_stage[0] = 0.0
+    t0 = time.perf_counter()
+    run(steps)
+    elapsed = time.perf_counter() - t0
+    mb = sum(len(q) + len(r) + d.nbytes for q, r, d in batches_msgs[0]) / 1e6
+    return {"pairs_per_s": round(B * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 4), "distinct_batches": nb,
+            "host_to_device_mb_per_step": round(mb, 2), "host_stage_ms_per_batch": round(t_stage[0] / steps * 1e3, 3),
+            "poses_ok_last_step": int(out["ok"].sum().item())}
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec this script under torch.distributed.run with N ranks (one per GPU,
+    backend nccl = RCCL) and return its exit code.  Refuses -- non-zero exit, nothing measured -- when the box has fewer GPUs than N."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.share_gpu:
+        print(f"[bench] --gpus {args.gpus} asked for, but only {have} GPU(s) are visible on this box: refusing to run fewer ranks than "
+              f"requested (use --gpus {max(have, 1)}, or --share-gpu --backend gloo for a dry run of the launch path)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(gdist.free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("[bench] spawning: " + " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
     """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a
     bounded sample of the same workload."""
@@ -282,7 +344,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
+    ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
+    ap.add_argument("--resident-batches", type=int, default=4, help="distinct staged batches (all resident in HBM) the timed steps rotate over")
+    ap.add_argument("--no-rccl-check", action="store_true", help="skip the world-1 RCCL self-check of the N = 1 run (multi_gpu.rccl_selfcheck_world1)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive streaming measurement (pcie_inclusive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (HBM bytes per step)")
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (batch-1 f32, batch-32 exact-f32 GEMMs)")
@@ -298,13 +363,34 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))            # no launcher around us: become one (N ranks over RCCL), or refuse
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        print(f"[bench] WORLD_SIZE={os.environ.get('WORLD_SIZE')} does not match --gpus {args.gpus}: refusing to report a line for a world the "
+              f"caller did not ask for", file=sys.stderr)
+        sys.exit(2)
+    if not args.share_gpu and torch.cuda.device_count() < args.gpus:
+        print(f"[bench] --gpus {args.gpus} asked for, but only {torch.cuda.device_count()} GPU(s) are visible on this box", file=sys.stderr)
+        sys.exit(2)
+    rccl_check = None
+    if args.gpus == 1 and args.backend == "nccl" and not args.debug_variant and not args.no_rccl_check:
+        try:                                   # the collectives of the N > 1 path on a world-1 RCCL group: what a 1-GPU lease can prove
+            rccl_check = gdist.rccl_selfcheck(0)
+        except Exception as exc:  # noqa: BLE001
+            rccl_check = {"ok": False, "error": repr(exc)[:300]}
     rank, local_rank, world = gdist.init(args.backend)
     if args.share_gpu:
         local_rank = 0
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # every rank alive, every rank on its own GPU -- or no line at all
+    idents = gdist.gather_strings(f"{rank}:{gdist.device_identity(local_rank)}")
+    ranks_seen = len({i.split(":", 1)[0] for i in idents})
+    gpus_distinct = len({i.split(":", 1)[1] for i in idents})
+    if ranks_seen != args.gpus or (gpus_distinct != args.gpus and not args.share_gpu):
+        if rank == 0:
+            print(f"[bench] {ranks_seen} ranks on {gpus_distinct} distinct GPUs, --gpus {args.gpus} asked for: refusing", file=sys.stderr)
+        sys.exit(2)
 
     # weights: seeded synthetic on rank 0, broadcast once over RCCL (no checkpoint is available offline)
     sd = synthetic_state_dict(0)
@@ -322,12 +408,17 @@ def main() -> None:
 
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
     shard = gdist.shard_range(args.batch * world, rank, world)
-    pairs = [make_pair(i, n_q=args.kpts, n_r=args.kpts) for i in shard]
+    nres = max(1, args.resident_batches)
+    # `nres` DISTINCT batches per rank (batch j of rank r = pairs j * B * world + shard), all staged into HBM before the timed region;
+    # the timed steps rotate over them, so no step re-reads what the previous one just touched
+    pair_sets = [[make_pair(j * args.batch * world + i, n_q=args.kpts, n_r=args.kpts) for i in shard] for j in range(nres)]
+    pairs = pair_sets[0]
     torch.cuda.synchronize()
     t_h = time.perf_counter()
     inp = eng.stage_inputs(pairs)
     torch.cuda.synchronize()
     h2d_ms = (time.perf_counter() - t_h) * 1e3     # host packing + PCIe upload of one batch (pageable host memory): what a per-message caller pays
+    inps = [inp] + [eng.stage_inputs(ps) for ps in pair_sets[1:]]
     out = eng.alloc_outputs(len(pairs))
     if args.overlap:
         eng.set_overlap(True)
@@ -336,20 +427,33 @@ def main() -> None:
     # run concurrently and a launch's HIP-event duration stops being that kernel's own time.  `value` is timed afterwards, in its own
     # K steps, with the sub-batch streams on.
     eng.set_substreams(1)
-    elapsed1, _ = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=True)   # (_ = this rank's own seconds)
+    elapsed1, _ = timed_steps(eng, inps, out, args.steps, args.warmup, dev, kernel_timing=True)   # (_ = this rank's own seconds)
     table = eng.kernel_table()
     eng.set_kernel_timing(0)
     if nsub > 1:
         eng.set_substreams(nsub)
-        elapsed, mine = timed_steps(eng, inp, out, args.steps, args.warmup, dev, kernel_timing=False)
+        elapsed, mine = timed_steps(eng, inps, out, args.steps, args.warmup, dev, kernel_timing=False)
     else:
         elapsed, mine = elapsed1, _
     tripped, trips = eng.guard_status()
 
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
     n_match_mean = float(out["n_match"].float().mean().item())
-    rec = gdist.gather_records(gdist.pack_records(shard.start, out))  # fixed-size result records, 128 B/pair
+    # the LAST timed step worked on batch (steps - 1) mod nres: its result records, gathered over RCCL, must contain this rank's block
+    last = (args.steps - 1) % nres
+    mine_rec = gdist.pack_records(last * args.batch * world + shard.start, out)
+    rec = gdist.gather_records(mine_rec)  # fixed-size result records, 128 B/pair
+    block_ok = bool(torch.equal(rec[rank * len(pairs): (rank + 1) * len(pairs)].cpu(), mine_rec.cpu()))
+    blocks_ok = int(gdist.sum_over_ranks(1.0 if block_ok else 0.0, dev))
+    import hashlib
+    rec_sha = hashlib.sha256(rec.cpu().numpy().tobytes()).hexdigest()
     per_rank_ms = gdist.gather_records(torch.tensor([[mine / args.steps * 1e3] + [0.0] * 15], dtype=torch.float64, device=dev))[:, 0].cpu().tolist()
+    stream = None
+    if not args.no_stream and not args.debug_variant and world == 1:
+        from gisnav_amd import wire
+        msgs = [[(wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q), wire.pack_keypoints(p.kp_r, p.size_r, p.angle_r, p.desc_r), p.dem)
+                 for p in ps] for ps in pair_sets]
+        stream = stream_new_pairs(eng, msgs, args.steps, args.warmup, dev)
     del eng
     torch.cuda.empty_cache()
 
@@ -394,7 +498,10 @@ def main() -> None:
                                          "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)",
                       "f16x2_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
                                          "significant bits, 3 fp16 MFMA partial products, f32 accumulate; error vs fp64 <= the f32 "
-                                         "MFMA path's; fp16-range guard active) + bf16 MFMA attention (f32 accumulate)"}[args.precision],
+                                         "MFMA path's; fp16-range guard active) + bf16 MFMA attention (f32 accumulate)",
+                      "f16x2_f16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
+                                        "significant bits, 3 fp16 MFMA partial products, f32 accumulate; fp16-range guard active) + "
+                                        "fp16 MFMA attention (q, k, v, p rounded to fp16 like the reference's CUDA SDPA; f32 softmax / accumulate)"}[args.precision],
             "data": "synthetic",
             "inputs_resident": True,
             "debug_variant": list(args.debug_variant),
@@ -411,7 +518,8 @@ def main() -> None:
                 "sub_batch_streams": nsub,
                 "single_stream_ms_per_step": round(elapsed1 / args.steps * 1e3, 4),
                 "weights": "seeded synthetic, kornia sift_lightglue state-dict layout",
-                "same_staged_batch_every_step": True,
+                "same_staged_batch_every_step": nres == 1,
+                "distinct_resident_batches_rotated": nres,
             },
             "poses_per_s": round(n_ok_all * args.steps / elapsed, 2),
             "poses_ok_per_step": int(n_ok_all),
@@ -423,11 +531,18 @@ def main() -> None:
                            "attention_only_frac": round(pairs_per_s / world * g_attn / 1e3 / e2e_peak, 4),
                            "ceiling_pairs_per_s_per_gpu": round(e2e_peak * 1e3 / g_pair, 0),
                            "note": "SURVEY.md 8(d): achieved = pairs/s x algorithmic GFLOP per pair; peak = dense 16-bit MFMA (f32 MFMA in the f32 mode)"},
-            "pcie_inclusive": {"stage_inputs_ms_per_batch": round(h2d_ms, 3),
-                               "pairs_per_s": round(args.batch * world / (elapsed / args.steps + h2d_ms * 1e-3), 2),
-                               "note": "one synchronous host-pack + H2D of the batch (1.1 MB/pair, pageable memory) added to every step: the reference's per-message "
-                                       "boundary (pose_node.py:254-265); never `value`"},
-            "multi_gpu": {"per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "weight_broadcast_ms": round(broadcast_ms, 2) if world > 1 else None},
+            "pcie_inclusive": {"pairs_per_s": stream["pairs_per_s"] if stream else None,
+                               "frac_of_value": round(stream["pairs_per_s"] / pairs_per_s, 4) if stream else None,
+                               "stream": stream,
+                               "synchronous_stage_inputs_ms_per_batch": round(h2d_ms, 3),
+                               "synchronous_pairs_per_s": round(args.batch * world / (elapsed / args.steps + h2d_ms * 1e-3), 2),
+                               "note": "stream: NEW pairs every step from host bytes (raw 532-byte keypoint records + DEM, pinned staging + copy stream, unpacked "
+                                       "on the device; result records copied back) -- the reference's per-message boundary (pose_node.py:207-213,254-265) "
+                                       "pipelined; synchronous_*: round 2's figure (one blocking host-pack + pageable H2D per step).  Never `value`"},
+            "multi_gpu": {"ranks_seen": ranks_seen, "gpus_distinct": gpus_distinct, "devices": idents, "backend": args.backend,
+                          "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "weight_broadcast_ms": round(broadcast_ms, 2) if world > 1 else None,
+                          "records_sha256": rec_sha, "rank_blocks_found_in_gathered_records": blocks_ok,
+                          "rccl_selfcheck_world1": rccl_check},
         }
         if dom is not None:
             dom_traffic = None

@@ -80,10 +80,12 @@ GN_PREC_F32 = 0
 GN_PREC_BF16_ATTN = 1
 GN_PREC_F32X3_BF16_ATTN = 2
 GN_PREC_F16X2_BF16_ATTN = 3
+GN_PREC_F16X2_F16_ATTN = 4
 GN_FEATURE_SIFT = 0
 GN_FEATURE_SUPERPOINT = 1
 GN_KPT_LAF = 0
 GN_KPT_XYSA = 1
+GN_KPT_RECORD = 2   # raw 532-byte KEYPOINT_DTYPE wire records (133 floats per keypoint)
 
 
 class GnError(RuntimeError):

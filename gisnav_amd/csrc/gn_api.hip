@@ -44,9 +44,16 @@ struct gn_ctx {
   int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
                            // (k_gemm_p2ln) when the grid fills the chip, 2 = always; 0 = separate k_ln_gelu (developer knob 10)
   // f16x2 domain guard (gn_set_guard): device word raised by any hm16 writer whose value does not fit fp16
-  unsigned int* ovf = nullptr; unsigned int* ovf_host = nullptr;   // device word, pinned host mirror
+  // ovf_base: [0..7] one word per sub-batch group of the matcher (groups run concurrently on their own streams and each clears / reads its own
+  // word), [8] the SuperPoint extractor's; ovf = the word of the group that is being enqueued (ovf_base + g); ovf_host: pinned mirror of all 16
+  unsigned int* ovf_base = nullptr; unsigned int* ovf = nullptr; unsigned int* ovf_host = nullptr;
+  int dbg_trip_group = 0;  // developer knob 25: g + 1 = the matcher starts group g's guard word RAISED instead of cleared (tests of the per-group words)
+  bool in_group = false;   // gn_estimate is enqueuing one of its sub-batch groups (gn_match then leaves ovf_groups_last alone)
+  int ovf_groups_last = 1; // number of group words the most recent matcher call used (gn_get_guard_status ORs exactly those)
   int guard = 1;           // 0 off, 1 flag (a tripped call reports zero matches), 2 flag + synchronous re-run in the f32x3 mode
   long long guard_trips = 0;   // calls that tripped (counted when observed: guard 2, or gn_get_guard_status)
+  int attn_f16 = 0;        // GN_PREC_F16X2_F16_ATTN: q | k rows, V^T panels and the probabilities are fp16 instead of bf16 (precision itself reads F16X2_BF16_ATTN)
+  int precision_api = 0;   // the gn_precision value gn_create was called with
   int feature = 0;         // GN_FEATURE_SIFT / GN_FEATURE_SUPERPOINT (gn_create_ex)
   float size_q[2] = {0.f, 0.f}, size_r[2] = {0.f, 0.f};   // gn_set_image_size: (w, h) per side for the keypoint normalisation, 0 = keypoint extent
   int npad_run = 0;        // padded keypoint count the matcher runs at (<= npad, gn_set_active_kpts); buffers are laid out for it per call
@@ -354,6 +361,7 @@ bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int 
   q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
   q.rot4 = c->rot4; q.rot_stride = (long long)c->Tmax; q.qkb = c->qkb; q.ldyb = cross ? kDim : 2 * kDim; q.vt = c->vtb; q.npad = np;
   q.qscale = 0.125f; q.scale = 0.35355339059327373f; q.vt_perm = vt_perm; q.T = T;
+  q.half_fmt = c->attn_f16; q.ovf = (c->attn_f16 && c->guard) ? c->ovf : nullptr;
   q.dbg_ts = (c->qkv_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 20
   ++c->launch_count;
   if (c->stop_after && c->launch_count > c->stop_after) return true;
@@ -433,7 +441,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int vt_perm = (bf16v2 ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v5 reads V^T with keys permuted inside 16-groups   // k_attn_bf16_v4 reads permuted V^T
   const bool attn_planes = c->planes_mode && bf16v2;   // k_attn_bf16_v5 writes the hm16 rows itself
   c->launch_count = 0;
-  if (c->planes_mode && c->guard) hipMemsetAsync(c->ovf, 0, sizeof(unsigned int), s);
+  if (c->planes_mode && c->guard) hipMemsetAsync(c->ovf, (c->dbg_trip_group && c->ovf == c->ovf_base + (c->dbg_trip_group - 1)) ? 1 : 0, sizeof(unsigned int), s);
   {
     StageTimer tm(c, s, ST_PREP);
     PrepArgs p;
@@ -466,7 +474,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
         if (bf16v2 && qkv_projection(c, blk, false, T, np, vt_perm, s)) {
         } else if (bf16v2) {
-          g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np; g.vt_perm = vt_perm;
+          g.Yb = c->qkb; g.ldyb = 2 * kDim; g.Vt = c->vtb; g.vt_start = 2 * kDim; g.q_cols = kDim; g.qscale = 0.125f; g.npad = np; g.vt_perm = vt_perm; g.half_fmt = c->attn_f16;
           gemm(c, EPI_ROTARY_BF16, g, s);
         } else {
           gemm(c, EPI_ROTARY, g, s);
@@ -477,8 +485,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         AttnArgs a; a.ovf = nullptr;
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
-        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb;
+        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
+        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -499,7 +507,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         g.scale_cols = kDim;
         if (bf16v2 && qkv_projection(c, blk, true, T, np, vt_perm, s)) {
         } else if (bf16v2) {
-          g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np; g.vt_perm = vt_perm;
+          g.Yb = c->qkb; g.ldyb = kDim; g.Vt = c->vtb; g.vt_start = kDim; g.q_cols = 0; g.qscale = 1.0f; g.npad = np; g.vt_perm = vt_perm; g.half_fmt = c->attn_f16;
           gemm(c, EPI_SCALE_BF16, g, s);
         } else {
           gemm(c, EPI_SCALE_COLS, g, s);
@@ -510,8 +518,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         AttnArgs a; a.ovf = nullptr;
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
-        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = attn_planes ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb;
+        a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
+        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -598,8 +606,10 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   gn_ctx* ctx = nullptr;
   if (!out || max_batch < 1 || max_kpts < 2) return fail(nullptr, GN_ERR_ARG, "bad gn_create argument");
   if (precision != GN_PREC_F32 && precision != GN_PREC_BF16_ATTN && precision != GN_PREC_F32X3_BF16_ATTN &&
-      precision != GN_PREC_F16X2_BF16_ATTN)
+      precision != GN_PREC_F16X2_BF16_ATTN && precision != GN_PREC_F16X2_F16_ATTN)
     return fail(nullptr, GN_ERR_ARG, "bad precision");
+  const int precision_api = precision;
+  if (precision == GN_PREC_F16X2_F16_ATTN) precision = GN_PREC_F16X2_BF16_ATTN;   // the same projections / FFN / head; only the attention operand format differs (ctx->attn_f16)
   GN_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   GN_HIP(hipGetDeviceProperties(&prop, device));
@@ -608,6 +618,7 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   ctx = new gn_ctx();
   if (feature != GN_FEATURE_SIFT && feature != GN_FEATURE_SUPERPOINT) { delete ctx; return fail(nullptr, GN_ERR_ARG, "bad feature type"); }
   ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision; ctx->feature = feature;
+  ctx->precision_api = precision_api; ctx->attn_f16 = precision_api == GN_PREC_F16X2_F16_ATTN ? 1 : 0;
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   ctx->npad = ((max_kpts + 127) / 128) * 128;
   ctx->npad_run = ctx->npad;
@@ -634,10 +645,11 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   GN_ALLOC(mask_ws, B * np * 16);
   GN_ALLOC(pts_ws, B * np * 5);
   GN_ALLOC(hyp_ws, B * 16);
-  GN_ALLOC(ovf, 4);
+  GN_ALLOC(ovf_base, 16);
+  ctx->ovf = ctx->ovf_base;
 #undef GN_ALLOC
-  if (hipHostMalloc((void**)&ctx->ovf_host, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
-  *ctx->ovf_host = 0u;
+  if (hipHostMalloc((void**)&ctx->ovf_host, 16 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  memset(ctx->ovf_host, 0, 16 * sizeof(unsigned int));
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
   // required tensor names
@@ -811,11 +823,14 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
              int64_t* idx, float* score, int32_t* n_match, void* stream) {
   int rc = check_fwd(ctx, B, stride_q, stride_r);
   if (rc != GN_OK) return rc;
-  if (!desc_q || !kpt_q || !n_q || !desc_r || !kpt_r || !n_r || !idx || !score || !n_match)
+  const int kfmt = kpt_format & 0xff;
+  if (kfmt != GN_KPT_LAF && kfmt != GN_KPT_XYSA && kfmt != GN_KPT_RECORD) return fail(ctx, GN_ERR_ARG, "bad kpt_format");
+  if (kfmt == GN_KPT_RECORD && ctx->feature != GN_FEATURE_SIFT) return fail(ctx, GN_ERR_ARG, "GN_KPT_RECORD (KEYPOINT_DTYPE wire records) needs a SIFT context");
+  if (((!desc_q || !desc_r) && kfmt != GN_KPT_RECORD) || !kpt_q || !n_q || !kpt_r || !n_r || !idx || !score || !n_match)
     return fail(ctx, GN_ERR_ARG, "null pointer passed to gn_match");
-  if ((kpt_format & 0xff) != GN_KPT_LAF && (kpt_format & 0xff) != GN_KPT_XYSA) return fail(ctx, GN_ERR_ARG, "bad kpt_format");
   GN_HIP(hipSetDevice(ctx->device));
   ctx->n_ev = 0;
+  if (!ctx->in_group) ctx->ovf_groups_last = 1;
   rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
                    (hipStream_t)stream);
   if (rc != GN_OK) return rc;
@@ -827,11 +842,12 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
     GN_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (*ctx->ovf_host != 0u) {
       ++ctx->guard_trips;
-      const int pm = ctx->planes_mode, gv = ctx->gemm_variant, npl = ctx->no_planes;
+      const int pm = ctx->planes_mode, gv = ctx->gemm_variant, npl = ctx->no_planes, af = ctx->attn_f16;
       ctx->planes_mode = 0; ctx->gemm_variant = 5; ctx->no_planes = 1;   // weights stay as hm16 planes: f32x3 splits the f32 weights on the fly
+      ctx->attn_f16 = 0;                                                   // and the attention operands go back to bf16 (f32's exponent range)
       rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
                        (hipStream_t)stream);
-      ctx->planes_mode = pm; ctx->gemm_variant = gv; ctx->no_planes = npl;
+      ctx->planes_mode = pm; ctx->gemm_variant = gv; ctx->no_planes = npl; ctx->attn_f16 = af;
       if (rc != GN_OK) return rc;
     }
   }
@@ -841,6 +857,11 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
 
 int gn_set_guard(gn_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return GN_ERR_ARG;
+  if (mode != ctx->guard && ctx->ovf_base) {   // a mode change starts from clean words: a trip raised under the old mode must not be seen by the new one
+    GN_HIP(hipSetDevice(ctx->device));
+    GN_HIP(hipDeviceSynchronize());
+    GN_HIP(hipMemset(ctx->ovf_base, 0, 8 * sizeof(unsigned int)));
+  }
   ctx->guard = mode;
   return GN_OK;
 }
@@ -848,9 +869,12 @@ int gn_set_guard(gn_ctx* ctx, int mode) {
 int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, int64_t* trips_total) {
   if (!ctx) return GN_ERR_ARG;
   GN_HIP(hipSetDevice(ctx->device));
-  GN_HIP(hipMemcpyAsync(ctx->ovf_host, ctx->ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  // (with deferred joins the caller flushes first: the words of unjoined groups are still being written)
+  GN_HIP(hipMemcpyAsync(ctx->ovf_host, ctx->ovf_base, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   GN_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const int tripped = (ctx->planes_mode && ctx->guard && *ctx->ovf_host != 0u) ? 1 : 0;
+  unsigned int any = 0u;
+  for (int g = 0; g < ctx->ovf_groups_last && g < 8; ++g) any |= ctx->ovf_host[g];
+  const int tripped = (ctx->planes_mode && ctx->guard && any != 0u) ? 1 : 0;
   if (tripped && ctx->guard == 1) ++ctx->guard_trips;
   if (last_call_tripped) *last_call_tripped = tripped;
   if (trips_total) *trips_total = ctx->guard_trips;
@@ -940,20 +964,23 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
     if (rcj != GN_OK) return rcj;
   }
   ctx->sub_last_B = B; ctx->sub_last_np = ctx->npad_run;
+  ctx->ovf_groups_last = groups;
   GN_HIP(hipEventRecord(ctx->ev_fork, s));
-  const int kw = (kpt_format & 0xff) == GN_KPT_LAF ? 6 : 4;
+  const int kw = (kpt_format & 0xff) == GN_KPT_LAF ? 6 : (kpt_format & 0xff) == GN_KPT_RECORD ? kRecordFloats : 4;
   const int in_dim = ctx->feature == GN_FEATURE_SIFT ? kInDim : kDim;
   int rc_all = GN_OK, b0 = 0;
   for (int g = 0; g < groups; ++g) {
     const int Bg = B / groups + (g < B % groups ? 1 : 0);
     GN_HIP(hipStreamWaitEvent(ctx->sub_s[g], ctx->ev_fork, 0));
     shift_workspaces(ctx, b0, +1);
+    ctx->in_group = true; ctx->ovf = ctx->ovf_base + g;            // this group's own guard word: cleared, raised and read on this group's stream only
     const int rc = estimate_impl(ctx, Bg, kpt_format,
-                                 desc_q + (size_t)b0 * stride_q * in_dim, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
-                                 desc_r + (size_t)b0 * stride_r * in_dim, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
+                                 desc_q ? desc_q + (size_t)b0 * stride_q * in_dim : nullptr, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
+                                 desc_r ? desc_r + (size_t)b0 * stride_r * in_dim : nullptr, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
                                  dem ? dem + (size_t)b0 * H * W : nullptr, H, W, K9, min_matches,
                                  R + (size_t)b0 * 9, t + (size_t)b0 * 3, n_match + b0, n_inliers + b0, ok + b0, ctx->sub_s[g]);
     shift_workspaces(ctx, b0, -1);
+    ctx->ovf = ctx->ovf_base; ctx->in_group = false;
     if (rc != GN_OK && rc_all == GN_OK) rc_all = rc;
     GN_HIP(hipEventRecord(ctx->ev_join[g], ctx->sub_s[g]));
     ctx->sub_pending[g] = true;
@@ -1389,13 +1416,13 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     const bool hm = split && ctx->sp[i].wfh != nullptr;
     const bool half_io = hm && ctx->sp_split == 2;
     sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
-            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf + 1, pool, ctx->sp_split == 2,
+            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf_base + 8, pool, ctx->sp_split == 2,
             half_io && i >= 1 && i <= 6, half_io && i >= 1 && i <= 5);
   };
   std::vector<int> counts((size_t)chunk * 4);
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
-    if (split) GN_HIP(hipMemsetAsync(ctx->ovf + 1, 0, sizeof(unsigned int), s));
+    if (split) GN_HIP(hipMemsetAsync(ctx->ovf_base + 8, 0, sizeof(unsigned int), s));
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s, split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr);
     // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
     // block 0 alone is 0.5 GB per 1080p image: writing it and reading it back was a quarter of the extractor's HBM traffic)
@@ -1412,7 +1439,7 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     sp_describe(Z, n, h, w, kpt_xysa + (size_t)b0 * max_kpts * 4, ctx->sp_counts, max_kpts, max_kpts, desc + (size_t)b0 * max_kpts * 256, s);
     GN_HIP(hipMemcpyAsync(counts.data(), ctx->sp_counts, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     unsigned int tripped = 0;
-    if (split) GN_HIP(hipMemcpyAsync(&tripped, ctx->ovf + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    if (split) GN_HIP(hipMemcpyAsync(&tripped, ctx->ovf_base + 8, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     GN_HIP(hipStreamSynchronize(s));
     if (split && tripped) { split = false; ++ctx->sp_split_trips; b0 -= chunk; continue; }   // repeat this pass with exact f32 convolutions
     for (int b = 0; b < n; ++b) {
@@ -1515,7 +1542,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   AttnArgs a; a.ovf = nullptr;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
-  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr;
+  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr; a.half_fmt = ctx->attn_f16;
   const long long cap = (long long)ctx->max_batch * 2 * ctx->npad;
   if (ctx->precision != GN_PREC_F32 && ctx->attn_variant >= 1 && ctx->qkb && ctx->vtb && (long long)BS * npad <= cap) {
     // the production kernel (k_attn_bf16_v5) on the layouts the projection epilogues would have written
@@ -1568,6 +1595,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 21) ctx->sp_split = value;
   else if (which == 24) gn::g_sp_conv_h = value;
   else if (which == 23) ctx->attn_split = value;
+  else if (which == 25) ctx->dbg_trip_group = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -328,11 +328,25 @@ __global__ __launch_bounds__(256) void k_attn_bf16(AttnArgs a) {
 // SPLIT (small grids: one to three pairs are 64 .. 192 workgroups on 256 CUs): gridDim.x = query blocks x a.nsplit; workgroup (qblk, s)
 // attends keys [s, s + 1) * ceil(nkv / 64) / nsplit * 64 only and leaves its unnormalised output, reference and denominator in a.part;
 // the workgroup that arrives last at the (slot, head, query block)'s ticket merges the nsplit partial results and writes the rows.
+// one 32x32x16 matrix instruction on 16-bit operands held as 8 shorts: bf16 (F16 = false) or fp16 (true), f32 accumulate
+template <bool F16> __device__ __forceinline__ f32x16 mfma16(const bf16x8& x, const bf16x8& y, const f32x16& c) {
+  if constexpr (F16) {
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, x), __builtin_bit_cast(f16x8_t, y), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+  }
+}
 template <typename T> __device__ __forceinline__ void st_dev(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ T ld_dev(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int ABL, int NW, int ND = 3, int NQ = 1, bool SPLIT = false>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
+// F16 (GN_PREC_F16X2_F16_ATTN): q, k, V^T and the probabilities are fp16 instead of bf16 -- what the reference's own CUDA path computes (kornia
+// casts q, k, v to half for SDPA, SURVEY.md:314): 11 significant bits instead of 8, at the same matrix-pipe rate.  fp16's range is what differs:
+// probabilities above 65504 become inf, so the optimistic reference falls back to the exact running maximum (whose lazy update keeps every
+// probability <= 2^8) as soon as a score exceeds the reference by ~16 in log2 units (bf16: ~100); probabilities below 2^-24 flush to zero (they
+// are below 2^-16 of the row's largest even under the lazy maximum), subnormals are honoured by the matrix pipe.
+template <int ABL, int NW, int ND = 3, int NQ = 1, bool SPLIT = false, bool F16 = false>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
-__global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
+__global__ __launch_bounds__(64 * NW, 2) void k_attn16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8 + ((ABL & 512) ? 24576 : 0)];   // ABL 512 (experiment): +48 KB so that only one workgroup fits a CU   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
 
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
     for (int r = 0; r < 16; ++r) { o[qi][0][r] = 0.f; o[qi][1][r] = 0.f; ol[qi][r] = 0.f; }
   bf16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+  for (int e = 0; e < 8; ++e) ones[e] = (short)(F16 ? 0x3c00 : 0x3f80);
   float m_run[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) m_run[qi] = -INFINITY;
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
       for (int kt = 0; kt < 2; ++kt) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[ro[kt] + (((2 * c + hh) ^ fsw[kt]) << 3)]);
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) S[qi][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][c], S[qi][kt], 0, 0, 0);
+        for (int qi = 0; qi < NQ; ++qi) S[qi][kt] = mfma16<F16>(kf, qf[qi][c], S[qi][kt]);
       }
   };
 
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
               p[0] = __builtin_amdgcn_exp2f(x2[0]);
               p[1] = __builtin_amdgcn_exp2f(x2[1]);
             }
-            pw[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
+            pw[e] = pack16<F16>(p[0], p[1]);   // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (RNE)
           }
           pf[qi][kt][u] = __builtin_bit_cast(bf16x8, pw);
         }
@@ -561,12 +575,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_bf16_v5(AttnArgs a) {   // 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) ol[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[qi][kt][u], ol[qi], 0, 0, 0);   // softmax denominator (rounded p)
+        for (int qi = 0; qi < NQ; ++qi) ol[qi] = mfma16<F16>(ones, pf[qi][kt][u], ol[qi]);   // softmax denominator (rounded p)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[ro[d] + (((4 * kt + 2 * u + hh) ^ fsw[d]) << 3)]);
 #pragma unroll
-          for (int qi = 0; qi < NQ; ++qi) o[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kt][u], o[qi][d], 0, 0, 0);
+          for (int qi = 0; qi < NQ; ++qi) o[qi][d] = mfma16<F16>(vf, pf[qi][kt][u], o[qi][d]);
         }
       }
     if (ABL & 4) __builtin_amdgcn_s_setprio(0);
@@ -719,7 +733,7 @@ namespace {
 // developer / test entry (gn_debug_attention): f32 q | k | v rows -> what k_attn_bf16_v5 reads (bf16 q * qscale and k rows, V^T panels
 // with the keys permuted inside 16-groups), i.e. what the projection epilogues of the matcher write
 __global__ void k_pack_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float qscale,
-                                 uint16_t* qb, uint16_t* kb, int ldb, uint16_t* vt, long long ntok, int npad) {
+                                 uint16_t* qb, uint16_t* kb, int ldb, uint16_t* vt, long long ntok, int npad, int f16) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ntok * 32) return;
   const long long tok = idx >> 5;
@@ -728,51 +742,62 @@ __global__ void k_pack_attn_bf16(const float* q, int ldq, const float* k, int ld
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int d = 8 * g8 + e;
-    const __bf16 qv = (__bf16)(q[tok * ldq + d] * qscale), kv = (__bf16)k[tok * ldk + d], vv = (__bf16)v[tok * ldv + d];
-    qb[tok * ldb + d] = __builtin_bit_cast(unsigned short, qv);
-    kb[tok * ldb + d] = __builtin_bit_cast(unsigned short, kv);
-    vt[(((size_t)bs * kHeads + (d >> 6)) * kHeadDim + (d & 63)) * npad + sp] = __builtin_bit_cast(unsigned short, vv);
+    const float qf = q[tok * ldq + d] * qscale, kf = k[tok * ldk + d], vf = v[tok * ldv + d];
+    qb[tok * ldb + d] = (unsigned short)(pack16_rt(qf, 0.f, f16) & 0xffffu);
+    kb[tok * ldb + d] = (unsigned short)(pack16_rt(kf, 0.f, f16) & 0xffffu);
+    vt[(((size_t)bs * kHeads + (d >> 6)) * kHeadDim + (d & 63)) * npad + sp] = (unsigned short)(pack16_rt(vf, 0.f, f16) & 0xffffu);
   }
 }
 }  // namespace
 void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s) {
   const long long ntok = (long long)a.BS * a.npad;
   hipLaunchKernelGGL(k_pack_attn_bf16, dim3((unsigned)((ntok * 32 + 255) / 256)), dim3(256), 0, s, a.q, a.ldq, a.k, a.ldk, a.v, a.ldv, a.qscale,
-                     qkb, qkb + kDim, 2 * kDim, vtb, ntok, a.npad);
+                     qkb, qkb + kDim, 2 * kDim, vtb, ntok, a.npad, a.half_fmt);
 }
 int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
-  g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1, false>";   // the name rocprofv3 prints (profiles up to r02g: "<0, 4, 3>", up to r02j: "<0, 4, 3, 1>")
+  g_last_kernel = "k_attn16_v5<0, 4, 3, 1, false, false>";   // the name rocprofv3 prints (profiles up to r02m: "k_attn_bf16_v5<0, 4, 3, 1, false>")
+  if (a.half_fmt) {   // fp16 operands (GN_PREC_F16X2_F16_ATTN)
+    if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr) {
+      hipLaunchKernelGGL((k_attn16_v5<0, 4, 3, 1, true, true>), dim3(a.npad / 128 * a.nsplit, kHeads, a.BS), dim3(256), 0, s, a);
+      g_last_kernel = "k_attn16_v5<0, 4, 3, 1, true, true>";
+      return;
+    }
+    if (g_attn_variant == 56) hipLaunchKernelGGL((k_attn16_v5<128, 4, 3, 1, false, true>), dim3(a.npad / 128, kHeads, a.BS), dim3(256), 0, s, a);   // exact running maximum in every tile
+    else hipLaunchKernelGGL((k_attn16_v5<0, 4, 3, 1, false, true>), dim3(a.npad / 128, kHeads, a.BS), dim3(256), 0, s, a);
+    g_last_kernel = "k_attn16_v5<0, 4, 3, 1, false, true>";
+    return;
+  }
   if (g_attn_variant == 48 && a.npad % 256 == 0) {   // experiment: 8 waves share each K / V^T tile (half the L2 -> LDS traffic per query); measured 6 % SLOWER
     dim3 grid(a.npad / 256, kHeads, a.BS), block(512);
     switch (g_attn_variant) {
-      default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 8>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_attn16_v5<0, 8>), grid, block, 0, s, a); break;
     }
     return;
   }
   if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr && (g_attn_variant == 4 || g_attn_variant == 59)) {
-    hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 1, true>), dim3(a.npad / 128 * a.nsplit, kHeads, a.BS), dim3(256), 0, s, a);
-    g_last_kernel = "k_attn_bf16_v5<0, 4, 3, 1, true>";
+    hipLaunchKernelGGL((k_attn16_v5<0, 4, 3, 1, true>), dim3(a.npad / 128 * a.nsplit, kHeads, a.BS), dim3(256), 0, s, a);
+    g_last_kernel = "k_attn16_v5<0, 4, 3, 1, true, false>";
     return;
   }
   dim3 grid(a.npad / 128, kHeads, a.BS), block(256);
   switch (g_attn_variant) {
-    case 43: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 4>), grid, block, 0, s, a); break;  // 4-deep rings
-    case 41: hipLaunchKernelGGL((k_attn_bf16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
-    case 42: hipLaunchKernelGGL((k_attn_bf16_v5<2, 4>), grid, block, 0, s, a); break;
-    case 44: hipLaunchKernelGGL((k_attn_bf16_v5<4, 4>), grid, block, 0, s, a); break;
-    case 46: hipLaunchKernelGGL((k_attn_bf16_v5<8, 4>), grid, block, 0, s, a); break;    // experiment: packed fma in front of the exponentials (5 % slower)
-    case 51: hipLaunchKernelGGL((k_attn_bf16_v5<16, 4>), grid, block, 0, s, a); break;    // timing probes (wrong results): no exponentials
-    case 52: hipLaunchKernelGGL((k_attn_bf16_v5<32, 4>), grid, block, 0, s, a); break;    //   no per-tile barrier
-    case 53: hipLaunchKernelGGL((k_attn_bf16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
-    case 54: hipLaunchKernelGGL((k_attn_bf16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
-    case 55: hipLaunchKernelGGL((k_attn_bf16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
-    case 58: hipLaunchKernelGGL((k_attn_bf16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
-    case 57: hipLaunchKernelGGL((k_attn_bf16_v5<256, 4>), grid, block, 0, s, a); break;   // steady-state tiles through a branch-free body in a loop of their own: <= 1 % faster, not the default (it is what exposed the ring race fixed by lgkmcnt(0) in front of the barriers)
-    case 56: hipLaunchKernelGGL((k_attn_bf16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)
-    case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn_bf16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
-             hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
-    default: hipLaunchKernelGGL((k_attn_bf16_v5<0, 4>), grid, block, 0, s, a); break;
+    case 43: hipLaunchKernelGGL((k_attn16_v5<0, 4, 4>), grid, block, 0, s, a); break;  // 4-deep rings
+    case 41: hipLaunchKernelGGL((k_attn16_v5<1, 4>), grid, block, 0, s, a); break;   // timing-only ablations
+    case 42: hipLaunchKernelGGL((k_attn16_v5<2, 4>), grid, block, 0, s, a); break;
+    case 44: hipLaunchKernelGGL((k_attn16_v5<4, 4>), grid, block, 0, s, a); break;
+    case 46: hipLaunchKernelGGL((k_attn16_v5<8, 4>), grid, block, 0, s, a); break;    // experiment: packed fma in front of the exponentials (5 % slower)
+    case 51: hipLaunchKernelGGL((k_attn16_v5<16, 4>), grid, block, 0, s, a); break;    // timing probes (wrong results): no exponentials
+    case 52: hipLaunchKernelGGL((k_attn16_v5<32, 4>), grid, block, 0, s, a); break;    //   no per-tile barrier
+    case 53: hipLaunchKernelGGL((k_attn16_v5<64, 4>), grid, block, 0, s, a); break;    //   no maximum search
+    case 54: hipLaunchKernelGGL((k_attn16_v5<112, 4>), grid, block, 0, s, a); break;   //   none of the three
+    case 55: hipLaunchKernelGGL((k_attn16_v5<33, 4>), grid, block, 0, s, a); break;    //   no barrier, no DMA
+    case 58: hipLaunchKernelGGL((k_attn16_v5<512, 4>), grid, block, 0, s, a); break;   // experiment: one workgroup (one wave per SIMD) per CU
+    case 57: hipLaunchKernelGGL((k_attn16_v5<256, 4>), grid, block, 0, s, a); break;   // steady-state tiles through a branch-free body in a loop of their own: <= 1 % faster, not the default (it is what exposed the ring race fixed by lgkmcnt(0) in front of the barriers)
+    case 56: hipLaunchKernelGGL((k_attn16_v5<128, 4>), grid, block, 0, s, a); break;   // the maximum searched in every tile (the exact path a workgroup falls back to)
+    case 45: if (a.npad % 256 == 0) { hipLaunchKernelGGL((k_attn16_v5<0, 4, 3, 2>), dim3(a.npad / 256, kHeads, a.BS), block, 0, s, a); break; }   // experiment: two query tiles per wave (every K / V^T fragment feeds two MFMAs, one wave per SIMD): bit-identical output, 27 % SLOWER (144 vs 113 us)
+             hipLaunchKernelGGL((k_attn16_v5<0, 4>), grid, block, 0, s, a); break;   // experiment: s_setprio(1) around the MFMA clusters (measured 3 % SLOWER: 107 vs 104 us)
+    default: hipLaunchKernelGGL((k_attn16_v5<0, 4>), grid, block, 0, s, a); break;
   }
 }
 }  // namespace gn

@@ -16,6 +16,7 @@ constexpr int kHeadDim = 64;
 constexpr int kInDim = 128;     // SIFT descriptor length
 constexpr int kFreq = 32;       // rotary frequencies per head (head_dim / 2)
 constexpr int kMaxLayers = 9;
+constexpr int kRecordFloats = 133;   // GN_KPT_RECORD: one 532-byte KEYPOINT_DTYPE record (ros/gisnav/gisnav/core/_shared.py:26-35) as floats
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,6 +53,20 @@ __host__ __device__ inline size_t hm16_off(size_t row, int ld, int col) {
 __device__ __forceinline__ void ovf_track(float& amax, float a, float b) { amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b))); }
 __device__ __forceinline__ void ovf_commit(unsigned int* flag, float amax) { if (flag != nullptr && !(amax < 65504.0f)) atomicOr(flag, 1u); }
 
+// two f32 -> one dword of two 16-bit floats, round to nearest even: v_cvt_pk_bf16_f32 (F16 = false) or v_cvt_pk_f16_f32 (true)
+template <bool F16> __device__ __forceinline__ unsigned int pack16(float lo, float hi) {
+  typedef float f32x2_p __attribute__((ext_vector_type(2)));
+  if constexpr (F16) {
+    typedef _Float16 f16x2_p __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_p){lo, hi}, f16x2_p));
+  } else {
+    typedef __bf16 bf16x2_p __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_p){lo, hi}, bf16x2_p));
+  }
+}
+// the same with the format chosen at run time (GEMM epilogues shared by both attention formats)
+__device__ __forceinline__ unsigned int pack16_rt(float lo, float hi, int f16) { return f16 ? pack16<true>(lo, hi) : pack16<false>(lo, hi); }
+
 // ---- GEMM -----------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
                EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6,
@@ -80,6 +95,7 @@ struct GemmArgs {
   // columns >= vt_start go to Vt (bf16, [slot][head][64][npad] = V transposed per (pair, side, head))
   uint16_t* Yb; int ldyb; uint16_t* Vt; int vt_start; int q_cols; float qscale; int npad;
   int vt_perm;                     // 1: V^T tokens permuted within 16-groups for k_attn_bf16_v4 (see the epilogue)
+  int half_fmt;                    // EPI_*_BF16: 0 = Yb / Vt hold bf16, 1 = fp16 (GN_PREC_F16X2_F16_ATTN; |value| >= 65504 raises ovf)
   // split-fp16 operands / outputs of k_gemm_p2 (gn_gemm_p2.hip) in the hm16 row format (see hm16_off): a row of
   // ld values occupies ld * 4 bytes, like the f32 row it shadows
   const uint16_t* Ap;                        // A (k < K1), row pitch lda values
@@ -129,6 +145,8 @@ struct QkvArgs {
   float scale;                        // cross: multiplied into qk (dim_head^-0.25)
   int vt_perm;                        // bit 0: keys permuted inside 16-groups (k_attn_bf16_v5); bit 1: timing probe, skip the V^T stores
   int T;                              // tokens, a multiple of 128
+  int half_fmt;                       // 0: qkb / vt hold bf16; 1: fp16 (GN_PREC_F16X2_F16_ATTN)
+  unsigned int* ovf;                  // half_fmt 1: domain guard word raised when a q / k / v value does not fit fp16, or nullptr
   long long* dbg_ts;                  // developer: nullptr, or [blocks][8 waves][8] s_memtime stamps
 };
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
@@ -149,6 +167,8 @@ struct AttnArgs {
   float qscale;              // multiplied into q before QK^T
   int BS;                    // number of (pair, side) slots
   unsigned int* ovf;         // f16x2 domain guard word for the hm16 output, or nullptr
+  int half_fmt = 0;          // k_attn16_v5: 0 = qb / kb / vt hold bf16 (v_mfma_f32_32x32x16_bf16), 1 = fp16 (v_mfma_f32_32x32x16_f16): the arithmetic of the
+                             // reference's own CUDA path (kornia casts q, k, v to half for SDPA); probabilities are rounded to the same format
   int nsplit = 1;            // k_attn_bf16_v5 on small grids: key ranges per (slot, head, query block), merged by the last workgroup to finish
   float* part = nullptr;     // [slot][head][query block][split][4 waves][34][64] partial results
   unsigned int* tickets = nullptr;   // [slot][head][query block], zero between launches
@@ -156,7 +176,7 @@ struct AttnArgs {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
-void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s);   // f32 rows -> the bf16 layouts k_attn_bf16_v5 reads (test entry)
+void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s);   // (a.half_fmt selects bf16 / fp16)   // f32 rows -> the bf16 layouts k_attn_bf16_v5 reads (test entry)
 extern int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------

@@ -73,6 +73,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
     const int slot = row0 / a.npad, i0 = row0 - slot * a.npad;
     const float bias = a.bias ? a.bias[colbase + lane] : 0.f;
     uint16_t* dst = a.Vt + (((size_t)slot * kHeads + head) * kHeadDim + lane) * a.npad + i0;
+    float vmax = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       unsigned int w[4];
@@ -81,10 +82,12 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
         const int t0 = (a.vt_perm & 1) ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] * ascale + bias;
         const float hi = slab[(t0 + 1) * ES + lane] * ascale + bias;
-        w[e] = pack_bf16(lo, hi);
+        w[e] = pack16_rt(lo, hi, a.half_fmt);
+        ovf_track(vmax, lo, hi);
       }
       if (!(a.vt_perm & 2)) *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);   // bit 1: timing probe, skip the stores
     }
+    if (a.half_fmt) ovf_commit(a.ovf, vmax);    // fp16 V^T panels: a value that does not fit fp16 raises the domain guard
     return;
   }
   const int c4 = (lane & 15) * 4;
@@ -155,8 +158,9 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = pack_bf16(v.x, v.y);
-      pk.y = pack_bf16(v.z, v.w);
+      pk.x = pack16_rt(v.x, v.y, a.half_fmt);
+      pk.y = pack16_rt(v.z, v.w, a.half_fmt);
+      ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;
@@ -167,7 +171,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmArgs& a, const float* s
       }
     }
   }
-  if (planes_out) ovf_commit(a.ovf, amax);
+  if (planes_out || (kBf16Out && a.half_fmt)) ovf_commit(a.ovf, amax);   // (fp16 q | k rows: same domain as the hm16 activations)
   // stores go last, from registers nothing writes any more
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

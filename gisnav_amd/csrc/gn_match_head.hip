@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   if (k >= a.n_match[b]) return;
   const size_t o = (size_t)b * a.kmax + k;
   const int iq = (int)a.idx[2 * o], ir = (int)a.idx[2 * o + 1];
-  const int w = a.kpt_format == GN_KPT_LAF ? 6 : 4;
+  const int w = a.kpt_format == GN_KPT_LAF ? 6 : a.kpt_format == GN_KPT_RECORD ? kRecordFloats : 4;
   const int xo = a.kpt_format == GN_KPT_LAF ? 2 : 0, yo = a.kpt_format == GN_KPT_LAF ? 5 : 1;
   const float* kq = a.kpt_q + ((size_t)b * a.stride_q + iq) * w;
   const float* kr = a.kpt_r + ((size_t)b * a.stride_r + ir) * w;

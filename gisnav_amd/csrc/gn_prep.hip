@@ -31,8 +31,9 @@ __device__ inline void read_kpt(const float* kp, int fmt, float& x, float& y, fl
     a00 = kp[0]; a01 = kp[1]; x = kp[2]; a10 = kp[3]; a11 = kp[4]; y = kp[5];
   } else {
     x = kp[0]; y = kp[1];
-    const float size = kp[2];
-    const float ang = kp[3] * kPi / 180.0f;  // kornia deg2rad
+    const bool rec = fmt == GN_KPT_RECORD;     // KEYPOINT_DTYPE record: x, y, z, size, angle, descriptor[128]
+    const float size = kp[rec ? 3 : 2];
+    const float ang = kp[rec ? 4 : 3] * kPi / 180.0f;  // kornia deg2rad
     const float c = cosf(ang), s = sinf(ang);
     a00 = size * c; a01 = size * s; a10 = size * (-s); a11 = size * c;
   }
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_extent(PrepArgs a) {
   const int n = min(side ? a.n_r[b] : a.n_q[b], a.npad);   // keypoints beyond the padded size of this call are ignored (gn_set_active_kpts)
   const int stride = side ? a.stride_r : a.stride_q;
   const int fmt = a.kpt_format & 0xff;
-  const int w = fmt == GN_KPT_LAF ? 6 : 4;
+  const int w = fmt == GN_KPT_LAF ? 6 : fmt == GN_KPT_RECORD ? kRecordFloats : 4;
   const int xo = fmt == GN_KPT_LAF ? 2 : 0, yo = fmt == GN_KPT_LAF ? 5 : 1;
   const float* kp = (side ? a.kpt_r : a.kpt_q) + (size_t)b * stride * w;
   float mx = -INFINITY, my = -INFINITY;
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
     if (lane < kFreq) { a.cos_t[tok * kFreq + lane] = 1.f; a.sin_t[tok * kFreq + lane] = 0.f; }
     return;
   }
-  const float* din = (side ? a.desc_r : a.desc_q) + ((size_t)b * stride + i) * kInDim;
+  const int fmt_ = a.kpt_format & 0xff;
+  // GN_KPT_RECORD: the descriptor is the tail of the keypoint's own 532-byte wire record (4-byte aligned only: scalar loads)
+  const float* din = fmt_ == GN_KPT_RECORD ? (side ? a.kpt_r : a.kpt_q) + ((size_t)b * stride + i) * kRecordFloats + 5
+                                           : (side ? a.desc_r : a.desc_q) + ((size_t)b * stride + i) * kInDim;
   const float d0 = din[lane], d1 = din[lane + 64];
   if (a.kpt_format & GN_DESC_ROOTSIFT) {
     dout[lane] = d0; dout[lane + 64] = d1;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
 
   if (lane < kFreq) {
     const int fmt = a.kpt_format & 0xff;
-    const int w = fmt == GN_KPT_LAF ? 6 : 4;
+    const int w = fmt == GN_KPT_LAF ? 6 : fmt == GN_KPT_RECORD ? kRecordFloats : 4;
     const float* kp = (side ? a.kpt_r : a.kpt_q) + ((size_t)b * stride + i) * w;
     float x, y, scale, ori;
     read_kpt(kp, fmt, x, y, scale, ori);

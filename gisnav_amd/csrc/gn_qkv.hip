@@ -20,13 +20,8 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-// two f32 -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 (the integer rounding it replaces was 9 VALU
-// instructions per pair and half of the q / k epilogues' instruction count)
-__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2v){lo, hi}, bf16x2v));
-}
+// pack16<F16> (gn_common.h): two f32 -> one dword of two bf16 / fp16 (round to nearest even): ONE v_cvt_pk_* (the integer rounding it
+// replaces was 9 VALU instructions per pair and half of the q / k epilogues' instruction count)
 
 constexpr int TM = 128;                 // tokens per workgroup
 constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of the token tile (hm16: 128 B per row): 16 KB
@@ -41,7 +36,8 @@ constexpr int NJ = TM / 32;             // token tiles of 32
 //                 and two rotary pairs;
 //   v pass:       tokens are the A operand: a lane owns one feature and, per 16 tokens, exactly the 8 keys of one 16-byte group
 //                 of the V^T layout (keys permuted inside 16-groups as k_attn_bf16_v5 reads them) = one 16-byte store.
-template <bool CROSS>
+// F16: the outputs are fp16 instead of bf16 (GN_PREC_F16X2_F16_ATTN, the reference's CUDA arithmetic); a value outside fp16's range raises a.ovf
+template <bool CROSS, bool F16 = false>
 __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   constexpr int NQK = CROSS ? kDim : 2 * kDim;      // q | k (or qk) features
   constexpr int NPASS = CROSS ? 2 : 3;
@@ -52,6 +48,7 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   long long ts[8];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg_ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
+  float amax = 0.f;   // F16: max |value| this lane stored
 
   // ---- token tile: thread -> (row, 16-byte chunk) of every k-tile; chunk c of row r sits at position c ^ swz(r)
   {
@@ -173,8 +170,9 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
             v = o;
             if (pass == 0) v *= a.qscale;
           }
-          pk[g].x = pack_bf16(v.x, v.y);
-          pk[g].y = pack_bf16(v.z, v.w);
+          pk[g].x = pack16<F16>(v.x, v.y);
+          pk[g].y = pack16<F16>(v.z, v.w);
+          if (F16) { ovf_track(amax, v.x, v.y); ovf_track(amax, v.z, v.w); }
         }
         // the two half-waves hold interleaved groups of 4 features (hh = 0: 8 g .. 8 g + 3, hh = 1: 8 g + 4 .. 8 g + 7): they trade every
         // other group, so that a lane stores 8 consecutive features (16 bytes) -- half as many scattered stores
@@ -210,13 +208,15 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
           for (int e = 0; e < 4; ++e) {
             const float lo = acc[j][8 * m + 2 * e] * ascale + bias;
             const float hi = acc[j][8 * m + 2 * e + 1] * ascale + bias;
-            w4[e] = pack_bf16(lo, hi);
+            w4[e] = pack16<F16>(lo, hi);
+            if (F16) ovf_track(amax, lo, hi);
           }
           if (!(a.vt_perm & 2)) *reinterpret_cast<uint4*>(dst + 32 * j + 8 * (2 * m + hh)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
     }
     stamp(3 + 2 * pass);
   }
+  if (F16) ovf_commit(a.ovf, amax);
   if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps per wave
     for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * 8 + wave) * 8 + k] = ts[k];
   }
@@ -224,8 +224,13 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
 }  // namespace
 
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s) {
-  if (cross) { hipLaunchKernelGGL((k_qkv<true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<true>"; }
-  else { hipLaunchKernelGGL((k_qkv<false>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<false>"; }
+  if (a.half_fmt) {
+    if (cross) { hipLaunchKernelGGL((k_qkv<true, true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<true, true>"; }
+    else { hipLaunchKernelGGL((k_qkv<false, true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<false, true>"; }
+    return;
+  }
+  if (cross) { hipLaunchKernelGGL((k_qkv<true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<true, false>"; }
+  else { hipLaunchKernelGGL((k_qkv<false>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<false, false>"; }
 }
 
 }  // namespace gn

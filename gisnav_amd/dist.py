@@ -9,6 +9,8 @@ ros/gisnav/gisnav/core/pose_node.py:178-184,497); batching and sharding are this
 from __future__ import annotations
 
 import os
+import socket
+import time
 from typing import Dict, Tuple
 
 import numpy as np
@@ -112,3 +114,73 @@ def gather_records(rec: torch.Tensor) -> torch.Tensor:
     parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, src)
     return torch.cat(parts, 0).to(rec.device)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def device_identity(index: int) -> str:
+    """A string that differs between physical GPUs (uuid when torch exposes it, else PCI location): N ranks must report N of them."""
+    p = torch.cuda.get_device_properties(index)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(p, attr, None)
+        if v is not None:
+            return f"{attr}:{v}|dev{getattr(p, 'pci_device_id', '')}|dom{getattr(p, 'pci_domain_id', '')}"
+    return f"index:{index}"
+
+
+def gather_strings(text: str) -> list:
+    """all_gather of one short string per rank (rank order); [text] at world 1."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [text]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, text)
+    return out
+
+
+def rccl_selfcheck(device_index: int = 0, weight_mb: float = 47.5) -> dict:
+    """The collectives the N > 1 path uses, on a WORLD-1 `nccl` (= RCCL) group bound to cuda:device_index: one broadcast of a
+    weight-sized f32 buffer, barrier, all_reduce MAX / SUM, all_gather of [32, 16] f64 result records.  A 1-GPU lease can run it, so
+    API / device-placement / IPC-mode errors of the RCCL path show up without an 8-GPU node.  Creates and destroys its own process
+    group; raises if one is already initialised."""
+    if dist.is_initialized():
+        raise RuntimeError("rccl_selfcheck creates its own process group; call it before dist.init()")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    t0 = time.perf_counter()
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
+    try:
+        init_ms = (time.perf_counter() - t0) * 1e3
+        n = int(weight_mb * 1e6 / 4)
+        buf = torch.arange(n, dtype=torch.float32, device=dev)
+        dist.broadcast(buf, src=0)                       # first call builds the communicator
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.broadcast(buf, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t1) * 1e3
+        dist.barrier(device_ids=[device_index])
+        mx = torch.tensor([3.5], dtype=torch.float64, device=dev); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = torch.tensor([32.0], dtype=torch.float64, device=dev); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        rec = torch.arange(32 * RECORD_F64, dtype=torch.float64, device=dev).reshape(32, RECORD_F64)
+        parts = [torch.empty_like(rec)]
+        dist.all_gather(parts, rec)
+        torch.cuda.synchronize()
+        ok = bool(float(mx.item()) == 3.5 and float(sm.item()) == 32.0 and torch.equal(parts[0], rec) and float(buf[-1].item()) == float(n - 1))
+        return {"ok": ok, "backend": dist.get_backend(), "world": dist.get_world_size(), "device": device_identity(device_index),
+                "init_ms": round(init_ms, 1), "broadcast_mb": round(n * 4 / 1e6, 1), "broadcast_ms": round(bcast_ms, 3)}
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    if "--selfcheck" in sys.argv:
+        res = rccl_selfcheck(0)
+        print(json.dumps(res), flush=True)
+        sys.exit(0 if res["ok"] else 1)

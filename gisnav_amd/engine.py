@@ -25,7 +25,7 @@ RANSAC_REPROJ_PX = 8.0    # cv2.solvePnPRansac default
 RANSAC_CONFIDENCE = 0.99  # cv2.solvePnPRansac default
 
 _PRECISIONS = {"f32": _lib.GN_PREC_F32, "bf16_attn": _lib.GN_PREC_BF16_ATTN, "f32x3_bf16_attn": _lib.GN_PREC_F32X3_BF16_ATTN,
-               "f16x2_bf16_attn": _lib.GN_PREC_F16X2_BF16_ATTN}
+               "f16x2_bf16_attn": _lib.GN_PREC_F16X2_BF16_ATTN, "f16x2_f16_attn": _lib.GN_PREC_F16X2_F16_ATTN}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -37,6 +37,64 @@ def _dev_tensor(t, dtype, device) -> torch.Tensor:
         t = torch.from_numpy(np.ascontiguousarray(t))
     t = t.to(device=device, dtype=dtype, non_blocking=True)
     return t.contiguous()
+
+
+class RecordStager:
+    """Input side of a STREAM of new frame<->tile pairs (pose_node.py:207-213, 254-265): the raw `query_sift` / reference keypoint payloads
+    (532-byte KEYPOINT_DTYPE records) and the DEM rasters of a batch are copied -- bytes, no unpacking -- into pinned host buffers and
+    uploaded on a copy stream into one of `depth` device slots, while the engine works on the previous batch; `k_prep` reads the records
+    as they are (GN_KPT_RECORD).  The reference builds per message: np.frombuffer + np.column_stack + six torch.tensor(...).to(device)
+    calls from pageable memory.
+
+        nxt = stager.stage(msgs)          # host memcpy into pinned memory + async H2D (any thread)
+        stager.wait(cur); eng.estimate(cur, K, out=out); stager.release(cur)
+    """
+
+    def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3):
+        self.eng, self.B, self.K, self.depth = engine, int(max_batch), int(max_kpts), int(depth)
+        dev, (H, W) = engine.device, dem_hw
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        mk = lambda shape, dt, **kw: torch.empty(shape, dtype=dt, **kw)  # noqa: E731
+        self.slots = []
+        for _ in range(self.depth):
+            host = dict(rec_q=mk((self.B, self.K, 133), torch.float32, pin_memory=True), rec_r=mk((self.B, self.K, 133), torch.float32, pin_memory=True),
+                        dem=mk((self.B, H, W), torch.uint8, pin_memory=True), n=mk((2, self.B), torch.int32, pin_memory=True))
+            devb = {k: torch.empty_like(v, device=dev) for k, v in host.items()}
+            self.slots.append(dict(host=host, host_np={k: v.numpy() for k, v in host.items()}, dev=devb,
+                                   uploaded=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False))
+        self._next = 0
+
+    def stage(self, msgs) -> dict:
+        """msgs: up to max_batch tuples (query_sift bytes, reference-keypoint bytes, dem (H, W) uint8).  Returns the inputs dict of
+        `PoseEngine.estimate`; call wait() on the compute stream before using it and release() after the last kernel that reads it."""
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % self.depth
+        if slot["used"]:
+            slot["consumed"].synchronize()           # the batch that last used this slot has been read by its kernels (and its H2D is long done)
+        h = slot["host_np"]
+        B = len(msgs)
+        for b, (q, r, dem) in enumerate(msgs):
+            nq, nr = len(q) // 532, len(r) // 532
+            if nq > self.K or nr > self.K:
+                raise _lib.GnError(f"{max(nq, nr)} keypoints exceed the stager's max_kpts {self.K}")
+            h["rec_q"][b, :nq] = np.frombuffer(q, dtype=np.float32).reshape(nq, 133)      # one memcpy: the wire bytes ARE the device layout
+            h["rec_r"][b, :nr] = np.frombuffer(r, dtype=np.float32).reshape(nr, 133)
+            h["dem"][b] = dem
+            h["n"][0, b], h["n"][1, b] = nq, nr
+        d = slot["dev"]
+        with torch.cuda.stream(self.copy_stream):
+            for k in ("rec_q", "rec_r", "dem", "n"):
+                d[k].copy_(slot["host"][k], non_blocking=True)
+            slot["uploaded"].record(self.copy_stream)
+        slot["used"] = True
+        return dict(kpt_q=d["rec_q"][:B], kpt_r=d["rec_r"][:B], n_q=d["n"][0, :B], n_r=d["n"][1, :B], dem=d["dem"][:B],
+                    desc_q=None, desc_r=None, kpt_format=_lib.GN_KPT_RECORD, _slot=slot)
+
+    def wait(self, inputs: dict) -> None:
+        torch.cuda.current_stream(self.eng.device).wait_event(inputs["_slot"]["uploaded"])
+
+    def release(self, inputs: dict) -> None:
+        inputs["_slot"]["consumed"].record(torch.cuda.current_stream(self.eng.device))
 
 
 class PoseEngine:
@@ -51,6 +109,10 @@ class PoseEngine:
         self.device = torch.device("cuda", device)
         self.max_batch, self.precision = max_batch, precision
         self._n_layers, self._filter_threshold, self._state_dict = n_layers, filter_threshold, None
+        # sticky context state set through this object: replayed onto the new context by grow()
+        self._image_size = (None, None)
+        self._substreams, self._deferred_join, self._overlap = 1, False, False
+        self._sp_state_dict, self._sp_arithmetic = None, None
         self._guard = {"off": 0, "flag": 1, "sync": 2}[guard]
         self.feature = feature
         self._feature = {"sift": _lib.GN_FEATURE_SIFT, "superpoint": _lib.GN_FEATURE_SUPERPOINT}[feature]
@@ -93,6 +155,31 @@ class PoseEngine:
         _lib.check(ctx, self.lib.gn_set_guard(ctx, self._guard), "gn_set_guard")
         if self._state_dict is not None:
             self.load_state_dict(self._state_dict)
+        # every other piece of sticky state this object set on the old context (a grow must not silently drop them)
+        self.set_image_size(*self._image_size)
+        if self._substreams > 1 or self._deferred_join:
+            self.set_substreams(self._substreams, self._deferred_join)
+        if self._overlap:
+            self.set_overlap(True)
+        if self._sp_arithmetic is not None:
+            self.sp_set_arithmetic(self._sp_arithmetic)
+        if self._sp_state_dict is not None:
+            self.sp_load_state_dict(self._sp_state_dict)
+
+    # SuperPoint weights / arithmetic live in the context too (gn_sp_*); kept here so that grow() can replay them
+    def sp_set_arithmetic(self, mode: int) -> None:
+        _lib.check(self.ctx, self.lib.gn_sp_set_arithmetic(self.ctx, int(mode)), "gn_sp_set_arithmetic")
+        self._sp_arithmetic = int(mode)
+
+    def sp_load_state_dict(self, sd) -> None:
+        for name, arr in sd.items():
+            if hasattr(arr, "detach"):
+                arr = arr.detach().cpu().numpy()
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
+            rc = self.lib.gn_sp_load_tensor(self.ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, max(arr.ndim, 1))
+            _lib.check(self.ctx, rc, f"gn_sp_load_tensor({name})")
+        self._sp_state_dict = sd
 
     def load_state_dict(self, sd) -> None:
         self._state_dict = sd
@@ -108,6 +195,7 @@ class PoseEngine:
     def set_image_size(self, wh_q=None, wh_r=None) -> None:
         """kornia LightGlueMatcher's hw1 / hw2 as (w, h): image sizes for the keypoint normalisation; None = keypoint extent (what
         PoseNode gets, pose_node.py:285-287)."""
+        self._image_size = (wh_q, wh_r)
         q, r = wh_q or (0.0, 0.0), wh_r or (0.0, 0.0)
         _lib.check(self.ctx, self.lib.gn_set_image_size(self.ctx, float(q[0]), float(q[1]), float(r[0]), float(r[1])), "gn_set_image_size")
 
@@ -147,15 +235,15 @@ class PoseEngine:
               out: Optional[tuple] = None):
         """gn_match.  Tensors are device tensors: desc [B,S,128] f32, kpt [B,S,4|6] f32, n [B] i32.
         Returns (idx [B,kmax,2] i64, score [B,kmax] f32, n_match [B] i32) on the device."""
-        B = desc_q.shape[0]
+        B = kpt_q.shape[0]
         if out is None:
             idx = torch.empty((B, self.kmax, 2), dtype=torch.int64, device=self.device)
             score = torch.empty((B, self.kmax), dtype=torch.float32, device=self.device)
             n_match = torch.empty((B,), dtype=torch.int32, device=self.device)
         else:
             idx, score, n_match = out
-        rc = self.lib.gn_match(self.ctx, B, kpt_format, _ptr(desc_q), _ptr(kpt_q), _ptr(n_q), desc_q.shape[1],
-                               _ptr(desc_r), _ptr(kpt_r), _ptr(n_r), desc_r.shape[1],
+        rc = self.lib.gn_match(self.ctx, B, kpt_format, _ptr(desc_q), _ptr(kpt_q), _ptr(n_q), kpt_q.shape[1],
+                               _ptr(desc_r), _ptr(kpt_r), _ptr(n_r), kpt_r.shape[1],
                                _ptr(idx), _ptr(score), _ptr(n_match), self._stream())
         _lib.check(self.ctx, rc, "gn_match")
         return idx, score, n_match
@@ -189,12 +277,14 @@ class PoseEngine:
         """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
         before reading R / t / n_inliers / ok."""
         _lib.check(self.ctx, self.lib.gn_set_overlap(self.ctx, int(enable)), "gn_set_overlap")
+        self._overlap = bool(enable)
 
     def set_substreams(self, n: int, deferred_join: bool = False) -> None:
         """Throughput option: every estimate() call runs its pairs as n groups on internal streams (gn_set_substreams).  With
         deferred_join the groups are only joined by flush(): keep the input tensors of a call alive until then."""
         _lib.check(self.ctx, self.lib.gn_set_substreams(self.ctx, int(n)), "gn_set_substreams")
         _lib.check(self.ctx, self.lib.gn_set_deferred_join(self.ctx, int(bool(deferred_join))), "gn_set_deferred_join")
+        self._substreams, self._deferred_join = int(n), bool(deferred_join)
 
     def set_active_kpts(self, max_kpts_per_side: int) -> int:
         """Padded keypoint count the following match()/estimate() calls run at (gn_set_active_kpts): pass the largest keypoint
@@ -209,15 +299,16 @@ class PoseEngine:
 
     def estimate(self, inputs: dict, K: np.ndarray, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
         """gn_estimate on staged inputs: PoseNode._pose lines 246-308 for the whole batch."""
-        B = inputs["desc_q"].shape[0]
+        B = inputs["kpt_q"].shape[0]
         if out is None:
             out = self.alloc_outputs(B)
         dem = inputs.get("dem")
         H, W = (dem.shape[1], dem.shape[2]) if dem is not None else (0, 0)
         K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+        # (GN_KPT_RECORD inputs carry the descriptors inside the keypoint records: desc_q / desc_r are None)
         rc = self.lib.gn_estimate(self.ctx, B, inputs["kpt_format"],
-                                  _ptr(inputs["desc_q"]), _ptr(inputs["kpt_q"]), _ptr(inputs["n_q"]), inputs["desc_q"].shape[1],
-                                  _ptr(inputs["desc_r"]), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["desc_r"].shape[1],
+                                  _ptr(inputs.get("desc_q")), _ptr(inputs["kpt_q"]), _ptr(inputs["n_q"]), inputs["kpt_q"].shape[1],
+                                  _ptr(inputs.get("desc_r")), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["kpt_r"].shape[1],
                                   _ptr(dem), H, W, K9.ctypes.data_as(_lib.c_f64p), min_matches,
                                   _ptr(out["R"]), _ptr(out["t"]), _ptr(out["n_match"]), _ptr(out["n_inliers"]), _ptr(out["ok"]),
                                   self._stream())
@@ -239,6 +330,13 @@ class PoseEngine:
         assert f.shape == t.shape and f.dim() == 3, "expected two (B, H, W) uint8 stacks of one size"
         B = int(f.shape[0])
         kpt, _, _, desc, n = sift.detect_and_compute_batch_device(torch.cat([f, t], 0))
+        totals = sift.last_totals(2 * B)
+        if int(totals.max()) > sift._max:
+            # cv2.SIFT_create() is unbounded (pose_node.py:122); the extractor kept the strongest max_keypoints by response.  Say so
+            # instead of silently matching a truncated cloud; a caller that wants them all passes a larger SIFT / engine.
+            import warnings
+            warnings.warn(f"SIFT found up to {int(totals.max())} keypoints per image, kept the {sift._max} strongest (max_keypoints); "
+                          "create the PoseEngine / SIFT with a larger max_kpts to match them all", RuntimeWarning, stacklevel=2)
         nd = torch.as_tensor(n, device=self.device)
         if dem is None:
             dem = torch.zeros((B, int(f.shape[1]), int(f.shape[2])), dtype=torch.uint8, device=self.device)

@@ -55,7 +55,7 @@ class LightGlueMatcher:
             pass
         for c in cands:
             if c and os.path.exists(c):
-                return torch.load(c, map_location="cpu")
+                return torch.load(c, map_location="cpu", weights_only=True)   # tensors only: never unpickle code from a cache directory
         return None
 
     # torch.nn.Module-shaped conveniences used by the call site
@@ -84,8 +84,6 @@ class LightGlueMatcher:
                  hw1=None, hw2=None):
         if self._engine is None:
             raise _lib.GnError("call .to(device) first")
-        # kornia: image_size = (w, h) from hw when given, else the keypoint extent -- PoseNode passes hw1 = hw2 = None (pose_node.py:285-287)
-        self._engine.set_image_size(None if hw1 is None else (hw1[1], hw1[0]), None if hw2 is None else (hw2[1], hw2[0]))
         dev = self._engine.device
         if desc1.shape[0] < 2 or desc2.shape[0] < 2:
             return torch.zeros((0, 1), dtype=desc1.dtype, device=desc1.device), torch.zeros((0, 2), dtype=torch.int64, device=desc1.device)
@@ -94,6 +92,9 @@ class LightGlueMatcher:
         d1, d2 = f(desc1).reshape(1, -1, D), f(desc2).reshape(1, -1, D)
         if max(d1.shape[1], d2.shape[1]) > self._engine.kmax:      # kornia's matcher takes any number of keypoints
             self._engine.grow(((max(d1.shape[1], d2.shape[1]) + 1023) // 1024) * 1024)
+        # kornia: image_size = (w, h) from hw when given, else the keypoint extent -- PoseNode passes hw1 = hw2 = None (pose_node.py:285-287).
+        # Set AFTER a possible grow(): the re-created context must normalise THIS call's keypoints by the sizes given with it.
+        self._engine.set_image_size(None if hw1 is None else (hw1[1], hw1[0]), None if hw2 is None else (hw2[1], hw2[0]))
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
         n1 = torch.tensor([d1.shape[1]], dtype=torch.int32, device=dev)
         n2 = torch.tensor([d2.shape[1]], dtype=torch.int32, device=dev)

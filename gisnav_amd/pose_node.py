@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from .engine import MIN_MATCHES, PoseEngine
-from .wire import CameraInfo, OrthoStereoImage, unpack_keypoints
+from .wire import CameraInfo, OrthoStereoImage, pack_keypoints
 
 
 class PoseNode:
@@ -48,29 +48,29 @@ class PoseNode:
 
     def estimate(self, camera_info: CameraInfo, msg: OrthoStereoImage) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         eng, dev = self._engine, self._engine.device
-        kp_q, desc_q, size_q, angle_q = unpack_keypoints(msg.query_sift)          # pose_node.py:207-213
+        # pose_node.py:207-213 parses the 532-byte records with np.frombuffer and re-assembles keypoint / descriptor arrays on the host;
+        # here the message bytes go to the device AS THEY ARE (GN_KPT_RECORD): k_prep reads x, y, size, angle and the descriptor
+        # straight from the records
+        n = len(msg.query_sift) // 532
         ref = np.asarray(msg.reference.data)
         assert ref.ndim == 2 or ref.shape[2] == 1
         dem = np.asarray(msg.dem.data)
         stamp = (msg.reference.stamp.sec, msg.reference.stamp.nanosec)
         if self._cached_stamp_kps_desc is None or self._cached_stamp_kps_desc[0] != stamp:  # pose_node.py:226-241
             kp_r, desc_r, size_r, angle_r = self._extractor(ref)
-            f = lambda a, w: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(1, -1, w)).to(dev)  # noqa: E731
-            cached = (f(desc_r, 128), f(np.column_stack([kp_r, size_r, angle_r]), 4),
-                      torch.tensor([len(kp_r)], dtype=torch.int32, device=dev))
+            rec_r = np.frombuffer(pack_keypoints(np.asarray(kp_r, np.float32).reshape(-1, 2), size_r, angle_r, desc_r), dtype=np.float32)
+            cached = (torch.from_numpy(rec_r.reshape(1, -1, 133).copy()).to(dev), torch.tensor([len(kp_r)], dtype=torch.int32, device=dev))
             self._cached_stamp_kps_desc = (stamp, cached)
             self._cached_n_r = len(kp_r)
-        desc_r_t, kpt_r_t, n_r_t = self._cached_stamp_kps_desc[1]
-        n = len(kp_q)
+        rec_r_t, n_r_t = self._cached_stamp_kps_desc[1]
         if n == 0:
             self.last_num_matches = 0
             return None
-        f = lambda a, w: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(1, -1, w)).to(dev)  # noqa: E731
-        inputs = dict(desc_q=f(desc_q, 128), kpt_q=f(np.column_stack([kp_q, size_q, angle_q]), 4),
-                      n_q=torch.tensor([n], dtype=torch.int32, device=dev),
-                      desc_r=desc_r_t, kpt_r=kpt_r_t, n_r=n_r_t,
+        rec_q = torch.from_numpy(np.frombuffer(msg.query_sift, dtype=np.float32).reshape(1, n, 133).copy()).to(dev)
+        inputs = dict(desc_q=None, kpt_q=rec_q, n_q=torch.tensor([n], dtype=torch.int32, device=dev),
+                      desc_r=None, kpt_r=rec_r_t, n_r=n_r_t,
                       dem=torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev),
-                      kpt_format=_lib.GN_KPT_XYSA)
+                      kpt_format=_lib.GN_KPT_RECORD)
         if max(n, self._cached_n_r) > eng.kmax:             # the reference accepts any keypoint count (pose_node.py:122,207): grow, never fail
             eng.grow(((max(n, self._cached_n_r) + 1023) // 1024) * 1024)
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)

@@ -27,19 +27,12 @@ class SuperPoint:
         self._eng = engine if engine is not None else PoseEngine(device, max_batch=1, max_kpts=128, precision="f32", feature="superpoint")
         self._max = int(max_keypoints)
         if arithmetic is not None:
-            _lib.check(self._eng.ctx, self._eng.lib.gn_sp_set_arithmetic(self._eng.ctx, self.ARITHMETIC[arithmetic]), "gn_sp_set_arithmetic")
+            self._eng.sp_set_arithmetic(self.ARITHMETIC[arithmetic])
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
     def load_state_dict(self, sd) -> None:
-        eng = self._eng
-        for name, arr in sd.items():
-            if hasattr(arr, "detach"):
-                arr = arr.detach().cpu().numpy()
-            arr = np.ascontiguousarray(arr, dtype=np.float32)
-            shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
-            rc = eng.lib.gn_sp_load_tensor(eng.ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, max(arr.ndim, 1))
-            _lib.check(eng.ctx, rc, f"gn_sp_load_tensor({name})")
+        self._eng.sp_load_state_dict(sd)     # kept by the engine: PoseEngine.grow() replays it onto the re-created context
 
     def detect_and_describe_device(self, images):
         """images: (B, H, W) uint8 (scaled by 1/255 like the published pre-processing) or float32 in [0, 1], numpy or device tensor;

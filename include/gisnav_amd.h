@@ -62,7 +62,7 @@ enum gn_precision {
                             matrix pipe: every f32 operand is split exactly into three bf16 terms and six
                             partial products are accumulated in f32 (error vs fp64 at or below the exact-f32
                             MFMA path's; see tests) */
-  GN_PREC_F16X2_BF16_ATTN = 3 /* as 2 at half the matrix-pipe work: every f32 operand is split into two fp16
+  GN_PREC_F16X2_BF16_ATTN = 3, /* as 2 at half the matrix-pipe work: every f32 operand is split into two fp16
                             terms (round to nearest, 22 significant bits, subnormals honoured by the gfx950
                             matrix pipe) and three partial products are accumulated in f32; weight planes are
                             pre-scaled by a power of two.  Domain |activation| < 65504 (the reference's fp32
@@ -71,13 +71,27 @@ enum gn_precision {
                             reports ZERO matches instead of inf / NaN, and gn_set_guard(ctx, 2) re-runs it in
                             mode 2 (see gn_set_guard).  Error vs fp64 at the level of an f32 accumulation
                             (see tests) */
+  GN_PREC_F16X2_F16_ATTN = 4  /* as 3, with QK^T / PV on the FP16 matrix instruction (v_mfma_f32_32x32x16_f16): q, k, v and
+                            the probabilities are rounded to fp16 (11 significant bits) instead of bf16 (8), f32 softmax
+                            and accumulation as before -- the arithmetic of the reference's own CUDA path (kornia casts
+                            q, k, v to half for F.scaled_dot_product_attention when flash=True; pose_node.py:285-287 via
+                            SURVEY.md:314), at the same matrix-pipe rate as bf16.  q / k / v share the guarded fp16 domain
+                            of the activations (|value| < 65504, else the guard word is raised; the guard-2 re-run uses bf16
+                            attention operands, which have f32's range) */
 };
 
 enum gn_kpt_format {
   GN_KPT_LAF = 0,        /* 6 floats/keypoint: kornia LAF (2x3 row-major) -- the B1 seam's argument */
-  GN_KPT_XYSA = 1        /* 4 floats/keypoint: x, y, size, angle_deg (cv2.KeyPoint fields,
+  GN_KPT_XYSA = 1,       /* 4 floats/keypoint: x, y, size, angle_deg (cv2.KeyPoint fields,
                             KEYPOINT_DTYPE in _shared.py:26-35); the LAF of pose_node.py:267-276
                             is formed in registers */
+  GN_KPT_RECORD = 2      /* 133 floats/keypoint = the RAW 532-byte wire record of KEYPOINT_DTYPE
+                            (_shared.py:26-35: x, y, z, size, angle, descriptor[128]; all float32,
+                            little endian) exactly as OrthoStereoImage.query_sift
+                            carries it (pose_node.py:207-213): kpt_* point at [B][stride] records, the
+                            descriptor is read from the record itself and the desc_* arguments are
+                            ignored (may be NULL).  The message bytes go to the device as they are --
+                            no host-side unpacking (np.frombuffer + column_stack).  SIFT contexts only. */
 };
 /* OR into kpt_format when the descriptors are ALREADY RootSIFT-normalised (the B1 seam: PoseNode
  * normalises at pose_node.py:278-284 before calling the matcher object); otherwise gn_match applies
@@ -92,7 +106,9 @@ const char* gn_last_error(const gn_ctx* ctx);
 /* The fp16-range guard of GN_PREC_F16X2_BF16_ATTN (no effect in the other modes):
  *   0  off (no checks; an out-of-range activation silently becomes inf / NaN -- for kernel experiments only);
  *   1  (default) flag: stream-ordered, no host sync.  A call in which any activation reached |x| >= 65504 returns
- *      n_match = 0 for every pair (and therefore ok = 0 from gn_estimate); gn_get_guard_status tells the host;
+ *      n_match = 0 for every pair (and therefore ok = 0 from gn_estimate); gn_get_guard_status tells the host.  With
+ *      gn_set_substreams(n > 1) every sub-batch group has its own guard word: a trip zeroes the matches of the pairs of
+ *      THAT group only, and gn_get_guard_status reports the OR over the groups of the last call;
  *   2  flag + fallback: gn_match / gn_estimate synchronise the stream once after the matcher, and a tripped call is
  *      re-run transparently with every operand split exactly into three bf16 terms (the arithmetic of mode
  *      GN_PREC_F32X3_BF16_ATTN: f32 range and accuracy, ~1.5x slower) before the call returns.  The Python mirrors of
@@ -312,7 +328,7 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * phase stamps, 13 out_proj folded into the tail, 14 k_ffn_fused workgroup shape (64 / 32 tokens), 15 PnP phase stamps,
  * 16 fused match head (0 = similarity GEMM + five passes), 17 / 18 k_head_fused phase stamps / ablations, 19 k_qkv projections
  * (0 = tiled GEMM, 2 = force at any batch size), 20 k_qkv phase stamps, 21 SuperPoint split-fp16 convolutions, 23 largest number of key ranges the
- * attention of a small batch is split into (default 1 = never; 4 gives -5 % latency at batch 1 but rounds the probabilities per split).  Knob 1 (attention) values: 4 default,
+ * attention of a small batch is split into (default 1 = never; 4 gives -5 % latency at batch 1 but rounds the probabilities per split), 25 start the guard word of sub-batch group value - 1 raised (tests).  Knob 1 (attention) values: 4 default,
  * 43 / 44 / 45 / 46 / 48 rejected variants kept for A/B timing, 51-55 timing probes with WRONG results, 56 the exact running maximum in every key
  * tile (the path a workgroup of the default kernel falls back to).  A bench line run with any knob set records it in `debug_variant`. */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);

@@ -456,7 +456,7 @@ def full_size(state_dict_np, dev):
     pairs = [make_pair(i) for i in range(32)]
     res = {}
     T = 32 * 2 * 1024
-    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):
+    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"):
         eng = PoseEngine(0, max_batch=32, max_kpts=1024, precision=prec, state_dict=state_dict_np)
         inp = eng.stage_inputs(pairs)
         idx, score, n_match = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
@@ -500,7 +500,7 @@ def test_full_size_matches_are_mutual_sorted_and_correct(full_size):
 
 def test_full_size_pose_close_to_ground_truth(full_size):
     pairs, res = full_size
-    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"):
+    for prec in ("f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"):
         out = res[prec][3]
         assert out["ok"].all()
         for b, p in enumerate(pairs):
@@ -510,7 +510,7 @@ def test_full_size_pose_close_to_ground_truth(full_size):
             assert out["n_inliers"][b] >= 0.9 * out["n_match"][b]
 
 
-@pytest.mark.parametrize("prec", ["bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
+@pytest.mark.parametrize("prec", ["bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
 def test_full_size_reduced_modes_give_the_same_correspondences(full_size, prec):
     _, res = full_size
     i0, s0, n0, _ = res["f32"]
@@ -521,7 +521,7 @@ def test_full_size_reduced_modes_give_the_same_correspondences(full_size, prec):
         assert np.abs(s0[b, : n0[b]] - s1[b, : n0[b]]).max() < 5e-3
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn"])
+@pytest.mark.parametrize("prec", ["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
 def test_full_size_bitwise_repeatable_including_first_run(full_size, prec):
     """Regression guard for a timing-dependent miscompile (SLP-packed v_pk_*_f32 in a GEMM epilogue): the residual
     stream after 9 layers must be bit-identical between the cold first run of a context and a later run."""
@@ -530,7 +530,7 @@ def test_full_size_bitwise_repeatable_including_first_run(full_size, prec):
     assert np.array_equal(x_first.view(np.int32), x_again.view(np.int32))
 
 
-@pytest.mark.parametrize("prec", ["bf16_attn", "f16x2_bf16_attn"])
+@pytest.mark.parametrize("prec", ["bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
 def test_full_size_bitwise_repeatable_over_many_runs(state_dict_np, dev, prec):
     """Sixty bench-sized forwards of one context: the residual stream after 9 layers and the matches are bit-identical every time.
     Two runs are not enough: the ring race this guards against (an LDS-DMA refill overtaking a fragment read that was issued just in

@@ -1,0 +1,470 @@
+"""Round-3 parity tests (-m gpu), closing what VERDICT r2 named:
+
+  * the FULL-SIZE oracle check is no longer a spot check: all 32 bench pairs in f32 mode, and 8 pairs of each FAST mode
+    (f16x2_bf16_attn, f16x2_f16_attn) compared DIRECTLY with the oracle (not with the f32 GPU result) -- indices identical,
+    scores 5e-3, pose 1e-8;
+  * the fp16-attention precision mode (GN_PREC_F16X2_F16_ATTN = the reference's CUDA arithmetic): kernel against fp64, the
+    optimistic-reference fallback at fp16's range, whole matcher against fixtures, low-margin mismatch counts beside bf16's;
+  * configs[4] at ITS size: the SuperPoint extractor at 1920x1080 (batch 2, k = 1024) against the oracle and against a
+    transformers-generated fixture, f32 and split-fp16 arithmetic: the keypoint sets are EQUAL except for keypoints whose
+    decision margin (distance of the score from the top-k cut-off) is below the stated score tolerance, and those are counted;
+  * per-group guard words of sub-batch streams: a trip in one group zeroes that group's pairs only;
+  * PoseEngine.grow() replays sticky context state;
+  * RCCL: a world-1 nccl process group on cuda:0 carries the broadcast / all_gather / all_reduce the N > 1 bench uses, and
+    `bench.py --gpus 2` on a 1-GPU box exits non-zero instead of silently running one rank.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_match
+from gisnav_amd.synthetic import K_MATRIX, make_pair
+from gisnav_amd.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FAST_MODES = ["f16x2_bf16_attn", "f16x2_f16_attn"]
+
+
+def _report(key, value):
+    path = os.path.join(ROOT, "gpurun_out", "parity_r03.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[key] = value
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ------------------------------------------------------------------ full size, directly against the oracle
+@pytest.fixture(scope="module")
+def bench_pairs():
+    return [make_pair(i) for i in range(32)]
+
+
+@pytest.fixture(scope="module")
+def oracle_32(bench_pairs, state_dict_t):
+    """The oracle on ALL 32 bench pairs (1024 keypoints per side): matches + pose.  ~10-20 s of host time."""
+    from oracle import pnp_ransac as pr
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    out = []
+    for p in bench_pairs:
+        mq, mr, sc, oidx = oracle_match(state_dict_t, p)
+        R, t = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
+        out.append((oidx.numpy(), sc.numpy()[:, 0], R, t))
+    return out
+
+
+def _run_mode(prec, pairs, sd):
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=len(pairs), max_kpts=1024, precision=prec, state_dict=sd)
+    inp = eng.stage_inputs(pairs)
+    idx, score, nm = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    out = eng.estimate(inp, K_MATRIX)
+    torch.cuda.synchronize()
+    res = (idx.cpu().numpy(), score.cpu().numpy(), nm.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items()})
+    del eng
+    return res
+
+
+def test_full_size_all_32_pairs_f32_against_oracle(bench_pairs, oracle_32, state_dict_np):
+    idx, score, nm, out = _run_mode("f32", bench_pairs, state_dict_np)
+    worst = [0.0, 0.0, 0.0]
+    for b, (oidx, osc, Ro, to) in enumerate(oracle_32):
+        k = int(nm[b])
+        assert k == len(oidx) and np.array_equal(idx[b, :k], oidx), b            # correspondence indices: bit-exact
+        worst[0] = max(worst[0], float(np.abs(score[b, :k] - osc).max()))
+        worst[1] = max(worst[1], float(np.linalg.norm(out["R"][b] - Ro)))
+        worst[2] = max(worst[2], float(np.linalg.norm(out["t"][b] - to) / np.linalg.norm(to)))
+        assert out["ok"][b] == 1
+    _report("full_size_f32_vs_oracle_32_pairs", {"max_score_err": worst[0], "max_dR": worst[1], "max_dt_rel": worst[2]})
+    assert worst[0] < 1e-5 and worst[1] < 1e-8 and worst[2] < 1e-8, worst
+
+
+@pytest.mark.parametrize("prec", FAST_MODES)
+def test_full_size_fast_modes_directly_against_oracle(prec, bench_pairs, oracle_32, state_dict_np):
+    """The bench's fast precision modes at the bench's size, against the ORACLE (not against the f32 GPU result): 8 of the 32 pairs
+    asserted (every fourth), all 32 counted in the parity report."""
+    idx, score, nm, out = _run_mode(prec, bench_pairs, state_dict_np)
+    mism = 0
+    worst = [0.0, 0.0, 0.0]
+    for b, (oidx, osc, Ro, to) in enumerate(oracle_32):
+        k = int(nm[b])
+        same = k == len(oidx) and np.array_equal(idx[b, :k], oidx)
+        mism += 0 if same else len({tuple(r) for r in idx[b, :k].tolist()} ^ {tuple(r) for r in oidx.tolist()})
+        if b % 4 == 0:
+            assert same, (prec, b)
+            assert np.abs(score[b, :k] - osc).max() < 5e-3
+            assert np.linalg.norm(out["R"][b] - Ro) < 1e-8 and np.linalg.norm(out["t"][b] - to) / np.linalg.norm(to) < 1e-8
+        if same:
+            worst[0] = max(worst[0], float(np.abs(score[b, :k] - osc).max()))
+            worst[1] = max(worst[1], float(np.linalg.norm(out["R"][b] - Ro)))
+            worst[2] = max(worst[2], float(np.linalg.norm(out["t"][b] - to) / np.linalg.norm(to)))
+    _report("full_size_" + prec + "_vs_oracle_32_pairs", {"index_mismatches": mism, "max_score_err": worst[0], "max_dR": worst[1], "max_dt_rel": worst[2]})
+    assert mism == 0, (prec, mism)
+
+
+# ------------------------------------------------------------------ fp16 attention mode
+@pytest.fixture(scope="module")
+def eng_f16(state_dict_np):
+    from gisnav_amd.engine import PoseEngine
+    return PoseEngine(0, max_batch=4, max_kpts=256, precision="f16x2_f16_attn", state_dict=state_dict_np)
+
+
+@pytest.fixture(scope="module")
+def eng_bf16(state_dict_np):
+    from gisnav_amd.engine import PoseEngine
+    return PoseEngine(0, max_batch=4, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+
+
+def _attn_ref(q, k, v, nkv, cross, cast):
+    BS, n, _ = q.shape
+    outs = []
+    for bs in range(BS):
+        kvs = bs ^ 1 if cross else bs
+        m = int(nkv[kvs])
+        qq = cast(q[bs] * 0.125).double().cpu().reshape(n, 4, 64).transpose(0, 1)
+        kk = cast(k[kvs, :m]).double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        vv = cast(v[kvs, :m]).double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        outs.append((torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(n, 256).numpy())
+    return outs
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_fp16_attention_against_fp64_and_tighter_than_bf16(eng_f16, eng_bf16, cross):
+    n, BS = 256, 4
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q, k, v = (torch.randn(BS, n, 256, generator=g).to(dev) for _ in range(3))
+    k[1, 7] *= 6.0
+    nkv = torch.tensor([256, 219, 5, 130], dtype=torch.int32, device=dev)
+    o16 = eng_f16.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+    ob = eng_bf16.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+    ref = _attn_ref(q, k, v, nkv, cross, lambda t: t)
+    e16 = max(_rel(o16[bs], ref[bs]) for bs in range(BS))
+    eb = max(_rel(ob[bs], ref[bs]) for bs in range(BS))
+    _report(f"attention_rel_err_vs_fp64_cross{int(cross)}", {"fp16": e16, "bf16": eb})
+    assert e16 < 3e-3 and eb < 2e-2 and e16 < 0.5 * eb, (e16, eb)      # three more significand bits: ~8x closer (measured)
+    ref16 = _attn_ref(q, k, v, nkv, cross, lambda t: t.half())
+    assert max(_rel(o16[bs], ref16[bs]) for bs in range(BS)) < 1.5e-3    # against fp64 on the fp16-rounded operands: only P's rounding is left
+
+
+@pytest.mark.parametrize("boost", [1.0, 6.0, 40.0])
+def test_fp16_attention_optimistic_reference_falls_back_at_fp16_range(eng_f16, boost):
+    """The optimistic softmax reference of k_attn16_v5 holds while probabilities stay below fp16's 65504 (scores within ~11 of the
+    reference); boosted late keys overflow them -> inf denominators -> the workgroup repeats with the exact running maximum.  The
+    result equals the always-exact variant (knob 1 = 56) and fp64 on fp16-rounded operands at every boost (boost 40: |q.k| ~ 40 x 8 x 0.125
+    is inside fp16's range for the operands, far outside for exp)."""
+    n, BS = 256, 2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q, k, v = (torch.randn(BS, n, 256, generator=g).to(dev) for _ in range(3))
+    k[:, 160:] *= boost
+    nkv = torch.tensor([256, 231], dtype=torch.int32, device=dev)
+    out = eng_f16.debug_attention(q, k, v, nkv, False, 0.125).cpu().numpy()
+    eng_f16.lib.gn_debug_set_variant(eng_f16.ctx, 1, 56)
+    try:
+        exact = eng_f16.debug_attention(q, k, v, nkv, False, 0.125).cpu().numpy()
+    finally:
+        eng_f16.lib.gn_debug_set_variant(eng_f16.ctx, 1, 4)
+    assert np.isfinite(out).all() and np.isfinite(exact).all()
+    ref = _attn_ref(q, k, v, nkv, False, lambda t: t.half())
+    for bs in range(BS):
+        assert _rel(out[bs], ref[bs]) < 3e-3 and _rel(exact[bs], ref[bs]) < 3e-3, (bs, boost)
+        assert _rel(out[bs], exact[bs]) < 2e-3, (bs, boost)
+
+
+@pytest.mark.parametrize("name", ["lightglue_seed0_q96_r80", "lightglue_seed0_q200_r256"])
+def test_fp16_attention_mode_on_golden_fixtures(eng_f16, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    dev = eng_f16.device
+    f = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)[None]  # noqa: E731
+    kq = np.column_stack([z["kp_q"], z["size_q"], z["angle_q"]]).astype(np.float32); kr = np.column_stack([z["kp_r"], z["size_r"], z["angle_r"]]).astype(np.float32)
+    inp = dict(desc_q=f(z["desc_q"]), kpt_q=f(kq), n_q=torch.tensor([len(kq)], dtype=torch.int32, device=dev),
+               desc_r=f(z["desc_r"]), kpt_r=f(kr), n_r=torch.tensor([len(kr)], dtype=torch.int32, device=dev), dem=f(z["dem"], torch.uint8), kpt_format=1)
+    idx, score, nm = eng_f16.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    k = int(nm[0])
+    assert k == len(z["idx"]) and np.array_equal(idx[0, :k].cpu().numpy(), z["idx"])
+    assert np.abs(score[0, :k].cpu().numpy() - z["scores"][:, 0]).max() < 5e-3
+    out = eng_f16.estimate(inp, z["K"])
+    R, t = out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()
+    assert int(out["ok"][0]) == 1 and np.linalg.norm(R - z["R"]) < 1e-8 and np.linalg.norm(t - z["t"]) / np.linalg.norm(z["t"]) < 1e-8
+
+
+def test_fp16_attention_mode_guard_trips_on_out_of_range_q_k_v(state_dict_np):
+    """q / k / v share the guarded fp16 domain.  The q rows of every Wqkv are scaled by 1e6 and the k rows by 1e-6: the scores -- and so the
+    f32 oracle -- are unchanged and every hm16 activation stays where it was, but q no longer fits fp16.  bf16 attention (f32's exponent
+    range) does not care; the fp16-attention mode raises the guard: 'flag' reports ZERO matches (never NaN), 'sync' re-runs the call with
+    bf16 attention operands and returns the oracle's correspondences."""
+    from gisnav_amd.engine import PoseEngine
+    sd = dict(state_dict_np)
+    for i in range(9):
+        for leaf, shape in (("weight", (4, 64, 3, 256)), ("bias", (4, 64, 3))):
+            key = f"transformers.{i}.self_attn.Wqkv.{leaf}"
+            w = sd[key].copy().reshape(shape)
+            w[:, :, 0] *= np.float32(1.0e6); w[:, :, 1] *= np.float32(1.0e-6)
+            sd[key] = w.reshape(sd[key].shape)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    pairs = [make_pair(700 + i, n_q=256, n_r=250) for i in range(2)]
+    ref = [oracle_match(tsd, p) for p in pairs]
+    assert all(len(r[3]) > 50 for r in ref)
+
+    def run(prec, guard):
+        eng = PoseEngine(0, max_batch=2, max_kpts=256, precision=prec, state_dict=sd, guard=guard)
+        inp = eng.stage_inputs(pairs)
+        idx, score, nm = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        torch.cuda.synchronize()
+        return idx.cpu().numpy(), nm.cpu().numpy(), eng.guard_status()
+
+    def close_to_oracle(idx, nm):
+        for b, (_, _, _, oidx) in enumerate(ref):
+            a_ = {tuple(r) for r in idx[b, : nm[b]].tolist()}; b_ = {tuple(r) for r in oidx.numpy().tolist()}
+            assert len(a_ ^ b_) <= 0.02 * len(b_), (b, len(a_ ^ b_), len(b_))
+
+    idx, nm, st = run("f16x2_bf16_attn", "flag")
+    assert st == (False, 0)
+    close_to_oracle(idx, nm)
+    idx, nm, st = run("f16x2_f16_attn", "flag")
+    assert st[0] and (nm == 0).all()
+    idx, nm, st = run("f16x2_f16_attn", "sync")
+    assert st[1] == 1
+    close_to_oracle(idx, nm)
+
+
+# ------------------------------------------------------------------ guard word per sub-batch group, grow() replays state
+def test_guard_words_are_per_substream_group(state_dict_np):
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    inp = eng.stage_inputs([make_pair(80 + i, n_q=256 - 7 * i, n_r=256 - 3 * i) for i in range(4)])
+    ref = {k: v.cpu().numpy().copy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    assert (ref["n_match"] > 30).all() and not eng.guard_status()[0]
+    eng.set_substreams(2)
+    try:
+        eng.lib.gn_debug_set_variant(eng.ctx, 25, 2)                  # group 1 (pairs 2, 3) starts with its guard word raised
+        for _ in range(3):                                             # back to back: group 0 of call n + 1 must not clear group 1's word of call n
+            out = eng.estimate(inp, K_MATRIX, out=eng.alloc_outputs(4))
+        eng.flush(); torch.cuda.synchronize()
+        o = {k: v.cpu().numpy() for k, v in out.items()}
+        assert np.array_equal(o["n_match"][:2], ref["n_match"][:2]) and np.array_equal(o["R"][:2], ref["R"][:2]) and o["ok"][:2].all()
+        assert (o["n_match"][2:] == 0).all() and (o["ok"][2:] == 0).all()
+        assert eng.guard_status()[0]
+        eng.lib.gn_debug_set_variant(eng.ctx, 25, 1)                  # now group 0 only
+        out = eng.estimate(inp, K_MATRIX, out=eng.alloc_outputs(4))
+        eng.flush(); torch.cuda.synchronize()
+        o = {k: v.cpu().numpy() for k, v in out.items()}
+        assert (o["n_match"][:2] == 0).all() and np.array_equal(o["n_match"][2:], ref["n_match"][2:]) and np.array_equal(o["t"][2:], ref["t"][2:])
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 25, 0)
+    out = eng.estimate(inp, K_MATRIX, out=eng.alloc_outputs(4))
+    eng.flush(); torch.cuda.synchronize()
+    assert all(np.array_equal(ref[k], out[k].cpu().numpy()) for k in ref) and not eng.guard_status()[0]
+
+
+def test_grow_replays_sticky_context_state(state_dict_np):
+    """LightGlueMatcher.__call__ with hw1 / hw2 on a cloud larger than the context: grow() first, image sizes after -- the call that
+    triggers the grow is normalised by the GIVEN sizes; a SuperPoint sharing a grown engine keeps its weights and arithmetic."""
+    from gisnav_amd.matcher import LightGlueMatcher
+    from oracle import lightglue_sift as lg
+    p = make_pair(33, n_q=300, n_r=280)
+    tq = torch.from_numpy
+    m = LightGlueMatcher("sift", params={"n_layers": 9, "filter_threshold": 0.5, "depth_confidence": -1, "width_confidence": -1},
+                         state_dict=state_dict_np, max_kpts=128).to("cuda:0").eval()
+    assert m._engine.kmax == 128
+    laf = lambda kp, s, a: lg.laf_from_center_scale_ori(tq(kp)[None], tq(s)[None, :, None, None], tq(a)[None, :, None])  # noqa: E731
+    dq, dr = lg.rootsift(tq(p.desc_q)), lg.rootsift(tq(p.desc_r))
+    hw = (480, 640)
+    dists, idx = m(dq.cuda(), dr.cuda(), laf(p.kp_q, p.size_q, p.angle_q).cuda(), laf(p.kp_r, p.size_r, p.angle_r).cuda(), hw1=hw, hw2=hw)
+    assert m._engine.kmax >= 300
+    dists2, idx2 = m(dq.cuda(), dr.cuda(), laf(p.kp_q, p.size_q, p.angle_q).cuda(), laf(p.kp_r, p.size_r, p.angle_r).cuda(), hw1=hw, hw2=hw)
+    assert torch.equal(idx, idx2) and torch.equal(dists, dists2)     # the growing call already used hw (it used the keypoint extent before)
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_bf16_attn", feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=64, state_dict=osp.synthetic_state_dict(0), arithmetic="fp16")
+    eng.set_substreams(2)
+    img = np.random.default_rng(0).uniform(0, 1, (1, 64, 96)).astype(np.float32)
+    a = [t.cpu().numpy().copy() if hasattr(t, "cpu") else t for t in sp.detect_and_describe_device(img)]
+    eng.grow(512)
+    b = [t.cpu().numpy() if hasattr(t, "cpu") else t for t in sp.detect_and_describe_device(img)]      # weights and arithmetic survived
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and eng._substreams == 2
+
+
+# ------------------------------------------------------------------ configs[4] at its size: SuperPoint at 1920x1080
+def _sp_image(seed, h, w):
+    sys.path.insert(0, GOLD)
+    from make_superpoint_extractor_golden import superpoint_test_image
+    return superpoint_test_image(seed, h, w)
+
+
+def _explain_set_difference(kp_gpu, sc_gpu, kp_ref, sc_ref, k, tol):
+    """Keypoints in exactly one of the two sets are admissible only if their decision margin is below the score tolerance: the score
+    is within `tol` of the top-k cut-off (the k-th score) -- the only decision a 1e-5 score difference can flip once the NMS maps
+    agree.  Returns (symmetric difference, unexplained)."""
+    g = {(int(x), int(y)): float(s) for (x, y), s in zip(kp_gpu, sc_gpu)}
+    r = {(int(x), int(y)): float(s) for (x, y), s in zip(kp_ref, sc_ref)}
+    cut = min(min(r.values()), min(g.values())) if len(r) >= k else 0.005
+    diff = set(g) ^ set(r)
+    bad = [c for c in diff if abs((g.get(c) if c in g else r[c]) - cut) > tol]
+    return len(diff), bad
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+def test_superpoint_extractor_1080p_against_oracle_and_transformers_fixture(prec):
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    z = np.load(os.path.join(GOLD, "superpoint_extractor_seed7_1920x1080.npz"))
+    h, w, k = int(z["h"]), int(z["w"]), int(z["k"])
+    u8a, u8b = _sp_image(int(z["seed"]), h, w), _sp_image(8, h, w)
+    assert hashlib.sha256(u8a.tobytes()).hexdigest() == str(z["image_sha256"]), "this platform regenerates different pixels: regenerate the fixture"
+    sd = osp.synthetic_state_dict(0)
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision=prec, feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=k, state_dict=sd)
+    batch = np.stack([u8a, u8b])                                                  # batch 2, as uint8 frames (scaled by 1/255 on the device)
+    kpt, score, desc, n = sp.detect_and_describe_device(batch)
+    torch.cuda.synchronize()
+    kpt, score, desc = kpt.cpu().numpy(), score.cpu().numpy(), desc.cpu().numpy()
+    rep = {}
+    for b, u8 in enumerate((u8a, u8b)):
+        img = torch.from_numpy(u8.astype(np.float32) * np.float32(1.0 / 255.0))
+        okp, osc, od = osp.detect_and_describe(sd, img, k)
+        m = int(n[b])
+        assert m == len(okp) == k
+        ndiff, bad = _explain_set_difference(kpt[b, :m, :2], score[b, :m], okp.numpy(), osc.numpy(), k, 2e-5)
+        assert not bad, (prec, b, bad[:5])
+        assert ndiff <= 8, (prec, b, ndiff)                                       # a handful of cut-off near-ties at most (measured: see the report)
+        got = {(int(x), int(y)): i for i, (x, y) in enumerate(kpt[b, :m, :2])}
+        ref = {(int(x), int(y)): i for i, (x, y) in enumerate(okp.numpy())}
+        common = sorted(set(got) & set(ref))
+        gi = np.array([got[c] for c in common]); ri = np.array([ref[c] for c in common])
+        s_err = float(np.abs(score[b][gi] - osc.numpy()[ri]).max()); d_err = float(np.abs(desc[b][gi] - od.numpy()[ri]).max())
+        assert s_err < 1e-5 and d_err < 1e-4, (s_err, d_err)
+        assert (np.diff(score[b, :m]) <= 0).all()
+        rep[f"image{b}"] = {"keypoints": m, "set_difference": ndiff, "max_score_err": s_err, "max_desc_err": d_err}
+    # image 0 against the transformers-generated fixture (third-party code, not the repo's oracle)
+    ndiff, bad = _explain_set_difference(kpt[0, :k, :2], score[0, :k], z["keypoints"], z["scores"], k, 2e-5)
+    assert not bad and ndiff <= 8, (prec, ndiff, bad[:5])
+    got = {(int(x), int(y)): i for i, (x, y) in enumerate(kpt[0, :k, :2])}
+    every4 = [(i, got.get((int(x), int(y)))) for i, (x, y) in enumerate(z["keypoints"]) if i % 4 == 0]
+    pairs = [(i // 4, j) for i, j in every4 if j is not None]
+    assert len(pairs) >= 250
+    d_err = float(np.abs(desc[0][[j for _, j in pairs]] - z["desc_every4"][[i for i, _ in pairs]]).max())
+    assert d_err < 1e-4, d_err
+    rep["vs_transformers_fixture"] = {"set_difference": ndiff, "max_desc_err_every4": d_err}
+    _report("superpoint_1080p_" + prec, rep)
+
+
+# ------------------------------------------------------------------ RCCL / N > 1 launch path
+def _env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_rccl_selfcheck_world1_on_cuda0():
+    """The collectives the N > 1 bench uses (broadcast of the flattened weights, barrier, all_reduce MAX / SUM, all_gather of result
+    records) on a world-1 `nccl` (= RCCL) process group on cuda:0, in a fresh process."""
+    r = subprocess.run([sys.executable, "-m", "gisnav_amd.dist", "--selfcheck"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["ok"] and line["world"] == 1 and line["broadcast_mb"] > 40
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_gpus():
+    """`python bench.py --gpus 2` without torchrun spawns 2 nccl ranks itself; on a box with ONE GPU it must exit non-zero with a clear
+    message (and print no JSON line) instead of silently measuring one rank."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a 1-GPU box (on a multi-GPU box the same command measures 2 ranks)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "visible" in r.stderr and "--gpus 2" in r.stderr, r.stderr[-2000:]
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+# ------------------------------------------------------------------ input side: raw wire records, pinned double-buffered staging
+def _wire_batch(seed0, B, n):
+    from gisnav_amd import wire
+    pairs = [make_pair(seed0 + i, n_q=n - 3 * i, n_r=n - 5 * i) for i in range(B)]
+    msgs = [(wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q), wire.pack_keypoints(p.kp_r, p.size_r, p.angle_r, p.desc_r), p.dem) for p in pairs]
+    return pairs, msgs
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2_bf16_attn"])
+def test_wire_records_on_the_device_equal_host_unpacked_inputs(prec, state_dict_np):
+    """GN_KPT_RECORD: the 532-byte KEYPOINT_DTYPE records of OrthoStereoImage.query_sift uploaded as they are give bit-identical
+    matches and poses to the host-unpacked (x, y, size, angle) + descriptor arrays (pose_node.py:207-213), also with sub-batch streams."""
+    from gisnav_amd import _lib
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=256, precision=prec, state_dict=state_dict_np)
+    pairs, msgs = _wire_batch(900, 4, 256)
+    inp = eng.stage_inputs(pairs)
+    ref = {k: v.cpu().numpy().copy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    ridx, rsc, rn = (v.cpu().numpy().copy() for v in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+    assert ref["ok"].all() and (ref["n_match"] > 30).all()
+    dev = eng.device
+    rec = lambda side: torch.zeros((4, 256, 133), dtype=torch.float32, device=dev)  # noqa: E731
+    rq, rr = rec(0), rec(1)
+    for b, (q, r, _) in enumerate(msgs):
+        rq[b, : len(q) // 532] = torch.from_numpy(np.frombuffer(q, dtype=np.float32).reshape(-1, 133).copy()).to(dev)
+        rr[b, : len(r) // 532] = torch.from_numpy(np.frombuffer(r, dtype=np.float32).reshape(-1, 133).copy()).to(dev)
+    rinp = dict(desc_q=None, desc_r=None, kpt_q=rq, kpt_r=rr, n_q=inp["n_q"], n_r=inp["n_r"], dem=inp["dem"], kpt_format=_lib.GN_KPT_RECORD)
+    idx, sc, nm = eng.match(None, rq, inp["n_q"], None, rr, inp["n_r"], kpt_format=_lib.GN_KPT_RECORD)
+    torch.cuda.synchronize()
+    assert np.array_equal(nm.cpu().numpy(), rn)
+    for b in range(4):
+        assert np.array_equal(idx[b, : rn[b]].cpu().numpy(), ridx[b, : rn[b]]) and np.array_equal(sc[b, : rn[b]].cpu().numpy(), rsc[b, : rn[b]])
+    for nsub in (1, 2):
+        eng.set_substreams(nsub)
+        out = eng.estimate(rinp, K_MATRIX)
+        eng.flush(); torch.cuda.synchronize()
+        assert all(np.array_equal(ref[k], out[k].cpu().numpy()) for k in ref), nsub
+    eng.set_substreams(1)
+    with pytest.raises(RuntimeError):        # 256-d feature contexts have no wire-record format
+        e2 = PoseEngine(0, max_batch=1, max_kpts=128, precision="f32", feature="superpoint", state_dict=synthetic_state_dict(0, feature="superpoint"))
+        e2.match(None, rq[:1, :128], inp["n_q"][:1], None, rr[:1, :128], inp["n_r"][:1], kpt_format=_lib.GN_KPT_RECORD)
+
+
+def test_record_stager_streams_new_batches_with_identical_results(state_dict_np):
+    """RecordStager: 7 DIFFERENT batches through 2 device slots (so slots are re-used while earlier work may still be running), staging of
+    batch i + 1 issued before the estimate of batch i is enqueued: every batch's outputs equal the plain serial path's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gisnav_amd.engine import PoseEngine, RecordStager
+    eng = PoseEngine(0, max_batch=3, max_kpts=256, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    batches = [_wire_batch(1000 + 10 * s, 3, 256 - 8 * s) for s in range(7)]
+    serial = []
+    for pairs, _ in batches:
+        o = eng.estimate(eng.stage_inputs(pairs), K_MATRIX)
+        torch.cuda.synchronize()
+        serial.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+    st = RecordStager(eng, max_batch=3, max_kpts=256, dem_hw=(480, 640), depth=2)
+    outs = [eng.alloc_outputs(3) for _ in batches]
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        cur = st.stage(batches[0][1])
+        for i in range(len(batches)):
+            fut = pool.submit(st.stage, batches[i + 1][1]) if i + 1 < len(batches) else None
+            st.wait(cur)
+            eng.estimate(cur, K_MATRIX, out=outs[i])
+            st.release(cur)
+            cur = fut.result() if fut else None
+    eng.flush(); torch.cuda.synchronize()
+    for s, o in zip(serial, outs):
+        assert s["ok"].all()
+        for k in s:
+            assert np.array_equal(s[k], o[k].cpu().numpy()), k

@@ -195,3 +195,44 @@ def test_bench_json_contract_fields_present_in_source():
                 '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"workload"',
                 '"traffic"', '"extra_configs"', '"inputs_resident"', '"debug_variant"', '"pcie_inclusive"', '"multi_gpu"', '"end_to_end"'):
         assert key in src, key
+
+
+def test_bench_refuses_more_gpus_than_visible_and_mismatched_world():
+    """`python bench.py --gpus N` must never silently run fewer ranks than asked for.  Without a launcher it spawns the
+    ranks itself -- and refuses (exit code 2, no JSON line) when the box shows fewer GPUs; under a launcher whose WORLD_SIZE differs from
+    --gpus it refuses as well.  (On this GPU-less container both paths stop before any device work.)"""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs: the same command would run the 2-rank bench")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "does not match --gpus 4" in r.stderr
+
+
+def _worker_ident(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from gisnav_amd import dist as gd
+    gd.init("gloo")
+    q.put((rank, gd.gather_strings(f"{rank}:gpu{rank}")))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo_rank_identity_gather():
+    """bench.py's liveness check: every rank contributes `rank:device-identity`; the line is only printed when N ranks on N devices answered."""
+    from gisnav_amd import dist as gd
+    world, port = 2, gd.free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ident, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ids == ["0:gpu0", "1:gpu1"] for _, ids in res)

@@ -266,3 +266,19 @@ def test_superpoint_split_convolutions_fall_back_when_activations_leave_fp16_ran
     a, b = res["f32"], res["f16x2_bf16_attn"]
     assert a[3] == b[3] > 0 and np.isfinite(b[2]).all()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])               # the SAME exact-f32 kernels ran
+
+
+def test_oracle_reproduces_the_transformers_extractor_fixture_at_1080p():
+    """configs[4]'s frame size: oracle/superpoint.py on the seeded 1920x1080 frame gives the keypoints / scores / descriptors that
+    transformers' SuperPointForKeypointDetection produced (tests/golden/make_superpoint_extractor_golden.py)."""
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_superpoint_extractor_golden import superpoint_test_image
+    from oracle import superpoint as osp
+    z = np.load(os.path.join(GOLD, "superpoint_extractor_seed7_1920x1080.npz"))
+    u8 = superpoint_test_image(int(z["seed"]), int(z["h"]), int(z["w"]))
+    assert hashlib.sha256(u8.tobytes()).hexdigest() == str(z["image_sha256"])
+    kp, sc, d = osp.detect_and_describe(osp.synthetic_state_dict(0), torch.from_numpy(u8.astype(np.float32) * np.float32(1.0 / 255.0)), int(z["k"]))
+    assert np.array_equal(kp.numpy().astype(np.int16), z["keypoints"])
+    assert np.abs(sc.numpy() - z["scores"]).max() < 1e-6 and np.abs(d.numpy()[::4] - z["desc_every4"]).max() < 1e-6
