@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgisnav_amd.so")
-SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_qkv.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip"]
+SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_qkv.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
 # -fno-slp-vectorize: with SLP packing on, hipcc (ROCm 7.2) turned the rotary epilogue's scalar f32 math into
 # v_pk_mul_f32 / v_pk_fma_f32 sequences with op_sel that produced timing-dependent wrong results on gfx950 when
 # two waves share a SIMD (one float4 component of a 16-lane group, a few elements per 10^7; found with a

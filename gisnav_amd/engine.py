@@ -50,8 +50,12 @@ class RecordStager:
         stager.wait(cur); eng.estimate(cur, K, out=out); stager.release(cur)
     """
 
-    def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3):
+    def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3, copy_threads: int = 4):
+        from concurrent.futures import ThreadPoolExecutor
         self.eng, self.B, self.K, self.depth = engine, int(max_batch), int(max_kpts), int(depth)
+        # the pinned-memory copies of a batch (35 MB at 32 x 1024 keypoints per side) run on a few host threads: one thread's memcpy
+        # (~6 GB/s) would be slower than the GPU's step; numpy releases the GIL inside the copies
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(copy_threads))) if copy_threads > 1 else None
         dev, (H, W) = engine.device, dem_hw
         self.copy_stream = torch.cuda.Stream(device=dev)
         mk = lambda shape, dt, **kw: torch.empty(shape, dtype=dt, **kw)  # noqa: E731
@@ -73,7 +77,9 @@ class RecordStager:
             slot["consumed"].synchronize()           # the batch that last used this slot has been read by its kernels (and its H2D is long done)
         h = slot["host_np"]
         B = len(msgs)
-        for b, (q, r, dem) in enumerate(msgs):
+
+        def copy_pair(b):
+            q, r, dem = msgs[b]
             nq, nr = len(q) // 532, len(r) // 532
             if nq > self.K or nr > self.K:
                 raise _lib.GnError(f"{max(nq, nr)} keypoints exceed the stager's max_kpts {self.K}")
@@ -81,6 +87,12 @@ class RecordStager:
             h["rec_r"][b, :nr] = np.frombuffer(r, dtype=np.float32).reshape(nr, 133)
             h["dem"][b] = dem
             h["n"][0, b], h["n"][1, b] = nq, nr
+
+        if self._pool is not None and B > 1:
+            list(self._pool.map(copy_pair, range(B)))
+        else:
+            for b in range(B):
+                copy_pair(b)
         d = slot["dev"]
         with torch.cuda.stream(self.copy_stream):
             for k in ("rec_q", "rec_r", "dem", "n"):

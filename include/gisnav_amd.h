@@ -302,6 +302,34 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
 enum { GN_SP_EXACT_F32 = 0, GN_SP_SPLIT_FP16 = 1, GN_SP_FP16 = 2 };
 int gn_sp_set_arithmetic(gn_ctx* ctx, int mode);
 
+/* ---- LoFTR (BASELINE.json north_star "LoFTR / SuperPoint+LightGlue", configs[1] "LoFTR matcher ... fp32"; not in the reference tree) ---- */
+/* kornia.feature.LoFTR(pretrained = "outdoor").forward({"image0", "image1"}) -> keypoints0 / keypoints1 / confidence for ONE pair of equally
+ * sized grayscale images (the detector-free matcher older GISNav releases used; at this tag only the word survives:
+ * docs/vitepress/docs/glossary.md:186).  f32 throughout: ResNet-FPN backbone on the exact f32 matrix instruction, 4 x (self, cross)
+ * LINEAR-attention encoder layers at 1/8 resolution, dual-softmax coarse matching (temperature 0.1, threshold 0.2, border 2, mutual
+ * maxima), and -- when `fine` is set -- the 5x5-window fine level that refines keypoints1 to sub-pixel positions.  Specification:
+ * the published architecture as restated in oracle/loftr.py (parity UNPINNED: kornia is not importable in the build image).
+ * A context is sized for one image shape (H, W multiples of 8); it is separate from gn_ctx and owns its weights. */
+typedef struct gn_loftr gn_loftr;
+int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loftr** out);
+void gn_loftr_destroy(gn_loftr* ctx);
+const char* gn_loftr_last_error(const gn_loftr* ctx);
+/* One tensor of kornia's LoFTR state dict from HOST memory (float32, torch layout): backbone.* (convolutions [out][in][k][k], BatchNorm
+ * weight / bias / running_mean / running_var), loftr_coarse.layers.{0..7}.* and loftr_fine.layers.{0,1}.* ({q,k,v}_proj, merge, mlp.0,
+ * mlp.2 weights; norm1 / norm2 weight + bias), fine_preprocess.{down_proj,merge_feat}.{weight,bias}.  pos_encoding.pe and
+ * num_batches_tracked entries are accepted and ignored. */
+int gn_loftr_load_tensor(gn_loftr* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+int gn_loftr_missing_tensors(const gn_loftr* ctx);
+/* image0 / image1: DEVICE f32 [H][W] in [0, 1].  Outputs (device): kpts0 / kpts1 [max_matches][2] (x, y) pixels (kpts0 on the 1/8 grid;
+ * kpts1 = coarse cell + fine offset, or the coarse cell without a fine level), conf [max_matches], ij (optional, may be NULL)
+ * [max_matches][2] int32 coarse cell indices (i in image0, j in image1); matches in ascending i.  *n_host (HOST): number of matches;
+ * the call synchronises `stream` once to return it. */
+int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, float* kpts0, float* kpts1, float* conf, int32_t* ij,
+                   int32_t* n_host, void* stream);
+/* test hook: internal tensor -> HOST after synchronising.  Names: "x1" "x2" "x3" "x3_out" "x1_out" (NHWC, 196 channels padded to 224),
+ * "tok" ([2][Lp][256] coarse features after the transformer), "sim", "crow", "ccol", "ftok".  Returns the element count or a negative status. */
+int64_t gn_loftr_debug_read(gn_loftr* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream);
+
 /* ---- test / profiling hooks (not part of the drop-in surface) --------------------------- */
 /* Copy an internal workspace tensor to HOST memory after synchronising `stream`.
  * Names: "desc" "cos" "sin" "x" "qkv" "ctx" "msg" "h" "md" "ls" "sim" "rowmax" "rowlog"
