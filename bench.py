@@ -302,6 +302,51 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def loftr_gflop_per_pair(h: int, w: int, fine: bool = True) -> float:
+    """Algorithmic work of one LoFTR pair (2 x MACs): ResNet-FPN backbone on both images, 8 encoder-layer applications per image at 1/8
+    resolution, the coarse similarity matrix (the fine level's per-match work is a few MFLOP per match and left out)."""
+    p2, p4, p8 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
+    macs = p2 * 128 * 49 + 4 * p2 * 128 * 128 * 9
+    macs += p4 * 196 * 128 * 9 + 3 * p4 * 196 * 196 * 9 + p4 * 196 * 128
+    macs += p8 * 256 * 196 * 9 + 3 * p8 * 256 * 256 * 9 + p8 * 256 * 196 + p8 * 256 * 256
+    if fine:
+        macs += p4 * 256 * 196 + p4 * 256 * 256 * 9 + p4 * 196 * 256 * 9 + p2 * 196 * 128 + p2 * 196 * 196 * 9 + p2 * 128 * 196 * 9
+    macs *= 2                                                            # two images
+    macs += 2 * 8 * p8 * (3 * 256 * 256 + 256 * 256 + 512 * 512 + 256 * 512)
+    macs += p8 * p8 * 256
+    return 2.0 * macs / 1e9
+
+
+def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True):
+    """BASELINE configs[1] as literally worded: ONE 640x480 pair through the LoFTR matcher in fp32 (gn_loftr_match: ResNet-FPN backbone on the
+    exact-f32 matrix instruction, linear-attention transformer, dual-softmax coarse matching, fine level), seeded random weights."""
+    from gisnav_amd.loftr import LoFTR
+
+    sd = olf.synthetic_state_dict(0)
+    i0, i1 = olf.synthetic_pair(1, h, w)
+    m = LoFTR(state_dict=sd, fine=fine).to(dev).eval()
+    data = {"image0": i0.to(dev), "image1": i1.to(dev)}
+    for _ in range(warmup):
+        out = m(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = m(data)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    g = loftr_gflop_per_pair(h, w, fine)
+    res = {"config": f"BASELINE configs[1] as worded: batch-1 {w}x{h} pair, LoFTR matcher (ResNet-FPN + 4x(self, cross) linear attention + dual-softmax coarse matching"
+                     f"{' + fine level' if fine else ''}), fp32 (exact-f32 MFMA)",
+           "batch": 1, "precision": "f32", "steps": steps, "warmup": warmup, "value": round(steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)",
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "matches": int(out["keypoints0"].shape[0]), "algorithmic_gflop_per_pair": round(g, 1),
+           "end_to_end_tflops": round(g / (elapsed / steps) / 1e3, 1), "peak_tflops": PEAK_F32_MFMA_TFLOPS,
+           "end_to_end_frac_of_peak": round(g / (elapsed / steps) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "note": "the model named by configs[1] is not in the reference tree; random-init weights calibrated so that the dual-softmax has confident mutual maxima"}
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
     """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a
     bounded sample of the same workload."""
@@ -346,6 +391,7 @@ def main() -> None:
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct staged batches (all resident in HBM) the timed steps rotate over")
+    ap.add_argument("--only-loftr", action="store_true", help="time only the LoFTR extra (configs[1] as worded) and print its JSON")
     ap.add_argument("--no-rccl-check", action="store_true", help="skip the world-1 RCCL self-check of the N = 1 run (multi_gpu.rccl_selfcheck_world1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive streaming measurement (pcie_inclusive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -363,6 +409,11 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
+    if args.only_loftr:
+        torch.cuda.set_device(0)
+        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0))), flush=True)
+        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), fine=False)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))            # no launcher around us: become one (N ranks over RCCL), or refuse
     if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
@@ -465,6 +516,7 @@ def main() -> None:
                                 args.batch, args.kpts, "bf16_attn", 6, 2, dev))
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
                                 1, args.kpts, args.precision, 30, 5, dev))
+        extras.append(run_extra_loftr(local_rank, 10, 2, dev))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev, arithmetic="fp16"))
 

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   long long ts[8];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg_ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
-  float amax = 0.f;   // F16: max |value| this lane stored
 
   // ---- token tile: thread -> (row, 16-byte chunk) of every k-tile; chunk c of row r sits at position c ^ swz(r)
   {
@@ -127,6 +126,7 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     stamp(2 + 2 * pass);
+    float amax = 0.f;   // F16: max |value| this lane stores in this pass (scoped to the epilogue: the k-loop has no register to spare)
     if (!vpass) {
       // register r of tile j <-> feature 32 tile + (r & 3) + 8 (r >> 2) + 4 hh, token 32 j + ql.  Every table entry and bias this lane
       // needs is requested FIRST, back to back (the weight ring and the token fragments are dead: the registers are there): the
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
           if (!(a.vt_perm & 2)) *reinterpret_cast<uint4*>(dst + 32 * j + 8 * (2 * m + hh)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
     }
+    if (F16) ovf_commit(a.ovf, amax);
     stamp(3 + 2 * pass);
   }
-  if (F16) ovf_commit(a.ovf, amax);
   if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps per wave
     for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * 8 + wave) * 8 + k] = ts[k];
   }

@@ -273,7 +273,7 @@ def synthetic_state_dict(seed: int = 0, mlp_out_gain: float = 0.25) -> Dict[str,
     block("backbone.layer1.0", d0, d0, 1); block("backbone.layer1.1", d0, d0, 1)
     block("backbone.layer2.0", d0, d1, 2); block("backbone.layer2.1", d1, d1, 1)
     block("backbone.layer3.0", d1, d2, 2); block("backbone.layer3.1", d2, d2, 1)
-    conv("backbone.layer3_outconv", d2, d2, 1)
+    conv("backbone.layer3_outconv", d2, d2, 1, gain=2.0)
     conv("backbone.layer2_outconv", d2, d1, 1)
     conv("backbone.layer2_outconv2.0", d2, d2, 3); bn("backbone.layer2_outconv2.1", d2); conv("backbone.layer2_outconv2.3", d1, d2, 3)
     conv("backbone.layer1_outconv", d1, d0, 1)

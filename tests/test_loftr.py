@@ -157,3 +157,13 @@ def test_loftr_coarse_only_context_and_drop_in_dictionary(sd):
     assert all(torch.equal(out[k], out2[k]) for k in out)
     with pytest.raises(RuntimeError):
         LoFTR(state_dict={"backbone.conv1.weight": sd["backbone.conv1.weight"]}).to("cuda:0")({"image0": i0.cuda(), "image1": i1.cuda()})
+
+
+def test_product_side_synthetic_generator_equals_the_oracles(sd):
+    """bench.py times LoFTR with gisnav_amd.loftr_synthetic (the product never imports oracle/): same tensors, same image pairs."""
+    from gisnav_amd import loftr_synthetic as ls
+    mine = ls.synthetic_state_dict(0)
+    assert set(mine) == set(sd) and all(torch.equal(mine[k], sd[k]) for k in sd)
+    a, b = lf.synthetic_pair(4, 64, 96)
+    c, d = ls.synthetic_pair(4, 64, 96)
+    assert torch.equal(a, c) and torch.equal(b, d)
