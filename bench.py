@@ -320,8 +320,8 @@ def loftr_gflop_per_pair(h: int, w: int, fine: bool = True) -> float:
 def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True):
     """BASELINE configs[1] as literally worded: ONE 640x480 pair through the LoFTR matcher in fp32 (gn_loftr_match: ResNet-FPN backbone on the
     exact-f32 matrix instruction, linear-attention transformer, dual-softmax coarse matching, fine level), seeded random weights."""
+    from gisnav_amd import loftr_synthetic as olf
     from gisnav_amd.loftr import LoFTR
-
     sd = olf.synthetic_state_dict(0)
     i0, i1 = olf.synthetic_pair(1, h, w)
     m = LoFTR(state_dict=sd, fine=fine).to(dev).eval()
@@ -389,7 +389,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--precision", default="f16x2_bf16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
+    ap.add_argument("--precision", default="f16x2_f16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct staged batches (all resident in HBM) the timed steps rotate over")
     ap.add_argument("--only-loftr", action="store_true", help="time only the LoFTR extra (configs[1] as worded) and print its JSON")
     ap.add_argument("--no-rccl-check", action="store_true", help="skip the world-1 RCCL self-check of the N = 1 run (multi_gpu.rccl_selfcheck_world1)")

@@ -593,6 +593,7 @@ constexpr int kNumConv = 22;
 // BatchNorm (eval) as scale / shift, padded channels, fragment-order weights
 int lf_finalise(gn_loftr* ctx) {
   for (int ci = 0; ci < kNumConv; ++ci) {
+    if (!ctx->fine && ci >= 16) continue;            // the FPN head below 1/8 resolution only feeds the fine level
     auto it = ctx->conv.find(kConvNames[ci]);
     if (it == ctx->conv.end() || it->second.hw.empty()) return lf_fail(ctx, GN_ERR_WEIGHTS, std::string("missing tensor ") + kConvNames[ci] + ".weight");
     LfConv& c = it->second;
