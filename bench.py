@@ -425,8 +425,12 @@ def main() -> None:
         sys.exit(2)
     rccl_check = None
     if args.gpus == 1 and args.backend == "nccl" and not args.debug_variant and not args.no_rccl_check:
-        try:                                   # the collectives of the N > 1 path on a world-1 RCCL group: what a 1-GPU lease can prove
-            rccl_check = gdist.rccl_selfcheck(0)
+        try:   # the collectives of the N > 1 path on a world-1 RCCL group: what a 1-GPU lease can prove.  In a child process: RCCL writes a
+            #      banner to the C-level stdout, and this process's stdout carries exactly one line
+            r = subprocess.run([sys.executable, "-m", "gisnav_amd.dist", "--selfcheck"], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            rccl_check = json.loads(js[-1]) if js else {"ok": False, "error": (r.stderr or r.stdout)[-300:]}
         except Exception as exc:  # noqa: BLE001
             rccl_check = {"ok": False, "error": repr(exc)[:300]}
     rank, local_rank, world = gdist.init(args.backend)
@@ -625,6 +629,11 @@ def main() -> None:
         line["extra_configs"] = extras
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, args.kpts)
+        try:   # anything libraries left in the C-level stdout buffer (RCCL's banner) goes out BEFORE the line: the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(line), flush=True)
     gdist.barrier()
 

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench_n1.json
+python $R/bench.py 2> $O/${TAG}_bench.err | grep '^{"metric' | tail -1 > $O/${TAG}_bench_n1.json
 rm -rf $O/${TAG}_prof && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --substreams 1 > /dev/null 2>&1
 cp $(ls $O/${TAG}_prof/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats.csv
 rm -rf $O/${TAG}_prof
