@@ -98,6 +98,19 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // weight fragments of one tap (CH / 8 channel steps x two 32-channel tiles) travel L2 -> registers one tap AHEAD of the MFMAs that use
+  // them: with one wave per SIMD nothing else hides the ~1 us of L2 latency (the first build fetched them right in front of each step's
+  // MFMAs and ran at 45 TF)
+  constexpr int NS = CH / 8;
+  f32x4 wcur[NS][2], wnxt[NS][2];
+  auto load_w = [&](f32x4 (&w)[NS][2], int c0_, int tap_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      w[s][0] = wf[(size_t)(((2 * og) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
+      if (two) w[s][1] = wf[(size_t)(((2 * og + 1) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
+    }
+  };
+  load_w(wcur, 0, 0);
   for (int c0 = 0; c0 < a.Cin; c0 += CH) {
     __syncthreads();
     constexpr int NP = LH * LW * NCH, NQ = (NP + 255) / 256, SB = 8;
@@ -128,11 +141,12 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
       const int ty = tap / KS, tx = tap - ty * KS;
+      // next tap of this slice, or the first tap of the next slice (its request then also overlaps the staging of that slice)
+      const bool last_tap = tap + 1 == TAPS;
+      if (!last_tap || c0 + CH < a.Cin) load_w(wnxt, last_tap ? c0 + CH : c0, last_tap ? 0 : tap + 1);
 #pragma unroll
-      for (int s = 0; s < CH / 8; ++s) {
-        f32x4 fa[2], fb[RPW];
-        fa[0] = wf[(size_t)(((2 * og) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
-        if (two) fa[1] = wf[(size_t)(((2 * og + 1) * TAPS + tap) * csteps + (c0 / 8 + s)) * 64];
+      for (int s = 0; s < NS; ++s) {
+        f32x4 fb[RPW];
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
           const int ly = (RPW * wave + j) * S + ty, lx = ql * S + tx;
@@ -142,10 +156,12 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int j = 0; j < RPW; ++j) {
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[j][e], acc[0][j], 0, 0, 0);
-            if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[j][e], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][0][e], fb[j][e], acc[0][j], 0, 0, 0);
+            if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][1][e], fb[j][e], acc[1][j], 0, 0, 0);
           }
       }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { wcur[s][0] = wnxt[s][0]; wcur[s][1] = wnxt[s][1]; }
     }
   }
   // epilogue: lane = pixel (row RPW wave + j, column ql); registers 4 g + c = output channels 64 og + 32 i + 8 g + 4 hh + c
@@ -655,6 +671,29 @@ void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const f
 void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pad, int d, int cross, int mode,
                 float* qkv, float* att, float* msg, float* hid, float* kvpart, float* kv, hipStream_t s) {
   const int heads = kLfHeads, hd = d / heads, nall = rows_pad / seq_rows;
+  if (cross && nall == 2 && hd == 32 && seq_rows % 128 == 0) {
+    // the coarse level's cross halves: only sequence a = mode - 1 is updated, only sequence b = 1 - a is attended to -- project q for a's rows,
+    // k | v for b's rows, and run merge / MLP / norms over a's rows alone (half the work of the general path below)
+    const int a = mode - 1, b = 1 - a;
+    float* xa = x + (size_t)a * seq_rows * d; const float* xb = x + (size_t)b * seq_rows * d;
+    float* qa = qkv + (size_t)a * seq_rows * 3 * d; float* kvb = qkv + (size_t)b * seq_rows * 3 * d + d;
+    float* atta = att + (size_t)a * seq_rows * d; float* msga = msg + (size_t)a * seq_rows * d; float* hida = hid + (size_t)a * seq_rows * 2 * d;
+    lf_gemm(xa, d, nullptr, 0, 0, ly.qkv.w, d, nullptr, qa, 3 * d, seq_rows, d, d, s);
+    lf_gemm(xb, d, nullptr, 0, 0, ly.qkv.w + (size_t)d * d, d, nullptr, kvb, 3 * d, seq_rows, 2 * d, d, s);
+    const int chunk = 192, nsplit = (Lseq + chunk - 1) / chunk;
+    const long long per = (long long)heads * 33 * 32;
+    hipLaunchKernelGGL(k_lf_kv_partial<32>, dim3(heads, nsplit, 1), dim3(256), 0, s, kvb, kvb + d, 3 * d, 0LL, Lseq, chunk, (float)Lseq, kvpart, nsplit, heads);
+    hipLaunchKernelGGL(k_lf_kv_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, kvpart, kv, nsplit, per, 1);
+    const size_t smem = (size_t)(per + 8 * d) * sizeof(float);
+    hipLaunchKernelGGL(k_lf_attn_apply<32>, dim3((Lseq + 7) / 8, 1), dim3(256), smem, s, qa, 3 * d, 0LL, kv, 0, atta, d, 0LL, Lseq, (float)Lseq, heads);
+    lf_gemm(atta, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msga, d, seq_rows, d, d, s);
+    hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((seq_rows + 3) / 4)), dim3(256), 0, s, msga, ly.n1g, ly.n1b, (const float*)nullptr, msga, (long long)seq_rows, d, seq_rows, 0);
+    lf_gemm(xa, d, msga, d, d, ly.mlp0.w, 2 * d, nullptr, hida, 2 * d, seq_rows, 2 * d, 2 * d, s);
+    hipLaunchKernelGGL(k_lf_relu, dim3((unsigned)(((long long)seq_rows * 2 * d / 4 + 255) / 256)), dim3(256), 0, s, hida, (long long)seq_rows * 2 * d / 4);
+    lf_gemm(hida, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, atta, d, seq_rows, d, 2 * d, s);
+    hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((seq_rows + 3) / 4)), dim3(256), 0, s, atta, ly.n2g, ly.n2b, xa, xa, (long long)seq_rows, d, seq_rows, 0);
+    return;
+  }
   lf_gemm(x, d, nullptr, 0, 0, ly.qkv.w, d, nullptr, qkv, 3 * d, rows_pad, 3 * d, d, s);
   const int chunk = Lseq <= 64 ? 64 : 192, nsplit = (Lseq + chunk - 1) / chunk;
   const long long per = (long long)heads * (hd + 1) * hd;
