@@ -385,8 +385,8 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--precision", default="f16x2_f16_attn", choices=["f32", "bf16_attn", "f32x3_bf16_attn", "f16x2_bf16_attn", "f16x2_f16_attn"])
