@@ -647,10 +647,35 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   a.in = in; a.Hin = Hin; a.Win = Win; a.Cin = c.cin_p; a.wf = c.wf; a.scale = c.scale; a.shift = c.shift; a.resid = resid;
   a.out = out; a.Hout = Hin / stride; a.Wout = Win / stride; a.Cout = c.cout_p; a.act = act;
   const int og = (c.cout_p + 63) / 64;
-  if (c.ks == 3 && stride == 1) hipLaunchKernelGGL((k_lf_conv<3, 1, 4, 32>), dim3((a.Wout + 31) / 32, (a.Hout + 15) / 16, N * og), dim3(256), 0, s, a);
-  else if (c.ks == 3) hipLaunchKernelGGL((k_lf_conv<3, 2, 2, 16>), dim3((a.Wout + 31) / 32, (a.Hout + 7) / 8, N * og), dim3(256), 0, s, a);
-  else if (stride == 1) hipLaunchKernelGGL((k_lf_conv<1, 1, 4, 32>), dim3((a.Wout + 31) / 32, (a.Hout + 15) / 16, N * og), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_lf_conv<1, 2, 2, 16>), dim3((a.Wout + 31) / 32, (a.Hout + 7) / 8, N * og), dim3(256), 0, s, a);
+  // rows per wave (RPW): the workgroup covers 4 RPW output rows x 32 columns x 64 channels and one workgroup fits a CU, so a launch takes
+  // ceil(workgroups / 256) rounds of RPW units each -- pick the RPW with the fewest units (layer1 at 240x320: 600 workgroups = 3 rounds of 4
+  // against 1200 = 5 rounds of 2; the 1/8-resolution layers fill 96 CUs with RPW = 4 and 192 with 2)
+  auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return ((wg + 255) / 256) * rpw; };
+  const dim3 blk(256);
+  auto grid = [&](int rpw) { return dim3((a.Wout + 31) / 32, (a.Hout + 4 * rpw - 1) / (4 * rpw), N * og); };
+  if (stride == 1) {
+    int rpw = 4;
+    if (units(2) < units(rpw)) rpw = 2;
+    if (units(1) < units(rpw)) rpw = 1;
+    if (c.ks == 3) {
+      if (rpw == 4) hipLaunchKernelGGL((k_lf_conv<3, 1, 4, 32>), grid(4), blk, 0, s, a);
+      else if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<3, 1, 2, 32>), grid(2), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_lf_conv<3, 1, 1, 32>), grid(1), blk, 0, s, a);
+    } else {
+      if (rpw == 4) hipLaunchKernelGGL((k_lf_conv<1, 1, 4, 32>), grid(4), blk, 0, s, a);
+      else if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<1, 1, 2, 32>), grid(2), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_lf_conv<1, 1, 1, 32>), grid(1), blk, 0, s, a);
+    }
+  } else {
+    const int rpw = units(1) < units(2) ? 1 : 2;
+    if (c.ks == 3) {
+      if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<3, 2, 2, 16>), grid(2), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_lf_conv<3, 2, 1, 16>), grid(1), blk, 0, s, a);
+    } else {
+      if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<1, 2, 2, 16>), grid(2), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_lf_conv<1, 2, 1, 16>), grid(1), blk, 0, s, a);
+    }
+  }
 }
 
 void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s) {

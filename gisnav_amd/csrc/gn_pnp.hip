@@ -1435,6 +1435,134 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
   }
 }
 
+// ---- P3P: cv::solvePnPRansac with npoints == 4 makes one solvePnP(SOLVEPNP_P3P) call (core/_shared.py:109-116 -> calib3d solvepnp.cpp): Gao's
+// P3P on the first three points (OpenCV p3p.cpp solve_for_lengths), the fourth point picks the pose.  Scalar f64 code run by ONE lane -- the
+// branch is unreachable from PoseNode (MIN_MATCHES 15) and TwistNode (30) and exists for the compute_pose seam.  Restated in oracle/pnp_ransac.py
+// (solve_p3p): same polynomial, same acceptance tests, same candidate order (ascending root), triad alignment on both sides.
+__device__ int quartic_real_roots(double A, double B, double C, double D, double E, double out[4]) {
+  // all four roots by Aberth-Ehrlich iteration in complex arithmetic (monic form), then the real ones, ascending
+  const double b = B / A, c = C / A, d = D / A, e = E / A;
+  const double rad = 1.0 + fmax(fmax(fabs(b), fabs(c)), fmax(fabs(d), fabs(e)));
+  double zr[4], zi[4];
+  for (int k = 0; k < 4; ++k) { const double ang = 0.7 + 1.5707963267948966 * k; zr[k] = 0.5 * rad * cos(ang); zi[k] = 0.5 * rad * sin(ang); }
+  for (int it = 0; it < 200; ++it) {
+    double moved = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      // p(z), p'(z) by Horner
+      double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
+      const double co[4] = {b, c, d, e};
+      for (int j = 0; j < 4; ++j) {
+        const double ndr = dr * zr[k] - di * zi[k] + pr, ndi = dr * zi[k] + di * zr[k] + pi;
+        dr = ndr; di = ndi;
+        const double npr = pr * zr[k] - pi * zi[k] + co[j], npi = pr * zi[k] + pi * zr[k];
+        pr = npr; pi = npi;
+      }
+      double dn = dr * dr + di * di;
+      if (dn == 0.0) { dr = 1e-300; dn = 1e-600; }
+      double wr = (pr * dr + pi * di) / dn, wi = (pi * dr - pr * di) / dn;       // w = p / p'
+      double sr = 0.0, si = 0.0;                                               // sum 1 / (z_k - z_j)
+      for (int j = 0; j < 4; ++j) {
+        if (j == k) continue;
+        const double xr = zr[k] - zr[j], xi = zi[k] - zi[j], xn = xr * xr + xi * xi;
+        if (xn > 0.0) { sr += xr / xn; si -= xi / xn; }
+      }
+      const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr), qn = qr * qr + qi * qi;
+      if (qn > 0.0) { const double ur = (wr * qr + wi * qi) / qn, ui = (wi * qr - wr * qi) / qn; wr = ur; wi = ui; }
+      zr[k] -= wr; zi[k] -= wi;
+      moved = fmax(moved, fabs(wr) + fabs(wi));
+    }
+    if (moved < 1e-15 * rad) break;
+  }
+  int n = 0;
+  for (int k = 0; k < 4; ++k)
+    if (fabs(zi[k]) <= 1e-9 * fmax(1.0, fabs(zr[k]))) out[n++] = zr[k];
+  for (int i = 1; i < n; ++i) for (int j = i; j > 0 && out[j - 1] > out[j]; --j) { const double tmp = out[j]; out[j] = out[j - 1]; out[j - 1] = tmp; }
+  return n;
+}
+
+__device__ inline void triad3(const double p0[3], const double p1[3], const double p2[3], double F[3][3]) {
+  double e1[3], u[3], e3[3], e2[3];
+  for (int i = 0; i < 3; ++i) { e1[i] = p1[i] - p0[i]; u[i] = p2[i] - p0[i]; }
+  double n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  for (int i = 0; i < 3; ++i) e1[i] /= n1;
+  cross3(e1, u, e3);
+  n1 = sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+  for (int i = 0; i < 3; ++i) e3[i] /= n1;
+  cross3(e3, e1, e2);
+  for (int i = 0; i < 3; ++i) { F[i][0] = e1[i]; F[i][1] = e2[i]; F[i][2] = e3[i]; }
+}
+
+__device__ __noinline__ bool p3p_gao(const float* obj, const float* img, const Cam& cam, double Rb[3][3], double tb[3]) {
+  double X[4][3], u[4][2], f[3][3];
+  for (int i = 0; i < 4; ++i) {
+    for (int k = 0; k < 3; ++k) X[i][k] = (double)obj[3 * i + k];
+    // cv::undistortPoints keeps the input's depth: normalised coordinates computed in double, stored as float32
+    u[i][0] = (double)(float)(((double)img[2 * i] - cam.cx) / cam.fx);
+    u[i][1] = (double)(float)(((double)img[2 * i + 1] - cam.cy) / cam.fy);
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double nn = sqrt(u[i][0] * u[i][0] + u[i][1] * u[i][1] + 1.0);
+    f[i][0] = u[i][0] / nn; f[i][1] = u[i][1] / nn; f[i][2] = 1.0 / nn;
+  }
+  auto dist = [&](int i, int j) { const double a0 = X[i][0] - X[j][0], a1 = X[i][1] - X[j][1], a2 = X[i][2] - X[j][2]; return sqrt(a0 * a0 + a1 * a1 + a2 * a2); };
+  auto dotf = [&](int i, int j) { return f[i][0] * f[j][0] + f[i][1] * f[j][1] + f[i][2] * f[j][2]; };
+  const double d0 = dist(1, 2), d1 = dist(0, 2), d2 = dist(0, 1);
+  if (d0 == 0.0 || d1 == 0.0 || d2 == 0.0) return false;
+  const double p = 2 * dotf(1, 2), q = 2 * dotf(0, 2), r = 2 * dotf(0, 1);
+  const double inv_d22 = 1.0 / (d2 * d2);
+  const double a = inv_d22 * d0 * d0, b = inv_d22 * d1 * d1;
+  const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, pr = p * r, pqr = q * p * r;
+  if (p2 + q2 + r2 - pqr - 1 == 0) return false;
+  const double ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+  const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+  if (A == 0) return false;
+  const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+  const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+  const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+  const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+  const double temp = p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr;
+  const double b0 = b * temp * temp;
+  if (b0 == 0) return false;
+  double roots[4];
+  const int nr = quartic_real_roots(A, B, C, D, E, roots);
+  const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+  double Fo[3][3];
+  triad3(X[0], X[1], X[2], Fo);
+  double best = INFINITY;
+  bool found = false;
+  for (int k = 0; k < nr; ++k) {
+    const double x = roots[k];
+    if (x <= 0) continue;
+    const double x2 = x * x;
+    const double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+        (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+          (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+         (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+          pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+         2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+         p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (b1 <= 0) continue;
+    const double y = b1 / b0, v = x2 + y * y - x * y * r;
+    if (v <= 0) continue;
+    const double Z = d2 / sqrt(v);
+    const double len[3] = {x * Z, y * Z, Z};
+    double M[3][3], Fc[3][3], R[3][3], t[3];
+    for (int i = 0; i < 3; ++i) for (int c2 = 0; c2 < 3; ++c2) M[i][c2] = f[i][c2] * len[i];
+    triad3(M[0], M[1], M[2], Fc);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = Fc[i][0] * Fo[j][0] + Fc[i][1] * Fo[j][1] + Fc[i][2] * Fo[j][2];
+    for (int i = 0; i < 3; ++i) t[i] = M[0][i] - (R[i][0] * X[0][0] + R[i][1] * X[0][1] + R[i][2] * X[0][2]);
+    double pc[3];
+    for (int i = 0; i < 3; ++i) pc[i] = R[i][0] * X[3][0] + R[i][1] * X[3][1] + R[i][2] * X[3][2] + t[i];
+    double err = INFINITY;
+    if (pc[2] != 0) { const double ex = pc[0] / pc[2] - u[3][0], ey = pc[1] / pc[2] - u[3][1]; err = ex * ex + ey * ey; }
+    if (!found || err < best) {
+      best = err; found = true;
+      for (int i = 0; i < 3; ++i) { tb[i] = t[i]; for (int j = 0; j < 3; ++j) Rb[i][j] = R[i][j]; }
+    }
+  }
+  return found;
+}
+
 constexpr int kLdsPts = 2048;   // inlier correspondences k_pnp_refine keeps in LDS (20 bytes each)
 __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   __shared__ Shared sh;
@@ -1449,6 +1577,20 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
   long long ts[8];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg_ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
+  if (n == 4 && a.min_pts <= 4) {   // solvePnPRansac's npoints == 4 branch: one P3P solve, every point an inlier, no refinement
+    if (lane == 0) {
+      double Rb[3][3], tb[3], rv[3], Rf[3][3], dummy[3][9];
+      bool ok4 = p3p_gao(a.obj + (size_t)b * a.kstride * 3, a.img + (size_t)b * a.kstride * 2, cam, Rb, tb);
+      if (ok4) {
+        rodrigues_m2v(Rb, rv);                       // the reference applies cv2.Rodrigues to the returned rvec
+        rodrigues_v2m(rv, Rf, dummy, false);
+        for (int i = 0; i < 3; ++i) { ok4 = ok4 && isfinite(tb[i]); for (int j = 0; j < 3; ++j) ok4 = ok4 && isfinite(Rf[i][j]); }
+      }
+      for (int i = 0; i < 3; ++i) { tout[i] = ok4 ? tb[i] : 0.0; for (int j = 0; j < 3; ++j) Rout[3 * i + j] = ok4 ? Rf[i][j] : (i == j ? 1.0 : 0.0); }
+      a.ok[b] = ok4 ? 1 : 0; a.n_inliers[b] = ok4 ? 4 : 0;
+    }
+    return;
+  }
   if (n < a.min_pts || n < 5) {
     if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
     if (lane < 3) tout[lane] = 0.0;

@@ -171,7 +171,8 @@ int gn_gather_points(gn_ctx* ctx, int B, int kpt_format,
 /* Batched solvePnPRansac + Rodrigues.
  *   obj [B][kstride][3] f32, img [B][kstride][2] f32, n_pts [B] int32, K9: HOST 3x3 row-major f64.
  * Outputs (device): R [B][9] f64 row-major, t [B][3] f64, n_inliers [B] int32,
- * ok [B] u8 (0 when n_pts < min_pts or RANSAC found no model with > 4 inliers). */
+ * ok [B] u8 (0 when n_pts < min_pts or RANSAC found no model with > 4 inliers).  n_pts == 4 with min_pts <= 4 takes OpenCV's
+ * `npoints == 4` branch: one P3P solve (Gao) on the first three points, the fourth picks the pose, all four are inliers, no refinement. */
 int gn_pnp_ransac(gn_ctx* ctx, int B, const float* obj, const float* img, const int32_t* n_pts, int kstride,
                   const double* K9_host, int iterations_count, float reproj_error_px, double confidence,
                   int min_pts, double* R, double* t, int32_t* n_inliers, uint8_t* ok, void* stream);

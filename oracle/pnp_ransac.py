@@ -572,23 +572,114 @@ def solve_pnp_iterative(obj: np.ndarray, img: np.ndarray, A: np.ndarray):
     return _levmarq_pose(obj, img, A, r, t)
 
 
+# ----------------------------------------------------------------------------- P3P (npoints == 4)
+def _p3p_lengths(distances, cosines):
+    """OpenCV p3p.cpp `solve_for_lengths` (Gao, Hou, Tang, Cheng 2003): the quartic in x = |OP0| / |OP2| and the rational y(x).
+    distances = (|P1P2|, |P0P2|, |P0P1|), cosines = (cos(f1, f2), cos(f0, f2), cos(f0, f1)) of the unit bearing vectors.
+    Returns up to 4 length triples (|OP0|, |OP1|, |OP2|).  The quartic's real roots come from numpy's companion-matrix solver (OpenCV: Ferrari)."""
+    p, q, r = 2 * cosines[0], 2 * cosines[1], 2 * cosines[2]
+    inv_d22 = 1.0 / (distances[2] * distances[2])
+    a = inv_d22 * distances[0] * distances[0]
+    b = inv_d22 * distances[1] * distances[1]
+    a2, b2, p2, q2, r2 = a * a, b * b, p * p, q * q, r * r
+    pr, pqr = p * r, q * p * r
+    if p2 + q2 + r2 - pqr - 1 == 0:
+        return []
+    ab, a_2, a_4 = a * b, 2 * a, 4 * a
+    A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2
+    if A == 0:
+        return []
+    B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab)
+    C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2
+    D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2)
+    E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2
+    temp = p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr
+    b0 = b * temp * temp
+    if b0 == 0:
+        return []
+    roots = np.roots([A, B, C, D, E])
+    real = sorted(float(z.real) for z in roots if abs(z.imag) <= 1e-9 * max(1.0, abs(z.real)))
+    r3, pr2 = r2 * r, p * r2
+    r3q = r3 * q
+    out = []
+    for x in real:
+        if x <= 0:
+            continue
+        x2 = x * x
+        b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) * (
+            ((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x
+             + (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2
+            + (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2)
+               + pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x
+            + 2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2)
+            + p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)))
+        if b1 <= 0:
+            continue
+        y = b1 / b0
+        v = x2 + y * y - x * y * r
+        if v <= 0:
+            continue
+        Z = distances[2] / np.sqrt(v)
+        out.append((x * Z, y * Z, Z))
+    return out
+
+
+def _triad(p0, p1, p2):
+    e1 = (p1 - p0) / np.linalg.norm(p1 - p0)
+    e3 = np.cross(e1, p2 - p0)
+    e3 = e3 / np.linalg.norm(e3)
+    return np.stack([e1, np.cross(e3, e1), e3], axis=1)
+
+
+def solve_p3p(obj: np.ndarray, und: np.ndarray):
+    """cv::solvePnP(SOLVEPNP_P3P) on exactly 4 correspondences (what solvePnPRansac does when npoints == 4, _shared.py:109-116): the first
+    three points give up to four poses (Gao's P3P), the fourth picks the one with the smallest reprojection error.  obj (4,3) f64,
+    und (4,2) normalised image points.  The rigid alignment of the three reconstructed camera-frame points with the object points is done
+    with orthonormal triads (OpenCV: Horn's quaternion least squares -- identical for congruent triangles, which these are to round-off).
+    Returns (R, t) or None."""
+    f = np.column_stack([und[:3], np.ones(3)])
+    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+    d = (np.linalg.norm(obj[1] - obj[2]), np.linalg.norm(obj[0] - obj[2]), np.linalg.norm(obj[0] - obj[1]))
+    c = (float(f[1] @ f[2]), float(f[0] @ f[2]), float(f[0] @ f[1]))
+    if min(d) == 0:
+        return None
+    best = None
+    for L in _p3p_lengths(d, c):
+        M = f * np.asarray(L)[:, None]
+        Fo, Fc = _triad(obj[0], obj[1], obj[2]), _triad(M[0], M[1], M[2])
+        R = Fc @ Fo.T
+        t = M[0] - R @ obj[0]
+        pc = R @ obj[3] + t
+        err = (pc[0] / pc[2] - und[3, 0]) ** 2 + (pc[1] / pc[2] - und[3, 1]) ** 2 if pc[2] != 0 else np.inf
+        if best is None or err < best[0]:
+            best = (err, R, t)
+    return None if best is None else (best[1], best[2])
+
+
 # ----------------------------------------------------------------------------- solvePnPRansac
 def solve_pnp_ransac(obj: np.ndarray, img: np.ndarray, A: np.ndarray, iterations_count: int = 10,
                      reproj_error: float = 8.0, confidence: float = 0.99):
     """cv2.solvePnPRansac(obj f32 (K,3), img f32 (K,2), A f64, dist=0, False, iterations_count).
 
     Returns (ok, rvec (3,1) f64, tvec (3,1) f64, inliers (n,) int or None).
-    The K == 4 (P3P) branch of OpenCV is out of scope: PoseNode never calls with fewer than
-    MIN_MATCHES = 15 points (pose_node.py:299-303).
+    K == 4: OpenCV makes ONE solvePnP(SOLVEPNP_P3P) call, every point an inlier, no refinement (`solve_p3p`); unreachable from PoseNode
+    (MIN_MATCHES = 15, pose_node.py:299-303) and TwistNode (30), reachable through compute_pose.  K < 4: cv2 raises; here (False, ...).
     """
     obj = np.asarray(obj, np.float32)
     img = np.asarray(img, np.float32)
     count = len(obj)
     model_points = 5
-    if count < model_points:
-        return False, None, None, None
     A = np.asarray(A, np.float64).reshape(3, 3)
     obj64, img64 = obj.astype(np.float64), img.astype(np.float64)
+    if count == 4:
+        und4 = np.column_stack([(img64[:, 0] - A[0, 2]) / A[0, 0], (img64[:, 1] - A[1, 2]) / A[1, 1]]).astype(np.float32).astype(np.float64)
+        sol = solve_p3p(obj64, und4)
+        if sol is None:
+            return False, None, None, None
+        r = rodrigues_mat2vec(sol[0])
+        return True, r.reshape(3, 1), np.asarray(sol[1]).reshape(3, 1), np.arange(4)
+    if count < model_points:
+        return False, None, None, None
     # solvePnP(SOLVEPNP_EPNP) runs cv::undistortPoints on the subset; its output Mat takes the INPUT's depth, so for the float32 image
     # points PoseNode passes, epnp reads normalised coordinates that were computed in double and stored as float32
     und = np.column_stack([(img64[:, 0] - A[0, 2]) / A[0, 0], (img64[:, 1] - A[1, 2]) / A[1, 1]]).astype(np.float32).astype(np.float64)

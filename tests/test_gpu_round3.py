@@ -468,3 +468,41 @@ def test_record_stager_streams_new_batches_with_identical_results(state_dict_np)
         assert s["ok"].all()
         for k in s:
             assert np.array_equal(s[k], o[k].cpu().numpy()), k
+
+
+# ------------------------------------------------------------------ solvePnPRansac's npoints == 4 branch (P3P) through the B2 seam
+def test_compute_pose_with_exactly_four_points_takes_the_p3p_branch():
+    """`compute_pose(camera_info, mkp_qry, mkp_ref, elevation)` with four matches (core/_shared.py:109-116 -> cv2's npoints == 4 branch): Gao's P3P
+    on the GPU against the oracle's restatement on 150 noisy scenes with DEM relief -- the same branch of the four-fold ambiguity, pose 1e-6
+    (the two sides find the quartic's roots differently: Aberth iteration vs numpy's companion matrix); 3 points -> None on both sides."""
+    from gisnav_amd import pose as gpose
+    from gisnav_amd.wire import CameraInfo
+    from oracle import pnp_ransac as pr
+    rs = np.random.default_rng(5)
+    K = K_MATRIX
+    cam = CameraInfo(k=K.reshape(-1))
+    dem = (20 + 15 * np.sin(np.arange(480)[:, None] / 40.0) * np.cos(np.arange(640)[None, :] / 55.0)).astype(np.uint8)
+    worst, done = 0.0, 0
+    while done < 150:
+        rv = rs.normal(0, 0.25, 3)
+        R = pr.rodrigues_vec2mat(rv.reshape(3, 1))
+        t = np.array([rs.uniform(-40, 40), rs.uniform(-40, 40), rs.uniform(220, 380)])
+        ref = np.column_stack([rs.uniform(60, 580, 4), rs.uniform(60, 420, 4)]).astype(np.float32)
+        x, y = np.floor(ref).astype(int).T
+        obj = np.column_stack([ref, dem[y, x]]).astype(np.float64)
+        pc = (R @ obj.T).T + t
+        if (pc[:, 2] <= 1).any():
+            continue
+        qry = ((K @ (pc / pc[:, 2:]).T).T[:, :2] + rs.normal(0, 0.3, (4, 2))).astype(np.float32)
+        want = pr.compute_pose(K.reshape(-1), qry, ref, dem)
+        got = gpose.compute_pose(cam, qry, ref, dem)
+        assert (want is None) == (got is None)
+        if want is None:
+            continue
+        done += 1
+        e = max(np.linalg.norm(got[0] - want[0]), np.linalg.norm(got[1] - want[1]) / np.linalg.norm(want[1]))
+        worst = max(worst, float(e))
+        assert e < 1e-6, (done, e)
+        assert abs(np.linalg.det(got[0]) - 1) < 1e-12
+    _report("p3p_four_point_branch_150_scenes", {"max_pose_delta_vs_oracle": worst})
+    assert gpose.compute_pose(cam, qry[:3], ref[:3], dem) is None and pr.compute_pose(K.reshape(-1), qry[:3], ref[:3], dem) is None

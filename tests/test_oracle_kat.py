@@ -269,3 +269,27 @@ def test_full_oracle_pipeline_on_synthetic_pair(state_dict_t):
     assert len(idx) >= 15 and (gt == idx[:, 1].numpy()).mean() > 0.98
     R, t = pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem)
     assert np.linalg.norm(R - p.R_gt) < 5e-3
+
+
+def test_p3p_branch_recovers_the_pose_from_exactly_four_points():
+    """cv2.solvePnPRansac with npoints == 4 (core/_shared.py:109-116): one P3P solve, the 4th point disambiguates, all four are inliers.
+    382 random valid scenes (every point in front of the camera), float32 inputs: the true pose within 2e-4; 3 points -> no pose."""
+    from oracle import pnp_ransac as pr
+    rs = np.random.default_rng(0)
+    K = np.array([[205.47, 0, 320], [0, 205.47, 240], [0, 0, 1.0]])
+    n = 0
+    for _ in range(400):
+        rv = rs.normal(0, 0.3, 3)
+        R = pr.rodrigues_vec2mat(rv.reshape(3, 1))
+        t = np.array([rs.uniform(-50, 50), rs.uniform(-50, 50), rs.uniform(200, 400)])
+        obj = np.column_stack([rs.uniform(100, 540, 4), rs.uniform(80, 400, 4), rs.uniform(0, 40, 4)])
+        pc = (R @ obj.T).T + t
+        if (pc[:, 2] <= 1).any():
+            continue
+        n += 1
+        img = (K @ (pc / pc[:, 2:]).T).T[:, :2]
+        ok, r, tt, inl = pr.solve_pnp_ransac(obj.astype(np.float32), img.astype(np.float32), K, 10)
+        assert ok and list(inl) == [0, 1, 2, 3]
+        assert np.linalg.norm(pr.rodrigues_vec2mat(r) - R) < 2e-4 and np.linalg.norm(tt.ravel() - t) / np.linalg.norm(t) < 2e-4
+    assert n > 300
+    assert pr.solve_pnp_ransac(obj[:3].astype(np.float32), img[:3].astype(np.float32), K, 10)[0] is False
