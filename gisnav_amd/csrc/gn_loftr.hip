@@ -650,7 +650,8 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   // rows per wave (RPW): the workgroup covers 4 RPW output rows x 32 columns x 64 channels and one workgroup fits a CU, so a launch takes
   // ceil(workgroups / 256) rounds of RPW units each -- pick the RPW with the fewest units (layer1 at 240x320: 600 workgroups = 3 rounds of 4
   // against 1200 = 5 rounds of 2; the 1/8-resolution layers fill 96 CUs with RPW = 4 and 192 with 2)
-  auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return ((wg + 255) / 256) * rpw; };
+  // (+ 0.75: the halo rows, the weight stream and the prologue a workgroup pays whatever its height -- without it RPW = 1 wins ties it loses on the GPU)
+  auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return (double)((wg + 255) / 256) * (rpw + 0.75); };
   const dim3 blk(256);
   auto grid = [&](int rpw) { return dim3((a.Wout + 31) / 32, (a.Hout + 4 * rpw - 1) / (4 * rpw), N * og); };
   if (stride == 1) {

@@ -1475,7 +1475,15 @@ __device__ int quartic_real_roots(double A, double B, double C, double D, double
   }
   int n = 0;
   for (int k = 0; k < 4; ++k)
-    if (fabs(zi[k]) <= 1e-9 * fmax(1.0, fabs(zr[k]))) out[n++] = zr[k];
+    if (fabs(zi[k]) <= 1e-9 * fmax(1.0, fabs(zr[k]))) {
+      double x = zr[k];
+      for (int it = 0; it < 4; ++it) {          // Newton polish on the real axis (the oracle does the same after numpy's eigenvalue solver)
+        const double pv = (((x + b) * x + c) * x + d) * x + e, dv = ((4.0 * x + 3.0 * b) * x + 2.0 * c) * x + d;
+        if (dv == 0.0) break;
+        x -= pv / dv;
+      }
+      out[n++] = x;
+    }
   for (int i = 1; i < n; ++i) for (int j = i; j > 0 && out[j - 1] > out[j]; --j) { const double tmp = out[j]; out[j] = out[j - 1]; out[j - 1] = tmp; }
   return n;
 }

@@ -598,7 +598,19 @@ def _p3p_lengths(distances, cosines):
     if b0 == 0:
         return []
     roots = np.roots([A, B, C, D, E])
-    real = sorted(float(z.real) for z in roots if abs(z.imag) <= 1e-9 * max(1.0, abs(z.real)))
+    real = []
+    bm, cm, dm, em = B / A, C / A, D / A, E / A
+    for z in roots:
+        if abs(z.imag) <= 1e-9 * max(1.0, abs(z.real)):
+            x = float(z.real)
+            for _ in range(4):                                   # Newton polish on the real axis (monic form), as the kernel does
+                pv = (((x + bm) * x + cm) * x + dm) * x + em
+                dv = ((4.0 * x + 3.0 * bm) * x + 2.0 * cm) * x + dm
+                if dv == 0.0:
+                    break
+                x -= pv / dv
+            real.append(x)
+    real.sort()
     r3, pr2 = r2 * r, p * r2
     r3q = r3 * q
     out = []
