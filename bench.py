@@ -317,14 +317,14 @@ def loftr_gflop_per_pair(h: int, w: int, fine: bool = True) -> float:
     return 2.0 * macs / 1e9
 
 
-def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True):
+def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, graph=True):
     """BASELINE configs[1] as literally worded: ONE 640x480 pair through the LoFTR matcher in fp32 (gn_loftr_match: ResNet-FPN backbone on the
     exact-f32 matrix instruction, linear-attention transformer, dual-softmax coarse matching, fine level), seeded random weights."""
     from gisnav_amd import loftr_synthetic as olf
     from gisnav_amd.loftr import LoFTR
     sd = olf.synthetic_state_dict(0)
     i0, i1 = olf.synthetic_pair(1, h, w)
-    m = LoFTR(state_dict=sd, fine=fine).to(dev).eval()
+    m = LoFTR(state_dict=sd, fine=fine, graph=graph).to(dev).eval()
     data = {"image0": i0.to(dev), "image1": i1.to(dev)}
     for _ in range(warmup):
         out = m(data)
@@ -337,7 +337,7 @@ def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True):
     g = loftr_gflop_per_pair(h, w, fine)
     res = {"config": f"BASELINE configs[1] as worded: batch-1 {w}x{h} pair, LoFTR matcher (ResNet-FPN + 4x(self, cross) linear attention + dual-softmax coarse matching"
                      f"{' + fine level' if fine else ''}), fp32 (exact-f32 MFMA)",
-           "batch": 1, "precision": "f32", "steps": steps, "warmup": warmup, "value": round(steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)",
+           "batch": 1, "precision": "f32", "hip_graph": bool(graph), "steps": steps, "warmup": warmup, "value": round(steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)",
            "ms_per_step": round(elapsed / steps * 1e3, 3), "matches": int(out["keypoints0"].shape[0]), "algorithmic_gflop_per_pair": round(g, 1),
            "end_to_end_tflops": round(g / (elapsed / steps) / 1e3, 1), "peak_tflops": PEAK_F32_MFMA_TFLOPS,
            "end_to_end_frac_of_peak": round(g / (elapsed / steps) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -413,6 +413,7 @@ def main() -> None:
         torch.cuda.set_device(0)
         print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0))), flush=True)
         print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), fine=False)), flush=True)
+        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), graph=False)), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))            # no launcher around us: become one (N ranks over RCCL), or refuse

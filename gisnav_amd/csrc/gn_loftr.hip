@@ -570,6 +570,7 @@ struct gn_loftr {
   float *k0c = nullptr, *k1c = nullptr, *mconf = nullptr;
   float *frows = nullptr, *fc = nullptr, *fwin = nullptr, *ftok = nullptr, *fqkv = nullptr, *fatt = nullptr, *fmsg = nullptr, *fhid = nullptr, *fkvpart = nullptr, *fkv = nullptr;
   int* n_host = nullptr;
+  int use_graph = 1; bool graph_failed = false; hipGraphExec_t graph_exec = nullptr; hipStream_t cap_stream = nullptr;   // gn_loftr_set_graph
 };
 
 namespace {
@@ -792,6 +793,8 @@ int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loft
 void gn_loftr_destroy(gn_loftr* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->cap_stream) hipStreamDestroy(ctx->cap_stream);
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->n_host) hipHostFree(ctx->n_host);
   delete ctx;
@@ -884,15 +887,10 @@ int gn_loftr_missing_tensors(const gn_loftr* ctx) {
 // LoFTR.forward on one pair of equally sized images.  image0 / image1: DEVICE f32 [H][W] in [0, 1].  Outputs (device): kpts0 / kpts1
 // [max_matches][2] (x, y) pixels -- kpts0 on the 1/8 grid, kpts1 refined by the fine level when the context has one --, conf [max_matches],
 // optional ij [max_matches][2] int32 coarse cell ids; *n_host (HOST) = number of matches (the call synchronises `stream` once to return it).
-int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, float* kpts0, float* kpts1, float* conf, int32_t* ij, int32_t* n_host, void* stream) {
-  if (!ctx || !image0 || !image1 || !kpts0 || !kpts1 || !conf || !n_host) return lf_fail(ctx, GN_ERR_ARG, "null pointer passed to gn_loftr_match");
-  LF_HIP(hipSetDevice(ctx->device));
-  if (gn_loftr_missing_tensors(ctx) != 0) return lf_fail(ctx, GN_ERR_WEIGHTS, "LoFTR weights not fully loaded");
-  if (!ctx->finalised) { const int rc = lf_finalise(ctx); if (rc != GN_OK) return rc; }
-  hipStream_t s = (hipStream_t)stream;
+// the whole forward from ctx->img to the context's result buffers (k0c, k1c / fc, mconf, i_ids, j_ids, n_dev) on stream s: ~190 dependent
+// launches with no host decision in between (the match count stays on the device), so it can be captured into one hipGraph
+static int lf_forward(gn_loftr* ctx, hipStream_t s) {
   const int H = ctx->H, W = ctx->W, h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, hc = ctx->hc, wc = ctx->wc, L = ctx->L, Lp = ctx->Lp;
-  LF_HIP(hipMemcpyAsync(ctx->img, image0, (size_t)H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
-  LF_HIP(hipMemcpyAsync(ctx->img + (size_t)H * W, image1, (size_t)H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
   // ---- backbone (both images as a batch of 2)
   {
     const LfConv& c = ctx->conv["backbone.conv1"];
@@ -952,12 +950,6 @@ int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, floa
   hipLaunchKernelGGL(k_lf_mutual, dim3(L), dim3(256), 0, s, ctx->sim, Lp, L, hc, wc, temp, 0.2f, 2, ctx->rmax, ctx->rsum, ctx->cmax, ctx->csum, ctx->crow, ctx->ccol, ctx->jsel, ctx->csel);
   hipLaunchKernelGGL(k_lf_compact, dim3(1), dim3(1024), 0, s, ctx->jsel, ctx->csel, L, wc, 8, ctx->max_matches, ctx->i_ids, ctx->j_ids, ctx->mconf, ctx->k0c, ctx->k1c, ctx->n_dev);
   const int M = ctx->max_matches, Mp = ctx->Mp;
-  LF_HIP(hipMemcpyAsync(kpts0, ctx->k0c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  LF_HIP(hipMemcpyAsync(conf, ctx->mconf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (ij) {
-    LF_HIP(hipMemcpy2DAsync(ij, 2 * sizeof(int), ctx->i_ids, sizeof(int), sizeof(int), M, hipMemcpyDeviceToDevice, s));
-    LF_HIP(hipMemcpy2DAsync(ij + 1, 2 * sizeof(int), ctx->j_ids, sizeof(int), sizeof(int), M, hipMemcpyDeviceToDevice, s));
-  }
   if (ctx->fine) {
     // ---- fine level: windows of both sides as 2 Mp sequences of 25 tokens (side 0 first); cross pairs are (m, Mp + m)
     const int R = 2 * Mp * kLfWW;                       // token rows; 2 * Mp * 25 is a multiple of 128 (Mp is)
@@ -988,9 +980,51 @@ int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, floa
       LF_HIP(hipMemcpy2DAsync(ctx->ftok + (size_t)side * Mp * kLfWW * 128, (size_t)kLfWW * 128 * sizeof(float), ft + (size_t)side * kLfWW * 128, 2 * (size_t)kLfWW * 128 * sizeof(float),
                               (size_t)kLfWW * 128 * sizeof(float), Mp, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_lf_fine_match, dim3((M + 3) / 4), dim3(256), 0, s, ctx->ftok, ctx->ftok + (size_t)Mp * kLfWW * 128, ctx->n_dev, ctx->k1c, ctx->fc);
-    LF_HIP(hipMemcpyAsync(kpts1, ctx->fc, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  } else {
-    LF_HIP(hipMemcpyAsync(kpts1, ctx->k1c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return GN_OK;
+}
+
+int gn_loftr_set_graph(gn_loftr* ctx, int enable) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->use_graph = enable ? 1 : 0;
+  return GN_OK;
+}
+
+int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, float* kpts0, float* kpts1, float* conf, int32_t* ij, int32_t* n_host, void* stream) {
+  if (!ctx || !image0 || !image1 || !kpts0 || !kpts1 || !conf || !n_host) return lf_fail(ctx, GN_ERR_ARG, "null pointer passed to gn_loftr_match");
+  LF_HIP(hipSetDevice(ctx->device));
+  if (gn_loftr_missing_tensors(ctx) != 0) return lf_fail(ctx, GN_ERR_WEIGHTS, "LoFTR weights not fully loaded");
+  if (!ctx->finalised) { const int rc = lf_finalise(ctx); if (rc != GN_OK) return rc; }
+  hipStream_t s = (hipStream_t)stream;
+  const int H = ctx->H, W = ctx->W, M = ctx->max_matches;
+  LF_HIP(hipMemcpyAsync(ctx->img, image0, (size_t)H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+  LF_HIP(hipMemcpyAsync(ctx->img + (size_t)H * W, image1, (size_t)H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+  bool ran = false;
+  if (ctx->use_graph) {
+    // every pointer inside the forward belongs to the context and the shapes are fixed at creation: capture the ~190 launches ONCE on an
+    // internal stream and replay them as one graph launch (the host was the slower side between the small kernels of the fine level)
+    if (!ctx->graph_exec && !ctx->graph_failed) {
+      hipGraph_t graph = nullptr;
+      bool ok = true;
+      if (!ctx->cap_stream) ok = hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc = lf_forward(ctx, ctx->cap_stream);
+        ok = hipStreamEndCapture(ctx->cap_stream, &graph) == hipSuccess && rc == GN_OK && graph != nullptr;
+      }
+      ok = ok && hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (!ok) { ctx->graph_failed = true; ctx->graph_exec = nullptr; (void)hipGetLastError(); }
+    }
+    if (ctx->graph_exec) { LF_HIP(hipGraphLaunch(ctx->graph_exec, s)); ran = true; }
+  }
+  if (!ran) { const int rc = lf_forward(ctx, s); if (rc != GN_OK) return rc; }
+  LF_HIP(hipMemcpyAsync(kpts0, ctx->k0c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  LF_HIP(hipMemcpyAsync(conf, ctx->mconf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, s));
+  LF_HIP(hipMemcpyAsync(kpts1, ctx->fine ? ctx->fc : ctx->k1c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (ij) {
+    LF_HIP(hipMemcpy2DAsync(ij, 2 * sizeof(int), ctx->i_ids, sizeof(int), sizeof(int), M, hipMemcpyDeviceToDevice, s));
+    LF_HIP(hipMemcpy2DAsync(ij + 1, 2 * sizeof(int), ctx->j_ids, sizeof(int), sizeof(int), M, hipMemcpyDeviceToDevice, s));
   }
   LF_HIP(hipMemcpyAsync(ctx->n_host, ctx->n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   LF_HIP(hipStreamSynchronize(s));

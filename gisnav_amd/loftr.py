@@ -19,10 +19,10 @@ class LoFTR:
     [0, 1] of equal size (H, W multiples of 8) -> {"keypoints0" (M, 2), "keypoints1" (M, 2), "confidence" (M,), "batch_indexes" (M,)} on the
     input device, matches in ascending coarse cell of image0.  `fine=False` stops after the coarse level (keypoints on the 1/8 grid)."""
 
-    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: int = 8192, fine: bool = True):
+    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: int = 8192, fine: bool = True, graph: bool = True):
         if state_dict is None:
             state_dict = self._find_pretrained(pretrained or "outdoor")
-        self._sd, self._max, self._fine = state_dict, int(max_matches), bool(fine)
+        self._sd, self._max, self._fine, self._graph = state_dict, int(max_matches), bool(fine), bool(graph)
         self._ctx, self._shape, self._device = None, None, None
         self.lib = None
 
@@ -77,6 +77,7 @@ class LoFTR:
         if rc < 0:
             raise _lib.GnError(f"gn_loftr_create failed ({rc}): {self.lib.gn_loftr_last_error(None).decode()}")
         self._ctx, self._shape = ctx, (H, W)
+        self.lib.gn_loftr_set_graph(ctx, int(self._graph))
         for name, arr in self._sd.items():
             if hasattr(arr, "detach"):
                 arr = arr.detach().cpu().numpy()
@@ -126,3 +127,31 @@ class LoFTR:
         if n < 0:
             raise _lib.GnError(f"gn_loftr_debug_read({name}) failed ({n})")
         return buf[: int(n)]
+
+
+def loftr_pose(matcher: "LoFTR", engine, frame01: torch.Tensor, tile01: torch.Tensor, dem, K, min_matches: int = 15, conf_threshold: float = 0.0):
+    """Camera frame <-> map tile pose with the detector-free matcher in front of the SAME solver as the SIFT / LightGlue path: LoFTR matches
+    (`keypoints0` in the frame, `keypoints1` in the tile) -> DEM lift of the tile points (`_shared.py:95-102`) -> solvePnPRansac + Rodrigues
+    (`gn_gather_points`, `gn_pnp_ransac`; seam B2).  Everything stays on the device.  frame01 / tile01: (H, W) float in [0, 1];
+    dem: (H, W) uint8 or None.  Returns (R (3,3), t (3,1), n_matches) or None below `min_matches` / when RANSAC finds no model."""
+    out = matcher({"image0": frame01, "image1": tile01})
+    keep = out["confidence"] > conf_threshold
+    k0, k1 = out["keypoints0"][keep], out["keypoints1"][keep]
+    n = int(k0.shape[0])
+    if n < min_matches or n > engine.kmax:
+        if n > engine.kmax:
+            engine.grow(((n + 1023) // 1024) * 1024)
+        if n < min_matches:
+            return None
+    dev = engine.device
+    pad = lambda k: torch.cat([k.to(dev), torch.zeros((n, 2), dtype=torch.float32, device=dev)], 1).reshape(1, n, 4).contiguous()  # noqa: E731  GN_KPT_XYSA rows
+    idx = torch.arange(n, dtype=torch.int64, device=dev).repeat_interleave(2).reshape(1, n, 2)
+    idx_full = torch.zeros((1, engine.kmax, 2), dtype=torch.int64, device=dev)
+    idx_full[0, :n] = idx[0]
+    nm = torch.tensor([n], dtype=torch.int32, device=dev)
+    d = None if dem is None else torch.as_tensor(np.ascontiguousarray(dem, np.uint8), device=dev)[None]
+    mkp, obj = engine.gather_points(pad(k0), pad(k1), idx_full, nm, d, _lib.GN_KPT_XYSA)
+    R, t, n_inl, ok = engine.pnp_ransac(obj, mkp, nm, np.asarray(K, np.float64).reshape(3, 3), min_pts=min_matches)
+    if not bool(ok.cpu()[0]):
+        return None
+    return R[0].cpu().numpy(), t[0].cpu().numpy(), n

@@ -327,6 +327,9 @@ int gn_loftr_missing_tensors(const gn_loftr* ctx);
  * the call synchronises `stream` once to return it. */
 int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, float* kpts0, float* kpts1, float* conf, int32_t* ij,
                    int32_t* n_host, void* stream);
+/* 1 (default): the forward's ~190 dependent launches are captured once into a hipGraph (all buffers belong to the context, the match count
+ * stays on the device) and replayed with one graph launch per call; 0: plain stream launches (same kernels, same results). */
+int gn_loftr_set_graph(gn_loftr* ctx, int enable);
 /* test hook: internal tensor -> HOST after synchronising.  Names: "x1" "x2" "x3" "x3_out" "x1_out" (NHWC, 196 channels padded to 224),
  * "tok" ([2][Lp][256] coarse features after the transformer), "sim", "crow", "ccol", "ftok".  Returns the element count or a negative status. */
 int64_t gn_loftr_debug_read(gn_loftr* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream);
