@@ -402,6 +402,8 @@ def main() -> None:
     ap.add_argument("--substreams", type=int, default=-1, help="sub-batch streams inside one gn_estimate call (gn_set_substreams): the batch is cut into that many "
                                                                "groups whose matcher / PnP stages overlap on internal streams, joined before the call returns; "
                                                                "default 2 for batches >= 16 pairs (measured -3 %% step time), else 1")
+    ap.add_argument("--deferred-join", action="store_true", help="with --substreams > 1: leave the join of the sub-batch groups to the flush at the end of the timed "
+                                                                 "region (gn_set_deferred_join): consecutive steps pipeline inside each group's stream")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE",
                     help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments; RECORDED in the JSON line, "
@@ -487,7 +489,7 @@ def main() -> None:
     table = eng.kernel_table()
     eng.set_kernel_timing(0)
     if nsub > 1:
-        eng.set_substreams(nsub)
+        eng.set_substreams(nsub, deferred_join=args.deferred_join)
         elapsed, mine = timed_steps(eng, inps, out, args.steps, args.warmup, dev, kernel_timing=False)
     else:
         elapsed, mine = elapsed1, _

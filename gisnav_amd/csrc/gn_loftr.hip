@@ -680,12 +680,13 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   }
 }
 
+int g_lf_gemm_variant = 3;
 void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = Wt; g.ldw = ldw; g.bias = bias; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.acc_scale = 1.f;
   const int saved = gn::g_gemm_variant;
-  gn::g_gemm_variant = 3;                                   // the exact-f32 MFMA GEMM, whatever other contexts selected
+  gn::g_gemm_variant = g_lf_gemm_variant;                   // 3 = the exact-f32 MFMA GEMM (default), whatever other contexts selected; 6 = split-fp16 on the fly (experiment)
   launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, s);
   gn::g_gemm_variant = saved;
 }
@@ -756,7 +757,9 @@ int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loft
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return lf_fail(nullptr, GN_ERR_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   ctx = new gn_loftr();
   ctx->device = device; ctx->H = H; ctx->W = W; ctx->hc = H / 8; ctx->wc = W / 8; ctx->L = ctx->hc * ctx->wc; ctx->Lp = (ctx->L + 127) / 128 * 128;
-  ctx->fine = fine ? 1 : 0; ctx->max_matches = std::min(max_matches, ctx->L); ctx->Mp = (ctx->max_matches + 127) / 128 * 128;
+  ctx->fine = fine ? 1 : 0;
+  ctx->max_matches = std::min(std::min(max_matches, ctx->L), 16384);   // 2 * Mp window sequences are a grid dimension of the fine level's kernels (< 65536)
+  ctx->Mp = (ctx->max_matches + 127) / 128 * 128;
   const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, hc = ctx->hc, wc = ctx->wc, Lp = ctx->Lp, L = ctx->L;
 #define LF_A(field, n) do { int rc_ = lf_alloc(ctx, &ctx->field, (n)); if (rc_ != GN_OK) { gn_loftr_destroy(ctx); return rc_; } } while (0)
   LF_A(img, 2 * (size_t)H * W);
@@ -986,6 +989,7 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
 
 int gn_loftr_set_graph(gn_loftr* ctx, int enable) {
   if (!ctx) return GN_ERR_ARG;
+  if (enable >= 100) { g_lf_gemm_variant = enable - 100; return GN_OK; }   // developer: 103 / 106 select the GEMM arithmetic (exact f32 / split fp16 on the fly)
   ctx->use_graph = enable ? 1 : 0;
   return GN_OK;
 }

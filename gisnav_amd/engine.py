@@ -48,6 +48,10 @@ class RecordStager:
 
         nxt = stager.stage(msgs)          # host memcpy into pinned memory + async H2D (any thread)
         stager.wait(cur); eng.estimate(cur, K, out=out); stager.release(cur)
+
+    Contract: every staged batch is release()d on the compute stream after the last kernel that reads it and BEFORE the stage() call that
+    re-uses its slot is issued (with `depth` slots: before the depth-th following stage()); a slot whose batch was never released is
+    overwritten without waiting.
     """
 
     def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3, copy_threads: int = 4):

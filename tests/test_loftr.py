@@ -197,3 +197,22 @@ def test_loftr_in_front_of_the_pose_solver(sd):
     if want is not None:
         assert got[2] == len(ref["i_ids"])
         assert np.linalg.norm(got[0] - want[0]) < 1e-4 and np.linalg.norm(got[1] - want[1]) / np.linalg.norm(want[1]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_loftr_no_matches_and_truncation(sd):
+    """A featureless pair has no confident mutual maximum -> zero matches, empty (0, 2) tensors like kornia; `max_matches` below the number of
+    matches keeps the FIRST ones in ascending cell order of image0 (kornia returns all: the cap is this build's, documented in the header)."""
+    from gisnav_amd.loftr import LoFTR
+    flat = torch.full((128, 160), 0.5)
+    m = LoFTR(state_dict=sd).to("cuda:0").eval()
+    out = m({"image0": flat.cuda(), "image1": flat.cuda()})
+    ref = lf.loftr_forward(sd, flat, flat)
+    assert len(ref["i_ids"]) == out["keypoints0"].shape[0]
+    assert out["keypoints1"].shape == (out["keypoints0"].shape[0], 2) and out["confidence"].shape == (out["keypoints0"].shape[0],)
+    i0, i1 = lf.synthetic_pair(1, 128, 160)
+    full = lf.loftr_forward(sd, i0, i1)
+    assert len(full["i_ids"]) > 40
+    capped = LoFTR(state_dict=sd, max_matches=40).to("cuda:0").eval()({"image0": i0.cuda(), "image1": i1.cuda()}, with_ids=True)
+    assert capped["keypoints0"].shape == (40, 2) and torch.equal(capped["i_ids"].cpu(), full["i_ids"][:40]) and torch.equal(capped["j_ids"].cpu(), full["j_ids"][:40])
+    assert (capped["keypoints1"].cpu() - full["keypoints1"][:40]).abs().max() < 2e-3
