@@ -317,14 +317,14 @@ def loftr_gflop_per_pair(h: int, w: int, fine: bool = True) -> float:
     return 2.0 * macs / 1e9
 
 
-def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, graph=True):
+def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, graph=True, arithmetic="exact_f32"):
     """BASELINE configs[1] as literally worded: ONE 640x480 pair through the LoFTR matcher in fp32 (gn_loftr_match: ResNet-FPN backbone on the
     exact-f32 matrix instruction, linear-attention transformer, dual-softmax coarse matching, fine level), seeded random weights."""
     from gisnav_amd import loftr_synthetic as olf
     from gisnav_amd.loftr import LoFTR
     sd = olf.synthetic_state_dict(0)
     i0, i1 = olf.synthetic_pair(1, h, w)
-    m = LoFTR(state_dict=sd, fine=fine, graph=graph).to(dev).eval()
+    m = LoFTR(state_dict=sd, fine=fine, graph=graph, arithmetic=arithmetic).to(dev).eval()
     data = {"image0": i0.to(dev), "image1": i1.to(dev)}
     for _ in range(warmup):
         out = m(data)
@@ -336,8 +336,9 @@ def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, gra
     elapsed = time.perf_counter() - t0
     g = loftr_gflop_per_pair(h, w, fine)
     res = {"config": f"BASELINE configs[1] as worded: batch-1 {w}x{h} pair, LoFTR matcher (ResNet-FPN + 4x(self, cross) linear attention + dual-softmax coarse matching"
-                     f"{' + fine level' if fine else ''}), fp32 (exact-f32 MFMA)",
-           "batch": 1, "precision": "f32", "hip_graph": bool(graph), "steps": steps, "warmup": warmup, "value": round(steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)",
+                     f"{' + fine level' if fine else ''}), " + ("fp32 (exact-f32 MFMA)" if arithmetic == "exact_f32" else
+                     "f32-ACCURATE split fp16 (each f32 operand as 2 fp16 terms, 3 MFMA products, f32 accumulate; fp16-range guard with exact re-run)"),
+           "batch": 1, "precision": "f32" if arithmetic == "exact_f32" else "f16x2 (f32-accurate)", "hip_graph": bool(graph), "steps": steps, "warmup": warmup, "value": round(steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)",
            "ms_per_step": round(elapsed / steps * 1e3, 3), "matches": int(out["keypoints0"].shape[0]), "algorithmic_gflop_per_pair": round(g, 1),
            "end_to_end_tflops": round(g / (elapsed / steps) / 1e3, 1), "peak_tflops": PEAK_F32_MFMA_TFLOPS,
            "end_to_end_frac_of_peak": round(g / (elapsed / steps) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -415,7 +416,8 @@ def main() -> None:
         torch.cuda.set_device(0)
         print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0))), flush=True)
         print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), fine=False)), flush=True)
-        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), graph=False)), flush=True)
+        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), arithmetic="split_fp16")), flush=True)
+        print(json.dumps(run_extra_loftr(0, args.steps, args.warmup, torch.device("cuda", 0), fine=False, arithmetic="split_fp16")), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))            # no launcher around us: become one (N ranks over RCCL), or refuse
@@ -524,6 +526,7 @@ def main() -> None:
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
                                 1, args.kpts, args.precision, 30, 5, dev))
         extras.append(run_extra_loftr(local_rank, 10, 2, dev))
+        extras.append(run_extra_loftr(local_rank, 10, 2, dev, arithmetic="split_fp16"))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev, arithmetic="fp16"))
 

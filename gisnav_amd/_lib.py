@@ -64,6 +64,7 @@ SIGNATURES = {
     "gn_loftr_load_tensor": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
     "gn_loftr_missing_tensors": (C.c_int, [VP]),
     "gn_loftr_set_graph": (C.c_int, [VP, C.c_int]),
+    "gn_loftr_set_arithmetic": (C.c_int, [VP, C.c_int]),
     "gn_loftr_match": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.POINTER(C.c_int32), VP]),
     "gn_loftr_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),
     "gn_debug_read": (C.c_int64, [VP, C.c_char_p, VP, C.c_int64, VP]),

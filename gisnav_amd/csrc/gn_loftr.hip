@@ -68,6 +68,9 @@ struct LfConvArgs {
   const float* resid;                       // optional NHWC [Hout][Wout][Cout]: added before the activation
   float* out; int Hout, Wout, Cout;         // Cout a multiple of 32 (padded channels carry zero weights, scale 1, shift 0)
   int act;                                  // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
+  // split-fp16 arithmetic (k_lf_conv_h): weights as fp16 pairs in fragment order (sp_weight_fragments_hm16), the affine scale with the
+  // inverse of the weights' power-of-two scale folded in, the fp16-range guard word
+  const uint16_t* wfh; const float* scale_h; unsigned int* ovf;
 };
 
 // grid (ceil(Wout / 32), ceil(Hout / (4 RPW)), N * ceil(Cout / 64)); 4 waves, wave w = output rows [RPW w, RPW w + RPW) of the tile,
@@ -179,6 +182,151 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        v = v * sc + sh;
+        const long long o = ((long long)gy * a.Wout + gx) * a.Cout + c;
+        if (res) v += *reinterpret_cast<const f32x4*>(res + o);
+        if (a.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (a.act == 2) { v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y; v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w; }
+        *reinterpret_cast<f32x4*>(out + o) = v;
+      }
+    }
+  }
+}
+
+// The same convolution in the SPLIT-fp16 arithmetic of the matcher's f16x2 GEMMs (gn_gemm_p2.hip, gn_superpoint.hip HM = 1): every f32 operand
+// as two fp16 terms (x = h + m, round to nearest, 22 significant bits), three v_mfma_f32_32x32x16_f16 per 16 input channels (W_m X_h, W_h X_m,
+// W_h X_h, small terms first), f32 accumulation -- f32-ACCURATE (error at the level of an f32 accumulation) at 5 x the matrix-pipe rate of
+// v_mfma_f32_32x32x2_f32.  Activations stay f32 in memory and are split while the halo tile is staged (hm16 pixel layout: per 16 channels 16
+// high terms then 16 residual terms); weights are pre-split at load time with a power-of-two scale (folded into the epilogue's affine map)
+// and, per tap, fetched ONCE per workgroup into a double-buffered LDS block (per-wave fetches would make the L2 -> CU ingest the bottleneck at
+// this MFMA rate).  An activation that does not fit fp16 raises a.ovf: the caller repeats the forward on the exact kernels.
+template <int KS, int S, int RPW, int CH>
+__global__ __launch_bounds__(256) void k_lf_conv_h(LfConvArgs a) {
+  typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int TH = 4 * RPW, LH = (TH - 1) * S + KS, LW = 31 * S + KS, NP16 = CH / 4;      // NP16: 16-byte pieces per pixel (CH * 4 B / 16)
+  constexpr int NKS = CH / 16;                                                               // k-steps (16 channels) per slice
+  constexpr int WB = 2 * NKS * 2 * 1024;                                                     // bytes of one tap's weight block: 2 tiles x k-steps x 2 terms x 1 KB
+  __shared__ __attribute__((aligned(16))) unsigned char tb[LH * LW * CH * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * WB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = (a.Cout + 63) / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const bool two = 64 * og + 32 < a.Cout;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH;
+  const int gy0 = y0 * S - PAD, gx0 = x0 * S - PAD;
+  const float* in = a.in + (long long)img * a.Hin * a.Win * a.Cin;
+  const int ksteps = a.Cin / 16;
+  const uint4* wfh = reinterpret_cast<const uint4*>(a.wfh) + lane;
+  auto sw = [](int lx) { const int u = lx / S; return (u ^ (u >> 3)) & (NP16 - 1); };
+
+  f32x16 acc[2][RPW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float amax = 0.f;
+  // this thread's share of a tap's weight block: WB / 16 pieces of 16 bytes over 256 threads
+  constexpr int WPT = WB / 16 / 256;            // 2 (CH = 32) or 1 (CH = 16)
+  auto wsrc = [&](int c0_, int tap_, int e) __attribute__((always_inline)) {
+    const int blk = WPT * 4 * 0 + 4 * e + (tid >> 6);      // block index inside the tap: ((i * NKS + ks) * 2 + pl), 4 blocks per e
+    const int i = blk / (2 * NKS), ks = (blk / 2) % NKS, pl = blk & 1;
+    const int tile = 2 * og + ((i == 1 && !two) ? 0 : i);  // a missing second tile re-reads the first (never multiplied)
+    return wfh[(size_t)((((size_t)tile * TAPS + tap_) * ksteps + (c0_ / 16 + ks)) * 2 + pl) * 64];
+  };
+  uint4 wnext[WPT];
+#pragma unroll
+  for (int e = 0; e < WPT; ++e) wnext[e] = wsrc(0, 0, e);
+  int par = 0;
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+    __syncthreads();
+    constexpr int NQF = LH * LW * (CH / 4), NQ = (NQF + 255) / 256, SB = 8;
+#pragma unroll 1
+    for (int q0 = 0; q0 < NQ; q0 += SB) {
+      f32x4 v[SB];
+#pragma unroll
+      for (int e = 0; e < SB; ++e) {
+        const int q = (q0 + e) * 256 + tid;
+        const int pix = q / (CH / 4), chunk = q - pix * (CH / 4);
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = gy0 + ly, gx = gx0 + lx;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[e] = z;
+        if (q < NQF && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+          v[e] = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.Win + gx) * a.Cin + c0 + chunk * 4);
+      }
+#pragma unroll
+      for (int e = 0; e < SB; ++e) {
+        const int q = (q0 + e) * 256 + tid;
+        if (q >= NQF) continue;
+        const int pix = q / (CH / 4), chunk = q - pix * (CH / 4);
+        const int lx = pix % LW;
+        // channels 4 chunk .. + 3 of the slice: k-step chunk >> 2, piece 4 (chunk >> 2) + 2 term + ((chunk & 3) >> 1), 8-byte half (chunk & 1)
+        const h16x4 h4 = __builtin_convertvector(v[e], h16x4);
+        const h16x4 m4 = __builtin_convertvector(v[e] - __builtin_convertvector(h4, f32x4), h16x4);
+        ovf_track(amax, v[e].x, v[e].y); ovf_track(amax, v[e].z, v[e].w);
+        const int piece = 4 * (chunk >> 2) + ((chunk & 3) >> 1), sub = (chunk & 1) * 8;
+        *reinterpret_cast<h16x4*>(tb + pix * (CH * 4) + ((piece ^ sw(lx)) * 16) + sub) = h4;
+        *reinterpret_cast<h16x4*>(tb + pix * (CH * 4) + (((piece + 2) ^ sw(lx)) * 16) + sub) = m4;
+      }
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ty = tap / KS, tx = tap - ty * KS;
+      unsigned char* const wb = wbuf + par * WB;
+#pragma unroll
+      for (int e = 0; e < WPT; ++e) *reinterpret_cast<uint4*>(wb + (4 * e + (tid >> 6)) * 1024 + lane * 16) = wnext[e];
+      const bool last_tap = tap + 1 == TAPS;
+      if (!last_tap || c0 + CH < a.Cin) {
+#pragma unroll
+        for (int e = 0; e < WPT; ++e) wnext[e] = wsrc(last_tap ? c0 + CH : c0, last_tap ? 0 : tap + 1, e);
+      }
+      __syncthreads();     // this tap's weights (and, at tap 0, the halo tile) are in LDS; the block written two taps ago is no longer read
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        h16x8 fa[2][2], fb[RPW][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + ((i * NKS + s) * 2 + pl) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          const int ly = (RPW * wave + j) * S + ty, lx = ql * S + tx;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + (ly * LW + lx) * (CH * 4) + (((4 * s + 2 * pl + hh) ^ sw(lx)) * 16));
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[0][j], 0, 0, 0);
+            if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[1][j], 0, 0, 0);
+          }
+      }
+      par ^= 1;
+    }
+  }
+  ovf_commit(a.ovf, amax);
+  const int gx = x0 + ql;
+  float* out = a.out + (long long)img * a.Hout * a.Wout * a.Cout;
+  const float* res = a.resid ? a.resid + (long long)img * a.Hout * a.Wout * a.Cout : nullptr;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int gy = y0 + RPW * wave + j;
+    if (gy >= a.Hout || gx >= a.Wout) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !two) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 64 * og + 32 * i + 8 * g + 4 * hh;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale_h + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         v = v * sc + sh;
         const long long o = ((long long)gy * a.Wout + gx) * a.Cout + c;
@@ -349,6 +497,14 @@ __global__ __launch_bounds__(256) void k_lf_scale(const float* x, float* y, floa
   f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
   v.x /= div; v.y /= div; v.z /= div; v.w /= div;
   reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
+// split-fp16 mode: any value that left fp16's range inside a GEMM shows up as inf / NaN downstream -- raise the guard word
+__global__ __launch_bounds__(256) void k_lf_check_finite(const float* x, long long n4, unsigned int* flag) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  if (!(fabsf(v.x) < 3.0e38f && fabsf(v.y) < 3.0e38f && fabsf(v.z) < 3.0e38f && fabsf(v.w) < 3.0e38f)) atomicOr(flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ coarse matching
@@ -548,6 +704,7 @@ struct LfConv {
   std::vector<float> hw; int cout = 0, cin = 0, ks = 0;                         // host copy [cout][cin][ks*ks] until finalised
   std::vector<float> bn[4]; bool has_bn = false;                                // weight, bias, running_mean, running_var
   float* wf = nullptr; float* scale = nullptr; float* shift = nullptr; int cout_p = 0, cin_p = 0;
+  uint16_t* wfh = nullptr; float* scale_h = nullptr;        // split-fp16 arithmetic: fp16 pairs in fragment order, affine scale x 1 / weight scale
 };
 int pad32(int c) { return (c + 31) / 32 * 32; }
 }  // namespace
@@ -570,7 +727,9 @@ struct gn_loftr {
   float *k0c = nullptr, *k1c = nullptr, *mconf = nullptr;
   float *frows = nullptr, *fc = nullptr, *fwin = nullptr, *ftok = nullptr, *fqkv = nullptr, *fatt = nullptr, *fmsg = nullptr, *fhid = nullptr, *fkvpart = nullptr, *fkv = nullptr;
   int* n_host = nullptr;
-  int use_graph = 1; bool graph_failed = false; hipGraphExec_t graph_exec = nullptr; hipStream_t cap_stream = nullptr;   // gn_loftr_set_graph
+  int use_graph = 1; bool graph_failed[2] = {false, false}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; hipStream_t cap_stream = nullptr;   // gn_loftr_set_graph; one graph per arithmetic
+  int arith = 0;                        // gn_loftr_set_arithmetic: 0 exact f32, 1 split fp16 (f32-accurate)
+  unsigned int* ovf = nullptr; long long ovf_trips = 0;   // split mode: fp16-range guard word (device), calls that fell back to the exact kernels
 };
 
 namespace {
@@ -637,6 +796,21 @@ int lf_finalise(gn_loftr* ctx) {
     std::vector<float> frag((size_t)c.cout_p * taps * c.cin_p);
     sp_weight_fragments(wp.data(), c.cout, c.cin_p, taps, c.cout_p, frag.data());
     rc = lf_upload(ctx, &c.wf, frag.data(), frag.size()); if (rc != GN_OK) return rc;
+    {   // split-fp16 arithmetic: power-of-two scale that puts max |w| in [2^12, 2^13) (both fp16 terms stay normal), inverse folded into the affine scale
+      float mx = 0.f;
+      for (float v : wp) mx = std::max(mx, std::fabs(v));
+      int e = 0;
+      if (mx > 0.f && std::isfinite(mx)) { std::frexp(mx, &e); e = 13 - e; }
+      e = std::max(-60, std::min(60, e));
+      const float wscale = std::ldexp(1.0f, e), inv = std::ldexp(1.0f, -e);
+      std::vector<uint16_t> fh((size_t)2 * c.cout_p * taps * c.cin_p);
+      sp_weight_fragments_hm16(wp.data(), c.cout, c.cin_p, taps, c.cout_p, wscale, fh.data());
+      if (!c.wfh) { rc = lf_alloc(ctx, &c.wfh, fh.size()); if (rc != GN_OK) return rc; }
+      LF_HIP(hipMemcpy(c.wfh, fh.data(), fh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      std::vector<float> sh2(scale);
+      for (float& v : sh2) v *= inv;
+      rc = lf_upload(ctx, &c.scale_h, sh2.data(), sh2.size()); if (rc != GN_OK) return rc;
+    }
   }
   ctx->finalised = true;
   return GN_OK;
@@ -647,6 +821,8 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   LfConvArgs a;
   a.in = in; a.Hin = Hin; a.Win = Win; a.Cin = c.cin_p; a.wf = c.wf; a.scale = c.scale; a.shift = c.shift; a.resid = resid;
   a.out = out; a.Hout = Hin / stride; a.Wout = Win / stride; a.Cout = c.cout_p; a.act = act;
+  a.wfh = c.wfh; a.scale_h = c.scale_h; a.ovf = ctx->ovf;
+  const bool hm = ctx->arith == 1 && c.wfh != nullptr;
   const int og = (c.cout_p + 63) / 64;
   // rows per wave (RPW): the workgroup covers 4 RPW output rows x 32 columns x 64 channels and one workgroup fits a CU, so a launch takes
   // ceil(workgroups / 256) rounds of RPW units each -- pick the RPW with the fewest units (layer1 at 240x320: 600 workgroups = 3 rounds of 4
@@ -659,24 +835,18 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
     int rpw = 4;
     if (units(2) < units(rpw)) rpw = 2;
     if (units(1) < units(rpw)) rpw = 1;
+#define LF_LAUNCH(KS_, S_, R_, C_) do { if (hm) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_>), grid(R_), blk, 0, s, a); \
+                                        else hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_>), grid(R_), blk, 0, s, a); } while (0)
     if (c.ks == 3) {
-      if (rpw == 4) hipLaunchKernelGGL((k_lf_conv<3, 1, 4, 32>), grid(4), blk, 0, s, a);
-      else if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<3, 1, 2, 32>), grid(2), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_lf_conv<3, 1, 1, 32>), grid(1), blk, 0, s, a);
+      if (rpw == 4) LF_LAUNCH(3, 1, 4, 32); else if (rpw == 2) LF_LAUNCH(3, 1, 2, 32); else LF_LAUNCH(3, 1, 1, 32);
     } else {
-      if (rpw == 4) hipLaunchKernelGGL((k_lf_conv<1, 1, 4, 32>), grid(4), blk, 0, s, a);
-      else if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<1, 1, 2, 32>), grid(2), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_lf_conv<1, 1, 1, 32>), grid(1), blk, 0, s, a);
+      if (rpw == 4) LF_LAUNCH(1, 1, 4, 32); else if (rpw == 2) LF_LAUNCH(1, 1, 2, 32); else LF_LAUNCH(1, 1, 1, 32);
     }
   } else {
     const int rpw = units(1) < units(2) ? 1 : 2;
-    if (c.ks == 3) {
-      if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<3, 2, 2, 16>), grid(2), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_lf_conv<3, 2, 1, 16>), grid(1), blk, 0, s, a);
-    } else {
-      if (rpw == 2) hipLaunchKernelGGL((k_lf_conv<1, 2, 2, 16>), grid(2), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_lf_conv<1, 2, 1, 16>), grid(1), blk, 0, s, a);
-    }
+    if (c.ks == 3) { if (rpw == 2) LF_LAUNCH(3, 2, 2, 16); else LF_LAUNCH(3, 2, 1, 16); }
+    else { if (rpw == 2) LF_LAUNCH(1, 2, 2, 16); else LF_LAUNCH(1, 2, 1, 16); }
+#undef LF_LAUNCH
   }
 }
 
@@ -686,7 +856,7 @@ void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const f
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = Wt; g.ldw = ldw; g.bias = bias; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.acc_scale = 1.f;
   const int saved = gn::g_gemm_variant;
-  gn::g_gemm_variant = g_lf_gemm_variant;                   // 3 = the exact-f32 MFMA GEMM (default), whatever other contexts selected; 6 = split-fp16 on the fly (experiment)
+  gn::g_gemm_variant = g_lf_gemm_variant;                   // 3 = the exact-f32 MFMA GEMM, whatever other contexts selected; 6 = every f32 operand split into two fp16 terms on the fly (gn_loftr_set_arithmetic)
   launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, s);
   gn::g_gemm_variant = saved;
 }
@@ -769,7 +939,7 @@ int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loft
   LF_A(pe, L * 256); LF_A(tok, 2 * Lp * 256); LF_A(qkv, 2 * Lp * 768); LF_A(att, 2 * Lp * 256); LF_A(msg, 2 * Lp * 256); LF_A(hid, 2 * Lp * 512);
   LF_A(kvpart, 2 * ((L + 191) / 192) * 8 * 33 * 32); LF_A(kv, 2 * 8 * 33 * 32); LF_A(fs, 2 * Lp * 256); LF_A(sim, Lp * Lp);
   LF_A(rmax, Lp); LF_A(rsum, Lp); LF_A(cmax, Lp); LF_A(csum, Lp); LF_A(crow, Lp); LF_A(ccol, Lp); LF_A(cpart_a, 32 * Lp); LF_A(cpart_b, 32 * Lp); LF_A(csel, Lp);
-  LF_A(jsel, Lp); LF_A(i_ids, ctx->Mp); LF_A(j_ids, ctx->Mp); LF_A(n_dev, 4); LF_A(k0c, 2 * (size_t)ctx->Mp); LF_A(k1c, 2 * (size_t)ctx->Mp); LF_A(mconf, ctx->Mp);
+  LF_A(ovf, 4); LF_A(jsel, Lp); LF_A(i_ids, ctx->Mp); LF_A(j_ids, ctx->Mp); LF_A(n_dev, 4); LF_A(k0c, 2 * (size_t)ctx->Mp); LF_A(k1c, 2 * (size_t)ctx->Mp); LF_A(mconf, ctx->Mp);
   if (ctx->fine) {
     const size_t R = 2 * (size_t)ctx->Mp * kLfWW;      // window tokens of both sides
     LF_A(fc, 2 * (size_t)ctx->Mp * 256); LF_A(fwin, 2 * (size_t)ctx->Mp * 128); LF_A(frows, R * 256); LF_A(ftok, R * 128); LF_A(fqkv, R * 384); LF_A(fatt, R * 128);
@@ -796,7 +966,7 @@ int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loft
 void gn_loftr_destroy(gn_loftr* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+  for (int i = 0; i < 2; ++i) if (ctx->graph_exec[i]) hipGraphExecDestroy(ctx->graph_exec[i]);
   if (ctx->cap_stream) hipStreamDestroy(ctx->cap_stream);
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->n_host) hipHostFree(ctx->n_host);
@@ -894,6 +1064,8 @@ int gn_loftr_missing_tensors(const gn_loftr* ctx) {
 // launches with no host decision in between (the match count stays on the device), so it can be captured into one hipGraph
 static int lf_forward(gn_loftr* ctx, hipStream_t s) {
   const int H = ctx->H, W = ctx->W, h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, hc = ctx->hc, wc = ctx->wc, L = ctx->L, Lp = ctx->Lp;
+  g_lf_gemm_variant = ctx->arith == 1 ? 6 : 3;
+  LF_HIP(hipMemsetAsync(ctx->ovf, 0, sizeof(unsigned int), s));
   // ---- backbone (both images as a batch of 2)
   {
     const LfConv& c = ctx->conv["backbone.conv1"];
@@ -939,6 +1111,7 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
       lf_encoder(ly, ctx->tok, Lp, L, 2 * Lp, kLfDim, 1, 2, ctx->qkv, ctx->att, ctx->msg, ctx->hid, ctx->kvpart, ctx->kv, s);
     }
   }
+  if (ctx->arith == 1) { const long long n4 = 2LL * Lp * 64; hipLaunchKernelGGL(k_lf_check_finite, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ctx->tok, n4, ctx->ovf); }
   // ---- coarse matching
   const float temp = 0.1f;
   { const long long n4 = 2LL * Lp * 64; hipLaunchKernelGGL(k_lf_scale, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ctx->tok, ctx->fs, 16.0f, n4); }
@@ -983,13 +1156,19 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
       LF_HIP(hipMemcpy2DAsync(ctx->ftok + (size_t)side * Mp * kLfWW * 128, (size_t)kLfWW * 128 * sizeof(float), ft + (size_t)side * kLfWW * 128, 2 * (size_t)kLfWW * 128 * sizeof(float),
                               (size_t)kLfWW * 128 * sizeof(float), Mp, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_lf_fine_match, dim3((M + 3) / 4), dim3(256), 0, s, ctx->ftok, ctx->ftok + (size_t)Mp * kLfWW * 128, ctx->n_dev, ctx->k1c, ctx->fc);
+    if (ctx->arith == 1) { const long long n4 = (long long)M * 2 / 4; if (n4 > 0) hipLaunchKernelGGL(k_lf_check_finite, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ctx->fc, n4, ctx->ovf); }
   }
+  return GN_OK;
+}
+
+int gn_loftr_set_arithmetic(gn_loftr* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return GN_ERR_ARG;
+  ctx->arith = mode;
   return GN_OK;
 }
 
 int gn_loftr_set_graph(gn_loftr* ctx, int enable) {
   if (!ctx) return GN_ERR_ARG;
-  if (enable >= 100) { g_lf_gemm_variant = enable - 100; return GN_OK; }   // developer: 103 / 106 select the GEMM arithmetic (exact f32 / split fp16 on the fly)
   ctx->use_graph = enable ? 1 : 0;
   return GN_OK;
 }
@@ -1007,7 +1186,8 @@ int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, floa
   if (ctx->use_graph) {
     // every pointer inside the forward belongs to the context and the shapes are fixed at creation: capture the ~190 launches ONCE on an
     // internal stream and replay them as one graph launch (the host was the slower side between the small kernels of the fine level)
-    if (!ctx->graph_exec && !ctx->graph_failed) {
+    hipGraphExec_t& gexec = ctx->graph_exec[ctx->arith];
+    if (!gexec && !ctx->graph_failed[ctx->arith]) {
       hipGraph_t graph = nullptr;
       bool ok = true;
       if (!ctx->cap_stream) ok = hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) == hipSuccess;
@@ -1016,13 +1196,24 @@ int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, floa
         const int rc = lf_forward(ctx, ctx->cap_stream);
         ok = hipStreamEndCapture(ctx->cap_stream, &graph) == hipSuccess && rc == GN_OK && graph != nullptr;
       }
-      ok = ok && hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      ok = ok && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) hipGraphDestroy(graph);
-      if (!ok) { ctx->graph_failed = true; ctx->graph_exec = nullptr; (void)hipGetLastError(); }
+      if (!ok) { ctx->graph_failed[ctx->arith] = true; gexec = nullptr; (void)hipGetLastError(); }
     }
-    if (ctx->graph_exec) { LF_HIP(hipGraphLaunch(ctx->graph_exec, s)); ran = true; }
+    if (gexec) { LF_HIP(hipGraphLaunch(gexec, s)); ran = true; }
   }
   if (!ran) { const int rc = lf_forward(ctx, s); if (rc != GN_OK) return rc; }
+  if (ctx->arith == 1) {   // split-fp16 arithmetic: a value outside fp16's range anywhere in the forward -> repeat it on the exact-f32 kernels
+    LF_HIP(hipMemcpyAsync(ctx->n_host + 1, ctx->ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    LF_HIP(hipStreamSynchronize(s));
+    if (ctx->n_host[1] != 0) {
+      ++ctx->ovf_trips;
+      ctx->arith = 0;
+      const int rc = lf_forward(ctx, s);
+      ctx->arith = 1;
+      if (rc != GN_OK) return rc;
+    }
+  }
   LF_HIP(hipMemcpyAsync(kpts0, ctx->k0c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
   LF_HIP(hipMemcpyAsync(conf, ctx->mconf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, s));
   LF_HIP(hipMemcpyAsync(kpts1, ctx->fine ? ctx->fc : ctx->k1c, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -19,10 +19,12 @@ class LoFTR:
     [0, 1] of equal size (H, W multiples of 8) -> {"keypoints0" (M, 2), "keypoints1" (M, 2), "confidence" (M,), "batch_indexes" (M,)} on the
     input device, matches in ascending coarse cell of image0.  `fine=False` stops after the coarse level (keypoints on the 1/8 grid)."""
 
-    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: int = 8192, fine: bool = True, graph: bool = True):
+    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: int = 8192, fine: bool = True, graph: bool = True,
+                 arithmetic: str = "exact_f32"):
         if state_dict is None:
             state_dict = self._find_pretrained(pretrained or "outdoor")
         self._sd, self._max, self._fine, self._graph = state_dict, int(max_matches), bool(fine), bool(graph)
+        self._arith = {"exact_f32": 0, "split_fp16": 1}[arithmetic]   # split_fp16: f32-accurate 2-term fp16 operands (gn_loftr_set_arithmetic)
         self._ctx, self._shape, self._device = None, None, None
         self.lib = None
 
@@ -78,6 +80,7 @@ class LoFTR:
             raise _lib.GnError(f"gn_loftr_create failed ({rc}): {self.lib.gn_loftr_last_error(None).decode()}")
         self._ctx, self._shape = ctx, (H, W)
         self.lib.gn_loftr_set_graph(ctx, int(self._graph))
+        self.lib.gn_loftr_set_arithmetic(ctx, self._arith)
         for name, arr in self._sd.items():
             if hasattr(arr, "detach"):
                 arr = arr.detach().cpu().numpy()

@@ -331,6 +331,10 @@ int gn_loftr_match(gn_loftr* ctx, const float* image0, const float* image1, floa
 /* 1 (default): the forward's ~190 dependent launches are captured once into a hipGraph (all buffers belong to the context, the match count
  * stays on the device) and replayed with one graph launch per call; 0: plain stream launches (same kernels, same results). */
 int gn_loftr_set_graph(gn_loftr* ctx, int enable);
+/* Arithmetic of the convolutions and linear layers: 0 (default) exact f32 (v_mfma_f32_32x32x2_f32) -- what configs[1] names; 1 split fp16: every
+ * f32 operand as two fp16 terms, three fp16 MFMA products, f32 accumulation (the matcher's f16x2 scheme: f32-accurate, 5 x the matrix-pipe
+ * rate).  Mode 1 guards fp16's range: a forward in which any activation left it is repeated on the exact kernels before the call returns. */
+int gn_loftr_set_arithmetic(gn_loftr* ctx, int mode);
 /* test hook: internal tensor -> HOST after synchronising.  Names: "x1" "x2" "x3" "x3_out" "x1_out" (NHWC, 196 channels padded to 224),
  * "tok" ([2][Lp][256] coarse features after the transformer), "sim", "crow", "ccol", "ftok".  Returns the element count or a negative status. */
 int64_t gn_loftr_debug_read(gn_loftr* ctx, const char* name, void* host_out, int64_t max_bytes, void* stream);

@@ -114,14 +114,17 @@ def _rel(a, b):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arithmetic", ["exact_f32", "split_fp16"])
 @pytest.mark.parametrize("h,w,seed", [(128, 160, 1), (136, 200, 2), (480, 640, 1)])
-def test_loftr_hip_against_oracle(h, w, seed, sd):
+def test_loftr_hip_against_oracle(h, w, seed, arithmetic, sd):
+    """Both arithmetics of the convolutions / linear layers: the exact f32 matrix instruction (configs[1]'s "fp32") and the f32-ACCURATE
+    split-fp16 scheme of the matcher (two fp16 terms per operand, three products, f32 accumulate) meet the same bars."""
     from gisnav_amd.loftr import LoFTR
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
     i0, i1 = lf.synthetic_pair(seed, h, w)
     taps = {}
     ref = lf.loftr_forward(sd, i0, i1, taps=taps)
-    m = LoFTR(state_dict=sd).to("cuda:0").eval()
+    m = LoFTR(state_dict=sd, arithmetic=arithmetic).to("cuda:0").eval()
     out = m({"image0": i0[None, None].cuda(), "image1": i1[None, None].cuda()}, with_ids=True)
     hc, wc, L = h // 8, w // 8, (h // 8) * (w // 8)
     Lp = (L + 127) // 128 * 128
@@ -216,3 +219,19 @@ def test_loftr_no_matches_and_truncation(sd):
     capped = LoFTR(state_dict=sd, max_matches=40).to("cuda:0").eval()({"image0": i0.cuda(), "image1": i1.cuda()}, with_ids=True)
     assert capped["keypoints0"].shape == (40, 2) and torch.equal(capped["i_ids"].cpu(), full["i_ids"][:40]) and torch.equal(capped["j_ids"].cpu(), full["j_ids"][:40])
     assert (capped["keypoints1"].cpu() - full["keypoints1"][:40]).abs().max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_loftr_split_arithmetic_falls_back_when_activations_leave_fp16_range(sd):
+    """An image scaled by 3e5 drives the backbone's activations past fp16's 65504: the split-fp16 forward raises its guard word and the call
+    is repeated on the exact kernels -- the outputs are then BIT-identical to an exact-f32 context's (and never NaN)."""
+    from gisnav_amd.loftr import LoFTR
+    i0, i1 = lf.synthetic_pair(1, 128, 160)
+    big = {"image0": (i0 * 3.0e5).cuda(), "image1": (i1 * 3.0e5).cuda()}
+    ex = LoFTR(state_dict=sd, arithmetic="exact_f32").to("cuda:0").eval()(big, with_ids=True)
+    sp = LoFTR(state_dict=sd, arithmetic="split_fp16").to("cuda:0").eval()
+    got = sp(big, with_ids=True)
+    assert all(torch.equal(ex[k], got[k]) for k in ex) and bool(torch.isfinite(got["keypoints1"]).all())
+    small = sp({"image0": i0.cuda(), "image1": i1.cuda()}, with_ids=True)       # the same context afterwards, in range: split arithmetic again
+    ref = lf.loftr_forward(sd, i0, i1)
+    assert torch.equal(small["i_ids"].cpu(), ref["i_ids"]) and torch.equal(small["j_ids"].cpu(), ref["j_ids"])
