@@ -458,6 +458,40 @@ __global__ __launch_bounds__(256) void k_lf_attn_apply(const float* q, int ldq, 
   }
 }
 
+// The fine level's linear attention in ONE launch: sequences of <= 32 tokens, 8 heads x 16 (d = 128).  One block per sequence; thread t -> (head
+// t >> 4, v = t & 15).  K^T V (values / S), sum K and the application to the block's own queries, all from LDS; the source is the sequence
+// itself or its partner seq ^ 1 (cross).  Same summation orders as k_lf_kv_partial<16> (one chunk) + k_lf_attn_apply<16>.
+__global__ __launch_bounds__(128) void k_lf_fine_attn(const float* qkv /*[nseq][S][384]*/, int S, int cross, float* out /*[nseq][S][128]*/) {
+  __shared__ float qs[32][128], ks[32][129], vs[32][128];
+  const int seq = blockIdx.x, src = cross ? (seq ^ 1) : seq, tid = threadIdx.x;
+  const float vdiv = (float)S;
+  for (int i = tid; i < S * 32; i += 128) {
+    const int r = i >> 5, c = (i & 31) * 4;
+    f32x4 q = *reinterpret_cast<const f32x4*>(qkv + ((long long)seq * S + r) * 384 + c);
+    f32x4 k = *reinterpret_cast<const f32x4*>(qkv + ((long long)src * S + r) * 384 + 128 + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(qkv + ((long long)src * S + r) * 384 + 256 + c);
+    qs[r][c] = elu1(q.x); qs[r][c + 1] = elu1(q.y); qs[r][c + 2] = elu1(q.z); qs[r][c + 3] = elu1(q.w);
+    ks[r][c] = elu1(k.x); ks[r][c + 1] = elu1(k.y); ks[r][c + 2] = elu1(k.z); ks[r][c + 3] = elu1(k.w);
+    vs[r][c] = v.x / vdiv; vs[r][c + 1] = v.y / vdiv; vs[r][c + 2] = v.z / vdiv; vs[r][c + 3] = v.w / vdiv;
+  }
+  __syncthreads();
+  const int h = tid >> 4, v = tid & 15;
+  float kv[16], ksum[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) { kv[d] = 0.f; ksum[d] = 0.f; }
+  for (int r = 0; r < S; ++r) {
+    const float vv = vs[r][h * 16 + v];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { const float kd = ks[r][h * 16 + d]; kv[d] += kd * vv; ksum[d] += kd; }
+  }
+  for (int r = 0; r < S; ++r) {
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { const float qd = qs[r][h * 16 + d]; num = fmaf(qd, kv[d], num); den = fmaf(qd, ksum[d], den); }
+    out[((long long)seq * S + r) * 128 + tid] = num * (1.0f / (den + 1e-6f)) * vdiv;
+  }
+}
+
 __device__ inline float wsum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -900,6 +934,8 @@ void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pa
     hipLaunchKernelGGL(k_lf_kv_partial<32>, dim3(heads, nsplit, nall), dim3(256), 0, s, qkv + d, qkv + 2 * d, 3 * d, (long long)seq_rows * 3 * d, Lseq, chunk, (float)Lseq, kvpart, nsplit, heads);
     hipLaunchKernelGGL(k_lf_kv_reduce, dim3((unsigned)((per * nall + 255) / 256)), dim3(256), 0, s, kvpart, kv, nsplit, per, nall);
     hipLaunchKernelGGL(k_lf_attn_apply<32>, dim3((Lseq + 7) / 8, nall), dim3(256), smem, s, qkv, 3 * d, (long long)seq_rows * 3 * d, kv, cross, att, d, (long long)seq_rows * d, Lseq, (float)Lseq, heads);
+  } else if (Lseq <= 32 && seq_rows == Lseq && d == 128) {
+    hipLaunchKernelGGL(k_lf_fine_attn, dim3(nall), dim3(128), 0, s, qkv, Lseq, cross, att);
   } else {
     hipLaunchKernelGGL(k_lf_kv_partial<16>, dim3(heads, nsplit, nall), dim3(256), 0, s, qkv + d, qkv + 2 * d, 3 * d, (long long)seq_rows * 3 * d, Lseq, chunk, (float)Lseq, kvpart, nsplit, heads);
     hipLaunchKernelGGL(k_lf_kv_reduce, dim3((unsigned)((per * nall + 255) / 256)), dim3(256), 0, s, kvpart, kv, nsplit, per, nall);
