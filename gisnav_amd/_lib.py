@@ -25,6 +25,7 @@ SIGNATURES = {
     "gn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
     "gn_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VP)]),
     "gn_set_image_size": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "gn_resize": (C.c_int, [VP, C.c_int]),
     "gn_destroy": (None, [VP]),
     "gn_load_tensor": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
     "gn_missing_tensors": (C.c_int, [VP]),

@@ -128,6 +128,7 @@ struct gn_ctx {
   float* pts_ws = nullptr;
   gn::HypResult* hyp_ws = nullptr;
   std::vector<void*> allocs;
+  std::vector<void*> ws_allocs;     // the max_kpts-dependent workspaces (alloc_workspace): replaced by gn_resize, weights stay
   // stage timing
   bool timing = false;
   hipEvent_t ev[2 * 128];
@@ -173,11 +174,22 @@ int dalloc(gn_ctx* ctx, T** p, size_t count) {
   return GN_OK;
 }
 
+// Every buffer whose size depends on max_kpts (the per-token / per-pair workspaces), tracked apart from the weights so that gn_resize can
+// replace them without touching a weight: ctx->ws_allocs.
+template <typename T_>
+int ws_alloc(gn_ctx* ctx, T_** p, size_t count) {
+  void* q = nullptr;
+  GN_HIP(hipMalloc(&q, count * sizeof(T_)));
+  GN_HIP(hipMemset(q, 0, count * sizeof(T_)));
+  ctx->ws_allocs.push_back(q);
+  *p = reinterpret_cast<T_*>(q);
+  return GN_OK;
+}
 // The [B][npad][npad] similarity buffer is no longer part of the matcher (fused match head): it exists only for TwistNode's
 // brute-force matcher, the unfused developer path and the phase-stamp tools, and is allocated on their first use.
 int ensure_sim(gn_ctx* ctx) {
   if (ctx->sim) return GN_OK;
-  return dalloc(ctx, &ctx->sim, (size_t)ctx->max_batch * ctx->npad * ctx->npad);
+  return ws_alloc(ctx, &ctx->sim, (size_t)ctx->max_batch * ctx->npad * ctx->npad);
 }
 
 std::string canonical(const std::string& k) {
@@ -575,6 +587,38 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   return GN_OK;
 }
 
+int alloc_workspace(gn_ctx* ctx, int max_kpts) {
+  ctx->npad = ((max_kpts + 127) / 128) * 128;
+  ctx->npad_run = ctx->npad;
+  const size_t np = ctx->npad, T = (size_t)ctx->max_batch * 2 * np, B = ctx->max_batch;
+#define GN_ALLOC(field, count)                                     \
+  do { int rc_ = ws_alloc(ctx, &ctx->field, (count)); if (rc_ != GN_OK) return rc_; } while (0)
+  GN_ALLOC(desc, T * kInDim); GN_ALLOC(cos_t, T * kFreq); GN_ALLOC(sin_t, T * kFreq);
+  GN_ALLOC(extent, B * 4); GN_ALLOC(nvalid, B * 2);
+  GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
+  GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
+  ctx->Tmax = T;
+  if (ctx->precision == GN_PREC_F16X2_BF16_ATTN) {
+    ctx->planes_mode = 1;
+    GN_ALLOC(desc_p, 2 * T * kInDim); GN_ALLOC(x_p, 2 * T * kDim); GN_ALLOC(ctx_p, 2 * T * kDim);
+    GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
+    GN_ALLOC(rot4, T * 2 * kFreq);
+  }
+  if (ctx->precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); GN_ALLOC(attn_part, (size_t)256 * 4 * 34 * 64); GN_ALLOC(attn_tickets, 256); }
+  GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
+  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
+  GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
+  GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
+  GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
+  GN_ALLOC(mask_ws, B * np * 16);
+  GN_ALLOC(pts_ws, B * np * 5);
+  GN_ALLOC(hyp_ws, B * 16);
+  GN_ALLOC(ovf_base, 16);
+  ctx->ovf = ctx->ovf_base;
+#undef GN_ALLOC
+  return GN_OK;
+}
+
 int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
   if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
@@ -620,34 +664,7 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   ctx->device = device; ctx->max_batch = max_batch; ctx->precision = precision; ctx->feature = feature;
   ctx->precision_api = precision_api; ctx->attn_f16 = precision_api == GN_PREC_F16X2_F16_ATTN ? 1 : 0;
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
-  ctx->npad = ((max_kpts + 127) / 128) * 128;
-  ctx->npad_run = ctx->npad;
-  const size_t np = ctx->npad, T = (size_t)max_batch * 2 * np, B = max_batch;
-#define GN_ALLOC(field, count)                                     \
-  do { int rc_ = dalloc(ctx, &ctx->field, (count)); if (rc_ != GN_OK) { gn_destroy(ctx); return rc_; } } while (0)
-  GN_ALLOC(desc, T * kInDim); GN_ALLOC(cos_t, T * kFreq); GN_ALLOC(sin_t, T * kFreq);
-  GN_ALLOC(extent, B * 4); GN_ALLOC(nvalid, B * 2);
-  GN_ALLOC(x, T * kDim); GN_ALLOC(qkv, T * 3 * kDim); GN_ALLOC(ctx, T * kDim); GN_ALLOC(msg, T * kDim);
-  GN_ALLOC(h, T * 2 * kDim); GN_ALLOC(md, T * kDim); GN_ALLOC(ls, T);
-  ctx->Tmax = T;
-  if (precision == GN_PREC_F16X2_BF16_ATTN) {
-    ctx->planes_mode = 1;
-    GN_ALLOC(desc_p, 2 * T * kInDim); GN_ALLOC(x_p, 2 * T * kDim); GN_ALLOC(ctx_p, 2 * T * kDim);
-    GN_ALLOC(msg_p, 2 * T * kDim); GN_ALLOC(h_p, 2 * T * 2 * kDim); GN_ALLOC(md_p, 2 * T * kDim);
-    GN_ALLOC(rot4, T * 2 * kFreq);
-  }
-  if (precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); GN_ALLOC(attn_part, (size_t)256 * 4 * 34 * 64); GN_ALLOC(attn_tickets, 256); }
-  GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
-  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
-  GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
-  GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
-  GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
-  GN_ALLOC(mask_ws, B * np * 16);
-  GN_ALLOC(pts_ws, B * np * 5);
-  GN_ALLOC(hyp_ws, B * 16);
-  GN_ALLOC(ovf_base, 16);
-  ctx->ovf = ctx->ovf_base;
-#undef GN_ALLOC
+  { const int rc_ws = alloc_workspace(ctx, max_kpts); if (rc_ws != GN_OK) { gn_destroy(ctx); return rc_ws; } }
   if (hipHostMalloc((void**)&ctx->ovf_host, 16 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
   memset(ctx->ovf_host, 0, 16 * sizeof(unsigned int));
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
@@ -667,10 +684,33 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   return GN_OK;
 }
 
+int gn_resize(gn_ctx* ctx, int max_kpts) {
+  if (!ctx || max_kpts < 2) return fail(ctx, GN_ERR_ARG, "bad gn_resize argument");
+  if (((max_kpts + 127) / 128) * 128 == ctx->npad) return GN_OK;
+  GN_HIP(hipSetDevice(ctx->device));
+  GN_HIP(hipDeviceSynchronize());                      // nothing may still be reading the old workspaces
+  for (void* p : ctx->ws_allocs) hipFree(p);
+  ctx->ws_allocs.clear();
+  ctx->sim = nullptr;                                  // allocated on first use (ensure_sim), for the new size
+  for (bool& b : ctx->sub_pending) b = false;
+  { const int rc = alloc_workspace(ctx, max_kpts); if (rc != GN_OK) return rc; }
+  if (ctx->s_pnp) {                                    // the overlapped pose stage's double buffers follow the padded size too
+    const size_t B = ctx->max_batch, np = ctx->npad;
+    for (int i = 0; i < 2; ++i) {
+      ctx->pnp_pending[i] = false;
+      int rc = ws_alloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return rc;
+      rc = ws_alloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return rc;
+      rc = ws_alloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return rc;
+    }
+  }
+  return GN_OK;
+}
+
 void gn_destroy(gn_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   for (void* p : ctx->allocs) hipFree(p);
+  for (void* p : ctx->ws_allocs) hipFree(p);
   if (ctx->ovf_host) hipHostFree(ctx->ovf_host);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
@@ -1069,9 +1109,9 @@ int gn_set_overlap(gn_ctx* ctx, int enable) {
     for (int i = 0; i < 2; ++i) {
       GN_HIP(hipEventCreateWithFlags(&ctx->ev_gather[i], hipEventDisableTiming));
       GN_HIP(hipEventCreateWithFlags(&ctx->ev_pnp[i], hipEventDisableTiming));
-      int rc = dalloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return rc;
-      rc = dalloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return rc;
-      rc = dalloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return rc;
+      int rc = ws_alloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return rc;
+      rc = ws_alloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return rc;
+      rc = ws_alloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return rc;
     }
   }
   if (!enable && ctx->s_pnp) GN_HIP(hipStreamSynchronize(ctx->s_pnp));

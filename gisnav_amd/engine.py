@@ -156,31 +156,15 @@ class PoseEngine:
 
     # ------------------------------------------------------------------ weights
     def grow(self, max_kpts: int) -> None:
-        """Re-create the context for more keypoints per side (weights re-loaded).  The reference accepts any keypoint count
-        (cv2.SIFT_create() is unbounded, pose_node.py:122); the mirrors call this instead of failing on a larger cloud."""
+        """Re-size the context for more keypoints per side (`gn_resize`: the workspaces are replaced, every weight, SuperPoint tensor and
+        setting stays).  The reference accepts any keypoint count (cv2.SIFT_create() is unbounded, pose_node.py:122); the mirrors call this
+        instead of failing on a larger cloud.  Costs a device synchronisation and a few allocations -- no weight reload (round 2 re-created
+        the whole context: a multi-100 ms stall on the first large tile)."""
         if max_kpts <= self.kmax:
             return
-        ctx = C.c_void_p()
-        _lib.check(None, self.lib.gn_create_ex(self.device.index or 0, self.max_batch, int(max_kpts), _PRECISIONS[self.precision], self._feature, C.byref(ctx)), "gn_create_ex")
-        old, self.ctx = self.ctx, ctx
-        self.lib.gn_destroy(old)
-        self.kmax = self.lib.gn_kmax(ctx)
+        _lib.check(self.ctx, self.lib.gn_resize(self.ctx, int(max_kpts)), "gn_resize")
+        self.kmax = self.lib.gn_kmax(self.ctx)
         self._sift = None
-        _lib.check(ctx, self.lib.gn_set_num_layers(ctx, self._n_layers), "gn_set_num_layers")
-        _lib.check(ctx, self.lib.gn_set_filter_threshold(ctx, self._filter_threshold), "gn_set_filter_threshold")
-        _lib.check(ctx, self.lib.gn_set_guard(ctx, self._guard), "gn_set_guard")
-        if self._state_dict is not None:
-            self.load_state_dict(self._state_dict)
-        # every other piece of sticky state this object set on the old context (ADVICE r2: a grow must not silently drop them)
-        self.set_image_size(*self._image_size)
-        if self._substreams > 1 or self._deferred_join:
-            self.set_substreams(self._substreams, self._deferred_join)
-        if self._overlap:
-            self.set_overlap(True)
-        if self._sp_arithmetic is not None:
-            self.sp_set_arithmetic(self._sp_arithmetic)
-        if self._sp_state_dict is not None:
-            self.sp_load_state_dict(self._sp_state_dict)
 
     # SuperPoint weights / arithmetic live in the context too (gn_sp_*); kept here so that grow() can replay them
     def sp_set_arithmetic(self, mode: int) -> None:

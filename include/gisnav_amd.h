@@ -133,6 +133,11 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
  * side; a non-positive value selects the keypoint extent (max_x, max_y) of that side, which is what PoseNode gets because it
  * passes hw1 = hw2 = None (pose_node.py:285-287).  Sticky host-side state, (0, 0, 0, 0) by default. */
 int gn_set_image_size(gn_ctx* ctx, float w_q, float h_q, float w_r, float h_r);
+/* Re-size the context for up to max_kpts keypoints per side: synchronises the device, replaces the max_kpts-dependent workspaces and keeps every
+ * weight (and its pre-split planes / fragment layouts) where it is -- the reference accepts any keypoint count (cv2.SIFT_create() is unbounded,
+ * pose_node.py:122), so the mirrors grow a context instead of failing, and a grow costs a few allocations, not a weight reload.  gn_kmax
+ * changes; gn_set_active_kpts is reset to the new size; every other setting stays. */
+int gn_resize(gn_ctx* ctx, int max_kpts);
 void gn_destroy(gn_ctx* ctx);
 
 /* Load one tensor of the kornia LightGlue("sift") state dict from HOST
