@@ -346,7 +346,7 @@ template <typename T> __device__ __forceinline__ T ld_dev(const T* p) { return _
 // are below 2^-16 of the row's largest even under the lazy maximum), subnormals are honoured by the matrix pipe.
 template <int ABL, int NW, int ND = 3, int NQ = 1, bool SPLIT = false, bool F16 = false>   // NW waves share one K / V^T tile stream; ND = ring depth (3 or 4 tiles; 4 measured no faster);
                                                      // NQ = query tiles of 32 per wave (2: every K / V^T fragment read from LDS feeds two MFMAs)
-__global__ __launch_bounds__(64 * NW, 2) void k_attn16_v5(AttnArgs a) {   // two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers
+__global__ __launch_bounds__(64 * NW, NQ == 1 ? 2 : 1) void k_attn16_v5(AttnArgs a) {   // NQ = 1: two waves per SIMD (two workgroups per CU at NW = 4): at most 256 registers; NQ = 2: one wave per SIMD with the whole register file
   constexpr int IPW = 8 / NW;                 // LDS-DMA instructions per wave per 8 KB tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * ND * kRing + 8 + ((ABL & 512) ? 24576 : 0)];   // ABL 512 (experiment): +48 KB so that only one workgroup fits a CU   // K ring [ND][64 keys][64], V^T ring [ND][64 dims][64 keys], overflow flag
 
