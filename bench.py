@@ -520,7 +520,7 @@ def main() -> None:
     torch.cuda.empty_cache()
 
     extras = []
-    if not args.no_extras and not args.debug_variant:
+    if not args.no_extras and not args.debug_variant and world == 1:   # per-GPU side configurations: reported by the N = 1 line; an N > 1 run times the sharded headline only
         extras.append(run_extra(local_rank, sd, "BASELINE configs[1] as SURVEY.md reads it: batch-1 640x480 pair, f32 everywhere (exact-f32 MFMA GEMMs and attention)",
                                 1, args.kpts, "f32", 30, 5, dev))
         extras.append(run_extra(local_rank, sd, "BASELINE configs[2] with exact-f32 MFMA projections/FFN (no fp16 split) + bf16 MFMA attention",
