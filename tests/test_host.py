@@ -43,6 +43,11 @@ def test_product_path_has_no_cpu_fallback():
     from gisnav_amd.matcher import LightGlueMatcher
     with pytest.raises(_lib.GnError):
         LightGlueMatcher("sift", params={"depth_confidence": -1, "width_confidence": -1}).to("cpu")
+    from gisnav_amd.loftr import LoFTR
+    with pytest.raises(_lib.GnError):
+        LoFTR(state_dict={"x": torch.zeros(1)}).to("cpu")                      # no CPU path
+    with pytest.raises(_lib.GnError):
+        LoFTR(pretrained="outdoor").to("cuda:0")                               # no checkpoint offline: fails loudly, never random weights
 
 
 def test_product_package_never_imports_the_oracle():
