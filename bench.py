@@ -185,7 +185,7 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
     from gisnav_amd.superpoint import SuperPoint
     from gisnav_amd import _lib as glib
     sd_m = synthetic_state_dict(0, feature="superpoint", identity_blocks=True)    # blocks = identity: the match is the mutual nearest neighbour of the descriptors
-    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision="f16x2_bf16_attn", state_dict=sd_m, filter_threshold=0.0, feature="superpoint")
+    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision="f16x2_f16_attn", state_dict=sd_m, filter_threshold=0.0, feature="superpoint")
     g = torch.Generator(device="cpu").manual_seed(5)
     conv_sd = {}
     sizes = [1, 64, 64, 128, 128]
@@ -230,7 +230,7 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
     fp16 = arithmetic == "fp16"
     res = {"config": ("BASELINE configs[4] per GPU with 16-bit convolution operands (what configs[4] names; one fp16 product per block, f32 accumulate -- NOT f32-accurate: ~99 % of the exact path's keypoints): 1920x1080 frames -> SuperPoint -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels" if fp16 else
                       "BASELINE configs[4] per GPU: 1920x1080 frames -> SuperPoint (split-fp16 MFMA convolutions: f32 operands as 2 fp16 terms, 3 products, f32 accumulate) -> LightGlue(superpoint), 1024 kpts -> PnP-RANSAC, from pixels"),
-           "batch": batch, "keypoints_per_side": kpts, "precision": ("fp16 (single product) convolutions" if fp16 else "f16x2 convolutions") + " + f16x2_bf16_attn matcher", "steps": steps, "warmup": warmup,
+           "batch": batch, "keypoints_per_side": kpts, "precision": ("fp16 (single product) convolutions" if fp16 else "f16x2 convolutions") + " + f16x2_f16_attn matcher", "steps": steps, "warmup": warmup,
            "value": round(batch * steps / elapsed, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 3),
            "superpoint_ms_per_image": round(t_sp / steps / (2 * batch) * 1e3, 3), "superpoint_gflop_per_image": 345.0,
            "superpoint_tflops": round(345.0 / (t_sp / steps / (2 * batch)) / 1e3, 1),
