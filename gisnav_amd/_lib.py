@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgisnav_amd.so")
+LIB_PATH = os.environ.get("GISNAV_AMD_LIB") or os.path.join(HERE, "libgisnav_amd.so")   # (the override is for developer A/B builds, tools/slp_variants.sh)
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)

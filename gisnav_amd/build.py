@@ -15,12 +15,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgisnav_amd.so")
 SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_qkv.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
-# SLP vectoriser: ON for every file except gn_qkv.hip.  With SLP packing on, hipcc (ROCm 7.2) turns the scalar f32 math of k_qkv's rotary
-# epilogue into v_pk_mul_f32 / v_pk_fma_f32 sequences with op_sel that produce timing-dependent wrong values on gfx950 when two waves
-# share a SIMD (word 3 of the 16-byte q / k stores, ~0.09 % of words; tools/qkv_var.py, tools/flake_layers.py: 40 of 40 bench-sized calls
-# differ from run to run).  Round 2 carried -fno-slp-vectorize library-wide; per-file runs showed every OTHER file bit-repeatable with SLP
-# on (0 of 40 each), so since round 3 the flag is scoped to the one file that needs it.  The root cause inside that
-# file is still open (tools/probes/pk_opsel.hip rules out the op_sel-ignored register half); the 60-run bitwise tests guard every mode.
+# SLP vectoriser: ON for every file except gn_qkv.hip.  With it, hipcc (ROCm 7.2) packs the second rotary pair of k_qkv's epilogue
+# (o.z = v.z cos' - v.w sin', o.w = v.w cos' + v.z sin') into `v_pk_fma_f32 D, A, B, C op_sel:[0,1,0]` -- the LOW lane multiplies by the HIGH
+# register of B -- and on the MI355X that instruction, in this kernel, intermittently returns C alone in the low lane (the product is dropped)
+# in lanes 48..63: o.z of ~0.1 % of the (token, pair) positions, different ones every run (tools/slp_diag.py).  Pinned by editing the SLP
+# build's assembly one thing at a time (tools/slp_variants.sh, 20 bench-sized runs each): the suspect alone replaced by two v_fma_f32 -> 0 of
+# 20 runs differ; kept packed but reading cos' from a low register (op_sel_hi:[1,0,1], the first pair's form) -> 0 of 20; s_nop 7 on both
+# sides of it, destination != source 0, every wait forced to 0, the neighbouring v_pk_mul_f32 scalarised -> still 20 of 20.  A standalone
+# loop of the same instruction (tools/probes/pk_fma_opsel.hip, 1.7e10 results next to MFMA waves) never fails, so it is legal code that
+# misbehaves in this kernel's company, not a missing wait state or a barrier protocol.  Without the vectoriser the compiler never emits a
+# low-lane op_sel on a packed fma; tests/test_host.py disassembles the shipped library and fails if one appears anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
 # attention: keep the MFMA accumulators in VGPRs (the softmax reads the scores and rescales the output every tile;
 # with the default AGPR form each tile paid ~255 v_accvgpr_read/write moves on the VALU, the kernel's bottleneck)

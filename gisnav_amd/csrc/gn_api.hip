@@ -1509,7 +1509,7 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"sp_scores", ctx->sp_maps[0], ctx->sp_maps[0] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},             // softmax + depth-to-space scores
       {"sp_nms", ctx->sp_maps[5], ctx->sp_maps[5] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},                // after simple_nms
       {"x_p", ctx->x_p, ctx->x_p ? T * kDim : 0}, {"msg_p", ctx->msg_p, ctx->msg_p ? T * kDim : 0},   // hm16 rows, raw (4 bytes per value)
-      {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
+      {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"rot4", ctx->rot4, ctx->rot4 ? T * 2 * kFreq : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
   for (const Ent& e : tab)
     if (strcmp(e.n, name) == 0) {
       size_t count = e.count;

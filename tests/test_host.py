@@ -33,6 +33,34 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     assert lib.gn_version().decode().endswith("gfx950")
 
 
+def test_shipped_device_code_has_no_low_lane_opsel_packed_fma(tmp_path):
+    """`v_pk_fma_f32 ... op_sel:[.,1,.]` (the LOW lane multiplies by the HIGH register of source 1) is the instruction behind k_qkv's run-to-run
+    differences when gn_qkv.hip is built with the SLP vectoriser (on the MI355X the low lane intermittently returns source 2 alone in
+    lanes 48..63; replacing that one instruction makes the kernel repeatable).  hipcc must not have emitted it anywhere in the library that ships."""
+    import shutil
+    import subprocess
+    from gisnav_amd import build, _lib
+    build.build(verbose=False)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    so = shutil.copy(os.path.join(ROOT, "gisnav_amd", "libgisnav_amd.so"), tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", os.path.basename(so)], cwd=tmp_path, check=True, capture_output=True)   # writes lib.so.N.hipv4-... beside it
+    objs = sorted(f for f in os.listdir(tmp_path) if "hipv4" in f)
+    assert len(objs) >= len(build.SOURCES) - 3, objs      # (a source without kernels has no bundle)
+    packed = bad = 0
+    for f in objs:
+        dis = subprocess.run([objdump, "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"v_pk_fma_f32 (.*)", dis):
+            packed += 1
+            sel = re.search(r"op_sel:\[([01]),([01]),([01])\]", m.group(1))
+            srcs = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", m.group(1).split(" op_sel")[0])][1:]
+            if sel and any(b == "1" and srcs[i].startswith("v") for i, b in enumerate(sel.groups())):
+                bad += 1
+    assert packed > 1000          # the check looked at real code
+    assert bad == 0, f"{bad} v_pk_fma_f32 read a VGPR source through a low-lane op_sel bit"
+
+
 def test_product_path_has_no_cpu_fallback():
     from gisnav_amd import _lib
     from gisnav_amd.engine import PoseEngine
