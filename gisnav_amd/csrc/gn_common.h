@@ -70,7 +70,8 @@ __device__ __forceinline__ unsigned int pack16_rt(float lo, float hi, int f16) {
 // ---- GEMM -----------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_SCALE_COLS = 1, EPI_ROTARY = 2, EPI_RESIDUAL = 3, EPI_PLAIN = 4,
                EPI_ROTARY_BF16 = 5, EPI_SCALE_BF16 = 6,
-               EPI_LN_GELU = 7 };   // bias -> LayerNorm over the N = 512 outputs of a row -> erf GELU -> hm16 (k_gemm_p2ln only)
+               EPI_LN_GELU = 7,     // bias -> LayerNorm over the N = 512 outputs of a row -> erf GELU -> hm16 (k_gemm_p2ln only)
+               EPI_RELU = 8 };      // (bias ->) max(., 0): the LoFTR encoder's MLP (k_gemm_f32_v3 / k_gemm_f16x2 only)
 
 struct GemmArgs {
   const float* A;    int lda;      // A[M][K1] (k < K1)
@@ -107,8 +108,8 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // fp16-plane operands (Ap, Wp)
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
 void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s);
-extern const char* g_last_kernel;   // bench facility: rocprof-style name of the kernel the last launch_* call dispatched (single-threaded use)
-extern int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking
+extern thread_local const char* g_last_kernel;   // bench facility: rocprof-style name of the kernel the last launch_* call of THIS host thread dispatched
+extern thread_local int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking (per host thread: every API entry sets it from its own context before it launches)
 extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 kernel when the shape allows
 
 // ---- fused block tail (gn_ffn.hip): x <- x + ffn.3(GELU(LayerNorm(ffn.0([x | msg])))) for hm16 rows ----------
@@ -177,7 +178,7 @@ void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
 void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s);   // (a.half_fmt selects bf16 / fp16)   // f32 rows -> the bf16 layouts k_attn_bf16_v5 reads (test entry)
-extern int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
+extern thread_local int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
 struct PrepArgs {

@@ -270,6 +270,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
       }
     } else if (EPI == EPI_RESIDUAL) {
       v += res16[it];
+    } else if (EPI == EPI_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
@@ -580,6 +582,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
       }
     } else if (EPI == EPI_RESIDUAL) {
       v += res16[it];
+    } else if (EPI == EPI_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
@@ -895,6 +899,8 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
       }
     } else if (EPI == EPI_RESIDUAL) {
       v += res16[it];
+    } else if (EPI == EPI_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
 }
 }  // namespace
 
-int g_gemm_variant = 3;
+thread_local int g_gemm_variant = 3;
 
 // Pure-MFMA ceiling probe: 4 waves per CU-resident block, 8 independent accumulators, no memory traffic.
 __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
@@ -1031,6 +1037,7 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
       case EPI_RESIDUAL: GN_H2(EPI_RESIDUAL) break;
       case EPI_ROTARY_BF16: GN_H2(EPI_ROTARY_BF16) break;
       case EPI_SCALE_BF16: GN_H2(EPI_SCALE_BF16) break;
+      case EPI_RELU: GN_H2(EPI_RELU) break;
       default: GN_H2(EPI_PLAIN) break;
     }
 #undef GN_H2
@@ -1060,6 +1067,7 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
     case EPI_RESIDUAL: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_RESIDUAL>, grid, block, 0, s, a); break;
     case EPI_ROTARY_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_ROTARY_BF16>, grid, block, 0, s, a); break;
     case EPI_SCALE_BF16: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_SCALE_BF16>, grid, block, 0, s, a); break;
+    case EPI_RELU: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_RELU>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(k_gemm_f32_v3<EPI_PLAIN>, grid, block, 0, s, a); break;
   }
 }

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(512) void k_gemm_p2ln(GemmArgs a) {
 }
 }  // namespace
 
-const char* g_last_kernel = "";
+thread_local const char* g_last_kernel = "";
 int g_p2_wide = 1;   // developer knob: 0 = always the 128x128 kernel
 
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s) {

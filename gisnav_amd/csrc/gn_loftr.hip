@@ -504,26 +504,32 @@ __global__ __launch_bounds__(256) void k_lf_layernorm(const float* in, const flo
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   if (mode != 0 && (int)((row / seq_rows) & 1) != mode - 1) return;
-  const int per = C / 64;                               // 2 or 4 values per lane
-  float v[4];
+  // a lane owns C / 64 = 2 or 4 CONSECUTIVE values: one 8- or 16-byte access each for the row, the affine pair and the residual
+  float v[4], gg[4], bb[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long base = row * C;
+  if (C == 256) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(in + base + lane * 4);
+    const f32x4 tg = *reinterpret_cast<const f32x4*>(g + lane * 4), tb = *reinterpret_cast<const f32x4*>(b + lane * 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    gg[0] = tg.x; gg[1] = tg.y; gg[2] = tg.z; gg[3] = tg.w; bb[0] = tb.x; bb[1] = tb.y; bb[2] = tb.z; bb[3] = tb.w;
+    if (resid) { const f32x4 tr = *reinterpret_cast<const f32x4*>(resid + base + lane * 4); rr[0] = tr.x; rr[1] = tr.y; rr[2] = tr.z; rr[3] = tr.w; }
+  } else {   // C == 128
+    const float2 t = *reinterpret_cast<const float2*>(in + base + lane * 2);
+    const float2 tg = *reinterpret_cast<const float2*>(g + lane * 2), tb = *reinterpret_cast<const float2*>(b + lane * 2);
+    v[0] = t.x; v[1] = t.y; v[2] = 0.f; v[3] = 0.f; gg[0] = tg.x; gg[1] = tg.y; gg[2] = gg[3] = 0.f; bb[0] = tb.x; bb[1] = tb.y; bb[2] = bb[3] = 0.f;
+    if (resid) { const float2 tr = *reinterpret_cast<const float2*>(resid + base + lane * 2); rr[0] = tr.x; rr[1] = tr.y; }
+  }
+  const int per = C / 64;
   float s = 0.f;
-  for (int e = 0; e < per; ++e) { v[e] = in[row * C + lane * per + e]; s += v[e]; }
+  for (int e = 0; e < per; ++e) s += v[e];
   const float mean = wsum(s) / (float)C;
   float sq = 0.f;
   for (int e = 0; e < per; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
   const float rstd = 1.0f / sqrtf(wsum(sq) / (float)C + 1e-5f);
-  for (int e = 0; e < per; ++e) {
-    const int c = lane * per + e;
-    const float y = v[e] * rstd * g[c] + b[c];
-    out[row * C + c] = resid ? resid[row * C + c] + y : y;
-  }
-}
-__global__ __launch_bounds__(256) void k_lf_relu(float* x, long long n4) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 v = reinterpret_cast<f32x4*>(x)[i];
-  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-  reinterpret_cast<f32x4*>(x)[i] = v;
+  float y[4];
+  for (int e = 0; e < 4; ++e) { y[e] = v[e] * rstd * gg[e] + bb[e]; if (resid) y[e] = rr[e] + y[e]; }
+  if (C == 256) *reinterpret_cast<f32x4*>(out + base + lane * 4) = (f32x4){y[0], y[1], y[2], y[3]};
+  else *reinterpret_cast<float2*>(out + base + lane * 2) = make_float2(y[0], y[1]);
 }
 __global__ __launch_bounds__(256) void k_lf_scale(const float* x, float* y, float div, long long n4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -884,14 +890,14 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   }
 }
 
-int g_lf_gemm_variant = 3;
-void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s) {
+thread_local int g_lf_gemm_variant = 3;   // set by lf_forward from the context it runs (per host thread)
+void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s, bool relu = false) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = Wt; g.ldw = ldw; g.bias = bias; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.acc_scale = 1.f;
   const int saved = gn::g_gemm_variant;
   gn::g_gemm_variant = g_lf_gemm_variant;                   // 3 = the exact-f32 MFMA GEMM, whatever other contexts selected; 6 = every f32 operand split into two fp16 terms on the fly (gn_loftr_set_arithmetic)
-  launch_gemm_f32(bias ? EPI_BIAS : EPI_PLAIN, g, 1, s);
+  launch_gemm_f32(relu ? EPI_RELU : bias ? EPI_BIAS : EPI_PLAIN, g, 1, s);      // (relu: the MLP's first layer, max(x, 0) applied to the value the plain epilogue would store)
   gn::g_gemm_variant = saved;
 }
 
@@ -920,8 +926,7 @@ void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pa
     hipLaunchKernelGGL(k_lf_attn_apply<32>, dim3((Lseq + 7) / 8, 1), dim3(256), smem, s, qa, 3 * d, 0LL, kv, 0, atta, d, 0LL, Lseq, (float)Lseq, heads);
     lf_gemm(atta, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msga, d, seq_rows, d, d, s);
     hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((seq_rows + 3) / 4)), dim3(256), 0, s, msga, ly.n1g, ly.n1b, (const float*)nullptr, msga, (long long)seq_rows, d, seq_rows, 0);
-    lf_gemm(xa, d, msga, d, d, ly.mlp0.w, 2 * d, nullptr, hida, 2 * d, seq_rows, 2 * d, 2 * d, s);
-    hipLaunchKernelGGL(k_lf_relu, dim3((unsigned)(((long long)seq_rows * 2 * d / 4 + 255) / 256)), dim3(256), 0, s, hida, (long long)seq_rows * 2 * d / 4);
+    lf_gemm(xa, d, msga, d, d, ly.mlp0.w, 2 * d, nullptr, hida, 2 * d, seq_rows, 2 * d, 2 * d, s, true);
     lf_gemm(hida, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, atta, d, seq_rows, d, 2 * d, s);
     hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((seq_rows + 3) / 4)), dim3(256), 0, s, atta, ly.n2g, ly.n2b, xa, xa, (long long)seq_rows, d, seq_rows, 0);
     return;
@@ -943,8 +948,7 @@ void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pa
   }
   lf_gemm(att, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msg, d, rows_pad, d, d, s);
   hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, msg, ly.n1g, ly.n1b, (const float*)nullptr, msg, (long long)rows_pad, d, seq_rows, 0);
-  lf_gemm(x, d, msg, d, d, ly.mlp0.w, 2 * d, nullptr, hid, 2 * d, rows_pad, 2 * d, 2 * d, s);
-  hipLaunchKernelGGL(k_lf_relu, dim3((unsigned)(((long long)rows_pad * 2 * d / 4 + 255) / 256)), dim3(256), 0, s, hid, (long long)rows_pad * 2 * d / 4);
+  lf_gemm(x, d, msg, d, d, ly.mlp0.w, 2 * d, nullptr, hid, 2 * d, rows_pad, 2 * d, 2 * d, s, true);
   lf_gemm(hid, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, att, d, rows_pad, d, 2 * d, s);
   hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, att, ly.n2g, ly.n2b, x, x, (long long)rows_pad, d, seq_rows, mode);
 }
