@@ -1,10 +1,23 @@
-"""Developer tool: latency of small batches (1, 2, 4 pairs; the reference's operating point is 1) in the headline precision, timed like bench.py's extra."""
+"""Developer tool: latency of small batches (1, 2, 4 pairs; the reference's operating point is 1) in the headline precision, timed like bench.py's extras.
+   python tools/small_batch.py [batch ...] [--knob WHICH:VALUE ...]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from gisnav_amd.engine import PoseEngine  # noqa: E402
+from gisnav_amd.synthetic import make_pair  # noqa: E402
 from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 dev = torch.device("cuda", 0)
 sd = synthetic_state_dict(0)
-for b in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
-    r = bench.run_extra(0, sd, f"batch-{b}", b, 1024, "f16x2_f16_attn", 300, 30, dev)
-    print(f"batch {b}: {r['ms_per_step']:.4f} ms per call, {r['value']:.1f} pairs/s, poses ok {r['poses_ok_per_step']}", flush=True)
+args = sys.argv[1:]
+knobs = [tuple(int(x) for x in a.split(":")) for i, a in enumerate(args) if i > 0 and args[i - 1] == "--knob"]
+batches = [int(a) for i, a in enumerate(args) if a.isdigit() and (i == 0 or args[i - 1] != "--knob")] or [1, 2, 4]
+for b in batches:
+    eng = PoseEngine(0, max_batch=b, max_kpts=1024, precision="f16x2_f16_attn", state_dict=sd)
+    for w, v in knobs:
+        eng.lib.gn_debug_set_variant(eng.ctx, w, v)
+    inp = eng.stage_inputs([make_pair(i, n_q=1024, n_r=1024) for i in range(b)])
+    out = eng.alloc_outputs(b)
+    torch.cuda.synchronize()
+    elapsed, _ = bench.timed_steps(eng, inp, out, 300, 30, dev)
+    print(f"batch {b} knobs {knobs}: {elapsed / 300 * 1e3:.4f} ms per call, {b * 300 / elapsed:.1f} pairs/s, poses ok {int(out['ok'].sum().item())}", flush=True)
+    del eng
