@@ -509,3 +509,57 @@ def test_compute_pose_with_exactly_four_points_takes_the_p3p_branch():
     _report("p3p_four_point_branch_150_scenes", {"max_pose_delta_vs_oracle": worst, "scenes_above_1e-6": int(loose)})
     assert loose <= 7, loose
     assert gpose.compute_pose(cam, qry[:3], ref[:3], dem) is None and pr.compute_pose(K.reshape(-1), qry[:3], ref[:3], dem) is None
+
+
+# ------------------------------------------------------------------ contexts on concurrent host threads
+def test_three_contexts_on_three_host_threads_keep_their_own_kernel_families(state_dict_np):
+    """The kernel-family selectors behind the launch functions (exact-f32 / split GEMM family, attention variant, the LoFTR GEMM arithmetic) are
+    per host thread and set from the calling context at every API entry: an f32 matcher context, an f16x2 matcher context and a split-fp16 LoFTR
+    context driven from three threads at once (ctypes releases the GIL inside the calls) each reproduce their own serial results bit for bit."""
+    import threading
+    from gisnav_amd import loftr_synthetic as olf
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.loftr import LoFTR
+    dev = torch.device("cuda", 0)
+    pairs = [make_pair(70 + i, n_q=256, n_r=256) for i in range(2)]
+    engs = {p: PoseEngine(0, max_batch=2, max_kpts=256, precision=p, state_dict=state_dict_np) for p in ("f32", "f16x2_f16_attn")}
+    inps = {p: e.stage_inputs(pairs) for p, e in engs.items()}
+    lf = LoFTR(state_dict=olf.synthetic_state_dict(0), fine=True, graph=False, arithmetic="split_fp16").to(dev).eval()
+    i0, i1 = olf.synthetic_pair(3, 96, 128)
+    data = {"image0": i0.to(dev), "image1": i1.to(dev)}
+
+    def run_matcher(p):
+        o = engs[p].estimate(inps[p], K_MATRIX)
+        torch.cuda.current_stream().synchronize()
+        return {k: v.cpu().numpy().copy() for k, v in o.items()}
+
+    def run_loftr():
+        o = lf(data)
+        torch.cuda.current_stream().synchronize()
+        return {k: v.cpu().numpy().copy() for k, v in o.items()}
+
+    jobs = {"f32": lambda: run_matcher("f32"), "f16x2_f16_attn": lambda: run_matcher("f16x2_f16_attn"), "loftr": run_loftr}
+    serial = {name: fn() for name, fn in jobs.items()}
+    assert serial["f32"]["ok"].all() and serial["f16x2_f16_attn"]["ok"].all() and len(serial["loftr"]["confidence"]) > 20
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def worker(name, fn):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                start.wait()
+                for it in range(25):
+                    got = fn()
+                    for k, v in serial[name].items():
+                        if not np.array_equal(v, got[k]):
+                            errors.append(f"{name} iteration {it}: {k} differs from the serial run")
+                            return
+        except Exception as e:   # noqa: BLE001
+            errors.append(f"{name}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(n, f)) for n, f in jobs.items()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
