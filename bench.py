@@ -431,11 +431,16 @@ def main() -> None:
         print(f"[bench] --gpus {args.gpus} asked for, but only {torch.cuda.device_count()} GPU(s) are visible on this box", file=sys.stderr)
         sys.exit(2)
     rccl_check = None
-    if args.gpus == 1 and args.backend == "nccl" and not args.debug_variant and not args.no_rccl_check:
+    if args.gpus == 1 and args.backend == "nccl" and not args.debug_variant and not args.no_rccl_check and "WORLD_SIZE" not in os.environ:
+        # (under a launcher -- WORLD_SIZE set, even to 1 -- the run below IS an nccl process group: its broadcast / gathers are the proof, and a
+        #  child that inherits the launcher's rendezvous variables was seen to hang on a 1-GPU box)
         try:   # the collectives of the N > 1 path on a world-1 RCCL group: what a 1-GPU lease can prove.  In a child process: RCCL writes a
             #      banner to the C-level stdout, and this process's stdout carries exactly one line
-            r = subprocess.run([sys.executable, "-m", "gisnav_amd.dist", "--selfcheck"], cwd=ROOT, capture_output=True, text=True, timeout=300,
-                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+            launcher_vars = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                             "MASTER_ADDR", "MASTER_PORT")
+            env = {k: v for k, v in os.environ.items() if k not in launcher_vars and not k.startswith("TORCHELASTIC_")}
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            r = subprocess.run([sys.executable, "-m", "gisnav_amd.dist", "--selfcheck"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
             js = [l for l in r.stdout.splitlines() if l.startswith("{")]
             rccl_check = json.loads(js[-1]) if js else {"ok": False, "error": (r.stderr or r.stdout)[-300:]}
         except Exception as exc:  # noqa: BLE001
