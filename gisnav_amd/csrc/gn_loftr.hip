@@ -780,8 +780,9 @@ int lf_fail(gn_loftr* ctx, int code, const std::string& m) { if (ctx) ctx->err =
 template <typename T> int lf_alloc(gn_loftr* ctx, T** p, size_t n) {
   void* q = nullptr;
   LF_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+  ctx->allocs.push_back(q);              // owned by the context from here on (gn_loftr_destroy frees it even if the clear below fails)
   LF_HIP(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
-  ctx->allocs.push_back(q); *p = reinterpret_cast<T*>(q);
+  *p = reinterpret_cast<T*>(q);
   return GN_OK;
 }
 int lf_upload(gn_loftr* ctx, float** dst, const float* src, size_t n) {

@@ -76,17 +76,25 @@ class RecordStager:
         """msgs: up to max_batch tuples (query_sift bytes, reference-keypoint bytes, dem (H, W) uint8).  Returns the inputs dict of
         `PoseEngine.estimate`; call wait() on the compute stream before using it and release() after the last kernel that reads it."""
         slot = self.slots[self._next]
+        h = slot["host_np"]
+        B = len(msgs)
+        if B < 1 or B > self.B:
+            raise _lib.GnError(f"{B} pairs staged, the stager holds 1..{self.B}")
+        for b, (q, r, dem) in enumerate(msgs):      # validated BEFORE anything is copied: a refused batch leaves the slot as it was
+            if len(q) % 532 or len(r) % 532:
+                raise _lib.GnError(f"pair {b}: keypoint payloads must be whole 532-byte KEYPOINT_DTYPE records (got {len(q)} and {len(r)} bytes)")
+            if max(len(q), len(r)) // 532 > self.K:
+                raise _lib.GnError(f"pair {b}: {max(len(q), len(r)) // 532} keypoints exceed the stager's max_kpts {self.K}")
+            if tuple(np.shape(dem)) != tuple(h["dem"].shape[1:]):
+                raise _lib.GnError(f"pair {b}: DEM raster {tuple(np.shape(dem))}, the stager was built for {tuple(h['dem'].shape[1:])}")
+
         self._next = (self._next + 1) % self.depth
         if slot["used"]:
             slot["consumed"].synchronize()           # the batch that last used this slot has been read by its kernels (and its H2D is long done)
-        h = slot["host_np"]
-        B = len(msgs)
 
         def copy_pair(b):
             q, r, dem = msgs[b]
             nq, nr = len(q) // 532, len(r) // 532
-            if nq > self.K or nr > self.K:
-                raise _lib.GnError(f"{max(nq, nr)} keypoints exceed the stager's max_kpts {self.K}")
             h["rec_q"][b, :nq] = np.frombuffer(q, dtype=np.float32).reshape(nq, 133)      # one memcpy: the wire bytes ARE the device layout
             h["rec_r"][b, :nr] = np.frombuffer(r, dtype=np.float32).reshape(nr, 133)
             h["dem"][b] = dem
@@ -111,6 +119,24 @@ class RecordStager:
 
     def release(self, inputs: dict) -> None:
         inputs["_slot"]["consumed"].record(torch.cuda.current_stream(self.eng.device))
+
+    def close(self) -> None:
+        """Stop the copy threads (the pinned buffers and device slots go with the object)."""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class PoseEngine:

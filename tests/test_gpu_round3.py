@@ -470,6 +470,31 @@ def test_record_stager_streams_new_batches_with_identical_results(state_dict_np)
             assert np.array_equal(s[k], o[k].cpu().numpy()), k
 
 
+def test_record_stager_refuses_malformed_batches_before_touching_a_slot(state_dict_np):
+    """A refused batch (torn record, too many keypoints, wrong DEM size, too many pairs) raises GnError naming the pair and leaves the slot
+    sequence untouched: the next good batch still gives the serial path's results."""
+    from gisnav_amd import _lib
+    from gisnav_amd.engine import PoseEngine, RecordStager
+    eng = PoseEngine(0, max_batch=2, max_kpts=128, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    pairs, msgs = _wire_batch(2000, 2, 120)
+    want = {k: v.cpu().numpy().copy() for k, v in eng.estimate(eng.stage_inputs(pairs), K_MATRIX).items()}
+    with RecordStager(eng, max_batch=2, max_kpts=128, dem_hw=(480, 640), depth=2, copy_threads=2) as st:
+        q, r, dem = msgs[0]
+        for bad, word in [([(q[:-7], r, dem)], "532-byte"), ([(q, r, dem[:100])], "DEM raster"), ([msgs[0]] * 3, "pairs staged"),
+                          ([(q + q, r, dem)], "exceed"), ([], "pairs staged")]:
+            with pytest.raises(_lib.GnError, match=word):
+                st.stage(bad)
+        assert st._next == 0
+        cur = st.stage(msgs)
+        st.wait(cur)
+        got = eng.estimate(cur, K_MATRIX)
+        st.release(cur)
+        torch.cuda.synchronize()
+        for k in want:
+            assert np.array_equal(want[k], got[k].cpu().numpy()), k
+    assert st._pool is None
+
+
 # ------------------------------------------------------------------ solvePnPRansac's npoints == 4 branch (P3P) through the B2 seam
 def test_compute_pose_with_exactly_four_points_takes_the_p3p_branch():
     """`compute_pose(camera_info, mkp_qry, mkp_ref, elevation)` with four matches (core/_shared.py:109-116 -> cv2's npoints == 4 branch): Gao's P3P
