@@ -379,10 +379,23 @@ def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
         if (len(times) >= 3 and time.perf_counter() - t_start > seconds_budget) or time.perf_counter() - t_start > 6 * seconds_budget:
             break
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} synthetic 640x480 pairs ({kpts} kpts/side) after 1 warm-up pair, median; "
-                      f"torch-CPU fp32 LightGlue-sift restatement + numpy solvePnPRansac restatement (oracle/); "
-                      f"cpu={platform.processor() or platform.machine()}"}
+    res = {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(times)} synthetic 640x480 pairs ({kpts} kpts/side) after 1 warm-up pair, median; "
+                     f"torch-CPU fp32 LightGlue-sift restatement + numpy solvePnPRansac restatement (oracle/); "
+                     f"cpu={platform.processor() or platform.machine()}"}
+    try:   # the same host cores on configs[1] as worded (the LoFTR restatement, oracle/loftr.py): one warm-up forward, one timed
+        from oracle import loftr as olf
+        sdl = olf.synthetic_state_dict(0)
+        i0, i1 = olf.synthetic_pair(1, 480, 640)
+        olf.loftr_forward(sdl, i0, i1)
+        t0 = time.perf_counter()
+        r = olf.loftr_forward(sdl, i0, i1)
+        dt = time.perf_counter() - t0
+        res["loftr_640x480"] = {"value": round(1.0 / dt, 4), "unit": "pairs/s", "ms_per_pair": round(dt * 1e3, 1), "matches": int(len(r["i_ids"])),
+                                "sample": "one 640x480 pair after one warm-up, torch-CPU fp32 restatement of kornia's LoFTR (oracle/loftr.py), same threads"}
+    except Exception as exc:  # noqa: BLE001   (a reported side number: never fails the line)
+        res["loftr_640x480"] = {"error": repr(exc)[:200]}
+    return res
 
 
 def main() -> None:
