@@ -30,7 +30,9 @@
  * gn_sift_detect_and_compute(_batch) (one sync at the end, to return the keypoint counts).
  * Return value: 0 on success, negative gn_status on failure; nothing throws.  One context
  * per GPU; a context is thread-compatible, not thread-safe (PoseNode calls from one executor
- * thread at a time, gisnav/__init__.py:140-154).
+ * thread at a time, gisnav/__init__.py:140-154).  DIFFERENT contexts (gn_ctx and gn_loftr alike)
+ * may be driven from different host threads at the same time: nothing the launch paths consult
+ * is process-wide (the kernel-family selectors and gn_last_error(NULL) are per thread).
  */
 #ifndef GISNAV_AMD_H
 #define GISNAV_AMD_H
