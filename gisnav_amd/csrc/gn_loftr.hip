@@ -969,7 +969,9 @@ int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loft
   ctx = new gn_loftr();
   ctx->device = device; ctx->H = H; ctx->W = W; ctx->hc = H / 8; ctx->wc = W / 8; ctx->L = ctx->hc * ctx->wc; ctx->Lp = (ctx->L + 127) / 128 * 128;
   ctx->fine = fine ? 1 : 0;
-  ctx->max_matches = std::min(std::min(max_matches, ctx->L), 16384);   // 2 * Mp window sequences are a grid dimension of the fine level's kernels (< 65536)
+  // at most one match per coarse cell of image0, so L is "all of them" (what kornia returns).  The fine level's token rows (2 Mp x 25) are the
+  // y dimension of its GEMM grids in units of 128: Mp <= 131072 keeps that below 65536 (a 4096 x 4096 image has 262144 cells: capped there)
+  ctx->max_matches = std::min(std::min(max_matches, ctx->L), 131072);
   ctx->Mp = (ctx->max_matches + 127) / 128 * 128;
   const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4, hc = ctx->hc, wc = ctx->wc, Lp = ctx->Lp, L = ctx->L;
 #define LF_A(field, n) do { int rc_ = lf_alloc(ctx, &ctx->field, (n)); if (rc_ != GN_OK) { gn_loftr_destroy(ctx); return rc_; } } while (0)

@@ -19,11 +19,12 @@ class LoFTR:
     [0, 1] of equal size (H, W multiples of 8) -> {"keypoints0" (M, 2), "keypoints1" (M, 2), "confidence" (M,), "batch_indexes" (M,)} on the
     input device, matches in ascending coarse cell of image0.  `fine=False` stops after the coarse level (keypoints on the 1/8 grid)."""
 
-    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: int = 8192, fine: bool = True, graph: bool = True,
+    def __init__(self, pretrained: Optional[str] = None, *, state_dict: Optional[Dict] = None, max_matches: Optional[int] = None, fine: bool = True, graph: bool = True,
                  arithmetic: str = "exact_f32"):
         if state_dict is None:
             state_dict = self._find_pretrained(pretrained or "outdoor")
-        self._sd, self._max, self._fine, self._graph = state_dict, int(max_matches), bool(fine), bool(graph)
+        # max_matches None = every mutual match (at most one per coarse cell of image0), as kornia returns them; a number caps the list (first in raster order)
+        self._sd, self._max, self._fine, self._graph = state_dict, (None if max_matches is None else int(max_matches)), bool(fine), bool(graph)
         self._arith = {"exact_f32": 0, "split_fp16": 1}[arithmetic]   # split_fp16: f32-accurate 2-term fp16 operands (gn_loftr_set_arithmetic)
         self._ctx, self._shape, self._device = None, None, None
         self.lib = None
@@ -68,6 +69,10 @@ class LoFTR:
             msg = self.lib.gn_loftr_last_error(self._ctx).decode() if self._ctx else self.lib.gn_loftr_last_error(None).decode()
             raise _lib.GnError(f"{what} failed ({rc}): {msg}")
 
+    def _cap(self, H: int, W: int) -> int:
+        L = (H // 8) * (W // 8)
+        return min(L if self._max is None else min(self._max, L), 131072)     # (gn_loftr_create's own bound)
+
     def _ensure(self, H: int, W: int) -> None:
         if self._ctx is not None and self._shape == (H, W):
             return
@@ -75,7 +80,7 @@ class LoFTR:
             self.lib.gn_loftr_destroy(self._ctx)
             self._ctx = None
         ctx = C.c_void_p()
-        rc = self.lib.gn_loftr_create(self._device.index or 0, H, W, self._max, int(self._fine), C.byref(ctx))
+        rc = self.lib.gn_loftr_create(self._device.index or 0, H, W, self._cap(H, W), int(self._fine), C.byref(ctx))
         if rc < 0:
             raise _lib.GnError(f"gn_loftr_create failed ({rc}): {self.lib.gn_loftr_last_error(None).decode()}")
         self._ctx, self._shape = ctx, (H, W)
@@ -107,7 +112,7 @@ class LoFTR:
         a, b = f(i0), f(i1)
         H, W = int(a.shape[0]), int(a.shape[1])
         self._ensure(H, W)
-        M = min(self._max, (H // 8) * (W // 8))
+        M = self._cap(H, W)
         k0 = torch.empty((M, 2), dtype=torch.float32, device=self._device); k1 = torch.empty_like(k0)
         conf = torch.empty((M,), dtype=torch.float32, device=self._device)
         ij = torch.empty((M, 2), dtype=torch.int32, device=self._device)

@@ -317,8 +317,9 @@ int gn_sp_set_arithmetic(gn_ctx* ctx, int mode);
  * LINEAR-attention encoder layers at 1/8 resolution, dual-softmax coarse matching (temperature 0.1, threshold 0.2, border 2, mutual
  * maxima), and -- when `fine` is set -- the 5x5-window fine level that refines keypoints1 to sub-pixel positions.  Specification:
  * the published architecture as restated in oracle/loftr.py (parity UNPINNED: kornia is not importable in the build image).
- * A context is sized for one image shape (H, W multiples of 8) and at most min(max_matches, H/8 * W/8, 16384) matches per call -- the first
- * ones in ascending cell order of image0 when a pair has more (kornia returns all of them); it is separate from gn_ctx and owns its weights. */
+ * A context is sized for one image shape (H, W multiples of 8) and at most min(max_matches, H/8 * W/8, 131072) matches per call: a pair has
+ * at most one match per coarse cell of image0, so max_matches >= H/8 * W/8 returns all of them, as kornia does (the Python mirror's default);
+ * a smaller number keeps the first ones in ascending cell order.  The context is separate from gn_ctx and owns its weights. */
 typedef struct gn_loftr gn_loftr;
 int gn_loftr_create(int device, int H, int W, int max_matches, int fine, gn_loftr** out);
 void gn_loftr_destroy(gn_loftr* ctx);

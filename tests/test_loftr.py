@@ -147,6 +147,22 @@ def test_loftr_hip_against_oracle(h, w, seed, arithmetic, sd):
 
 
 @pytest.mark.gpu
+def test_loftr_returns_every_match_of_a_large_pair(sd):
+    """kornia returns ALL mutual matches; so does the mirror's default (max_matches=None -> one slot per coarse cell of image0).  736 x 1280 has
+    14 720 coarse cells -- more than the 8 192 the mirror once defaulted to and the fine level then runs on > 10 000 windows: indices identical to the
+    oracle's, every match there, split-fp16 arithmetic (the faster one; the exact one is swept by tools/fuzz_loftr_sizes.py up to 1080 x 1920)."""
+    from gisnav_amd.loftr import LoFTR
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    i0, i1 = lf.synthetic_pair(4, 736, 1280)
+    ref = lf.loftr_forward(sd, i0, i1)
+    out = LoFTR(state_dict=sd, arithmetic="split_fp16").to("cuda:0").eval()({"image0": i0[None, None].cuda(), "image1": i1[None, None].cuda()}, with_ids=True)
+    assert len(ref["i_ids"]) > 8192
+    assert torch.equal(out["i_ids"].cpu(), ref["i_ids"]) and torch.equal(out["j_ids"].cpu(), ref["j_ids"])
+    assert (out["confidence"].cpu() - ref["confidence"]).abs().max() < 2e-4
+    assert (out["keypoints1"].cpu() - ref["keypoints1"]).abs().max() < 2e-3
+
+
+@pytest.mark.gpu
 def test_loftr_coarse_only_context_and_drop_in_dictionary(sd):
     from gisnav_amd.loftr import LoFTR
     i0, i1 = lf.synthetic_pair(5, 128, 160)

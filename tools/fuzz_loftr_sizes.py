@@ -1,5 +1,5 @@
 """Developer tool: LoFTR at a sweep of image sizes (multiples of 8, non-square, tiny to mid) against its oracle, both arithmetics: coarse indices
-must be identical, confidences / fine keypoints within the test-suite bars.   python tools/fuzz_loftr_sizes.py"""
+must be identical, confidences / fine keypoints within the test-suite bars.   python tools/fuzz_loftr_sizes.py [HxW ...]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,8 @@ from gisnav_amd.loftr import LoFTR  # noqa: E402
 torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
 sd = lf.synthetic_state_dict(0)
 sizes = [(32, 32), (40, 72), (64, 48), (88, 136), (104, 104), (120, 248), (168, 96), (200, 312), (256, 256), (72, 400)]
+if len(sys.argv) > 1:      # e.g. 960x1280 1080x1920: the large end (the coarse similarity matrix is (H W / 64)^2 floats)
+    sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 bad = 0
 for k, (h, w) in enumerate(sizes):
     i0, i1 = lf.synthetic_pair(10 + k, h, w)
