@@ -39,6 +39,9 @@ class PoseNode:
         self.camera_info: Optional[CameraInfo] = None
         self.pose_image: Optional[OrthoStereoImage] = None
         self.last_num_matches = 0
+        self.cache_dem = True        # keep the DEM raster on the device while its stamp and shape do not change (False: upload it with every message)
+        self._dem_dev = None
+        self._io_kmax = -1
 
     # `narrow_types` behaviour (gisnav/_decorators.py:117-160): no result until both inputs exist
     def pose(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
@@ -66,21 +69,49 @@ class PoseNode:
         if n == 0:
             self.last_num_matches = 0
             return None
-        rec_q = torch.from_numpy(np.frombuffer(msg.query_sift, dtype=np.float32).reshape(1, n, 133).copy()).to(dev)
-        inputs = dict(desc_q=None, kpt_q=rec_q, n_q=torch.tensor([n], dtype=torch.int32, device=dev),
-                      desc_r=None, kpt_r=rec_r_t, n_r=n_r_t,
-                      dem=torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev),
-                      kpt_format=_lib.GN_KPT_RECORD)
         if max(n, self._cached_n_r) > eng.kmax:             # the reference accepts any keypoint count (pose_node.py:122,207): grow, never fail
             eng.grow(((max(n, self._cached_n_r) + 1023) // 1024) * 1024)
+        # One message = ONE host-to-device copy and ONE device-to-host copy (the device work of a 1024-keypoint pair is 1.2 ms: six small pageable
+        # transfers and four blocking reads, as a literal transcription of pose_node.py:254-265 would issue, were a sixth of the message latency):
+        #   in : a pinned staging block [n as int32 | 3 pad | n records of 133 floats], copied with one asynchronous transfer;
+        #        the DEM raster is uploaded when its stamp (or shape) changes, like the tile's features;
+        #   out: R | t | n_match | n_inliers | ok are views of one device block, read back with one transfer.
+        self._ensure_io(eng.kmax)
+        self._pin_np[4:4 + n * 133] = np.frombuffer(msg.query_sift, dtype=np.float32, count=n * 133)
+        self._pin_np[:1].view(np.int32)[0] = n
+        self._dev_in[:4 + n * 133].copy_(self._pin[:4 + n * 133], non_blocking=True)
+        dem_key = (msg.dem.stamp.sec, msg.dem.stamp.nanosec, dem.shape[0], dem.shape[1])
+        if self._dem_dev is None or self._dem_dev[0] != dem_key or not self.cache_dem:
+            self._dem_dev = (dem_key, torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev))
+        inputs = dict(desc_q=None, kpt_q=self._dev_in[4:4 + n * 133].view(1, n, 133), n_q=self._dev_in[:1].view(torch.int32),
+                      desc_r=None, kpt_r=rec_r_t, n_r=n_r_t, dem=self._dem_dev[1], kpt_format=_lib.GN_KPT_RECORD)
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)
         try:
-            out = eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES)
+            eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES, out=self._out)
         finally:
             eng.set_active_kpts(eng.kmax)                   # sticky context state: restore
-        self.last_num_matches = int(out["n_match"].cpu()[0])
+        self._out_host.copy_(self._out_flat, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        h = self._out_host_np
+        self.last_num_matches = int(h[96:100].view(np.int32)[0])
         if self.last_num_matches < self.MIN_MATCHES:        # pose_node.py:299-303
             return None
-        if not bool(out["ok"].cpu()[0]):                    # pose_node.py:305-307
+        if not h[104]:                                      # pose_node.py:305-307
             return None
-        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()
+        return h[0:72].view(np.float64).reshape(3, 3).copy(), h[72:96].view(np.float64).reshape(3, 1).copy()
+
+    def _ensure_io(self, kmax: int) -> None:
+        """Pinned staging block, its device mirror and the output block (re-made when the engine grew)."""
+        if self._io_kmax == kmax:
+            return
+        dev = self._engine.device
+        self._pin = torch.empty(4 + kmax * 133, dtype=torch.float32, pin_memory=True)
+        self._pin_np = self._pin.numpy()
+        self._dev_in = torch.empty(4 + kmax * 133, dtype=torch.float32, device=dev)
+        self._out_flat = torch.zeros(112, dtype=torch.uint8, device=dev)      # R 72 B | t 24 B | n_match 4 | n_inliers 4 | ok 1 (+ pad)
+        f = self._out_flat
+        self._out = dict(R=f[0:72].view(torch.float64).view(1, 3, 3), t=f[72:96].view(torch.float64).view(1, 3, 1), n_match=f[96:100].view(torch.int32),
+                         n_inliers=f[100:104].view(torch.int32), ok=f[104:105])
+        self._out_host = torch.empty(112, dtype=torch.uint8, pin_memory=True)
+        self._out_host_np = self._out_host.numpy()
+        self._io_kmax = kmax

@@ -495,6 +495,36 @@ def test_record_stager_refuses_malformed_batches_before_touching_a_slot(state_di
     assert st._pool is None
 
 
+def test_pose_node_shim_single_transfer_path_and_dem_cache(state_dict_np):
+    """PoseNode.estimate stages one message with one host-to-device copy and reads its result with one device-to-host copy; the DEM raster is kept
+    on the device per (stamp, shape) like the tile's features (pose_node.py:225-241 caches by stamp): a new stamp uploads the new raster, the same
+    stamp re-uses the cached one, `cache_dem = False` uploads every message.  Results equal the engine's plain path bit for bit."""
+    from gisnav_amd import wire
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.pose_node import PoseNode
+    p = make_pair(86, n_q=300, n_r=280)
+    node = PoseNode(state_dict_np, lambda ref: (p.kp_r, p.desc_r, p.size_r, p.angle_r), max_kpts=512, precision="f16x2_f16_attn")
+    cam = wire.CameraInfo(k=K_MATRIX.reshape(-1), height=480, width=640)
+    q = wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q)
+    mk = lambda dem, sec: wire.OrthoStereoImage(query_sift=q, reference=wire.ImageMsg(p.ref, wire.Stamp(7, 0)), dem=wire.ImageMsg(dem, wire.Stamp(sec, 0)))  # noqa: E731
+    r1 = node.estimate(cam, mk(p.dem, 7))
+    eng = PoseEngine(0, max_batch=1, max_kpts=512, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    plain = eng.estimate(eng.stage_inputs([p]), K_MATRIX)
+    assert r1 is not None and np.array_equal(r1[0], plain["R"][0].cpu().numpy()) and np.array_equal(r1[1], plain["t"][0].cpu().numpy())
+    assert node.last_num_matches == int(plain["n_match"][0])
+    flat = np.zeros_like(p.dem)
+    r_same_stamp = node.estimate(cam, mk(flat, 7))             # same DEM stamp: the cached raster
+    assert np.array_equal(r_same_stamp[0], r1[0]) and np.array_equal(r_same_stamp[1], r1[1])
+    r_new_stamp = node.estimate(cam, mk(flat, 8))              # new stamp: the new raster
+    assert r_new_stamp is not None and not np.array_equal(r_new_stamp[1], r1[1])
+    node.cache_dem = False
+    r_nocache = node.estimate(cam, mk(p.dem, 8))               # caching off: uploaded again although the stamp did not change
+    assert np.array_equal(r_nocache[0], r1[0]) and np.array_equal(r_nocache[1], r1[1])
+    few = wire.pack_keypoints(p.kp_q[:9], p.size_q[:9], p.angle_q[:9], p.desc_q[:9])
+    assert node.estimate(cam, wire.OrthoStereoImage(query_sift=few, reference=wire.ImageMsg(p.ref, wire.Stamp(7, 0)), dem=wire.ImageMsg(p.dem, wire.Stamp(8, 0)))) is None
+    assert node.last_num_matches < node.MIN_MATCHES
+
+
 # ------------------------------------------------------------------ solvePnPRansac's npoints == 4 branch (P3P) through the B2 seam
 def test_compute_pose_with_exactly_four_points_takes_the_p3p_branch():
     """`compute_pose(camera_info, mkp_qry, mkp_ref, elevation)` with four matches (core/_shared.py:109-116 -> cv2's npoints == 4 branch): Gao's P3P
