@@ -299,6 +299,39 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_pnp_ransac")
         return R, t, n_inl, ok
 
+    def pnp_ransac_host(self, obj: np.ndarray, img: np.ndarray, K: np.ndarray, iterations: int = RANSAC_ITERATIONS,
+                        reproj_px: float = RANSAC_REPROJ_PX, confidence: float = RANSAC_CONFIDENCE, min_pts: int = 5):
+        """gn_pnp_ransac for ONE correspondence list given as host arrays (seam B2): obj (n, 3), img (n, 2) -> (R (3,3) f64, t (3,1) f64, n_inliers, ok)
+        as host values.  One pinned staging block in ([n | pad | obj | img], one asynchronous copy), one 112-byte block out: pageable transfers of
+        this size were measured to stall for ~90 ms every few dozen calls on the MI355X boxes (tools/bench_seams.py), pinned ones never."""
+        n = int(len(obj))
+        if n > self.kmax:
+            raise _lib.GnError(f"{n} correspondences exceed this context's max_kpts {self.kmax}")
+        io = getattr(self, "_pnp_io", None)
+        if io is None or io["cap"] != self.kmax:
+            cap = self.kmax
+            pin = torch.empty(8 + 5 * cap, dtype=torch.float32, pin_memory=True)
+            out = torch.zeros(112, dtype=torch.uint8, device=self.device)
+            io = self._pnp_io = dict(cap=cap, pin=pin, pin_np=pin.numpy(), dev=torch.empty(8 + 5 * cap, dtype=torch.float32, device=self.device), out=out,
+                                     host=torch.empty(112, dtype=torch.uint8, pin_memory=True))
+            io["host_np"] = io["host"].numpy()
+        h = io["pin_np"]
+        h[:1].view(np.int32)[0] = n
+        i0 = 4 + (3 * n + 3) // 4 * 4                       # the image points start on a 16-byte boundary, like the object points
+        h[4:4 + 3 * n] = np.asarray(obj, np.float32).reshape(-1)
+        h[i0:i0 + 2 * n] = np.asarray(img, np.float32).reshape(-1)
+        d, o = io["dev"], io["out"]
+        d[:i0 + 2 * n].copy_(io["pin"][:i0 + 2 * n], non_blocking=True)
+        K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+        rc = self.lib.gn_pnp_ransac(self.ctx, 1, _ptr(d[4:4 + 3 * n]), _ptr(d[i0:i0 + 2 * n]), _ptr(d[:1].view(torch.int32)), n,
+                                    K9.ctypes.data_as(_lib.c_f64p), iterations, reproj_px, confidence, min_pts,
+                                    _ptr(o[0:72]), _ptr(o[72:96]), _ptr(o[100:104]), _ptr(o[104:105]), self._stream())
+        _lib.check(self.ctx, rc, "gn_pnp_ransac")
+        io["host"].copy_(o, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        r = io["host_np"]
+        return (r[0:72].view(np.float64).reshape(3, 3).copy(), r[72:96].view(np.float64).reshape(3, 1).copy(), int(r[100:104].view(np.int32)[0]), bool(r[104]))
+
     def set_overlap(self, enable: bool) -> None:
         """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
         before reading R / t / n_inliers / ok."""

@@ -96,10 +96,16 @@ class LightGlueMatcher:
         # Set AFTER a possible grow(): the re-created context must normalise THIS call's keypoints by the sizes given with it.
         self._engine.set_image_size(None if hw1 is None else (hw1[1], hw1[0]), None if hw2 is None else (hw2[1], hw2[0]))
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
-        n1 = torch.tensor([d1.shape[1]], dtype=torch.int32, device=dev)
-        n2 = torch.tensor([d2.shape[1]], dtype=torch.int32, device=dev)
+        n1 = torch.full((1,), d1.shape[1], dtype=torch.int32, device=dev)     # (a fill kernel on the stream, not a blocking pageable upload)
+        n2 = torch.full((1,), d2.shape[1], dtype=torch.int32, device=dev)
         idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, _lib.GN_KPT_LAF | 0x100)   # 0x100: descriptors are already normalised by the caller
-        k = int(n_match.item())  # the D2H sync the reference has at pose_node.py:296-297
+        # the D2H sync the reference has at pose_node.py:296-297 -- through a pinned word (pageable reads of a few bytes were measured to stall for
+        # ~90 ms every few dozen calls on the MI355X boxes, tools/bench_seams.py)
+        if getattr(self, "_n_host", None) is None:
+            self._n_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self._n_host.copy_(n_match, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        k = int(self._n_host[0])
         return score[0, :k].reshape(-1, 1), idx[0, :k]
 
     forward = __call__

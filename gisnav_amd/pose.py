@@ -47,12 +47,10 @@ def compute_pose(camera_info, mkp_qry: np.ndarray, mkp_ref: np.ndarray, elevatio
     if n < 4:                     # cv2.solvePnPRansac asserts npoints >= 4 (the reference would raise); the shim reports "no pose"
         return None
     eng = engine or _engine(n)
-    obj = np.ascontiguousarray(_compute_3d_points(mkp_ref, elevation), dtype=np.float32)[None]
-    img = np.ascontiguousarray(mkp_qry, dtype=np.float32)[None]
+    obj = np.ascontiguousarray(_compute_3d_points(mkp_ref, elevation), dtype=np.float32)
+    img = np.ascontiguousarray(mkp_qry, dtype=np.float32)
     k_matrix = np.asarray(camera_info.k, dtype=np.float64).reshape((3, 3))
-    dev = eng.device
-    R, t, n_inl, ok = eng.pnp_ransac(torch.from_numpy(obj).to(dev), torch.from_numpy(img).to(dev),
-                                     torch.tensor([n], dtype=torch.int32, device=dev), k_matrix, RANSAC_ITERATIONS, min_pts=4)   # n == 4: OpenCV's P3P branch
-    if not bool(ok.cpu()[0]):
+    R, t, _, ok = eng.pnp_ransac_host(obj, img, k_matrix, RANSAC_ITERATIONS, min_pts=4)   # n == 4: OpenCV's P3P branch
+    if not ok:
         return None
-    return R[0].cpu().numpy(), t[0].cpu().numpy()
+    return R, t

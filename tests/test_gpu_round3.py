@@ -525,6 +525,45 @@ def test_pose_node_shim_single_transfer_path_and_dem_cache(state_dict_np):
     assert node.last_num_matches < node.MIN_MATCHES
 
 
+def test_pinned_uploader_matches_plain_uploads_and_seams_accept_its_views(state_dict_np):
+    """gisnav_amd.upload.PinnedUploader: same values and shapes as torch.tensor(a).to(device), dtype conversion on the way,
+    buffers that grow, empty arrays; the views it returns drive seams B1 + B2 to the same matches and pose as plain uploads."""
+    from gisnav_amd.matcher import LightGlueMatcher
+    from gisnav_amd.pose import compute_pose
+    from gisnav_amd.upload import PinnedUploader
+    dev = torch.device("cuda", 0)
+    up = PinnedUploader(dev)
+    rng = np.random.default_rng(4)
+    for shape in [(5, 128), (300, 128), (7, 2, 3), (0, 128), (301, 128)]:
+        a = rng.standard_normal(shape)                                   # float64 on the host
+        t = up("x", a)
+        assert t.shape == torch.Size(shape) and t.dtype == torch.float32 and t.device == dev
+        assert torch.equal(t.cpu(), torch.tensor(a, dtype=torch.float32))
+    ids = up("ids", np.arange(17, dtype=np.int64), dtype=torch.int32)
+    assert ids.dtype == torch.int32 and ids.cpu().tolist() == list(range(17))
+    p = make_pair(87, n_q=256, n_r=240)
+    m = LightGlueMatcher("sift", params={"filter_threshold": 0.5, "depth_confidence": -1, "width_confidence": -1}, state_dict=state_dict_np,
+                         max_kpts=256, precision="f32").to(dev).eval()
+
+    def laf(kp, size, ang):
+        a = np.deg2rad(ang)
+        L = np.zeros((len(kp), 2, 3), np.float32)
+        L[:, 0, 0], L[:, 0, 1], L[:, 1, 0], L[:, 1, 1] = size * np.cos(a), size * np.sin(a), -size * np.sin(a), size * np.cos(a)
+        L[:, :, 2] = kp
+        return L
+
+    d_plain, i_plain = m(torch.tensor(p.desc_q).to(dev), torch.tensor(p.desc_r).to(dev), torch.tensor(laf(p.kp_q, p.size_q, p.angle_q)).to(dev)[None],
+                         torch.tensor(laf(p.kp_r, p.size_r, p.angle_r)).to(dev)[None])
+    d_pin, i_pin = m(up("desc_q", p.desc_q), up("desc_r", p.desc_r), up("laf_q", laf(p.kp_q, p.size_q, p.angle_q))[None], up("laf_r", laf(p.kp_r, p.size_r, p.angle_r))[None])
+    assert len(i_plain) > 30 and torch.equal(i_plain, i_pin) and torch.equal(d_plain, d_pin)
+
+    class Cam:
+        k = K_MATRIX.reshape(-1)
+    idx = i_pin.cpu().numpy()
+    pose = compute_pose(Cam, p.kp_q[idx[:, 0]], p.kp_r[idx[:, 1]], p.dem)
+    assert pose is not None and pose[0].shape == (3, 3) and pose[1].shape == (3, 1) and abs(np.linalg.det(pose[0]) - 1) < 1e-9
+
+
 # ------------------------------------------------------------------ solvePnPRansac's npoints == 4 branch (P3P) through the B2 seam
 def test_compute_pose_with_exactly_four_points_takes_the_p3p_branch():
     """`compute_pose(camera_info, mkp_qry, mkp_ref, elevation)` with four matches (core/_shared.py:109-116 -> cv2's npoints == 4 branch): Gao's P3P
