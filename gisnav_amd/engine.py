@@ -299,6 +299,22 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_pnp_ransac")
         return R, t, n_inl, ok
 
+    def to_device(self, name: str, array, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """Host array -> device tensor through this engine's pinned staging (gisnav_amd.upload.PinnedUploader); a device tensor passes through."""
+        if isinstance(array, torch.Tensor):
+            return array
+        if getattr(self, "_uploader", None) is None:
+            from .upload import PinnedUploader
+            self._uploader = PinnedUploader(self.device)
+        return self._uploader(name, array, dtype)
+
+    def to_host(self, *tensors: torch.Tensor):
+        """Small device tensors -> numpy copies through one pinned block and one synchronisation (gisnav_amd.upload.PinnedDownloader)."""
+        if getattr(self, "_downloader", None) is None:
+            from .upload import PinnedDownloader
+            self._downloader = PinnedDownloader(self.device)
+        return self._downloader(*tensors)
+
     def pnp_ransac_host(self, obj: np.ndarray, img: np.ndarray, K: np.ndarray, iterations: int = RANSAC_ITERATIONS,
                         reproj_px: float = RANSAC_REPROJ_PX, confidence: float = RANSAC_CONFIDENCE, min_pts: int = 5):
         """gn_pnp_ransac for ONE correspondence list given as host arrays (seam B2): obj (n, 3), img (n, 2) -> (R (3,3) f64, t (3,1) f64, n_inliers, ok)

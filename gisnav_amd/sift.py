@@ -34,7 +34,7 @@ class SIFT:
         """image: (H, W) uint8 numpy array or device tensor.  Returns (kpt_xysa [N,4] f32, response [N], octave [N] i32,
         desc [N,128] f32) as device tensors, N keypoints in OpenCV's order."""
         eng = self._eng
-        t = image if isinstance(image, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(image, np.uint8), device=eng.device)
+        t = eng.to_device("sift_image", image, torch.uint8)       # (pinned staging: pageable uploads stall on this platform, gisnav_amd/upload.py)
         assert t.dtype == torch.uint8 and t.dim() == 2, "expected a single-channel uint8 image"
         H, W = int(t.shape[0]), int(t.shape[1])
         kpt = torch.empty((self._max, 4), dtype=torch.float32, device=eng.device)
@@ -53,7 +53,7 @@ class SIFT:
         (`gn_sift_detect_and_compute_batch`).  Returns (kpt_xysa [B,max,4], response [B,max], octave [B,max], desc [B,max,128],
         n [B] int32 on the host): image b's keypoints are rows [0, n[b]) -- the padded layout `PoseEngine.estimate` takes."""
         eng = self._eng
-        t = images if isinstance(images, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(images, np.uint8), device=eng.device)
+        t = eng.to_device("sift_images", images, torch.uint8)
         assert t.dtype == torch.uint8 and t.dim() == 3, "expected a (B, H, W) uint8 stack"
         B, H, W = (int(v) for v in t.shape)
         kpt = torch.empty((B, self._max, 4), dtype=torch.float32, device=eng.device)
@@ -77,9 +77,9 @@ class SIFT:
         if mask is not None:
             raise ValueError("masks are not supported (GISNav passes None)")
         kpt, resp, octv, desc = self.detect_and_compute_device(image)
-        k, r, o = kpt.cpu().numpy(), resp.cpu().numpy(), octv.cpu().numpy()
+        k, r, o, d = self._eng.to_host(kpt, resp, octv, desc)
         kps: List[KeyPoint] = [KeyPoint((float(k[i, 0]), float(k[i, 1])), float(k[i, 2]), float(k[i, 3]), float(r[i]), int(o[i])) for i in range(len(k))]
-        return kps, desc.cpu().numpy()
+        return kps, d
 
     def as_extractor(self):
         """The `extractor(ref_u8) -> (kp, desc, size, angle)` callable `gisnav_amd.pose_node.PoseNode` takes."""
@@ -89,6 +89,6 @@ class SIFT:
             if total > self._max:                      # cv2.SIFT_create() is unbounded (pose_node.py:122): enlarge the buffers, extract again
                 self._max = ((total + 1023) // 1024) * 1024
                 kpt, _, _, desc = self.detect_and_compute_device(ref_u8)
-            k = kpt.cpu().numpy()
-            return k[:, :2], desc.cpu().numpy(), k[:, 2], k[:, 3]
+            k, d = self._eng.to_host(kpt, desc)
+            return k[:, :2], d, k[:, 2], k[:, 3]
         return extractor

@@ -19,7 +19,7 @@ from .engine import PoseEngine, _ptr
 def rotate_and_crop_center(engine: PoseEngine, image, angle_degrees: float, shape: Tuple[int, int]):
     """`StereoNode._rotate_and_crop_center(image, angle_degrees, shape)` for an (H, W, 2) u8 stack (numpy array or device
     tensor).  Returns (cropped (h, w, 2) u8 device tensor, 3x3 f64 matrix back to the original frame)."""
-    t = image if isinstance(image, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(image, np.uint8), device=engine.device)
+    t = engine.to_device("stereo_image", image, torch.uint8)      # (pinned staging, gisnav_amd/upload.py)
     assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 2, "expected an (H, W, 2) uint8 stack"
     H, W = int(t.shape[0]), int(t.shape[1])
     out = torch.empty((shape[0], shape[1], 2), dtype=torch.uint8, device=engine.device)
@@ -33,8 +33,8 @@ def rotate_and_crop_center(engine: PoseEngine, image, angle_degrees: float, shap
 def stereo_reference(engine: PoseEngine, orthoimage_bgr, dem, map_rotation: float, crop_shape: Tuple[int, int]):
     """stereo_node.py:229-262 in one device pass: (reference (h, w) u8, dem (h, w) u8, 3x3 f64 matrix)."""
     dev = engine.device
-    b = orthoimage_bgr if isinstance(orthoimage_bgr, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(orthoimage_bgr, np.uint8), device=dev)
-    d = dem if isinstance(dem, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(dem, np.uint8), device=dev)
+    b = engine.to_device("stereo_bgr", orthoimage_bgr, torch.uint8)
+    d = engine.to_device("stereo_dem", dem, torch.uint8)
     assert b.dtype == torch.uint8 and b.dim() == 3 and b.shape[2] == 3 and d.shape == b.shape[:2]
     H, W = int(b.shape[0]), int(b.shape[1])
     ref = torch.empty(crop_shape, dtype=torch.uint8, device=dev)

@@ -38,7 +38,7 @@ class SuperPoint:
         """images: (B, H, W) uint8 (scaled by 1/255 like the published pre-processing) or float32 in [0, 1], numpy or device tensor;
         H and W multiples of 8.  Returns (kpt_xysa [B,max,4], score [B,max], desc [B,max,256] device tensors, n [B] int32 host)."""
         eng = self._eng
-        t = images if isinstance(images, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(images), device=eng.device)
+        t = images if isinstance(images, torch.Tensor) else eng.to_device("sp_images", images, torch.float32 if np.asarray(images).dtype != np.uint8 else torch.uint8)
         if t.dtype == torch.uint8:
             t = t.to(torch.float32) * (1.0 / 255.0)
         t = t.to(device=eng.device, dtype=torch.float32).contiguous()

@@ -27,7 +27,7 @@ class PinnedUploader:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.GnError("PinnedUploader stages uploads to an MI355X (no CPU path)")
-        self._buf: Dict[Tuple[str, torch.dtype], Tuple[torch.Tensor, np.ndarray, torch.Tensor]] = {}
+        self._buf: Dict[Tuple[str, torch.dtype], tuple] = {}      # (pinned tensor, its numpy view, device tensor, event of the last copy out of it)
 
     def __call__(self, name: str, array, dtype: torch.dtype = torch.float32) -> torch.Tensor:
         a = np.asarray(array)
@@ -36,10 +36,39 @@ class PinnedUploader:
         ent = self._buf.get(key)
         if ent is None or ent[0].numel() < n:
             cap = max(n, 1) if ent is None else max(n, 2 * ent[0].numel())
+            if ent is not None:
+                ent[3].synchronize()                       # the old buffers may still be the source / target of a copy in flight
             pin = torch.empty(cap, dtype=dtype, pin_memory=True)
-            ent = self._buf[key] = (pin, pin.numpy(), torch.empty(cap, dtype=dtype, device=self.device))
-        pin, pin_np, dev = ent
+            ent = self._buf[key] = (pin, pin.numpy(), torch.empty(cap, dtype=dtype, device=self.device), torch.cuda.Event())
+        pin, pin_np, dev, done = ent
         if n:
+            done.synchronize()                             # the previous transfer out of this staging buffer has finished (no-op the first time)
             pin_np[:n] = a.reshape(-1)                     # the one host copy (numpy converts the dtype on the way if it differs)
             dev[:n].copy_(pin[:n], non_blocking=True)
+            done.record(torch.cuda.current_stream(self.device))
         return dev[:n].view(a.shape)
+
+
+class PinnedDownloader:
+    """The other direction: `a, b = down(t_a, t_b)` returns host copies (numpy) of small device tensors through ONE pinned block and ONE
+    synchronisation of the current stream -- instead of one blocking pageable read per tensor (`t.cpu()`), which stalls the same way."""
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        self._pin = None
+
+    def __call__(self, *tensors: torch.Tensor):
+        sizes = [(t.numel() * t.element_size() + 15) // 16 * 16 for t in tensors]
+        total = max(sum(sizes), 16)
+        if self._pin is None or self._pin.numel() < total:
+            self._pin = torch.empty(max(total, 2 * (0 if self._pin is None else self._pin.numel())), dtype=torch.uint8, pin_memory=True)
+        views, off = [], 0
+        for t, sz in zip(tensors, sizes):
+            nb = t.numel() * t.element_size()
+            v = self._pin[off:off + nb].view(t.dtype).view(t.shape)
+            if nb:
+                v.copy_(t, non_blocking=True)
+            views.append(v)
+            off += sz
+        torch.cuda.current_stream(self.device).synchronize()
+        return [v.numpy().copy() for v in views]

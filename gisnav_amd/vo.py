@@ -42,10 +42,10 @@ class BFMatcher:
 
     def _run(self, desc_qry: np.ndarray, desc_ref: np.ndarray, ratio: float):
         dev = self._eng.device
-        dq = torch.as_tensor(np.ascontiguousarray(desc_qry, np.float32)[None], device=dev)
-        dr = torch.as_tensor(np.ascontiguousarray(desc_ref, np.float32)[None], device=dev)
-        nq = torch.tensor([dq.shape[1]], dtype=torch.int32, device=dev)
-        nr = torch.tensor([dr.shape[1]], dtype=torch.int32, device=dev)
+        dq = self._eng.to_device("vo_desc_q", np.asarray(desc_qry)[None])     # (pinned staging, gisnav_amd/upload.py)
+        dr = self._eng.to_device("vo_desc_r", np.asarray(desc_ref)[None])
+        nq = torch.full((1,), dq.shape[1], dtype=torch.int32, device=dev)
+        nr = torch.full((1,), dr.shape[1], dtype=torch.int32, device=dev)
         return self._eng.vo_match(dq, nq, dr, nr, ratio, want_knn=True)
 
     def knnMatch(self, desc_qry: np.ndarray, desc_ref: np.ndarray, k: int = 2) -> List[Tuple[DMatch, ...]]:
@@ -55,15 +55,15 @@ class BFMatcher:
         if n_q == 0:
             return []
         _, _, _, nn_idx, nn_dist = self._run(desc_qry, desc_ref, CONFIDENCE_THRESHOLD)
-        ii, dd = nn_idx[0, :n_q].cpu().numpy(), nn_dist[0, :n_q].cpu().numpy()
+        ii, dd = self._eng.to_host(nn_idx[0, :n_q], nn_dist[0, :n_q])
         kk = min(2, n_r)
         return [tuple(DMatch(q, int(ii[q, c]), float(dd[q, c])) for c in range(kk)) for q in range(n_q)]
 
     def ratio_matches(self, desc_qry: np.ndarray, desc_ref: np.ndarray, ratio: float = CONFIDENCE_THRESHOLD) -> List[DMatch]:
         """knnMatch(k=2) + `m.distance < ratio * n.distance` in one device pass (twist_node.py:263-267)."""
         idx, dist, n_good = self._run(desc_qry, desc_ref, ratio)[:3]
-        k = int(n_good[0])
-        ii, dd = idx[0, :k].cpu().numpy(), dist[0, :k].cpu().numpy()
+        k = int(self._eng.to_host(n_good)[0][0])
+        ii, dd = self._eng.to_host(idx[0, :k], dist[0, :k])
         return [DMatch(int(ii[c, 0]), int(ii[c, 1]), float(dd[c])) for c in range(k)]
 
 
@@ -76,16 +76,17 @@ def twist_pose(engine: PoseEngine, k_matrix: np.ndarray, kp_qry: np.ndarray, des
         return None
     dev = engine.device
 
-    def pack(kp, desc):
+    def pack(kp, desc, side):
         k4 = np.zeros((1, len(kp), 4), np.float32)
         k4[0, :, :2] = kp
-        return (torch.as_tensor(np.ascontiguousarray(desc, np.float32)[None], device=dev), torch.as_tensor(k4, device=dev),
-                torch.tensor([len(kp)], dtype=torch.int32, device=dev))
+        return (engine.to_device("vo_desc_" + side, np.asarray(desc)[None]), engine.to_device("vo_kpt_" + side, k4),
+                torch.full((1,), len(kp), dtype=torch.int32, device=dev))
 
-    dq, kq, nq = pack(kp_qry, desc_qry)
-    dr, kr, nr = pack(kp_ref, desc_ref)
+    dq, kq, nq = pack(kp_qry, desc_qry, "q")
+    dr, kr, nr = pack(kp_ref, desc_ref, "r")
     out = engine.vo_estimate(dict(desc_q=dq, kpt_q=kq, n_q=nq, desc_r=dr, kpt_r=kr, n_r=nr, kpt_format=_lib.GN_KPT_XYSA),
                              k_matrix, ratio, min_matches)
-    if not bool(out["ok"][0]):
+    ok, R, t = engine.to_host(out["ok"], out["R"], out["t"])
+    if not bool(ok[0]):
         return None
-    return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy()
+    return R[0], t[0]
