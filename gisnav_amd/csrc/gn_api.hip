@@ -665,8 +665,9 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   ctx->precision_api = precision_api; ctx->attn_f16 = precision_api == GN_PREC_F16X2_F16_ATTN ? 1 : 0;
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   { const int rc_ws = alloc_workspace(ctx, max_kpts); if (rc_ws != GN_OK) { gn_destroy(ctx); return rc_ws; } }
-  if (hipHostMalloc((void**)&ctx->ovf_host, 16 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
-  memset(ctx->ovf_host, 0, 16 * sizeof(unsigned int));
+  // pinned host words: [0, 16) guard words, [16, 16 + 4096) the per-image counters the SIFT / SuperPoint calls read back (up to 1024 images per call)
+  if (hipHostMalloc((void**)&ctx->ovf_host, (16 + 4096) * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  memset(ctx->ovf_host, 0, (16 + 4096) * sizeof(unsigned int));
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
   // required tensor names
@@ -1337,8 +1338,10 @@ int gn_sift_detect_and_compute_batch(gn_ctx* ctx, const uint8_t* gray, int B, in
   const int max_out = std::min(max_kpts, ctx->sift_max_kp);
   sift_sort_dedup(B, ctx->sift_kp, ctx->sift_kp_stride, ctx->sift_counts, max_raw, max_out, kpt_xysa, response, octave, max_kpts, s);
   sift_descriptors(py, B, ctx->sift_kp + 2 * max_raw, ctx->sift_kp_stride, ctx->sift_counts, max_out, desc, max_kpts, s);
-  std::vector<int> counts((size_t)B * 4, 0);
-  GN_HIP(hipMemcpyAsync(counts.data(), ctx->sift_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  std::vector<int> counts_v;
+  int* counts = reinterpret_cast<int*>(ctx->ovf_host + 16);       // pinned (every per-message transfer of the library is: gisnav_amd/upload.py has the reason)
+  if (B > 1024) { counts_v.assign((size_t)B * 4, 0); counts = counts_v.data(); }
+  GN_HIP(hipMemcpyAsync(counts, ctx->sift_counts, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   GN_HIP(hipStreamSynchronize(s));
   for (int b = 0; b < B; ++b) {
     if (counts[4 * b] > ctx->sift_max_cand) return fail(ctx, GN_ERR_ARG, "SIFT candidate buffer overflow (raise max_kpts)");
