@@ -23,7 +23,7 @@ namespace gn {
 namespace {
 
 thread_local std::string g_lf_err;
-constexpr int kLfDim = 256, kLfHeads = 8, kLfHd = 32, kLfFine = 128, kLfWW = 25;
+constexpr int kLfDim = 256, kLfHeads = 8, kLfFine = 128, kLfWW = 25;
 
 // ------------------------------------------------------------------------------------------------ stem: 7x7 stride 2, 1 -> 128
 // thread -> (output pixel, 16-channel group); weights [128][49] + affine in LDS

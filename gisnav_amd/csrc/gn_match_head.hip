@@ -203,10 +203,6 @@ constexpr int kHeadTile = 8 * kHeadKT;   // 64 KB
 constexpr int kHeadRows = 128;           // rows of image 0 per workgroup
 constexpr int kHeadMaxSplit = 8;         // column splits (grid.z) the partial buffers are sized for
 constexpr float kLog2e = 1.4426950408889634f;
-#ifndef GN_HEAD_SCHED
-#define GN_HEAD_SCHED 0
-#endif
-constexpr bool kHeadSchedGroups = GN_HEAD_SCHED;
 __device__ __forceinline__ int hswz(int row) { return (row ^ (row >> 3)) & 7; }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 // (m, s) <- (m, s) (+) (om, os): running maximum and sum of exp(. - maximum); -inf maxima are empty sets

@@ -1458,7 +1458,7 @@ __device__ int quartic_real_roots(double A, double B, double C, double D, double
         pr = npr; pi = npi;
       }
       double dn = dr * dr + di * di;
-      if (dn == 0.0) { dr = 1e-300; dn = 1e-600; }
+      if (dn == 0.0) { dr = 1e-150; dn = 1e-300; }     // (a vanishing derivative: step away instead of dividing by zero; 1e-600 would itself round to 0)
       double wr = (pr * dr + pi * di) / dn, wi = (pi * dr - pr * di) / dn;       // w = p / p'
       double sr = 0.0, si = 0.0;                                               // sum 1 / (z_k - z_j)
       for (int j = 0; j < 4; ++j) {
