@@ -1,8 +1,8 @@
 """Developer tool: LoFTR at a sweep of image sizes (multiples of 8, non-square, tiny to mid) against its oracle, both arithmetics: coarse indices
-must be identical, confidences / fine keypoints within the test-suite bars.   python tools/fuzz_loftr_sizes.py [HxW ...]"""
+must be identical, confidences / fine keypoints within the test-suite bars.   python tests/sweeps/fuzz_loftr_sizes.py [HxW ...]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import loftr as lf  # noqa: E402   (checker, as in tests/)
 from gisnav_amd.loftr import LoFTR  # noqa: E402

@@ -2,10 +2,10 @@
 heavy outlier fractions, duplicated points, collinear image points, a flat DEM, points on a plane tilted against the DEM, large coordinates.  Same
 None / pose decision and poses within 1e-6 (the suite's bar is 1e-8 on well-posed scenes).  Scenes with DUPLICATED correspondences are reported, not
 asserted: a 5-point RANSAC sample that holds a point twice is a rank-deficient EPnP system (OpenCV's PnP callback has no subset check either), its
-null-space basis is decided by rounding, and two correct implementations pick different hypotheses from it.   python tools/fuzz_pnp.py"""
+null-space basis is decided by rounding, and two correct implementations pick different hypotheses from it.   python tests/sweeps/fuzz_pnp.py"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pnp_ransac as pr  # noqa: E402   (checker, as in tests/)
 from gisnav_amd.pose import compute_pose  # noqa: E402

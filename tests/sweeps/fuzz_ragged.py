@@ -1,8 +1,8 @@
 """Developer tool: random ragged batches (keypoint counts anywhere in [2, max_kpts] per side, mixed inside one batch) through the C ABI against the
-oracle: correspondence indices must be identical in f32 mode; the fast mode is reported.   python tools/fuzz_ragged.py [trials] [max_kpts]"""
+oracle: correspondence indices must be identical in f32 mode; the fast mode is reported.   python tests/sweeps/fuzz_ragged.py [trials] [max_kpts]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import oracle_match  # noqa: E402   (the oracle is the checker here, as in tests/)
 from gisnav_amd.engine import PoseEngine  # noqa: E402

@@ -1,8 +1,8 @@
 """Developer tool: the SIFT extractor against its oracle over image sizes / contents the test-suite does not hold: odd sizes, very wide / tall, high
-noise (many keypoints), strong edges, saturated regions.  Every keypoint field and descriptor byte must be identical.   python tools/fuzz_sift.py"""
+noise (many keypoints), strong edges, saturated regions.  Every keypoint field and descriptor byte must be identical.   python tests/sweeps/fuzz_sift.py"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import sift as osift  # noqa: E402   (checker, as in tests/)
 from gisnav_amd.sift import SIFT  # noqa: E402

@@ -1,10 +1,10 @@
 """Developer tool: StereoNode's reference raster (BGR -> gray + DEM, rotate, centre crop) against its oracle over random tile sizes (odd ones too),
 crop sizes (smaller than / equal to the tile) and angles: every u8 pixel identical.  A crop LARGER than the tile must be refused (GnError): the
 reference's numpy slice `rotated[dy:dy + h, dx:dx + w]` with a negative start wraps around and returns a differently shaped (often empty) array there,
-which nothing downstream can use; GISNav's tiles are always padded beyond the crop.   python tools/fuzz_stereo.py [trials]"""
+which nothing downstream can use; GISNav's tiles are always padded beyond the crop.   python tests/sweeps/fuzz_stereo.py [trials]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import stereo_warp as sw  # noqa: E402   (checker, as in tests/)
 from gisnav_amd.engine import PoseEngine  # noqa: E402

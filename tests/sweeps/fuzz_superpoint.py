@@ -1,9 +1,9 @@
 """Developer tool: the SuperPoint extractor against its oracle over image sizes the suite does not hold (small, very wide / tall, 8-multiples that are
 not 16- or 32-multiples, and sizes that are NOT multiples of 8), both f32-accurate arithmetics: keypoint sets equal up to score ties, scores 1e-5,
-descriptors 1e-4.   python tools/fuzz_superpoint.py"""
+descriptors 1e-4.   python tests/sweeps/fuzz_superpoint.py"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import superpoint as osp  # noqa: E402   (checker, as in tests/)
 from gisnav_amd.engine import PoseEngine  # noqa: E402
