@@ -56,15 +56,17 @@ class BFMatcher:
             return []
         _, _, _, nn_idx, nn_dist = self._run(desc_qry, desc_ref, CONFIDENCE_THRESHOLD)
         ii, dd = self._eng.to_host(nn_idx[0, :n_q], nn_dist[0, :n_q])
-        kk = min(2, n_r)
-        return [tuple(DMatch(q, int(ii[q, c]), float(dd[q, c])) for c in range(kk)) for q in range(n_q)]
+        il, dl = ii.tolist(), dd.tolist()            # (one pass to Python numbers instead of 4 n numpy scalar reads)
+        if n_r >= 2:
+            return [(DMatch(q, i[0], d[0]), DMatch(q, i[1], d[1])) for q, (i, d) in enumerate(zip(il, dl))]
+        return [(DMatch(q, i[0], d[0]),) for q, (i, d) in enumerate(zip(il, dl))]
 
     def ratio_matches(self, desc_qry: np.ndarray, desc_ref: np.ndarray, ratio: float = CONFIDENCE_THRESHOLD) -> List[DMatch]:
         """knnMatch(k=2) + `m.distance < ratio * n.distance` in one device pass (twist_node.py:263-267)."""
         idx, dist, n_good = self._run(desc_qry, desc_ref, ratio)[:3]
         k = int(self._eng.to_host(n_good)[0][0])
         ii, dd = self._eng.to_host(idx[0, :k], dist[0, :k])
-        return [DMatch(int(ii[c, 0]), int(ii[c, 1]), float(dd[c])) for c in range(k)]
+        return [DMatch(i[0], i[1], d) for i, d in zip(ii.tolist(), dd.tolist())]
 
 
 def twist_pose(engine: PoseEngine, k_matrix: np.ndarray, kp_qry: np.ndarray, desc_qry: np.ndarray,
