@@ -407,7 +407,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     f.xp = c->x_p; f.mp = c->msg_p; f.w1s = fold ? blk.ffn0.wf2 : blk.ffn0.wf; f.w1_scale = blk.ffn0.acc_scale; f.b1 = blk.ffn0.b; f.ln_g = blk.ln_g; f.ln_b = blk.ln_b;
     f.w2s = blk.ffn3.wf; f.w2_scale = blk.ffn3.acc_scale; f.b2 = blk.ffn3.b; f.yp = c->x_p; f.y = keep_f32 ? c->x : nullptr; f.T = T;
     f.ovf = c->guard ? c->ovf : nullptr;
-    f.dbg_ts = (gn::g_ffn_ablate == 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
+    f.dbg_ts = (gn::g_ffn_ablate & 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
     if (c->stop_after && c->launch_count > c->stop_after) return;
     const bool rec = c->ktiming && c->kused < c->kflops.size();
@@ -1610,7 +1610,7 @@ int gn_sp_set_arithmetic(gn_ctx* ctx, int mode) {
 
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
-  if ((which == 12 && value == 8) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value) || (which == 20 && value)) {   // these developer paths use the similarity buffer
+  if ((which == 12 && (value & 8)) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value) || (which == 20 && value)) {   // these developer paths use the similarity buffer
     GN_HIP(hipSetDevice(ctx->device));
     const int rc = ensure_sim(ctx); if (rc != GN_OK) return rc;
   }

@@ -129,6 +129,7 @@ struct FfnArgs {
   long long* dbg_ts;                       // developer: [blocks][8 waves][8] s_memtime stamps (ablation 8), or nullptr
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
+void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s);   // gn_ffn128.hip: 128 tokens per workgroup (a.cp set, a.T % 128 == 0); ablate: developer knob 12
 extern int g_ffn_ablate;
 extern int g_ffn_shape;
 extern int g_sp_conv_h;

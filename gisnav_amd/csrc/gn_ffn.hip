@@ -24,65 +24,11 @@
 // [32 w, 32 w + 32) in the second (1 x 2 tiles).  Arithmetic is the hm16 scheme of gn_gemm_p2.hip: x = xh + xm in fp16, three
 // v_mfma_f32_32x32x16_f16 per block (small terms first), f32 accumulation.
 #include "gn_common.h"
+#include "gn_ffn_util.h"
 
 namespace gn {
 
 namespace {
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-
-// Shapes of the same kernel: NW waves x NJ token tiles of 32 per workgroup.  (8, 2) is the bulk shape (64 tokens, one workgroup per
-// CU); (8, 1) halves the tokens per workgroup for small grids (batch 1: 2048 tokens are 32 workgroups of 64 on 256 CUs).  (4, 1) --
-// two workgroups per CU, whose VALU and MFMA phases could overlap -- was measured SLOWER at every batch size (each wave then streams
-// twice the weight bytes with the same number of loads in flight) and is not instantiated.
-//   NJ            token tiles of 32 per workgroup (every wave covers all of them)
-//   NI = 16 / NW  hidden tiles of 32 per wave in GEMM 1;   NO = 8 / NW  output tiles of 32 per wave in GEMM 0 and GEMM 2
-constexpr int YP = 260;                 // float pitch of the output tile staged for the row-wise epilogue (aliases the hidden tile)
-
-__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
-
-// Two-wide f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 work on an aligned register pair at the rate of a single
-// v_fma_f32: the VALU phases between the GEMMs are issue-bound with two waves per SIMD).  Written out by hand: this file is built
-// without the SLP vectoriser.  Per element the operations and their order are those of gelu_erf (gn_common.h): same bits.
-__device__ __forceinline__ f32x2v pair(const f32x16& v, int r) { return (f32x2v){v[r], v[r + 1]}; }
-__device__ __forceinline__ void set_pair(f32x16& v, int r, f32x2v p) { v[r] = p[0]; v[r + 1] = p[1]; }
-__device__ __forceinline__ f32x2v splat2(float c) { return (f32x2v){c, c}; }
-__device__ __forceinline__ f32x2v gelu_erf2(f32x2v y) {
-  const f32x2v ys = y * splat2(0.70710678118654752440f);
-  const f32x2v t = {fminf(fabsf(ys[0]), 4.0f), fminf(fabsf(ys[1]), 4.0f)};
-  f32x2v q = splat2(4.6081331674940884e-05f);
-  q = q * t + splat2(-0.00045161080197431147f);
-  q = q * t + splat2(0.0015096671413630247f);
-  q = q * t + splat2(0.0007409505778923631f);
-  q = q * t + splat2(-0.028223754838109016f);
-  q = q * t + splat2(0.1484677642583847f);
-  q = q * t + splat2(0.918419361114502f);
-  q = q * t + splat2(1.6279083490371704f);
-  const f32x2v qt = q * t;
-  const f32x2v ex = {__builtin_amdgcn_exp2f(-qt[0]), __builtin_amdgcn_exp2f(-qt[1])};
-  const f32x2v e = splat2(1.0f) - ex;
-  const f32x2v cs = {copysignf(e[0], y[0]), copysignf(e[1], y[1])};
-  return (splat2(0.5f) * y) * (splat2(1.0f) + cs);
-}
-
-// 8 f32 -> 8 fp16 high terms and the 8 fp16 residual terms (round to nearest), as two 16-byte fragments
-__device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m) {
-  unsigned int hw[4], mw[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const f32x2v x = {v[2 * e], v[2 * e + 1]};
-    const f16x2v hv = __builtin_convertvector(x, f16x2v);
-    const f32x2v r = x - __builtin_convertvector(hv, f32x2v);
-    const f16x2v mv = __builtin_convertvector(r, f16x2v);
-    hw[e] = __builtin_bit_cast(unsigned int, hv);
-    mw[e] = __builtin_bit_cast(unsigned int, mv);
-  }
-  h = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  m = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-}
-
 // FOLD: the message is not read from memory but computed here, msg = out_proj(ctx) (kornia `self.out_proj` / `self.to_out`), from
 // the attention output rows -- the out_proj GEMM launch and the msg round trip through HBM disappear.
 template <int ABL = 0, bool FOLD = true, int NW = 8, int NJ = 2>   // ABL, timing-only ablations: 1 no weight loads inside the loops, 2 no second GEMM, 4 no GELU; 8 = s_memtime stamps per phase into a.dbg_ts
@@ -458,6 +404,8 @@ void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
     else { hipLaunchKernelGGL((k_ffn_fused<0, false, 8, 2>), dim3(a.T / 64), dim3(512), 0, s, a); g_last_kernel = "k_ffn_fused<0, false, 8, 2>"; }
     return;
   }
+  // bulk grids: 128 tokens per workgroup, one wave per SIMD (gn_ffn128.hip); developer knob 14 = 128 / 64 / 32 forces a shape
+  if (a.T % 128 == 0 && (g_ffn_shape == 128 || (g_ffn_shape == 0 && a.T / 128 >= 256))) { launch_ffn128(a, g_ffn_ablate, s); return; }
   if (small) {
     if (g_ffn_ablate == 8) hipLaunchKernelGGL((k_ffn_fused<8, true, 8, 1>), dim3(a.T / 32), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_ffn_fused<0, true, 8, 1>), dim3(a.T / 32), dim3(512), 0, s, a);

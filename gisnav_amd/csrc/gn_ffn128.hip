@@ -1,0 +1,646 @@
+// Fused transformer-block tail, 128 tokens per workgroup (round 4): the same arithmetic as k_ffn_fused (gn_ffn.hip)
+//
+//     msg = out_proj(ctx);   x  <-  x + ffn.3( GELU( LayerNorm( ffn.0( [x | msg] ) ) ) )
+//
+// i.e. kornia's TransformerLayer / CrossBlock tail `x + self.ffn(torch.cat([x, message], -1))` (reached from
+// ros/gisnav/gisnav/core/pose_node.py:285-287), re-shaped around what round 3 measured about k_ffn_fused: a 64-token workgroup
+// pulls the block's 1.79 MB of weight fragments from L2 once per 64 tokens -- at the matrix-pipe floor of its GEMM 1 that is
+// 42 B/clk/CU, more than a CU's L2 port delivers (~30 B/clk measured), so the k-loops ran at the weight stream's pace, and the
+// LayerNorm / GELU / split phases of its eight waves (two per SIMD, in lock-step) never overlapped with matrix work.
+//
+// Here ONE wave per SIMD (4 waves, 256 arch + 256 accumulator registers each) covers 128 tokens:
+//  * every weight byte is fetched once per 128 tokens: 21 B/clk/CU at the matrix-pipe floor;
+//  * GEMM 1's accumulators (128 hidden units x 128 tokens per wave = 256 registers) stay in the accumulator file through LayerNorm:
+//    the statistics pass only READS them (shifted one-pass sums per lane, merged with Chan's formula across the 8 partials of a token),
+//    and normalisation is re-applied from the raw accumulator when a value is consumed;
+//  * the hidden tensor (256 KB as hm16 for 128 tokens) never exists as a whole: it is normalised, GELU'd, split and published to LDS
+//    a QUARTER at a time (32 units per wave = 4 k-tiles = 64 KB, two buffers); quarters 2 and 3 are produced INSIDE the second GEMM's
+//    instruction stream, one ~8-instruction VALU stage in the shadow of each MFMA (VALU and MFMA overlap inside one wave's stream,
+//    not between the two waves of a SIMD: tools/probes/overlap.hip);
+//  * token rows (attention output, then x) stream through a two-slot ring of 32-wide k-tiles (16 KB each) behind the 128 KB message tile:
+//    LDS = 160 KB exactly.
+// The instruction order of every k-step is pinned (sched_barrier after each MFMA): one memory instruction or one VALU stage per MFMA
+// gap -- left alone the machine scheduler clumps the weight loads (each stalls the wave's issue for ~30 cycles) and runs the VALU
+// work of a GELU chunk as one dependent chain per value pair BETWEEN the MFMA groups.
+// Weight fragments: the layouts of gn_ffn.hip (build_weight_fragments), unchanged.  Accumulation order per output element equals
+// k_ffn_fused's for GEMM 0 and GEMM 1 (bitwise the same message and pre-LayerNorm values); the LayerNorm statistics, the last
+// multiply of the GELU (one fma instead of mul + add + mul) and GEMM 2's k order differ at rounding level.
+#include "gn_common.h"
+#include "gn_ffn_util.h"
+
+namespace gn {
+
+namespace {
+
+#define GN_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int ABL>   // timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
+__global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
+  constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
+  constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 128 token rows (hm16: 128 B per row)
+  constexpr int RING = 8 * KT;            // two staging slots behind the message tile
+  constexpr int STAT = 8 * KT;            // LayerNorm statistics (4 KB) and the LayerNorm constants (4 KB) alias the ring (dead after GEMM 1)
+  constexpr int CST = STAT + 4096;        // [2][512] floats: LayerNorm weight, LayerNorm bias
+  constexpr int SMEM = 10 * KT;           // 163,840 B
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int bm = blockIdx.x * TM;
+  long long ts[12], ts2[16];
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (ABL & 8) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // Addressing discipline (one wave per SIMD, 256 arch VGPRs beside 256 accumulator registers): every global access is
+  // `buffer descriptor (SGPRs) + 32-bit lane offset (VGPR) + uniform offset (SGPR / literal)`, every LDS access `one of a few base
+  // registers + 16-bit immediate` -- left to itself the compiler keeps one 64-bit pointer pair per weight load and one address
+  // register per distinct LDS constant, and spills them around the k-loops.
+  // ---- token-row staging: thread -> (row srow + 32 q, 16-byte chunk) of a k-tile; sources are hm16 rows of 256 values (1 KB)
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.cp) + (size_t)bm * 512, 0, TM * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.xp) + (size_t)bm * 512, 0, TM * 1024, 0x00020000);
+  unsigned int soff[4], sdst[4];
+  // (re-derived before the x half of GEMM 1, like the LDS windows below, from an OPAQUE copy of the thread index: otherwise the
+  // compiler recognises the expressions of the first derivation and keeps -- i.e. spills and reloads -- those registers)
+  auto stage_addr = [&]() __attribute__((always_inline)) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int sr = t_ >> 3, sc = t_ & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      soff[q] = (unsigned int)((sr + 32 * q) * 1024 + sc * 16);
+      sdst[q] = (unsigned int)(RING + (sr + 32 * q) * 128 + ((sc ^ swz(sr + 32 * q)) * 16));
+    }
+  };
+  stage_addr();
+  // two register sets, staged tile t travels in set t & 1 -- eight named registers, not an array: an array indexed by the (unrolled) loop
+  // counters is left in scratch memory
+  uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+  auto stv = [&](int set, int q) __attribute__((always_inline)) -> uint4& {
+    return set == 0 ? (q == 0 ? sa0 : (q == 1 ? sa1 : (q == 2 ? sa2 : sa3))) : (q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3)));
+  };
+  // staged tiles 0..7 = k-tiles of the attention output (GEMM 0), 8..15 = k-tiles of x (second half of GEMM 1); one piece = 32 rows
+  auto stage_load = [&](int t, int q) __attribute__((always_inline)) {
+    stv(t & 1, q) = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(t < 8 ? crs : xrs, soff[q], (t & 7) * 128, 0));
+  };
+  auto stage_write = [&](int t, int q) __attribute__((always_inline)) {
+    *reinterpret_cast<uint4*>(smem + sdst[q] + (t & 1) * KT) = stv(t & 1, q);
+  };
+  // ---- token fragments: lane (row 32 j + ql, hh), k-step ks of a k-tile, term pl -> chunk 4 ks + 2 pl + hh; swz(32 j + ql) depends on j & 1 only.
+  // LDS byte address = bo[window][j & 1][2 ks + pl] + immediate < 64 KB: three 64 KB windows (made opaque so that the compiler keeps them)
+  // (the windows a phase needs are re-derived at its start: a window register that lived from here to the second GEMM was spilled,
+  // and each reload inside a k-loop costs a vmcnt(0) -- the whole weight ring drained)
+  unsigned int bo[3][2][4];
+  auto window = [&](int w) __attribute__((always_inline)) {
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));
+    const int q_ = l_ & 31, h_ = l_ >> 5;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bo[w][jp][c] = (unsigned int)((32 * jp + q_) * 128 + (((2 * c + h_) ^ swz(32 * jp + q_)) * 16)) + 65536u * w;
+        asm volatile("" : "+v"(bo[w][jp][c]));
+      }
+  };
+  window(2);
+  // three fragment buffers: j-step g (k-step sequence number * 4 + token tile) lives in buffer g % 3 and is read one (GEMM 1: 12 MFMAs
+  // per j-step) or two (GEMM 0 / 2: 6 MFMAs per j-step) j-steps ahead of its MFMAs
+  f16x8 bq[3][2];
+  // tile_off: byte offset of the k-tile inside smem (a compile-time constant after unrolling)
+  auto read_b = [&](int g, int tile_off, int ks, int j) __attribute__((always_inline)) {
+    const int off = tile_off + (j >> 1) * 8192;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) bq[g % 3][pl] = *reinterpret_cast<const f16x8*>(smem + bo[off >> 16][j & 1][2 * ks + pl] + (off & 65535));
+  };
+  // a lane's accumulator registers 8 ks' .. 8 ks' + 7 of tile (., j) ARE one 16-byte B-operand fragment of a following transposed
+  // GEMM (whose weight columns are permuted to this order in the re-layout): publishing costs two ds_write_b128 per fragment.
+  // pb: the publishing wave's base registers (its own k-tile inside the 64 KB window), off < 64 KB
+  float amax = 0.f;
+  unsigned int pb[2][4];
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+  // one weight fragment: buffer descriptor of the wave's slice (SGPRs) + uniform byte offset (a multiple of 1 KB, an SGPR / literal) + lane * 16
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int uoff) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, uoff, 0));
+  };
+
+  // ---- the VALU stage machine of one fragment (8 values of one token = one 16-byte B operand of the next GEMM): 8 independent
+  // instructions per stage, so that a stage neither stalls on its own results nor outlasts the MFMA it hides behind
+  float gy[8], gt[8], gq[8];
+  unsigned int gh[4], gm[4];
+  f32x4 c2[2], c3[2];             // LayerNorm weight, LayerNorm bias of the fragment's two groups of 4 units
+  float rs[NJ], nmr[NJ];          // per token tile: s1 / sqrt(var + eps) (applied to the raw accumulator), -mean / sqrt(var + eps)
+  const float s1 = a.w1_scale;    // a power of two: ffn.0's bias enters the accumulators as b1 / s1 before the first MFMA (exact)
+  const unsigned int cbase = (unsigned int)(CST + hh * 16 + 32 * NI * wave * 4);
+  // stages 18..21 (maximum, fp16 split, publish) are shared by the message and the hidden fragments
+  auto tail_stage = [&](int st, int off, int j, int ksp) __attribute__((always_inline)) {
+    if (st == 18) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) { amax = fmaxf(amax, fmaxf(fabsf(gy[e]), fabsf(gy[e + 1]))); gh[e >> 1] = pack16<true>(gy[e], gy[e + 1]); }
+    } else if (st == 19) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f16x2v hv = __builtin_bit_cast(f16x2v, gh[e >> 1]);
+        gt[e] = (float)hv[0]; gt[e + 1] = (float)hv[1];
+      }
+    } else if (st == 20) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt[e] = gy[e] - gt[e];
+    } else if (st == 21) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) gm[e >> 1] = pack16<true>(gt[e], gt[e + 1]);
+      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp] + (off + (j >> 1) * 8192)) = make_uint4(gh[0], gh[1], gh[2], gh[3]);
+      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + (off + (j >> 1) * 8192)) = make_uint4(gm[0], gm[1], gm[2], gm[3]);
+    }
+  };
+
+  // ================================================================ GEMM 0 (transposed): Msg^T[256][128] = Wo[256][256] . Ctx^T; wave w: features 64 w ..
+  const __amdgpu_buffer_rsrc_t wob = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.wos) + (size_t)(NO * wave) * 16 * 2 * 512, 0, NO * 16 * 2 * 1024, 0x00020000);      // output tile NO w + o: 1 KB block ((tile * 16 + kstep) * 2 + term)
+  constexpr int RO = 6;      // ring slots: k-step kk uses slot kk % RO and refills the slot k-step kk - 1 has freed (loads may then sit anywhere in the k-step)
+  f16x8 go[RO][NO][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage_load(0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage_load(1, q);
+#pragma unroll
+  for (int q = 0; q < RO; ++q)
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) go[q][o][pl] = ldw(wob, ((o * 16 + q) * 2 + pl) * 1024);
+  f32x16 acc0[NO][NJ];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[o][j][r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage_write(0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage_load(2, q);
+  __syncthreads();
+  stamp(1);
+  f32x4 bo4[NO][4];    // out_proj bias of the wave's features, requested during the last k-steps
+  f32x4 b1q = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 128) b1q = *reinterpret_cast<const f32x4*>(a.b1 + 4 * tid);
+  read_b(0, RING, 0, 0);
+  read_b(1, RING, 0, 1);
+  GN_PIN();
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int s = kk >> 1, ks = kk & 1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int g = 4 * kk + j, g2 = g + 2, kk2 = g2 >> 2;
+      if (kk2 < 16) read_b(g2, RING + ((kk2 >> 1) & 1) * KT, kk2 & 1, g2 & 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const int m = 6 * j + 2 * p + o;
+          acc0[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(go[kk % RO][o][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc0[o][j], 0, 0, 0);
+          if (ks == 0 && m % 6 == 1) stage_write(s + 1, m / 6);          // tile 8 = the first x k-tile
+          if (!(ABL & 1) && m % 6 == 3 && kk >= 1 && kk + RO - 1 < 16) {
+            const int lo = (m / 6) >> 1, lpl = (m / 6) & 1;
+            go[(kk - 1) % RO][lo][lpl] = ldw(wob, ((lo * 16 + kk + RO - 1) * 2 + lpl) * 1024);
+          }
+          if (!(ABL & 2) && ks == 0 && m % 6 == 5 && s + 3 <= 8) stage_load(s + 3, m / 6);
+          if (kk == 12 && m % 6 == 5)
+#pragma unroll
+            for (int g4 = 0; g4 < 2; ++g4) {
+              const int u = 2 * (m / 6) + g4;      // 0..7 -> (o, g)
+              bo4[u >> 2][u & 3] = *reinterpret_cast<const f32x4*>(a.bo + 32 * (NO * wave + (u >> 2)) + 8 * (u & 3) + 4 * hh);
+            }
+          GN_PIN();
+        }
+    }
+    if (!(ABL & 16)) __syncthreads();     // after k-step 0: tile s + 1 is visible; after k-step 1: tile s's slot may be overwritten
+    GN_PIN();
+  }
+  stamp(2);
+
+  // GEMM 1's weight ring is requested now: its latency hides behind the message publish
+  const __amdgpu_buffer_rsrc_t w1b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w1s) + (size_t)(NI * wave) * 32 * 2 * 512, 0, NI * 32 * 2 * 1024, 0x00020000);
+  constexpr int RA = 4;     // ring slots (8 KB per wave each); k-step n2 uses slot n2 % RA and refills slot (n2 - 1) % RA
+  f16x8 fa[RA][NI][2];
+  // GEMM 1 visits the k-tiles in the order 8..15 (message), 0..7 (x): sequence number n2 (k-steps) -> weight k-step (n2 + 16) & 31
+  auto load_a = [&](int slot, int n2, int i, int pl) __attribute__((always_inline)) {
+    fa[slot][i][pl] = ldw(w1b, ((i * 32 + ((n2 + 16) & 31)) * 2 + pl) * 1024);
+  };
+#pragma unroll
+  for (int q = 0; q < RA - 2; ++q)      // (the other two slots are requested after the publish: registers)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
+  // ffn.0's bias, as b1 / s1, travels through ring slot 1 (free from here until x tile 9 is staged): requested in the prologue, readable after the
+  // message barrier -- GEMM 1's accumulators start from it
+  if (tid < 128) *reinterpret_cast<f32x4*>(smem + RING + KT + 16 * tid) = b1q * (1.0f / s1);
+  // message = acc0 * scale + bias: feature 32 (NO w + o) + 8 g + 4 hh + c in register 4 g + c -> k-tile NO w + o of the message tile
+  window(0);
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pb[jp][c] = bo[0][jp][c] + (unsigned int)(NO * wave * KT);
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x2v y[8], t[8];
+      unsigned int hw[8], mw[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = pair(acc0[o][j], 2 * k) * splat2(a.wo_scale) + (f32x2v){bo4[o][k >> 1][2 * (k & 1)], bo4[o][k >> 1][2 * (k & 1) + 1]};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { amax = fmaxf(amax, fmaxf(fabsf(y[k][0]), fabsf(y[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y[k], f16x2v)); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = y[k] - t[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
+#pragma unroll
+      for (int ksp = 0; ksp < 2; ++ksp) {
+        *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp] + (o * KT + (j >> 1) * 8192)) = make_uint4(hw[4 * ksp], hw[4 * ksp + 1], hw[4 * ksp + 2], hw[4 * ksp + 3]);
+        *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + (o * KT + (j >> 1) * 8192)) = make_uint4(mw[4 * ksp], mw[4 * ksp + 1], mw[4 * ksp + 2], mw[4 * ksp + 3]);
+      }
+      GN_PIN();
+    }
+  __syncthreads();     // message tile complete
+  stamp(3);
+
+  // ================================================================ GEMM 1 (transposed): H^T[512][128] = W1[512][512] . [x | msg]^T; wave w: hidden units 128 w ..
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    f32x4 bi[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = *reinterpret_cast<const f32x4*>(smem + RING + KT + (32 * (NI * wave + i) + 8 * g + 4 * hh) * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j][4 * g + c] = bi[g][c];
+    GN_PIN();
+  }
+#pragma unroll
+  for (int q = RA - 2; q < RA; ++q)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
+  uint4 cst_a;      // the thread's share of the LayerNorm weight / bias arrays on their way to LDS
+  read_b(0, 0, 0, 0);
+  GN_PIN();
+  auto gemm1_kstep = [&](int n2) __attribute__((always_inline)) {       // k-tile n = n2 >> 1: n < 8: message k-tile n; n >= 8: staged tile n (x k-tile n - 8) in ring slot n & 1
+    const int n = n2 >> 1, ks = n2 & 1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int g = 4 * n2 + j, g1 = g + 1, m2 = g1 >> 2, nn = m2 >> 1;
+      if (m2 < 32 && !((ABL & 64) && n2 > 0)) read_b(g1, nn < 8 ? nn * KT : RING + (nn & 1) * KT, m2 & 1, g1 & 3);
+      // products: W_m X_h, W_h X_m, W_h X_h (small terms first), the four hidden tiles round-robin
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int mj = 4 * p + i;       // MFMA number inside the j-step
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[n2 % RA][i][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+          if (n >= 8 && ks == 0 && n + 1 < 16 && mj == 2) stage_write(n + 1, j);
+          if (!(ABL & 1) && (mj == 5 || mj == 10) && n2 >= 1 && n2 + RA - 1 < 32) {
+            const int u = 2 * j + (mj == 10 ? 1 : 0);   // 0..7 -> (i, term)
+            load_a((n2 - 1) % RA, n2 + RA - 1, u >> 1, u & 1);
+          }
+          if (!(ABL & 2) && ks == 0 && n + 3 >= 9 && n + 3 < 16 && mj == 7) stage_load(n + 3, j);     // (x tiles 9, 10 are requested during the last message k-tiles)
+          if (n2 == 29 && mj == 7 && j == 0) cst_a = *reinterpret_cast<const uint4*>((tid < 128 ? a.ln_g : a.ln_b - 512) + 4 * tid);
+          GN_PIN();
+        }
+    }
+    if (n >= 8 && !(ABL & 16)) __syncthreads();
+    if (n2 == 15) stamp(10);
+    if ((ABL & 128) && ks == 1) ts2[n] = (long long)__builtin_amdgcn_s_memtime();
+    GN_PIN();
+  };
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) gemm1_kstep(n2);
+  window(1);        // message k-tiles 4..7 (first use: the prefetch out of k-step 7)
+#pragma unroll
+  for (int n2 = 7; n2 < 11; ++n2) gemm1_kstep(n2);
+  stage_addr();     // (first use: the loads of x tile 9 at k-tile 6)
+#pragma unroll
+  for (int n2 = 11; n2 < 15; ++n2) gemm1_kstep(n2);
+  window(2);        // the x half reads the ring (first use: the prefetch out of k-step 15)
+#pragma unroll
+  for (int n2 = 15; n2 < 32; ++n2) gemm1_kstep(n2);
+  stamp(4);
+
+  // wave w: output features 64 w ..; k-steps are visited quarter by quarter: sequence number c = 8 q + 2 w' + ks -> weight k-step 8 w' + 2 q + ks
+  const __amdgpu_buffer_rsrc_t w2b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w2s) + (size_t)(NO * wave) * 32 * 2 * 512, 0, NO * 32 * 2 * 1024, 0x00020000);        // output tile NO w + o: 1 KB block ((tile * 32 + kstep) * 2 + term)
+  constexpr int RG = 6;
+  f16x8 ga[RG][NO][2];
+  auto load_g = [&](int slot, int c, int o, int pl) __attribute__((always_inline)) {
+    const int kstep = 8 * ((c >> 1) & 3) + 2 * (c >> 3) + (c & 1);
+    ga[slot][o][pl] = ldw(w2b, ((o * 32 + kstep) * 2 + pl) * 1024);
+  };
+  // constants -> LDS (the ring is dead: every wave is past GEMM 1's last barrier)
+  *reinterpret_cast<uint4*>(smem + CST + 16 * tid) = cst_a;                       // ln_g[0..511], ln_b[0..511]
+
+  // ---------------------------------------------------------------- LayerNorm(512) statistics, eps 1e-5 -- read-only over the accumulators
+  // lane (ql, hh) holds, for tokens 32 j + ql, the hidden units  32 (NI w + i) + 8 g + 4 hh + c   (register r = 4 g + c): 64 values per
+  // token.  Shifted sums (shift = the lane's first value) -> (mean, M2) of the 64; Chan's merge with the other half-wave, then across
+  // the 4 waves through LDS: one exchange, no catastrophic cancellation whatever the mean.
+  {
+    float* const stat = reinterpret_cast<float*>(smem + STAT);     // [NW][TM][2]
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float K = acc[0][j][0];      // statistics in accumulator units (times s1 below)
+      f32x2v sd = splat2(0.f), sq = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2v d = pair(acc[i][j], r) - splat2(K);
+          sd += d;
+          sq += d * d;
+        }
+        GN_PIN();      // (left alone the compiler copies all 256 accumulators into VGPRs first, and spills)
+      }
+      const float sdl = sd[0] + sd[1], sql = sq[0] + sq[1];
+      const float mu = sdl * (1.0f / 64.0f);
+      float mean_a = K + mu, m2_a = sql - sdl * mu;
+      const float mean_b = __shfl_xor(mean_a, 32), m2_b = __shfl_xor(m2_a, 32);
+      const float dl = mean_a - mean_b;
+      m2_a = m2_a + m2_b + 32.0f * dl * dl;
+      mean_a = 0.5f * (mean_a + mean_b);
+      if (hh == 0) *reinterpret_cast<f32x2v*>(stat + ((wave * TM + 32 * j + ql) * 2)) = (f32x2v){mean_a, m2_a};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x2v pw[NW];
+#pragma unroll
+      for (int w4 = 0; w4 < NW; ++w4) pw[w4] = *reinterpret_cast<const f32x2v*>(stat + ((w4 * TM + 32 * j + ql) * 2));
+      const float mean = 0.25f * ((pw[0][0] + pw[1][0]) + (pw[2][0] + pw[3][0]));
+      float m2 = (pw[0][1] + pw[1][1]) + (pw[2][1] + pw[3][1]);
+#pragma unroll
+      for (int w4 = 0; w4 < NW; ++w4) { const float dl = pw[w4][0] - mean; m2 += 128.0f * dl * dl; }
+      const float rstd = 1.0f / sqrtf(m2 * (s1 * s1) * (1.0f / 512.0f) + 1e-5f);
+      rs[j] = rstd * s1;
+      nmr[j] = -(mean * s1) * rstd;
+    }
+  }
+  stamp(5);
+  // the second GEMM's first weight fragments: their latency hides behind the two exposed GELU quarters
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) load_g(q, q, o, pl);
+
+  // ---------------------------------------------------------------- normalise + erf GELU + split + publish of one fragment, as 22 stages
+  // wave w's hidden units 32 (NI w + q) .. of quarter q -> k-tile w of buffer q & 1 (the message tile's space: GEMM 1 is done with it)
+  auto gelu_stage = [&](int st, int q, int j, int ksp) __attribute__((always_inline)) {
+    if (st == 0) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int cof = (32 * q + 8 * (2 * ksp + gg)) * 4;
+        c2[gg] = *reinterpret_cast<const f32x4*>(smem + cbase + cof);
+        c3[gg] = *reinterpret_cast<const f32x4*>(smem + cbase + cof + 2048);
+      }
+    } else if (st == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gy[e] = acc[q][j][8 * ksp + e] * rs[j] + nmr[j];
+    } else if (st == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gy[e] = gy[e] * c2[e >> 2][e & 3] + c3[e >> 2][e & 3];
+    } else if (ABL & 4) {
+      if (st >= 18) tail_stage(st, 0, j, ksp);
+    } else if (st == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt[e] = gy[e] * 0.70710678118654752440f;
+    } else if (st == 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt[e] = fminf(fabsf(gt[e]), 4.0f);
+    } else if (st == 5) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = 4.6081331674940884e-05f * gt[e] + -0.00045161080197431147f;
+    } else if (st >= 6 && st <= 11) {
+      const float cf = st == 6 ? 0.0015096671413630247f : st == 7 ? 0.0007409505778923631f : st == 8 ? -0.028223754838109016f
+                     : st == 9 ? 0.1484677642583847f : st == 10 ? 0.918419361114502f : 1.6279083490371704f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = gq[e] * gt[e] + cf;
+    } else if (st == 12) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = gq[e] * gt[e];
+    } else if (st == 13) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = __builtin_amdgcn_exp2f(-gq[e]);
+    } else if (st == 14) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = 1.0f - gq[e];
+    } else if (st == 15) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gq[e] = copysignf(gq[e], gy[e]);
+    } else if (st == 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt[e] = 0.5f * gy[e];
+    } else if (st == 17) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gy[e] = gt[e] * gq[e] + gt[e];
+    } else if (st >= 18) {
+      tail_stage(st, 0, j, ksp);
+    }
+  };
+  auto set_pb = [&](int q) __attribute__((always_inline)) {      // quarter q goes to k-tile `wave` of buffer q & 1 (64 KB each)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pb[jp][c] = bo[q & 1][jp][c] + (unsigned int)(wave * KT);
+  };
+  window(0);
+  window(1);
+  // quarters 0 and 1 before the second GEMM starts (its 128 accumulators and the 256 of GEMM 1 do not fit the accumulator file together)
+  // (no MFMA runs beside this code: two-wide v_pk_* arithmetic halves its instruction count -- one wave issues a VALU instruction
+  // every ~6 cycles whatever its width (tools/probes/stream1w.hip) -- while beside MFMAs a packed instruction costs what two
+  // scalar ones do; the staged scalar form above is for the quarters produced inside the second GEMM)
+  auto gelu_tile_pk = [&](int q, int j) __attribute__((always_inline)) {
+    f32x4 w4[4], b4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      w4[g] = *reinterpret_cast<const f32x4*>(smem + cbase + (32 * q + 8 * g) * 4);
+      b4[g] = *reinterpret_cast<const f32x4*>(smem + cbase + (32 * q + 8 * g) * 4 + 2048);
+    }
+    f32x2v y[8], t[8], u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = pair(acc[q][j], 2 * k) * splat2(rs[j]) + splat2(nmr[j]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = y[k] * (f32x2v){w4[k >> 1][2 * (k & 1)], w4[k >> 1][2 * (k & 1) + 1]} + (f32x2v){b4[k >> 1][2 * (k & 1)], b4[k >> 1][2 * (k & 1) + 1]};
+    if (!(ABL & 4)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = y[k] * splat2(0.70710678118654752440f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = (f32x2v){fminf(fabsf(t[k][0]), 4.0f), fminf(fabsf(t[k][1]), 4.0f)};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = splat2(4.6081331674940884e-05f) * t[k] + splat2(-0.00045161080197431147f);
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        const float cf = st == 0 ? 0.0015096671413630247f : st == 1 ? 0.0007409505778923631f : st == 2 ? -0.028223754838109016f
+                       : st == 3 ? 0.1484677642583847f : st == 4 ? 0.918419361114502f : 1.6279083490371704f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = u[k] * t[k] + splat2(cf);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = u[k] * t[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = (f32x2v){__builtin_amdgcn_exp2f(-u[k][0]), __builtin_amdgcn_exp2f(-u[k][1])};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = splat2(1.0f) - u[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = (f32x2v){copysignf(u[k][0], y[k][0]), copysignf(u[k][1], y[k][1])};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = splat2(0.5f) * y[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = t[k] * u[k] + t[k];
+    }
+    // maximum, fp16 split, publish: registers 0..7 -> the fragment of k-step 0, 8..15 -> k-step 1
+    unsigned int hw[8], mw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { amax = fmaxf(amax, fmaxf(fabsf(y[k][0]), fabsf(y[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y[k], f16x2v)); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = y[k] - t[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
+#pragma unroll
+    for (int ksp = 0; ksp < 2; ++ksp) {
+      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp] + ((j >> 1) * 8192)) = make_uint4(hw[4 * ksp], hw[4 * ksp + 1], hw[4 * ksp + 2], hw[4 * ksp + 3]);
+      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + ((j >> 1) * 8192)) = make_uint4(mw[4 * ksp], mw[4 * ksp + 1], mw[4 * ksp + 2], mw[4 * ksp + 3]);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    set_pb(q);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { gelu_tile_pk(q, j); GN_PIN(); }
+  }
+  __syncthreads();     // quarters 0 and 1 visible; every wave is past its LayerNorm statistics
+  stamp(6);
+
+  // ================================================================ GEMM 2 (transposed): Y^T[256][128] = W2[256][512] . H^T;  wave w: output features 64 w ..
+  f32x16 acc2[NO][NJ];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[o][j][r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int buf = (q & 1) * 4 * KT;
+    const bool fill = q >= 1 && q + 1 < 4;       // quarter q + 1 is produced (into the buffer quarter q - 1 has released) while quarter q is consumed
+    if (fill) set_pb(q + 1);
+    read_b(32 * q, buf, 0, 0);
+    read_b(32 * q + 1, buf, 0, 1);
+    GN_PIN();
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = 8 * q + cc, w4 = cc >> 1, ks = cc & 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int g = 4 * c + j, g2 = g + 2, c2_ = g2 >> 2;
+        if ((c2_ >> 3) == q) read_b(g2, buf + ((c2_ >> 1) & 3) * KT, c2_ & 1, g2 & 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            const int m = 6 * j + 2 * p + o;
+            acc2[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[c % RG][o][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc2[o][j], 0, 0, 0);
+            // the VALU stage of the next quarter's fragment (token tile w4, k-step ks) that shares this MFMA's gap
+            if (fill && m < 22) gelu_stage(m, q + 1, w4, ks);
+            if (!(ABL & 1) && m % 6 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 6) >> 1, (m / 6) & 1);
+            GN_PIN();
+          }
+      }
+    }
+    __syncthreads();     // quarter q + 1 visible, buffer q & 1 free again
+    GN_PIN();
+  }
+  ovf_commit(a.ovf, amax);
+  stamp(7);
+
+  // ---------------------------------------------------------------- epilogue: + bias + residual x, hm16 (and optionally f32) rows
+  // (the hidden buffers are dead: their space becomes the [128 tokens][256 features] f32 tile of the row-wise epilogue)
+  float* const yt = reinterpret_cast<float*>(smem);
+  // lane -> (row parity lane >> 5, feature octet lane & 31): a wave finishes two 1 KB rows per step with 16-byte accesses
+  const int oct = lane & 31, f0 = 8 * oct;
+  constexpr int RW = TM / NW;   // token rows per wave
+  uint4 rh[RW / 2], rm[RW / 2];
+#pragma unroll
+  for (int it = 0; it < RW / 2; ++it) {   // residual rows requested up front: one memory latency, not RW / 2
+    const uint16_t* rp = a.xp + hm16_off((size_t)(bm + RW * wave + 2 * it + hh), kDim, f0);
+    rh[it] = *reinterpret_cast<const uint4*>(rp);
+    rm[it] = *reinterpret_cast<const uint4*>(rp + 16);
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc2[o][j][4 * g], acc2[o][j][4 * g + 1], acc2[o][j][4 * g + 2], acc2[o][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(yt + (32 * j + ql) * YP + 32 * (NO * wave + o) + 8 * g + 4 * hh) = v;
+      }
+  const float s2 = a.w2_scale;
+  const f32x4 bias_a = *reinterpret_cast<const f32x4*>(a.b2 + f0), bias_b = *reinterpret_cast<const f32x4*>(a.b2 + f0 + 4);
+  __syncthreads();
+  stamp(8);
+  float amax2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < RW / 2; ++it) {
+    const int row = RW * wave + 2 * it + hh;
+    const f32x4 ya = *reinterpret_cast<const f32x4*>(yt + row * YP + f0), yb = *reinterpret_cast<const f32x4*>(yt + row * YP + f0 + 4);
+    const f16x8 xh = __builtin_bit_cast(f16x8, rh[it]), xm = __builtin_bit_cast(f16x8, rm[it]);
+    float v8[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v8[e] = (ya[e] * s2 + bias_a[e]) + ((float)xh[e] + (float)xm[e]);
+      v8[4 + e] = (yb[e] * s2 + bias_b[e]) + ((float)xh[4 + e] + (float)xm[4 + e]);
+    }
+    uint4 h4, m4;
+    split8(v8, h4, m4);
+    uint16_t* yp = a.yp + hm16_off((size_t)(bm + row), kDim, f0);
+    *reinterpret_cast<uint4*>(yp) = h4;
+    *reinterpret_cast<uint4*>(yp + 16) = m4;
+    if (a.y != nullptr) {
+      float* yo = a.y + (size_t)(bm + row) * kDim + f0;
+      *reinterpret_cast<f32x4*>(yo) = (f32x4){v8[0], v8[1], v8[2], v8[3]};
+      *reinterpret_cast<f32x4*>(yo + 4) = (f32x4){v8[4], v8[5], v8[6], v8[7]};
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) ovf_track(amax2, v8[e], v8[e + 1]);
+  }
+  ovf_commit(a.ovf, amax2);
+  if (ABL & 8) {
+    stamp(9);
+    if (a.dbg_ts != nullptr && lane == 0)
+      for (int k = 0; k < 12; ++k) a.dbg_ts[((size_t)blockIdx.x * NW + wave) * 12 + k] = ts[k];
+    if ((ABL & 128) && a.dbg_ts != nullptr && lane == 0)
+      for (int k = 0; k < 16; ++k) a.dbg_ts[(size_t)gridDim.x * NW * 12 + ((size_t)blockIdx.x * NW + wave) * 16 + k] = ts2[k];
+  }
+}
+#undef GN_PIN
+}  // namespace
+
+void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
+  const dim3 grid(a.T / 128), block(256);
+  switch (ablate) {
+    case 8: hipLaunchKernelGGL((k_ffn128<8>), grid, block, 0, s, a); break;
+    case 9: hipLaunchKernelGGL((k_ffn128<9>), grid, block, 0, s, a); break;
+    case 12: hipLaunchKernelGGL((k_ffn128<12>), grid, block, 0, s, a); break;
+    case 136: hipLaunchKernelGGL((k_ffn128<136>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_ffn128<0>), grid, block, 0, s, a); break;
+  }
+  g_last_kernel = "k_ffn128<0>";
+}
+
+}  // namespace gn
