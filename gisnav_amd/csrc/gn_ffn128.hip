@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   long long ts[12], ts2[16];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (ABL & 8) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
+  f32x4 b1q = {0.f, 0.f, 0.f, 0.f};      // ffn.0's bias, requested first: it is needed after GEMM 0 (see below)
+  if (tid < 128) b1q = *reinterpret_cast<const f32x4*>(a.b1 + 4 * tid);
 
   // Addressing discipline (one wave per SIMD, 256 arch VGPRs beside 256 accumulator registers): every global access is
   // `buffer descriptor (SGPRs) + 32-bit lane offset (VGPR) + uniform offset (SGPR / literal)`, every LDS access `one of a few base
@@ -180,8 +182,6 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   __syncthreads();
   stamp(1);
   f32x4 bo4[NO][4];    // out_proj bias of the wave's features, requested during the last k-steps
-  f32x4 b1q = {0.f, 0.f, 0.f, 0.f};
-  if (tid < 128) b1q = *reinterpret_cast<const f32x4*>(a.b1 + 4 * tid);
   read_b(0, RING, 0, 0);
   read_b(1, RING, 0, 1);
   GN_PIN();
@@ -526,6 +526,17 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   __syncthreads();     // quarters 0 and 1 visible; every wave is past its LayerNorm statistics
   stamp(6);
 
+  // residual rows of the epilogue: lane -> (row parity lane >> 5, feature octet lane & 31): a wave finishes two 1 KB rows per step with
+  // 16-byte accesses; the first half of the rows is requested inside the last quarter of GEMM 2 (whose VALU stages are idle)
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const int oct = lane & 31, f0 = 8 * oct;
+  constexpr int RW = TM / NW;   // token rows per wave
+  const unsigned int roff = (unsigned int)(hh * 1024 + (oct >> 1) * 64 + (oct & 1) * 16);
+  uint4 rh[RW / 2], rm[RW / 2];
+  auto res_load = [&](int it) __attribute__((always_inline)) {
+    rh[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, roff, (RW * wave + 2 * it) * 1024, 0));
+    rm[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, roff + 32, (RW * wave + 2 * it) * 1024, 0));
+  };
   // ================================================================ GEMM 2 (transposed): Y^T[256][128] = W2[256][512] . H^T;  wave w: output features 64 w ..
   f32x16 acc2[NO][NJ];
 #pragma unroll
@@ -557,6 +568,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
             acc2[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[c % RG][o][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc2[o][j], 0, 0, 0);
             // the VALU stage of the next quarter's fragment (token tile w4, k-step ks) that shares this MFMA's gap
             if (fill && m < 22) gelu_stage(m, q + 1, w4, ks);
+            if (q == 3 && m == 2) res_load(cc);
             if (!(ABL & 1) && m % 6 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 6) >> 1, (m / 6) & 1);
             GN_PIN();
           }
@@ -571,53 +583,54 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   // ---------------------------------------------------------------- epilogue: + bias + residual x, hm16 (and optionally f32) rows
   // (the hidden buffers are dead: their space becomes the [128 tokens][256 features] f32 tile of the row-wise epilogue)
   float* const yt = reinterpret_cast<float*>(smem);
-  // lane -> (row parity lane >> 5, feature octet lane & 31): a wave finishes two 1 KB rows per step with 16-byte accesses
-  const int oct = lane & 31, f0 = 8 * oct;
-  constexpr int RW = TM / NW;   // token rows per wave
-  uint4 rh[RW / 2], rm[RW / 2];
 #pragma unroll
-  for (int it = 0; it < RW / 2; ++it) {   // residual rows requested up front: one memory latency, not RW / 2
-    const uint16_t* rp = a.xp + hm16_off((size_t)(bm + RW * wave + 2 * it + hh), kDim, f0);
-    rh[it] = *reinterpret_cast<const uint4*>(rp);
-    rm[it] = *reinterpret_cast<const uint4*>(rp + 16);
-  }
+  for (int it = RW / 4; it < RW / 2; ++it) res_load(it);     // second half of the residual rows (the first was requested during quarter 3)
 #pragma unroll
   for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 v = {acc2[o][j][4 * g], acc2[o][j][4 * g + 1], acc2[o][j][4 * g + 2], acc2[o][j][4 * g + 3]};
         *reinterpret_cast<f32x4*>(yt + (32 * j + ql) * YP + 32 * (NO * wave + o) + 8 * g + 4 * hh) = v;
       }
+      GN_PIN();
+    }
   const float s2 = a.w2_scale;
   const f32x4 bias_a = *reinterpret_cast<const f32x4*>(a.b2 + f0), bias_b = *reinterpret_cast<const f32x4*>(a.b2 + f0 + 4);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.yp + (size_t)bm * 512, 0, TM * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(a.y != nullptr ? a.y + (size_t)bm * kDim : reinterpret_cast<float*>(a.yp), 0, a.y != nullptr ? TM * 1024 : 0, 0x00020000);
+  const unsigned int foff = (unsigned int)(hh * 1024 + f0 * 4);
   __syncthreads();
   stamp(8);
   float amax2 = 0.f;
 #pragma unroll
   for (int it = 0; it < RW / 2; ++it) {
-    const int row = RW * wave + 2 * it + hh;
-    const f32x4 ya = *reinterpret_cast<const f32x4*>(yt + row * YP + f0), yb = *reinterpret_cast<const f32x4*>(yt + row * YP + f0 + 4);
+    const int rowl = RW * wave + 2 * it;      // (+ hh: in the lane offsets)
+    const f32x4 ya = *reinterpret_cast<const f32x4*>(yt + (rowl + hh) * YP + f0), yb = *reinterpret_cast<const f32x4*>(yt + (rowl + hh) * YP + f0 + 4);
     const f16x8 xh = __builtin_bit_cast(f16x8, rh[it]), xm = __builtin_bit_cast(f16x8, rm[it]);
-    float v8[8];
+    f32x2v v[4], t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v8[e] = (ya[e] * s2 + bias_a[e]) + ((float)xh[e] + (float)xm[e]);
-      v8[4 + e] = (yb[e] * s2 + bias_b[e]) + ((float)xh[4 + e] + (float)xm[4 + e]);
+    for (int k = 0; k < 4; ++k) {
+      const f32x2v yk = k < 2 ? (f32x2v){ya[2 * k], ya[2 * k + 1]} : (f32x2v){yb[2 * k - 4], yb[2 * k - 3]};
+      const f32x2v bk = k < 2 ? (f32x2v){bias_a[2 * k], bias_a[2 * k + 1]} : (f32x2v){bias_b[2 * k - 4], bias_b[2 * k - 3]};
+      const f32x2v xk = (f32x2v){(float)xh[2 * k], (float)xh[2 * k + 1]} + (f32x2v){(float)xm[2 * k], (float)xm[2 * k + 1]};
+      v[k] = (yk * splat2(s2) + bk) + xk;
     }
-    uint4 h4, m4;
-    split8(v8, h4, m4);
-    uint16_t* yp = a.yp + hm16_off((size_t)(bm + row), kDim, f0);
-    *reinterpret_cast<uint4*>(yp) = h4;
-    *reinterpret_cast<uint4*>(yp + 16) = m4;
+    unsigned int hw[4], mw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { amax2 = fmaxf(amax2, fmaxf(fabsf(v[k][0]), fabsf(v[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[k], f16x2v)); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = v[k] - __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){hw[0], hw[1], hw[2], hw[3]}, yrs, roff, rowl * 1024, 0);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){mw[0], mw[1], mw[2], mw[3]}, yrs, roff + 32, rowl * 1024, 0);
     if (a.y != nullptr) {
-      float* yo = a.y + (size_t)(bm + row) * kDim + f0;
-      *reinterpret_cast<f32x4*>(yo) = (f32x4){v8[0], v8[1], v8[2], v8[3]};
-      *reinterpret_cast<f32x4*>(yo + 4) = (f32x4){v8[4], v8[5], v8[6], v8[7]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v[0][0], v[0][1], v[1][0], v[1][1]}), frs, foff, rowl * 1024, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v[2][0], v[2][1], v[3][0], v[3][1]}), frs, foff + 16, rowl * 1024, 0);
     }
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) ovf_track(amax2, v8[e], v8[e + 1]);
+    GN_PIN();
   }
   ovf_commit(a.ovf, amax2);
   if (ABL & 8) {

@@ -79,6 +79,7 @@ struct Shared {
   double us[10];
   double pws[15];
   double cws[12];
+  double cam[4];   // fu, fv, uc, vc as OpenCV's epnp constructor takes them from the camera matrix: us = x fu + uc (epnp::init_points)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -702,7 +703,7 @@ __device__ inline double epnp_Rt(const Shared& sh, const double be[4], double R[
     const double X = R[0][0] * w[0] + R[0][1] * w[1] + R[0][2] * w[2] + t[0];
     const double Y = R[1][0] * w[0] + R[1][1] * w[1] + R[1][2] * w[2] + t[1];
     const double Z = R[2][0] * w[0] + R[2][1] * w[1] + R[2][2] * w[2] + t[2];
-    const double du = sh.us[2 * p] - X / Z, dv = sh.us[2 * p + 1] - Y / Z;
+    const double du = sh.us[2 * p] - (sh.cam[2] + sh.cam[0] * X / Z), dv = sh.us[2 * p + 1] - (sh.cam[3] + sh.cam[1] * Y / Z);   // epnp::reprojection_error, pixels
     err += sqrt(du * du + dv * dv);
   }
   return err * 0.2;
@@ -766,17 +767,18 @@ __device__ bool epnp5(Shared& sh, int lane, double Rb[3][3], double tb[3], doubl
     }
   }
   wave_sync();
-  // M^T M (12 x 12), M is 10 x 12 with fu = fv = 1, uc = vc = 0
+  // M^T M (12 x 12), M is 10 x 12 (epnp::fill_M: the rows carry fu / fv, the image points are in pixels)
+  const double cfu = sh.cam[0], cfv = sh.cam[1], cuc = sh.cam[2], cvc = sh.cam[3];
   for (int idx = lane; idx < 144; idx += 64) {
     const int r = idx / 12, c = idx % 12;
     const int jr = r / 3, kr = r % 3, jc = c / 3, kc = c % 3;
     double v = 0;
     for (int p = 0; p < 5; ++p) {
       const double ar = sh.alphas[p * 4 + jr], ac = sh.alphas[p * 4 + jc];
-      const double u = sh.us[2 * p], w = sh.us[2 * p + 1];
-      // row 2p:   [a, 0, -a u]   row 2p+1: [0, a, -a w]
-      const double m0r = kr == 0 ? ar : (kr == 2 ? -ar * u : 0.0), m0c = kc == 0 ? ac : (kc == 2 ? -ac * u : 0.0);
-      const double m1r = kr == 1 ? ar : (kr == 2 ? -ar * w : 0.0), m1c = kc == 1 ? ac : (kc == 2 ? -ac * w : 0.0);
+      const double u = cuc - sh.us[2 * p], w = cvc - sh.us[2 * p + 1];
+      // row 2p:   [a fu, 0, a (uc - u)]   row 2p+1: [0, a fv, a (vc - v)]
+      const double m0r = kr == 0 ? ar * cfu : (kr == 2 ? ar * u : 0.0), m0c = kc == 0 ? ac * cfu : (kc == 2 ? ac * u : 0.0);
+      const double m1r = kr == 1 ? ar * cfv : (kr == 2 ? ar * w : 0.0), m1c = kc == 1 ? ac * cfv : (kc == 2 ? ac * w : 0.0);
       v += m0r * m0c + m1r * m1c;
     }
     sh.A[idx] = v;
@@ -1391,9 +1393,11 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(PnpArgs a) {
       for (int i = 0; i < 5; ++i) if (i == lane) id = idx[i];
       sh.pws[lane * 3 + 0] = obj[3 * id]; sh.pws[lane * 3 + 1] = obj[3 * id + 1]; sh.pws[lane * 3 + 2] = obj[3 * id + 2];
       // cv::undistortPoints output takes the input's depth (float32): computed in double, stored as float (oracle: solve_pnp_ransac)
-      sh.us[2 * lane] = (double)(float)(((double)img[2 * id] - cam.cx) / cam.fx);
-      sh.us[2 * lane + 1] = (double)(float)(((double)img[2 * id + 1] - cam.cy) / cam.fy);
+      // ... and epnp::init_points re-applies the intrinsics to them: us = x fu + uc, in double
+      sh.us[2 * lane] = (double)(float)(((double)img[2 * id] - cam.cx) / cam.fx) * cam.fx + cam.cx;
+      sh.us[2 * lane + 1] = (double)(float)(((double)img[2 * id + 1] - cam.cy) / cam.fy) * cam.fy + cam.cy;
     }
+    if (lane == 0) { sh.cam[0] = cam.fx; sh.cam[1] = cam.fy; sh.cam[2] = cam.cx; sh.cam[3] = cam.cy; }
     wave_sync();
     double R[3][3], t[3];
     long long ts[9];
@@ -1599,6 +1603,21 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
     }
     return;
   }
+  if (n == 5 && a.min_pts <= 5) {   // the same `model_points == npoints` block: one solvePnP(SOLVEPNP_EPNP) on all five points (hypothesis 0 IS that solve), every point an inlier, no refinement
+    if (lane == 0) {
+      bool ok5 = hyp[0].valid != 0;
+      double Rb[3][3], rv[3], Rf[3][3], dummy[3][9];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[i][j] = hyp[0].R[3 * i + j];
+      if (ok5) {
+        rodrigues_m2v(Rb, rv);
+        rodrigues_v2m(rv, Rf, dummy, false);
+        for (int i = 0; i < 3; ++i) { ok5 = ok5 && isfinite(hyp[0].t[i]); for (int j = 0; j < 3; ++j) ok5 = ok5 && isfinite(Rf[i][j]); }
+      }
+      for (int i = 0; i < 3; ++i) { tout[i] = ok5 ? hyp[0].t[i] : 0.0; for (int j = 0; j < 3; ++j) Rout[3 * i + j] = ok5 ? Rf[i][j] : (i == j ? 1.0 : 0.0); }
+      a.ok[b] = ok5 ? 1 : 0; a.n_inliers[b] = ok5 ? 5 : 0;
+    }
+    return;
+  }
   if (n < a.min_pts || n < 5) {
     if (lane < 9) Rout[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
     if (lane < 3) tout[lane] = 0.0;
@@ -1728,11 +1747,12 @@ __global__ __launch_bounds__(64) void k_pnp_refine(PnpArgs a) {
 
 // test hook: EPnP on n independent 5-point sets (world points f64 [n][5][3], normalised image points
 // f64 [n][5][2]); out [n][64]: R (9), t (3), candidate errors (3), candidate betas (12), eigenvalues (12), rho(6), L row 0 (10)
-__global__ __launch_bounds__(64) void k_epnp_debug(const double* pws, const double* us, double* out) {
+__global__ __launch_bounds__(64) void k_epnp_debug(const double* pws, const double* us, double* out, const double* cam4) {
   __shared__ Shared sh;
   const int b = blockIdx.x, lane = threadIdx.x;
   if (lane < 15) sh.pws[lane] = pws[b * 15 + lane];
   if (lane < 10) sh.us[lane] = us[b * 10 + lane];
+  if (lane < 4) sh.cam[lane] = cam4 ? cam4[lane] : (lane < 2 ? 1.0 : 0.0);      // default: identity camera (us are normalised coordinates)
   __syncthreads();
   double R[3][3], t[3];
   double* o = out + (size_t)b * 64;
@@ -1751,7 +1771,7 @@ __global__ __launch_bounds__(64) void k_epnp_debug(const double* pws, const doub
 }
 
 void launch_epnp_debug(const double* pws, const double* us, double* out, int n, hipStream_t s) {
-  hipLaunchKernelGGL(k_epnp_debug, dim3(n), dim3(64), 0, s, pws, us, out);
+  hipLaunchKernelGGL(k_epnp_debug, dim3(n), dim3(64), 0, s, pws, us, out, (const double*)nullptr);
 }
 
 void launch_pnp(const PnpArgs& a, hipStream_t s) {

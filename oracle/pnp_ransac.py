@@ -676,6 +676,11 @@ def solve_pnp_ransac(obj: np.ndarray, img: np.ndarray, A: np.ndarray, iterations
     Returns (ok, rvec (3,1) f64, tvec (3,1) f64, inliers (n,) int or None).
     K == 4: OpenCV makes ONE solvePnP(SOLVEPNP_P3P) call, every point an inlier, no refinement (`solve_p3p`); unreachable from PoseNode
     (MIN_MATCHES = 15, pose_node.py:299-303) and TwistNode (30), reachable through compute_pose.  K < 4: cv2 raises; here (False, ...).
+    K == 5: the same `if (model_points == npoints)` block of solvepnp.cpp: ONE solvePnP(SOLVEPNP_EPNP) on all five points, every point an
+    inlier, no RANSAC loop and no ITERATIVE refinement.
+    EPnP receives the camera matrix: epnp::init_points re-applies the intrinsics to the undistorted (normalised, float32-stored) points,
+    us = x fu + uc, so the rows of M carry fu / fv and the candidate-selection error is in pixels -- equivalent to working on normalised
+    points only when fx == fy.
     """
     obj = np.asarray(obj, np.float32)
     img = np.asarray(img, np.float32)
@@ -692,9 +697,21 @@ def solve_pnp_ransac(obj: np.ndarray, img: np.ndarray, A: np.ndarray, iterations
         return True, r.reshape(3, 1), np.asarray(sol[1]).reshape(3, 1), np.arange(4)
     if count < model_points:
         return False, None, None, None
+    fu, fv, uc, vc = float(A[0, 0]), float(A[1, 1]), float(A[0, 2]), float(A[1, 2])
     # solvePnP(SOLVEPNP_EPNP) runs cv::undistortPoints on the subset; its output Mat takes the INPUT's depth, so for the float32 image
     # points PoseNode passes, epnp reads normalised coordinates that were computed in double and stored as float32
     und = np.column_stack([(img64[:, 0] - A[0, 2]) / A[0, 0], (img64[:, 1] - A[1, 2]) / A[1, 1]]).astype(np.float32).astype(np.float64)
+    us_px = np.column_stack([und[:, 0] * fu + uc, und[:, 1] * fv + vc])      # epnp::init_points
+    if count == model_points:      # solvePnPRansac's `model_points == npoints` early return
+        try:
+            R, t = epnp(obj64, us_px, fu, fv, uc, vc)
+            rvec = rodrigues_mat2vec(R)
+            ok = bool(np.all(np.isfinite(rvec)) and np.all(np.isfinite(t)))
+        except (np.linalg.LinAlgError, ValueError, ZeroDivisionError):
+            ok = False
+        if not ok:
+            return False, None, None, None
+        return True, rvec.reshape(3, 1), np.asarray(t).reshape(3, 1), np.arange(count)
     rng = CvRNG(0xFFFFFFFFFFFFFFFF)
     niters = iterations_count
     max_good = 0
@@ -702,12 +719,9 @@ def solve_pnp_ransac(obj: np.ndarray, img: np.ndarray, A: np.ndarray, iterations
     thr = np.float32(reproj_error * reproj_error)
     it = 0
     while it < niters:
-        if count > model_points:
-            idx = get_subset(rng, count, model_points)
-        else:
-            idx = list(range(count))
+        idx = get_subset(rng, count, model_points)
         try:
-            R, t = epnp(obj64[idx], und[idx])
+            R, t = epnp(obj64[idx], us_px[idx], fu, fv, uc, vc)
             rvec = rodrigues_mat2vec(R)
             ok = bool(np.all(np.isfinite(rvec)) and np.all(np.isfinite(t)))
         except (np.linalg.LinAlgError, ValueError, ZeroDivisionError):

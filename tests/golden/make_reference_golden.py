@@ -85,6 +85,23 @@ def pnp_cases():
         rs = np.random.default_rng(seed)
         mq[:n_out] = np.column_stack([rs.uniform(0, 640, n_out), rs.uniform(0, 480, n_out)]).astype(np.float32)
         cases.append((name, mq, mr, p.dem, K_MATRIX))
+    # round 4: the two places where the restatement had departed from solvepnp.cpp / epnp.cpp -- exactly five points (the
+    # `model_points == npoints` early return: one EPnP solve, no refinement), planar and with relief, and non-square pixels (epnp::init_points
+    # re-applies the intrinsics, so the rows of M carry fx / fy): the day cv2 is available these pin both
+    K_ns = K_MATRIX.copy()
+    K_ns[1, 1] = 231.0
+    for name, seed, flat, K, k in (("pnp_five_points_dem", 31, False, K_MATRIX, 5), ("pnp_five_points_flat", 32, True, K_MATRIX, 5),
+                                   ("pnp_five_points_fy231", 33, False, K_ns, 5), ("pnp_dem_out60_fy231", 34, False, K_ns, 300),
+                                   ("pnp_flat_out60_fy231", 35, True, K_ns, 300)):
+        p = make_pair(seed, flat_dem=flat)
+        q = np.nonzero(p.gt_q2r >= 0)[0][:k]
+        mq, mr = p.kp_q[q].copy(), p.kp_r[p.gt_q2r[q]]
+        if K is K_ns:      # the synthetic query points were projected with square pixels: stretch v about the principal point
+            mq[:, 1] = ((mq[:, 1] - K_MATRIX[1, 2]) * (K_ns[1, 1] / K_MATRIX[1, 1]) + K_ns[1, 2]).astype(np.float32)
+        if k > 5:
+            rs = np.random.default_rng(seed)
+            mq[:60] = np.column_stack([rs.uniform(0, 640, 60), rs.uniform(0, 480, 60)]).astype(np.float32)
+        cases.append((name, mq, mr, p.dem, K))
     return cases
 
 

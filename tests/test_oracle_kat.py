@@ -293,3 +293,57 @@ def test_p3p_branch_recovers_the_pose_from_exactly_four_points():
         assert np.linalg.norm(pr.rodrigues_vec2mat(r) - R) < 2e-4 and np.linalg.norm(tt.ravel() - t) / np.linalg.norm(t) < 2e-4
     assert n > 300
     assert pr.solve_pnp_ransac(obj[:3].astype(np.float32), img[:3].astype(np.float32), K, 10)[0] is False
+
+
+def test_five_point_branch_is_one_epnp_solve_without_refinement():
+    """cv2.solvePnPRansac with npoints == 5 (core/_shared.py:104-123 -> solvepnp.cpp `if (model_points == npoints)`): ONE
+    solvePnP(SOLVEPNP_EPNP) on all five points, all five inliers, no RANSAC loop, no ITERATIVE refinement.  Exact (noise-free, float32-rounded)
+    non-planar scenes: the true pose within 2e-3; the result IS the bare EPnP pose (Rodrigues round trip), whatever fy."""
+    from oracle import pnp_ransac as pr
+    rs = np.random.default_rng(3)
+    n = 0
+    for trial in range(200):
+        K = np.array([[205.47, 0, 320], [0, 205.47 if trial % 2 else 231.0, 240], [0, 0, 1.0]])
+        R = pr.rodrigues_vec2mat(rs.normal(0, 0.3, 3).reshape(3, 1))
+        t = np.array([rs.uniform(-50, 50), rs.uniform(-50, 50), rs.uniform(200, 400)])
+        obj = np.column_stack([rs.uniform(100, 540, 5), rs.uniform(80, 400, 5), rs.uniform(0, 40, 5)])
+        pc = (R @ obj.T).T + t
+        if (pc[:, 2] <= 1).any():
+            continue
+        n += 1
+        img = (K @ (pc / pc[:, 2:]).T).T[:, :2]
+        o32, i32 = obj.astype(np.float32), img.astype(np.float32)
+        ok, r, tt, inl = pr.solve_pnp_ransac(o32, i32, K, 10)
+        assert ok and list(inl) == [0, 1, 2, 3, 4]
+        und = np.column_stack([(i32[:, 0].astype(np.float64) - K[0, 2]) / K[0, 0], (i32[:, 1].astype(np.float64) - K[1, 2]) / K[1, 1]]).astype(np.float32).astype(np.float64)
+        Re, te = pr.epnp(o32.astype(np.float64), np.column_stack([und[:, 0] * K[0, 0] + K[0, 2], und[:, 1] * K[1, 1] + K[1, 2]]), K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        assert np.allclose(pr.rodrigues_vec2mat(r), pr.rodrigues_vec2mat(pr.rodrigues_mat2vec(Re)), atol=1e-12) and np.allclose(tt.ravel(), te, atol=1e-12)
+        assert np.linalg.norm(pr.rodrigues_vec2mat(r) - R) < 2e-3 and np.linalg.norm(tt.ravel() - t) / np.linalg.norm(t) < 2e-3
+    assert n > 150
+
+
+def test_epnp_rows_carry_the_camera_matrix():
+    """epnp::init_points re-applies the intrinsics (us = x fu + uc) and fill_M weights the rows by fu / fv: with square pixels the pose equals
+    the normalised-coordinate form's to round-off; with fx != fy the noisy 5-point candidates differ (the oracle SEES the weighting) while
+    both stay near the truth."""
+    from oracle import pnp_ransac as pr
+    rs = np.random.default_rng(8)
+    diff_sq, diff_ns = [], []
+    for trial in range(60):
+        fy = 205.47 if trial % 2 == 0 else 231.0
+        K = np.array([[205.47, 0, 320], [0, fy, 240], [0, 0, 1.0]])
+        R = pr.rodrigues_vec2mat(rs.normal(0, 0.25, 3).reshape(3, 1))
+        t = np.array([rs.uniform(-40, 40), rs.uniform(-40, 40), rs.uniform(220, 380)])
+        obj = np.column_stack([rs.uniform(100, 540, 5), rs.uniform(80, 400, 5), rs.uniform(0, 40, 5)])
+        pc = (R @ obj.T).T + t
+        if (pc[:, 2] <= 1).any():
+            continue
+        img = (K @ (pc / pc[:, 2:]).T).T[:, :2] + rs.normal(0, 0.5, (5, 2))
+        und = np.column_stack([(img[:, 0] - K[0, 2]) / K[0, 0], (img[:, 1] - K[1, 2]) / K[1, 1]])
+        Rn, tn = pr.epnp(obj, und)                                                   # normalised coordinates, unit weights
+        Rp, tp = pr.epnp(obj, np.column_stack([und[:, 0] * K[0, 0] + K[0, 2], und[:, 1] * fy + K[1, 2]]), K[0, 0], fy, K[0, 2], K[1, 2])
+        d = np.linalg.norm(Rn - Rp) + np.linalg.norm(tn - tp) / np.linalg.norm(tp)
+        (diff_sq if trial % 2 == 0 else diff_ns).append(d)
+    assert len(diff_sq) > 20 and len(diff_ns) > 20
+    assert max(diff_sq) < 1e-6, max(diff_sq)            # fx == fy: a common row scale, same null space, same winner
+    assert np.median(diff_ns) > 1e-6, np.median(diff_ns)   # fx != fy: the weighting moves the noisy solution
