@@ -621,6 +621,7 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
 
 int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (ctx->npad <= 0) return fail(ctx, GN_ERR_ARG, "context has no workspaces (a gn_resize failed): call gn_resize again");
   if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
   if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
     return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
@@ -694,14 +695,17 @@ int gn_resize(gn_ctx* ctx, int max_kpts) {
   ctx->ws_allocs.clear();
   ctx->sim = nullptr;                                  // allocated on first use (ensure_sim), for the new size
   for (bool& b : ctx->sub_pending) b = false;
-  { const int rc = alloc_workspace(ctx, max_kpts); if (rc != GN_OK) return rc; }
+  // A failure part-way (out of memory while growing) must not leave the context pointing at freed workspaces: every entry point goes
+  // through check_fwd, which refuses a context whose npad is 0 until a later gn_resize succeeds.
+  auto broken = [&](int rc) { for (void* p : ctx->ws_allocs) hipFree(p); ctx->ws_allocs.clear(); ctx->npad = 0; ctx->npad_run = 0; return rc; };
+  { const int rc = alloc_workspace(ctx, max_kpts); if (rc != GN_OK) return broken(rc); }
   if (ctx->s_pnp) {                                    // the overlapped pose stage's double buffers follow the padded size too
     const size_t B = ctx->max_batch, np = ctx->npad;
     for (int i = 0; i < 2; ++i) {
       ctx->pnp_pending[i] = false;
-      int rc = ws_alloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return rc;
-      rc = ws_alloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return rc;
-      rc = ws_alloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return rc;
+      int rc = ws_alloc(ctx, &ctx->o_mkp[i], B * np * 2); if (rc != GN_OK) return broken(rc);
+      rc = ws_alloc(ctx, &ctx->o_obj[i], B * np * 3); if (rc != GN_OK) return broken(rc);
+      rc = ws_alloc(ctx, &ctx->o_nmatch[i], B); if (rc != GN_OK) return broken(rc);
     }
   }
   return GN_OK;
@@ -995,6 +999,7 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   if (groups <= 1 || ctx->overlap)
     return estimate_impl(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, dem, H, W, K9, min_matches,
                          R, t, n_match, n_inliers, ok, stream);
+  if (ctx->npad <= 0) return fail(ctx, GN_ERR_ARG, "context has no workspaces (a gn_resize failed): call gn_resize again");
   if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
   GN_HIP(hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1135,6 +1140,7 @@ int gn_vo_match(gn_ctx* ctx, int B, const float* desc_q, const int32_t* n_q, int
                 const float* desc_r, const int32_t* n_r, int stride_r, double ratio,
                 int64_t* idx, float* dist, int32_t* n_good, int32_t* nn_idx, float* nn_dist, void* stream) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (ctx->npad <= 0) return fail(ctx, GN_ERR_ARG, "context has no workspaces (a gn_resize failed): call gn_resize again");
   if (B < 1 || B > ctx->max_batch) return fail(ctx, GN_ERR_ARG, "B out of range for this context");
   if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
     return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");

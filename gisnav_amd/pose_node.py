@@ -39,8 +39,13 @@ class PoseNode:
         self.camera_info: Optional[CameraInfo] = None
         self.pose_image: Optional[OrthoStereoImage] = None
         self.last_num_matches = 0
-        self.cache_dem = True        # keep the DEM raster on the device while its stamp and shape do not change (False: upload it with every message)
+        # The DEM raster goes to the device with EVERY message, like in the reference (which never caches it): upstream re-stamps dem_msg with
+        # the keypoint cloud's stamp on each message (stereo_node.py:272), so a cache keyed on the DEM's own stamp never hits on real traffic and
+        # serves a stale raster to a caller that reuses a stamp.  cache_dem = True keys the device copy on the REFERENCE image's stamp instead --
+        # the stamp the reference itself trusts for the tile's features (pose_node.py:226-241): dem and reference are cut from the same raster.
+        self.cache_dem = False
         self._dem_dev = None
+        self._dem_pin = None
         self._io_kmax = -1
 
     # `narrow_types` behaviour (gisnav/_decorators.py:117-160): no result until both inputs exist
@@ -80,9 +85,15 @@ class PoseNode:
         self._pin_np[4:4 + n * 133] = np.frombuffer(msg.query_sift, dtype=np.float32, count=n * 133)
         self._pin_np[:1].view(np.int32)[0] = n
         self._dev_in[:4 + n * 133].copy_(self._pin[:4 + n * 133], non_blocking=True)
-        dem_key = (msg.dem.stamp.sec, msg.dem.stamp.nanosec, dem.shape[0], dem.shape[1])
+        dem_key = (stamp, dem.shape[0], dem.shape[1])
         if self._dem_dev is None or self._dem_dev[0] != dem_key or not self.cache_dem:
-            self._dem_dev = (dem_key, torch.from_numpy(np.ascontiguousarray(dem.reshape(1, *dem.shape[:2]))).to(dev))
+            # through a pinned staging raster and one asynchronous copy (a pageable .to(dev) stalls the stream for ~90 us)
+            if self._dem_pin is None or self._dem_pin.shape[1:] != dem.shape[:2]:
+                self._dem_pin = torch.empty((1, dem.shape[0], dem.shape[1]), dtype=torch.uint8, pin_memory=True)
+                self._dem_buf = torch.empty((1, dem.shape[0], dem.shape[1]), dtype=torch.uint8, device=dev)
+            self._dem_pin.numpy()[0] = dem.reshape(dem.shape[0], dem.shape[1])
+            self._dem_buf.copy_(self._dem_pin, non_blocking=True)
+            self._dem_dev = (dem_key, self._dem_buf)
         inputs = dict(desc_q=None, kpt_q=self._dev_in[4:4 + n * 133].view(1, n, 133), n_q=self._dev_in[:1].view(torch.int32),
                       desc_r=None, kpt_r=rec_r_t, n_r=n_r_t, dem=self._dem_dev[1], kpt_format=_lib.GN_KPT_RECORD)
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)

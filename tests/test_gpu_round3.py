@@ -496,9 +496,11 @@ def test_record_stager_refuses_malformed_batches_before_touching_a_slot(state_di
 
 
 def test_pose_node_shim_single_transfer_path_and_dem_cache(state_dict_np):
-    """PoseNode.estimate stages one message with one host-to-device copy and reads its result with one device-to-host copy; the DEM raster is kept
-    on the device per (stamp, shape) like the tile's features (pose_node.py:225-241 caches by stamp): a new stamp uploads the new raster, the same
-    stamp re-uses the cached one, `cache_dem = False` uploads every message.  Results equal the engine's plain path bit for bit."""
+    """PoseNode.estimate stages one message with one host-to-device copy and reads its result with one device-to-host copy.  The DEM raster is
+    uploaded with EVERY message by default (the reference never caches it, and upstream re-stamps dem_msg per message, stereo_node.py:272: a
+    cache keyed on the DEM's stamp would never hit and would serve a stale raster to a caller that reuses a stamp -- ADVICE r3): a new raster
+    under an old DEM stamp is used at once.  `cache_dem = True` keeps the device copy per REFERENCE stamp, the key the reference trusts for
+    the tile's features (pose_node.py:225-241).  Results equal the engine's plain path bit for bit."""
     from gisnav_amd import wire
     from gisnav_amd.engine import PoseEngine
     from gisnav_amd.pose_node import PoseNode
@@ -506,20 +508,25 @@ def test_pose_node_shim_single_transfer_path_and_dem_cache(state_dict_np):
     node = PoseNode(state_dict_np, lambda ref: (p.kp_r, p.desc_r, p.size_r, p.angle_r), max_kpts=512, precision="f16x2_f16_attn")
     cam = wire.CameraInfo(k=K_MATRIX.reshape(-1), height=480, width=640)
     q = wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q)
-    mk = lambda dem, sec: wire.OrthoStereoImage(query_sift=q, reference=wire.ImageMsg(p.ref, wire.Stamp(7, 0)), dem=wire.ImageMsg(dem, wire.Stamp(sec, 0)))  # noqa: E731
+    mk = lambda dem, sec, rsec=7: wire.OrthoStereoImage(query_sift=q, reference=wire.ImageMsg(p.ref, wire.Stamp(rsec, 0)), dem=wire.ImageMsg(dem, wire.Stamp(sec, 0)))  # noqa: E731
+    assert node.cache_dem is False
     r1 = node.estimate(cam, mk(p.dem, 7))
     eng = PoseEngine(0, max_batch=1, max_kpts=512, precision="f16x2_f16_attn", state_dict=state_dict_np)
     plain = eng.estimate(eng.stage_inputs([p]), K_MATRIX)
     assert r1 is not None and np.array_equal(r1[0], plain["R"][0].cpu().numpy()) and np.array_equal(r1[1], plain["t"][0].cpu().numpy())
     assert node.last_num_matches == int(plain["n_match"][0])
     flat = np.zeros_like(p.dem)
-    r_same_stamp = node.estimate(cam, mk(flat, 7))             # same DEM stamp: the cached raster
-    assert np.array_equal(r_same_stamp[0], r1[0]) and np.array_equal(r_same_stamp[1], r1[1])
-    r_new_stamp = node.estimate(cam, mk(flat, 8))              # new stamp: the new raster
-    assert r_new_stamp is not None and not np.array_equal(r_new_stamp[1], r1[1])
+    r_flat = node.estimate(cam, mk(flat, 7))                   # a NEW raster under the SAME DEM stamp: used, not a stale copy
+    assert r_flat is not None and not np.array_equal(r_flat[1], r1[1])
+    r_back = node.estimate(cam, mk(p.dem, 9))                  # and back, whatever the DEM stamp says
+    assert np.array_equal(r_back[0], r1[0]) and np.array_equal(r_back[1], r1[1])
+    node.cache_dem = True                                      # opt-in: device copy per reference stamp
+    r_c1 = node.estimate(cam, mk(p.dem, 10))
+    r_c2 = node.estimate(cam, mk(flat, 11))                    # same reference stamp: the cached raster (documented behaviour of the opt-in)
+    assert np.array_equal(r_c1[1], r1[1]) and np.array_equal(r_c2[1], r1[1])
+    r_c3 = node.estimate(cam, mk(flat, 11, rsec=8))            # new reference stamp: the new raster
+    assert np.array_equal(r_c3[1], r_flat[1])
     node.cache_dem = False
-    r_nocache = node.estimate(cam, mk(p.dem, 8))               # caching off: uploaded again although the stamp did not change
-    assert np.array_equal(r_nocache[0], r1[0]) and np.array_equal(r_nocache[1], r1[1])
     few = wire.pack_keypoints(p.kp_q[:9], p.size_q[:9], p.angle_q[:9], p.desc_q[:9])
     assert node.estimate(cam, wire.OrthoStereoImage(query_sift=few, reference=wire.ImageMsg(p.ref, wire.Stamp(7, 0)), dem=wire.ImageMsg(p.dem, wire.Stamp(8, 0)))) is None
     assert node.last_num_matches < node.MIN_MATCHES

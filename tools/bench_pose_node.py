@@ -16,7 +16,7 @@ msgs = []
 for i in range(8):        # eight different frames over the same tile
     q = make_pair(3, n_q=1024, n_r=1024) if i == 0 else make_pair(3 + 0, n_q=1024 - 8 * i, n_r=1024)
     msgs.append(wire.OrthoStereoImage(query_sift=wire.pack_keypoints(q.kp_q, q.size_q, q.angle_q, q.desc_q), reference=wire.ImageMsg(p.ref, wire.Stamp(1, 0)),
-                                      dem=wire.ImageMsg(p.dem, wire.Stamp(1, 0))))
+                                      dem=wire.ImageMsg(p.dem, wire.Stamp(100 + i, 0))))      # (upstream re-stamps the DEM with every message: stereo_node.py:272)
 for i in range(20):
     r = node.estimate(cam, msgs[i % 8])
 assert r is not None
