@@ -104,6 +104,7 @@ struct gn_ctx {
   // sub-batch streams (gn_set_substreams): the pairs of one call are split into groups that run the whole path on
   // internal streams, out of phase with each other (fork / join events around them on the caller's stream)
   int defer_join = 0, sub_last_B = 0, sub_last_np = 0;   // gn_set_deferred_join; shape of the last unjoined sub-stream call
+  int sub_serial = 0;      // developer knob 26: the sub-batch groups run one after the other on ONE stream (a working set the size of the Infinity Cache) instead of concurrently
   int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
   int overlap = 0; unsigned long long calls = 0;
@@ -1017,18 +1018,19 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   int rc_all = GN_OK, b0 = 0;
   for (int g = 0; g < groups; ++g) {
     const int Bg = B / groups + (g < B % groups ? 1 : 0);
-    GN_HIP(hipStreamWaitEvent(ctx->sub_s[g], ctx->ev_fork, 0));
+    hipStream_t sg = ctx->sub_serial ? ctx->sub_s[0] : ctx->sub_s[g];
+    GN_HIP(hipStreamWaitEvent(sg, ctx->ev_fork, 0));
     shift_workspaces(ctx, b0, +1);
     ctx->in_group = true; ctx->ovf = ctx->ovf_base + g;            // this group's own guard word: cleared, raised and read on this group's stream only
     const int rc = estimate_impl(ctx, Bg, kpt_format,
                                  desc_q ? desc_q + (size_t)b0 * stride_q * in_dim : nullptr, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
                                  desc_r ? desc_r + (size_t)b0 * stride_r * in_dim : nullptr, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
                                  dem ? dem + (size_t)b0 * H * W : nullptr, H, W, K9, min_matches,
-                                 R + (size_t)b0 * 9, t + (size_t)b0 * 3, n_match + b0, n_inliers + b0, ok + b0, ctx->sub_s[g]);
+                                 R + (size_t)b0 * 9, t + (size_t)b0 * 3, n_match + b0, n_inliers + b0, ok + b0, sg);
     shift_workspaces(ctx, b0, -1);
     ctx->ovf = ctx->ovf_base; ctx->in_group = false;
     if (rc != GN_OK && rc_all == GN_OK) rc_all = rc;
-    GN_HIP(hipEventRecord(ctx->ev_join[g], ctx->sub_s[g]));
+    GN_HIP(hipEventRecord(ctx->ev_join[g], sg));
     ctx->sub_pending[g] = true;
     b0 += Bg;
   }
@@ -1645,6 +1647,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 24) gn::g_sp_conv_h = value;
   else if (which == 23) ctx->attn_split = value;
   else if (which == 25) ctx->dbg_trip_group = value;
+  else if (which == 26) ctx->sub_serial = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -390,6 +390,40 @@ class PoseEngine:
         _lib.check(self.ctx, rc, "gn_estimate")
         return out
 
+    def estimate_bucketed(self, inputs: dict, K: np.ndarray, n_q_host, n_r_host, bucket_pairs: int = 8, min_matches: int = MIN_MATCHES,
+                          out: Optional[dict] = None):
+        """Length-bucketing scheduler for ragged batches: `cv2.SIFT_create()` is unbounded (pose_node.py:122), so the keypoint counts of a
+        batch of messages spread widely, and one gn_estimate call pads every pair to the batch maximum (attention cost grows with the
+        SQUARE of the padded length).  The pairs are sorted by max(n_q, n_r) (host-side counts: no device read), run as groups of
+        `bucket_pairs` consecutive pairs each padded to ITS maximum (gn_set_active_kpts), and the results are returned in the caller's
+        order.  Results do not depend on the padding (tests), so they equal the single padded call's.  Returns (out, stats)."""
+        n_q_host = np.asarray(n_q_host).astype(np.int64)
+        n_r_host = np.asarray(n_r_host).astype(np.int64)
+        B = len(n_q_host)
+        if out is None:
+            out = self.alloc_outputs(B)
+        need = np.maximum(np.maximum(n_q_host, n_r_host), 1)
+        order = np.argsort(-need, kind="stable")
+        perm = torch.as_tensor(order, device=self.device)
+        srt = {k: (v.index_select(0, perm) if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
+        tmp = self.alloc_outputs(B)
+        pad_tokens = 0
+        try:
+            for a in range(0, B, bucket_pairs):
+                b = min(B, a + bucket_pairs)
+                pad = self.set_active_kpts(int(need[order[a:b]].max()))
+                pad_tokens += 2 * pad * (b - a)
+                grp = {k: (v[a:b] if isinstance(v, torch.Tensor) else v) for k, v in srt.items()}
+                self.estimate(grp, K, min_matches, out={k: v[a:b] for k, v in tmp.items()})
+        finally:
+            self.set_active_kpts(self.kmax)
+        for k in out:
+            out[k].index_copy_(0, perm, tmp[k])
+        real = int((n_q_host + n_r_host).sum())
+        one_call_pad = 2 * B * (((int(need.max()) + 127) // 128) * 128)
+        return out, {"real_tokens": real, "padded_tokens_bucketed": int(pad_tokens), "padded_tokens_one_call": int(one_call_pad),
+                     "groups": (B + bucket_pairs - 1) // bucket_pairs}
+
     def estimate_images(self, frames, tiles, K: np.ndarray, dem=None, sift=None, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
         """Frames -> pose from pixels for B pairs, everything in HBM: one batched SIFT pass over the B camera frames and the
         B map tiles (`gn_sift_detect_and_compute_batch`), the matcher padded to what the batch needs (`gn_set_active_kpts`),

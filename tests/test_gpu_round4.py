@@ -150,3 +150,55 @@ def test_ffn128_matches_the_64_token_tail_and_is_bitwise_repeatable(state_dict_n
             assert np.array_equal(x2.view(np.uint32), x1.view(np.uint32)) and np.array_equal(i2, i1) and np.array_equal(s2.view(np.uint32), s1.view(np.uint32))
         res[prec] = rel
     _report("ffn128_vs_ffn64_final_feature_rel_diff", res)
+
+
+def test_georeferencing_of_a_gpu_pose_matches_the_oracle(state_dict_np):
+    """Rows a13 / f4 on the GPU box (their only parity test was CPU-marked, so the driver never exercised it): a pose estimated on the
+    device goes through the library's host C code (`gn_pose_to_earth`, `gn_proj_to_affine`, `gn_wgs84_to_ecef`; pose_node.py:333-381) and through
+    the oracle's restatement -- ECEF position within 1e-7 m, lon / lat / alt 1e-12, quaternion 1e-10; plus the CPU test's 200 random poses."""
+    import test_georef as tg
+    from gisnav_amd import georef as gg
+    from gisnav_amd.engine import PoseEngine
+    from oracle import georef as og
+    tg.test_library_georeferencing_matches_oracle()
+    eng = PoseEngine(0, max_batch=4, max_kpts=512, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    pairs = [make_pair(410 + i, n_q=512 - 9 * i, n_r=500) for i in range(4)]
+    out = eng.estimate(eng.stage_inputs(pairs), K_MATRIX)
+    torch.cuda.synchronize()
+    s, _ = tg._crs()
+    done = 0
+    for b in range(4):
+        if not int(out["ok"][b]):
+            continue
+        R, t = out["R"][b].cpu().numpy(), out["t"][b].cpu().numpy()
+        o = og.pose_to_earth(R, t, s, (480, 640))
+        g = gg.pose_to_earth(R, t, s, (480, 640))
+        assert (o is None) == (g is None)
+        if o is None:
+            continue
+        done += 1
+        assert np.allclose(g["position"], o["position"], rtol=0, atol=1e-7) and np.allclose(g["lonlatalt"], o["lonlatalt"], rtol=0, atol=1e-12)
+        assert min(np.abs(g["orientation"] - o["orientation"]).max(), np.abs(g["orientation"] + o["orientation"]).max()) < 1e-10
+    assert done >= 2
+
+
+def test_length_bucketing_scheduler_returns_the_padded_call_s_results(state_dict_np):
+    """PoseEngine.estimate_bucketed (ragged batches: an unbounded cv2.SIFT_create(), pose_node.py:122): 12 pairs with 200..1500 keypoints per side, groups
+    of 4 sorted by length and padded to their own maximum -- same n_match / ok per pair as ONE call padded to the batch maximum, poses within 1e-8,
+    results in the caller's order; fewer padded tokens."""
+    from gisnav_amd.engine import PoseEngine
+    rs = np.random.default_rng(9)
+    nq, nr = rs.integers(200, 1501, 12), rs.integers(200, 1501, 12)
+    eng = PoseEngine(0, max_batch=12, max_kpts=1536, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    pairs = [make_pair(430 + i, n_q=int(nq[i]), n_r=int(nr[i])) for i in range(12)]
+    inp = eng.stage_inputs(pairs)
+    n_q = np.array([len(p.kp_q) for p in pairs]); n_r = np.array([len(p.kp_r) for p in pairs])
+    eng.set_active_kpts(int(max(n_q.max(), n_r.max())))
+    one = {k: v.cpu().numpy().copy() for k, v in eng.estimate(inp, K_MATRIX).items()}
+    eng.set_active_kpts(eng.kmax)
+    got, stats = eng.estimate_bucketed(inp, K_MATRIX, n_q, n_r, bucket_pairs=4)
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    assert np.array_equal(got["ok"], one["ok"]) and np.array_equal(got["n_match"], one["n_match"]) and np.array_equal(got["n_inliers"], one["n_inliers"])
+    assert one["ok"].sum() >= 10
+    assert np.abs(got["R"] - one["R"]).max() < 1e-8 and np.abs(got["t"] - one["t"]).max() < 1e-6
+    assert stats["groups"] == 3 and stats["padded_tokens_bucketed"] < stats["padded_tokens_one_call"] and stats["real_tokens"] == int((n_q + n_r).sum())
