@@ -99,7 +99,8 @@ def kernel_rows(table, steps, precision):
         attn = r["name"].startswith("k_attn")
         f32_pipe = r["name"].startswith("k_gemm_f32_v3") or r["name"].startswith("k_attn_f32")
         peak = PEAK_F32_MFMA_TFLOPS if f32_pipe else PEAK_16BIT_MFMA_TFLOPS
-        mult = 1 if (attn or f32_pipe) else 6 if r["name"].startswith("k_gemm_f32x3") else 3   # matrix-pipe flops issued per algorithmic flop
+        two = r["name"].startswith("k_qkv") and r["name"].rstrip(">").endswith(", 2")         # attention input projections: two partial products (gn_qkv.hip)
+        mult = 1 if (attn or f32_pipe) else 6 if r["name"].startswith("k_gemm_f32x3") else 2 if two else 3   # matrix-pipe flops issued per algorithmic flop
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
         rows.append({"name": r["name"], "launches_per_step": round(n / steps, 2), "avg_launch_us": round(r["ms"] * 1e3 / n, 2),
                      "share_of_timed_kernel_time": round(r["ms"] / total_ms, 4),

@@ -31,7 +31,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "gn_qkv.hip": ["-fno-slp-vectorize"],
                # k_ffn128 places its VALU work instruction by instruction beside the MFMAs: packed f32 arithmetic is an anti-lever there
-               "gn_ffn128.hip": ["-fno-slp-vectorize"],
+               # (and is one straight line of ~17 k instructions: the default size limit of `#pragma unroll` would silently leave a loop rolled, and its
+               # register arrays in scratch memory)
+               "gn_ffn128.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
                # SIFT: no fused multiply-adds -- every float operation rounds separately, as in the oracle (and in OpenCV's scalar code)
                "gn_sift.hip": ["-ffp-contract=off"]}
 

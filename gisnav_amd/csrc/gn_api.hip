@@ -1648,6 +1648,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 23) ctx->attn_split = value;
   else if (which == 25) ctx->dbg_trip_group = value;
   else if (which == 26) ctx->sub_serial = value;
+  else if (which == 27) gn::g_qkv_products = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

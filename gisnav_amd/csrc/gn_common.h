@@ -152,6 +152,7 @@ struct QkvArgs {
   long long* dbg_ts;                  // developer: nullptr, or [blocks][8 waves][8] s_memtime stamps
 };
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
+extern int g_qkv_products;
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {

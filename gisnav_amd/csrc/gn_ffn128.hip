@@ -34,6 +34,10 @@ namespace {
 
 #define GN_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// y - float(fp16 half of h): one v_fma_mix_f32 (the f16 operand is converted inside the instruction) instead of a conversion and a subtraction
+__device__ __forceinline__ float resid_lo(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+__device__ __forceinline__ float resid_hi(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+
 template <int ABL>   // timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
 __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
@@ -139,13 +143,8 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
       for (int e = 0; e < 8; e += 2) { amax = fmaxf(amax, fmaxf(fabsf(gy[e]), fabsf(gy[e + 1]))); gh[e >> 1] = pack16<true>(gy[e], gy[e + 1]); }
     } else if (st == 19) {
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const f16x2v hv = __builtin_bit_cast(f16x2v, gh[e >> 1]);
-        gt[e] = (float)hv[0]; gt[e + 1] = (float)hv[1];
-      }
+      for (int e = 0; e < 8; e += 2) { gt[e] = resid_lo(gh[e >> 1], gy[e]); gt[e + 1] = resid_hi(gh[e >> 1], gy[e + 1]); }
     } else if (st == 20) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gt[e] = gy[e] - gt[e];
     } else if (st == 21) {
 #pragma unroll
       for (int e = 0; e < 8; e += 2) gm[e >> 1] = pack16<true>(gt[e], gt[e + 1]);
@@ -575,6 +574,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
       }
     }
     __syncthreads();     // quarter q + 1 visible, buffer q & 1 free again
+    if (ABL & 128) ts2[q] = (long long)__builtin_amdgcn_s_memtime();      // (overwrites the first GEMM 1 stamps: tools/ffn128_ab.py reads both)
     GN_PIN();
   }
   ovf_commit(a.ovf, amax);

@@ -37,7 +37,8 @@ constexpr int NJ = TM / 32;             // token tiles of 32
 //   v pass:       tokens are the A operand: a lane owns one feature and, per 16 tokens, exactly the 8 keys of one 16-byte group
 //                 of the V^T layout (keys permuted inside 16-groups as k_attn_bf16_v5 reads them) = one 16-byte store.
 // F16: the outputs are fp16 instead of bf16 (GN_PREC_F16X2_F16_ATTN, the reference's CUDA arithmetic); a value outside fp16's range raises a.ovf
-template <bool CROSS, bool F16 = false>
+// NP = 2 (developer knob 27, an accuracy experiment): the x_m . w_h product is dropped -- the outputs are rounded to 16 bits anyway
+template <bool CROSS, bool F16 = false, int NP = 3>
 __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   constexpr int NQK = CROSS ? kDim : 2 * kDim;      // q | k (or qk) features
   constexpr int NPASS = CROSS ? 2 : 3;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+          if (NP == 2 && p == 1) continue;
           const f16x8 w = fa[rs][p == 0 ? 1 : 0], x = fb[cb][j][p == 1 ? 1 : 0];
           acc[j] = vpass ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, acc[j], 0, 0, 0)     // rows = tokens, columns = features
                          : __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc[j], 0, 0, 0);    // rows = features, columns = tokens
@@ -223,14 +225,25 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
 }
 }  // namespace
 
+// Partial products per block of the attention input projections.  q, k and v leave this kernel rounded to 16 bits (fp16: 11 significant bits,
+// bf16: 8), so the x_m . w_h product -- a 2^-12 relative correction of every x -- is below their rounding: with TWO products (x_h w_h + x_h w_m)
+// the low-margin index-mismatch count against the oracle is 2 / 7173 (three products: 5 / 7173), mid-margin 0 / 3954 both ways, the 32 bench
+// pairs are index-identical, and the launches drop from 87 / 62 us to 72 / 53 us (tools/qkv2_study.py, profiles/r04_qkv2_study.json).
+// Developer knob 27 = 3 restores the third product.  (The block tail and the match head keep all three: their outputs are f32-accurate values.)
+int g_qkv_products = 2;
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s) {
-  if (a.half_fmt) {
-    if (cross) { hipLaunchKernelGGL((k_qkv<true, true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<true, true>"; }
-    else { hipLaunchKernelGGL((k_qkv<false, true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<false, true>"; }
-    return;
+  const dim3 grid(a.T / TM), block(512);
+  const int sel = (a.half_fmt ? 4 : 0) | (cross ? 2 : 0) | (g_qkv_products == 2 ? 1 : 0);
+  switch (sel) {
+    case 7: hipLaunchKernelGGL((k_qkv<true, true, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, true, 2>"; break;
+    case 6: hipLaunchKernelGGL((k_qkv<true, true, 3>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, true, 3>"; break;
+    case 5: hipLaunchKernelGGL((k_qkv<false, true, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<false, true, 2>"; break;
+    case 4: hipLaunchKernelGGL((k_qkv<false, true, 3>), grid, block, 0, s, a); g_last_kernel = "k_qkv<false, true, 3>"; break;
+    case 3: hipLaunchKernelGGL((k_qkv<true, false, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, false, 2>"; break;
+    case 2: hipLaunchKernelGGL((k_qkv<true, false, 3>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, false, 3>"; break;
+    case 1: hipLaunchKernelGGL((k_qkv<false, false, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<false, false, 2>"; break;
+    default: hipLaunchKernelGGL((k_qkv<false, false, 3>), grid, block, 0, s, a); g_last_kernel = "k_qkv<false, false, 3>"; break;
   }
-  if (cross) { hipLaunchKernelGGL((k_qkv<true>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<true, false>"; }
-  else { hipLaunchKernelGGL((k_qkv<false>), dim3(a.T / TM), dim3(512), 0, s, a); g_last_kernel = "k_qkv<false, false>"; }
 }
 
 }  // namespace gn

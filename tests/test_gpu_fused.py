@@ -58,6 +58,7 @@ def test_qkv_kernel_equals_projection_gemm():
     inp = eng.stage_inputs(pairs)
     T = 4 * 2 * 256
     out, panels = {}, {}
+    eng.lib.gn_debug_set_variant(eng.ctx, 27, 3)       # all three partial products, like the GEMM (the default drops x_m . w_h: checked below)
     for knob in (0, 2):                                # 0: k_gemm_p2 with the bf16 epilogues, 2: k_qkv forced at this (small) batch size
         eng.lib.gn_debug_set_variant(eng.ctx, 19, knob)
         for stop in (3 + knob // 2, 6 + knob // 2):    # after the first self projection / the first cross projection (k_qkv adds k_rot_table to the launch count)
@@ -79,3 +80,19 @@ def test_qkv_kernel_equals_projection_gemm():
             assert same > 0.999, (stop, same)          # bf16 outputs of the same f32 arithmetic: identical up to the rounding of sums taken in another order
             fa = (a16.astype(np.uint32) << 16).view(np.float32); fc = (c16.astype(np.uint32) << 16).view(np.float32)
             assert np.abs(fa - fc).max() <= 2.0 ** -7 * max(1.0, float(np.abs(fa).max()))
+    # the shipped default: TWO partial products (x_h w_h + x_h w_m).  The dropped term is 2^-12 of every x, below the 16-bit rounding of q / k / v: most
+    # outputs keep their bits, the rest move by one unit in the last place, and the correspondences do not change
+    eng.lib.gn_debug_set_variant(eng.ctx, 27, 2)
+    eng.lib.gn_debug_set_variant(eng.ctx, 19, 2)
+    for stop in (4, 7):
+        eng.lib.gn_debug_set_variant(eng.ctx, 4, stop)
+        _match(eng, inp)
+        for a, c in zip(panels[(2, stop - 1)], (eng.debug_read("qkb", T * 256), eng.debug_read("vtb", T * 128))):
+            a16, c16 = a.view(np.uint16), c.view(np.uint16)
+            assert np.mean(a16 == c16) > 0.8, (stop, np.mean(a16 == c16))
+            fa = (a16.astype(np.uint32) << 16).view(np.float32); fc = (c16.astype(np.uint32) << 16).view(np.float32)
+            assert np.abs(fa - fc).max() <= 2.0 ** -7 * max(1.0, float(np.abs(fa).max()))
+    eng.lib.gn_debug_set_variant(eng.ctx, 4, 0)
+    two = _match(eng, inp)
+    eng.lib.gn_debug_set_variant(eng.ctx, 19, 1)
+    assert torch.equal(two[2], out[2][2]) and all(torch.equal(two[0][b, : int(two[2][b])], out[2][0][b, : int(two[2][b])]) for b in range(4))

@@ -58,5 +58,7 @@ for abl in ([int(v) for v in sys.argv[2:]] if len(sys.argv) > 2 else []):
     if abl & 128:
         t2 = eng.debug_read("sim", (nb * 4 * 12 + nb * 4 * 16) * 2, np.uint32).view(np.int64)[nb * 4 * 12:].reshape(nb, 4, 16)
         full = np.concatenate([raw[:, :, 3:4], t2], axis=2)
-        print("  GEMM 1 per k-tile (wave 0, median):", " ".join(f"{v:.0f}" for v in np.median(np.diff(full[:, 0, :], axis=1), axis=0)))
+        print("  GEMM 1 per k-tile 4.. (wave 0, median):", " ".join(f"{v:.0f}" for v in np.median(np.diff(t2[:, 0, 4:], axis=1), axis=0)))
+        q4 = np.concatenate([raw[:, :, 6:7], t2[:, :, :4]], axis=2)
+        print("  GEMM 2 per quarter (wave 0, median):", " ".join(f"{v:.0f}" for v in np.median(np.diff(q4[:, 0, :], axis=1), axis=0)))
     print("  block total median", np.median(tot), " kernel span (max end - min start)", ts[:, :, -1].max() - ts[:, :, 0].min(), flush=True)
