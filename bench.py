@@ -610,7 +610,7 @@ def main() -> None:
         extras.append(run_extra(local_rank, sd, "BASELINE configs[2] with exact-f32 MFMA projections/FFN (no fp16 split) + bf16 MFMA attention",
                                 args.batch, args.kpts, "bf16_attn", 6, 2, dev))
         extras.append(run_extra(local_rank, sd, f"BASELINE configs[2] in the GUARANTEED mode: batch-{args.batch}, f32 everywhere (exact-f32 MFMA GEMMs and attention) -- "
-                                                "correspondence indices bit-exact against the oracle on every weight set tested, low-margin ones included",
+                                                "correspondence indices bit-exact against the CPU restatement of the reference on every weight set tested, low-margin ones included",
                                 args.batch, args.kpts, "f32", 3, 1, dev))
         extras.append(run_extra_ragged(local_rank, sd, args.batch, args.precision, 5, 2, dev))
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
@@ -659,7 +659,7 @@ def main() -> None:
                 "index_exact": "guaranteed" if args.precision == "f32" else "tolerance mode",
                 "note": "north_star asks for bit-exact correspondence indices: GN_PREC_F32 guarantees them (f32 MFMA everywhere; extra_configs carries its batch-32 "
                         "throughput).  The headline mode computes what the reference's own CUDA path computes (fp32-accurate linear layers, half-precision SDPA) and "
-                        "is index-identical to the f32 oracle on all 32 bench pairs and on mid-margin weights; on LOW-margin synthetic weights it differs in a few "
+                        "is index-identical to the f32 CPU restatement of the reference on all 32 bench pairs and on mid-margin weights; on LOW-margin synthetic weights it differs in a few "
                         "decisions per thousand, like the reference's CUDA path differs from its CPU path",
                 "low_margin_index_mismatches": {"f32": "0 / 1220", "f16x2_f16_attn": "1 / 1220", "f16x2_bf16_attn": "4 / 1220",
                                                 "mid_margin_all_modes": "0 / 687",

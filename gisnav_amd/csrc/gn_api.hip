@@ -24,6 +24,9 @@ struct Block {       // one SelfBlock or CrossBlock
   Linear ffn0;       // 512x512
   float* ln_g = nullptr; float* ln_b = nullptr;
   Linear ffn3;       // 256x512
+  // out_proj / to_out COMPOSED into ffn.0 (round 4): ffn.0([x | out_proj(ctx)]) = [W1_x | W1_m Wo] [x | ctx] + (b1 + W1_m bo) -- the message tile and
+  // its GEMM (14 % of the block tail's matrix work) disappear; built at the first forward call after the tensors were (re)loaded
+  uint16_t* wfc = nullptr; float* b1c = nullptr; float wfc_scale = 1.f; bool comp_dirty = true;
 };
 
 enum Stage { ST_PREP = 0, ST_PROJ, ST_ATTN, ST_FFN, ST_HEAD, ST_GATHER, ST_PNP, ST_COUNT };
@@ -40,6 +43,7 @@ struct gn_ctx {
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
+  int ffn_compose = 1;     // with ffn_fused == 3 and ffn_fold: out_proj / to_out composed into ffn.0's weights (developer knob 28; 0 = the kernel computes the message)
   int ffn_fold = 1;        // with ffn_fused == 3: out_proj / to_out folded into the block-tail kernel (developer knob 13; 0 = separate GEMM launch)
   int ffn_fused = 3;       // f16x2 mode: 3 = the whole block tail in one launch (k_ffn_fused, gn_ffn.hip); 1 = ffn.0 + LayerNorm + GELU in one launch
                            // (k_gemm_p2ln) when the grid fills the chip, 2 = always; 0 = separate k_ln_gelu (developer knob 10)
@@ -393,6 +397,58 @@ bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int 
   return true;
 }
 
+// [W1_x | W1_m Wo] and b1 + W1_m bo in double on the host, then the power-of-two scale and the fragment order of the other weights (natural k)
+int build_composed(gn_ctx* ctx, Block& blk) {
+  if (!blk.comp_dirty) return GN_OK;
+  const Linear &F = blk.ffn0, &P = blk.proj_out;
+  if (!ctx->planes_mode || !F.w || !F.b || !P.w || !P.b || F.out != 2 * kDim || F.in != 2 * kDim || P.out != kDim || P.in != kDim) return GN_OK;
+  const int H = 2 * kDim, D = kDim;
+  std::vector<float> w1((size_t)H * H), b1(H), wo((size_t)D * D), bo(D);
+  GN_HIP(hipMemcpy(w1.data(), F.w, w1.size() * 4, hipMemcpyDeviceToHost));
+  GN_HIP(hipMemcpy(b1.data(), F.b, b1.size() * 4, hipMemcpyDeviceToHost));
+  GN_HIP(hipMemcpy(wo.data(), P.w, wo.size() * 4, hipMemcpyDeviceToHost));
+  GN_HIP(hipMemcpy(bo.data(), P.b, bo.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<float> wc((size_t)H * H), bc(H);
+  std::vector<double> row(D);
+  float mx = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const float* w1h = &w1[(size_t)h * H];
+    for (int k = 0; k < D; ++k) { row[k] = 0.0; wc[(size_t)h * H + k] = w1h[k]; }
+    double bb = b1[h];
+    for (int f = 0; f < D; ++f) {
+      const double wm = w1h[D + f];
+      const float* wof = &wo[(size_t)f * D];
+      for (int k = 0; k < D; ++k) row[k] += wm * wof[k];
+      bb += wm * bo[f];
+    }
+    for (int k = 0; k < D; ++k) wc[(size_t)h * H + D + k] = (float)row[k];
+    bc[h] = (float)bb;
+    for (int k = 0; k < H; ++k) { const float av = fabsf(wc[(size_t)h * H + k]); if (av > mx) mx = av; }
+  }
+  int e = 0;
+  if (mx > 0.f && std::isfinite(mx)) { frexpf(mx, &e); e = 13 - e; }
+  if (e > 60) e = 60;
+  if (e < -60) e = -60;
+  std::vector<uint16_t> frag((size_t)2 * H * H);
+  build_weight_fragments(wc.data(), H, H, ldexpf(1.0f, e), 0, frag.data());
+  if (!blk.wfc) { int rc = dalloc(ctx, &blk.wfc, frag.size()); if (rc != GN_OK) return rc; }
+  if (!blk.b1c) { int rc = dalloc(ctx, &blk.b1c, (size_t)H); if (rc != GN_OK) return rc; }
+  GN_HIP(hipMemcpy(blk.wfc, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  GN_HIP(hipMemcpy(blk.b1c, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
+  blk.wfc_scale = ldexpf(1.0f, -e);
+  blk.comp_dirty = false;
+  return GN_OK;
+}
+
+int ensure_composed(gn_ctx* ctx) {
+  if (!ctx->planes_mode || !ctx->ffn_compose) return GN_OK;
+  for (int i = 0; i < ctx->n_layers; ++i) {
+    int rc = build_composed(ctx, ctx->self_blk[i]); if (rc != GN_OK) return rc;
+    rc = build_composed(ctx, ctx->cross_blk[i]); if (rc != GN_OK) return rc;
+  }
+  return GN_OK;
+}
+
 // true when the block-tail kernel also computes msg = out_proj(ctx): the schedule then skips the out_proj GEMM launch
 bool tail_folds_out_proj(const gn_ctx* c, const Block& blk, int T) {
   return c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && c->ffn_fold && blk.ffn0.wf && blk.ffn0.wf2 && blk.ffn3.wf && blk.proj_out.wf &&
@@ -407,6 +463,8 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     f.cp = fold ? c->ctx_p : nullptr; f.wos = blk.proj_out.wf; f.wo_scale = blk.proj_out.acc_scale; f.bo = blk.proj_out.b;
     f.xp = c->x_p; f.mp = c->msg_p; f.w1s = fold ? blk.ffn0.wf2 : blk.ffn0.wf; f.w1_scale = blk.ffn0.acc_scale; f.b1 = blk.ffn0.b; f.ln_g = blk.ln_g; f.ln_b = blk.ln_b;
     f.w2s = blk.ffn3.wf; f.w2_scale = blk.ffn3.acc_scale; f.b2 = blk.ffn3.b; f.yp = c->x_p; f.y = keep_f32 ? c->x : nullptr; f.T = T;
+    const bool comp = fold && c->ffn_compose && blk.wfc && blk.b1c && !blk.comp_dirty;
+    if (comp) { f.composed = 1; f.w1s = blk.wfc; f.w1_scale = blk.wfc_scale; f.b1 = blk.b1c; }
     f.ovf = c->guard ? c->ovf : nullptr;
     f.dbg_ts = (gn::g_ffn_ablate & 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
@@ -416,7 +474,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     launch_ffn_fused(f, s);
     if (rec) {
       hipEventRecord(c->kev[2 * c->kused + 1], s);
-      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + (fold ? 256.0 * 256.0 : 0.0));
+      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + ((fold && !comp) ? 256.0 * 256.0 : 0.0));   // composed: the flops the kernel's own formulation needs
       c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
       c->kclass[c->kused] = 0;
       c->kname[c->kused] = gn::g_last_kernel;
@@ -627,7 +685,7 @@ int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
   if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
     return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
   if (gn_missing_tensors(ctx) != 0) return fail(ctx, GN_ERR_WEIGHTS, "weights not fully loaded");
-  return GN_OK;
+  return ensure_composed(ctx);      // (host work on the first call after a (re)load only)
 }
 
 }  // namespace
@@ -837,11 +895,11 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
       if (is_w) { rc = upload(&L.w, tmp.data(), tmp.size()); } else { rc = upload(&L.b, tmp.data(), tmp.size()); }
       L.out = 3 * kDim; L.in = kDim;
       if (is_w && rc == GN_OK) rc = build_planes(ctx, L);
-    } else if (self && leaf == "out_proj") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
+    } else if (self && leaf == "out_proj") { blk.comp_dirty = true; blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
     else if (cross && leaf == "to_qk") { blk.proj_in.frag_order = 0; rc = load_linear(blk.proj_in, kDim, kDim, 0, 2 * kDim); }
     else if (cross && leaf == "to_v") { blk.proj_in.frag_order = 0; rc = load_linear(blk.proj_in, kDim, kDim, kDim, 2 * kDim); }
-    else if (cross && leaf == "to_out") { blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
-    else if (leaf == "ffn.0") { blk.ffn0.frag_order = 0; rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim); }
+    else if (cross && leaf == "to_out") { blk.comp_dirty = true; blk.proj_out.frag_order = 0; rc = load_linear(blk.proj_out, kDim, kDim, 0, kDim); }
+    else if (leaf == "ffn.0") { blk.comp_dirty = true; blk.ffn0.frag_order = 0; rc = load_linear(blk.ffn0, 2 * kDim, 2 * kDim, 0, 2 * kDim); }
     else if (leaf == "ffn.3") { blk.ffn3.frag_order = 1; rc = load_linear(blk.ffn3, kDim, 2 * kDim, 0, kDim); }
     else if (leaf == "ffn.1") {
       if (d0 != 2 * kDim || d1 != 1) return shape_err();
@@ -1649,6 +1707,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 25) ctx->dbg_trip_group = value;
   else if (which == 26) ctx->sub_serial = value;
   else if (which == 27) gn::g_qkv_products = value;
+  else if (which == 28) ctx->ffn_compose = value;
   else return GN_ERR_ARG;
   return GN_OK;
 }

@@ -116,6 +116,8 @@ extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 ke
 struct FfnArgs {
   const uint16_t* xp;                      // [T][256] hm16 residual stream: k < 256 of ffn.0's input and the residual rows
   const uint16_t* mp;                      // [T][256] hm16 message: k >= 256 of ffn.0's input (used when cp == nullptr)
+  int composed = 0;                        // 1: out_proj is composed into ffn.0 at load time (w1s = [W1_x | W1_m Wo] in natural k order, b1 = b1 + W1_m bo): cp holds the attention
+                                           // output rows and is the k >= 256 half of ffn.0's input; wos / bo unused
   const uint16_t* cp;                      // [T][256] hm16 attention output: when set, message = out_proj(cp) is computed in the kernel ...
   const uint16_t* wos; float wo_scale; const float* bo;   // ... with the out_proj / to_out weight [256][256] in fragment order (natural k) and its bias
   const uint16_t* w1s; float w1_scale;     // ffn.0 weight [512][512] in MFMA fragment order (build_weight_fragments: natural k, or order 2 when cp is set), accumulator scale

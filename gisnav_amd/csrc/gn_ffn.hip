@@ -396,7 +396,12 @@ __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
 
 int g_ffn_ablate = 0;   // developer knob 12: timing-only ablations of k_ffn_fused (wrong results)
 int g_ffn_shape = 0;    // developer knob 14: 0 = automatic, 64 / 32 = force the 64-token / 32-token workgroup shape
-void launch_ffn_fused(const FfnArgs& a, hipStream_t s) {
+void launch_ffn_fused(const FfnArgs& a_in, hipStream_t s) {
+  FfnArgs a = a_in;
+  if (a.composed && !(a.T % 128 == 0 && (g_ffn_shape == 128 || (g_ffn_shape == 0 && a.T / 128 >= 256)))) {
+    // composed weights on a small grid: k_ffn_fused's "message rows from memory" form IS ffn.0 over [x | rows] -- the rows are the attention output
+    a.mp = a.cp; a.cp = nullptr; a.composed = 0;
+  }
   // small grids: 32-token workgroups give twice the workgroups (fewer than one 64-token workgroup per CU leaves CUs idle)
   const bool small = g_ffn_shape == 32 || (g_ffn_shape == 0 && a.T / 64 < 256);
   if (a.cp == nullptr) {   // message rows from memory (separate out_proj launch)

@@ -36,9 +36,14 @@ namespace {
 
 // y - float(fp16 half of h): one v_fma_mix_f32 (the f16 operand is converted inside the instruction) instead of a conversion and a subtraction
 __device__ __forceinline__ float resid_lo(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+// float(fp16 half of h) + y (the residual rows: x = x_h + x_m + v in two instructions)
+__device__ __forceinline__ float addh_lo(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+__device__ __forceinline__ float addh_hi(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
 __device__ __forceinline__ float resid_hi(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
 
-template <int ABL>   // timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
+// COMP: out_proj is composed into ffn.0 at load time (W1' = [W1_x | W1_m Wo], b1' = b1 + W1_m bo: gn_api.hip build_composed) -- no GEMM 0, no message
+// tile: GEMM 1 runs over [x | ctx], all sixteen k-tiles through the ring
+template <int ABL, bool COMP>   // timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
 __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
   constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 128 token rows (hm16: 128 B per row)
@@ -83,9 +88,9 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   auto stv = [&](int set, int q) __attribute__((always_inline)) -> uint4& {
     return set == 0 ? (q == 0 ? sa0 : (q == 1 ? sa1 : (q == 2 ? sa2 : sa3))) : (q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3)));
   };
-  // staged tiles 0..7 = k-tiles of the attention output (GEMM 0), 8..15 = k-tiles of x (second half of GEMM 1); one piece = 32 rows
+  // staged tiles 0..7 = k-tiles of the attention output (GEMM 0), 8..15 = k-tiles of x (second half of GEMM 1); COMP: 0..7 = x, 8..15 = attention output; one piece = 32 rows
   auto stage_load = [&](int t, int q) __attribute__((always_inline)) {
-    stv(t & 1, q) = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(t < 8 ? crs : xrs, soff[q], (t & 7) * 128, 0));
+    stv(t & 1, q) = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128((COMP ? t >= 8 : t < 8) ? crs : xrs, soff[q], (t & 7) * 128, 0));
   };
   auto stage_write = [&](int t, int q) __attribute__((always_inline)) {
     *reinterpret_cast<uint4*>(smem + sdst[q] + (t & 1) * KT) = stv(t & 1, q);
@@ -153,6 +158,35 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
     }
   };
 
+  // GEMM 1's weight ring is requested now: its latency hides behind the message publish
+  const __amdgpu_buffer_rsrc_t w1b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w1s) + (size_t)(NI * wave) * 32 * 2 * 512, 0, NI * 32 * 2 * 1024, 0x00020000);
+  constexpr int RA = 4;     // ring slots (8 KB per wave each); k-step n2 uses slot n2 % RA and refills slot (n2 - 1) % RA
+  f16x8 fa[RA][NI][2];
+  // GEMM 1 visits the k-tiles in the order 8..15 (message), 0..7 (x): sequence number n2 (k-steps) -> weight k-step (n2 + 16) & 31
+  auto load_a = [&](int slot, int n2, int i, int pl) __attribute__((always_inline)) {
+    fa[slot][i][pl] = ldw(w1b, ((i * 32 + (COMP ? n2 : ((n2 + 16) & 31))) * 2 + pl) * 1024);
+  };
+  constexpr int B1OFF = COMP ? 0 : RING + KT;      // where b1 / s1 waits for GEMM 1 (COMP: the message region is free; else ring slot 1, free until x tile 9 is staged)
+  if constexpr (COMP) {
+    // ---------------------------------------------------------------- prologue of the composed form: tiles 0, 1 (, 2), the whole weight ring, b1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_load(0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_load(1, q);
+#pragma unroll
+    for (int q = 0; q < RA; ++q)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
+    if (tid < 128) *reinterpret_cast<f32x4*>(smem + B1OFF + 16 * tid) = b1q * (1.0f / s1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_write(0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_load(2, q);
+    __syncthreads();
+    stamp(1); stamp(2); stamp(3);
+  } else {
   // ================================================================ GEMM 0 (transposed): Msg^T[256][128] = Wo[256][256] . Ctx^T; wave w: features 64 w ..
   const __amdgpu_buffer_rsrc_t wob = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.wos) + (size_t)(NO * wave) * 16 * 2 * 512, 0, NO * 16 * 2 * 1024, 0x00020000);      // output tile NO w + o: 1 KB block ((tile * 16 + kstep) * 2 + term)
   constexpr int RO = 6;      // ring slots: k-step kk uses slot kk % RO and refills the slot k-step kk - 1 has freed (loads may then sit anywhere in the k-step)
@@ -217,14 +251,6 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   }
   stamp(2);
 
-  // GEMM 1's weight ring is requested now: its latency hides behind the message publish
-  const __amdgpu_buffer_rsrc_t w1b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w1s) + (size_t)(NI * wave) * 32 * 2 * 512, 0, NI * 32 * 2 * 1024, 0x00020000);
-  constexpr int RA = 4;     // ring slots (8 KB per wave each); k-step n2 uses slot n2 % RA and refills slot (n2 - 1) % RA
-  f16x8 fa[RA][NI][2];
-  // GEMM 1 visits the k-tiles in the order 8..15 (message), 0..7 (x): sequence number n2 (k-steps) -> weight k-step (n2 + 16) & 31
-  auto load_a = [&](int slot, int n2, int i, int pl) __attribute__((always_inline)) {
-    fa[slot][i][pl] = ldw(w1b, ((i * 32 + ((n2 + 16) & 31)) * 2 + pl) * 1024);
-  };
 #pragma unroll
   for (int q = 0; q < RA - 2; ++q)      // (the other two slots are requested after the publish: registers)
 #pragma unroll
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
       for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
   // ffn.0's bias, as b1 / s1, travels through ring slot 1 (free from here until x tile 9 is staged): requested in the prologue, readable after the
   // message barrier -- GEMM 1's accumulators start from it
-  if (tid < 128) *reinterpret_cast<f32x4*>(smem + RING + KT + 16 * tid) = b1q * (1.0f / s1);
+  if (tid < 128) *reinterpret_cast<f32x4*>(smem + B1OFF + 16 * tid) = b1q * (1.0f / s1);
   // message = acc0 * scale + bias: feature 32 (NO w + o) + 8 g + 4 hh + c in register 4 g + c -> k-tile NO w + o of the message tile
   window(0);
 #pragma unroll
@@ -251,9 +277,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { amax = fmaxf(amax, fmaxf(fabsf(y[k][0]), fabsf(y[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y[k], f16x2v)); }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = y[k] - t[k];
+      for (int k = 0; k < 8; ++k) t[k] = (f32x2v){resid_lo(hw[k], y[k][0]), resid_hi(hw[k], y[k][1])};
 #pragma unroll
       for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
 #pragma unroll
@@ -266,13 +290,15 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   __syncthreads();     // message tile complete
   stamp(3);
 
+  }
+
   // ================================================================ GEMM 1 (transposed): H^T[512][128] = W1[512][512] . [x | msg]^T; wave w: hidden units 128 w ..
   f32x16 acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     f32x4 bi[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bi[g] = *reinterpret_cast<const f32x4*>(smem + RING + KT + (32 * (NI * wave + i) + 8 * g + 4 * hh) * 4);
+    for (int g = 0; g < 4; ++g) bi[g] = *reinterpret_cast<const f32x4*>(smem + B1OFF + (32 * (NI * wave + i) + 8 * g + 4 * hh) * 4);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -281,21 +307,23 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
         for (int j = 0; j < NJ; ++j) acc[i][j][4 * g + c] = bi[g][c];
     GN_PIN();
   }
+  if constexpr (!COMP) {
 #pragma unroll
-  for (int q = RA - 2; q < RA; ++q)
+    for (int q = RA - 2; q < RA; ++q)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
+        for (int pl = 0; pl < 2; ++pl) load_a(q, q, i, pl);
+  }
   uint4 cst_a;      // the thread's share of the LayerNorm weight / bias arrays on their way to LDS
-  read_b(0, 0, 0, 0);
+  read_b(0, COMP ? RING : 0, 0, 0);
   GN_PIN();
   auto gemm1_kstep = [&](int n2) __attribute__((always_inline)) {       // k-tile n = n2 >> 1: n < 8: message k-tile n; n >= 8: staged tile n (x k-tile n - 8) in ring slot n & 1
     const int n = n2 >> 1, ks = n2 & 1;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int g = 4 * n2 + j, g1 = g + 1, m2 = g1 >> 2, nn = m2 >> 1;
-      if (m2 < 32 && !((ABL & 64) && n2 > 0)) read_b(g1, nn < 8 ? nn * KT : RING + (nn & 1) * KT, m2 & 1, g1 & 3);
+      if (m2 < 32 && !((ABL & 64) && n2 > 0)) read_b(g1, (!COMP && nn < 8) ? nn * KT : RING + (nn & 1) * KT, m2 & 1, g1 & 3);
       // products: W_m X_h, W_h X_m, W_h X_h (small terms first), the four hidden tiles round-robin
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -303,32 +331,37 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
         for (int i = 0; i < NI; ++i) {
           const int mj = 4 * p + i;       // MFMA number inside the j-step
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[n2 % RA][i][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
-          if (n >= 8 && ks == 0 && n + 1 < 16 && mj == 2) stage_write(n + 1, j);
+          if ((COMP || n >= 8) && ks == 0 && n + 1 < 16 && mj == 2) stage_write(n + 1, j);
           if (!(ABL & 1) && (mj == 5 || mj == 10) && n2 >= 1 && n2 + RA - 1 < 32) {
             const int u = 2 * j + (mj == 10 ? 1 : 0);   // 0..7 -> (i, term)
             load_a((n2 - 1) % RA, n2 + RA - 1, u >> 1, u & 1);
           }
-          if (!(ABL & 2) && ks == 0 && n + 3 >= 9 && n + 3 < 16 && mj == 7) stage_load(n + 3, j);     // (x tiles 9, 10 are requested during the last message k-tiles)
+          if (!(ABL & 2) && ks == 0 && (COMP || n + 3 >= 9) && n + 3 < 16 && mj == 7) stage_load(n + 3, j);     // (x tiles 9, 10 are requested during the last message k-tiles)
           if (n2 == 29 && mj == 7 && j == 0) cst_a = *reinterpret_cast<const uint4*>((tid < 128 ? a.ln_g : a.ln_b - 512) + 4 * tid);
           GN_PIN();
         }
     }
-    if (n >= 8 && !(ABL & 16)) __syncthreads();
+    if ((COMP || n >= 8) && !(ABL & 16)) __syncthreads();
     if (n2 == 15) stamp(10);
     if ((ABL & 128) && ks == 1) ts2[n] = (long long)__builtin_amdgcn_s_memtime();
     GN_PIN();
   };
+  if constexpr (COMP) {
 #pragma unroll
-  for (int n2 = 0; n2 < 7; ++n2) gemm1_kstep(n2);
-  window(1);        // message k-tiles 4..7 (first use: the prefetch out of k-step 7)
+    for (int n2 = 0; n2 < 32; ++n2) gemm1_kstep(n2);
+  } else {
 #pragma unroll
-  for (int n2 = 7; n2 < 11; ++n2) gemm1_kstep(n2);
-  stage_addr();     // (first use: the loads of x tile 9 at k-tile 6)
+    for (int n2 = 0; n2 < 7; ++n2) gemm1_kstep(n2);
+    window(1);        // message k-tiles 4..7 (first use: the prefetch out of k-step 7)
 #pragma unroll
-  for (int n2 = 11; n2 < 15; ++n2) gemm1_kstep(n2);
-  window(2);        // the x half reads the ring (first use: the prefetch out of k-step 15)
+    for (int n2 = 7; n2 < 11; ++n2) gemm1_kstep(n2);
+    stage_addr();     // (first use: the loads of x tile 9 at k-tile 6)
 #pragma unroll
-  for (int n2 = 15; n2 < 32; ++n2) gemm1_kstep(n2);
+    for (int n2 = 11; n2 < 15; ++n2) gemm1_kstep(n2);
+    window(2);        // the x half reads the ring (first use: the prefetch out of k-step 15)
+#pragma unroll
+    for (int n2 = 15; n2 < 32; ++n2) gemm1_kstep(n2);
+  }
   stamp(4);
 
   // wave w: output features 64 w ..; k-steps are visited quarter by quarter: sequence number c = 8 q + 2 w' + ks -> weight k-step 8 w' + 2 q + ks
@@ -505,9 +538,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { amax = fmaxf(amax, fmaxf(fabsf(y[k][0]), fabsf(y[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y[k], f16x2v)); }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = y[k] - t[k];
+    for (int k = 0; k < 8; ++k) t[k] = (f32x2v){resid_lo(hw[k], y[k][0]), resid_hi(hw[k], y[k][1])};
 #pragma unroll
     for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
 #pragma unroll
@@ -608,20 +639,21 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   for (int it = 0; it < RW / 2; ++it) {
     const int rowl = RW * wave + 2 * it;      // (+ hh: in the lane offsets)
     const f32x4 ya = *reinterpret_cast<const f32x4*>(yt + (rowl + hh) * YP + f0), yb = *reinterpret_cast<const f32x4*>(yt + (rowl + hh) * YP + f0 + 4);
-    const f16x8 xh = __builtin_bit_cast(f16x8, rh[it]), xm = __builtin_bit_cast(f16x8, rm[it]);
+    const unsigned int xhw[4] = {rh[it].x, rh[it].y, rh[it].z, rh[it].w}, xmw[4] = {rm[it].x, rm[it].y, rm[it].z, rm[it].w};
     f32x2v v[4], t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const f32x2v yk = k < 2 ? (f32x2v){ya[2 * k], ya[2 * k + 1]} : (f32x2v){yb[2 * k - 4], yb[2 * k - 3]};
       const f32x2v bk = k < 2 ? (f32x2v){bias_a[2 * k], bias_a[2 * k + 1]} : (f32x2v){bias_b[2 * k - 4], bias_b[2 * k - 3]};
-      const f32x2v xk = (f32x2v){(float)xh[2 * k], (float)xh[2 * k + 1]} + (f32x2v){(float)xm[2 * k], (float)xm[2 * k + 1]};
-      v[k] = (yk * splat2(s2) + bk) + xk;
+      const f32x2v f = yk * splat2(s2) + bk;
+      // + x = + x_m + x_h, the small term first (v_fma_mix_f32 converts the fp16 operand inside the instruction)
+      v[k] = (f32x2v){addh_lo(xhw[k], addh_lo(xmw[k], f[0])), addh_hi(xhw[k], addh_hi(xmw[k], f[1]))};
     }
     unsigned int hw[4], mw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { amax2 = fmaxf(amax2, fmaxf(fabsf(v[k][0]), fabsf(v[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v[k], f16x2v)); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = v[k] - __builtin_convertvector(__builtin_bit_cast(f16x2v, hw[k]), f32x2v);
+    for (int k = 0; k < 4; ++k) t[k] = (f32x2v){resid_lo(hw[k], v[k][0]), resid_hi(hw[k], v[k][1])};
 #pragma unroll
     for (int k = 0; k < 4; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
     __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){hw[0], hw[1], hw[2], hw[3]}, yrs, roff, rowl * 1024, 0);
@@ -646,14 +678,21 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
 
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
   const dim3 grid(a.T / 128), block(256);
-  switch (ablate) {
-    case 8: hipLaunchKernelGGL((k_ffn128<8>), grid, block, 0, s, a); break;
-    case 9: hipLaunchKernelGGL((k_ffn128<9>), grid, block, 0, s, a); break;
-    case 12: hipLaunchKernelGGL((k_ffn128<12>), grid, block, 0, s, a); break;
-    case 136: hipLaunchKernelGGL((k_ffn128<136>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_ffn128<0>), grid, block, 0, s, a); break;
+  if (a.composed) {
+    switch (ablate) {
+      case 8: hipLaunchKernelGGL((k_ffn128<8, true>), grid, block, 0, s, a); break;
+      case 136: hipLaunchKernelGGL((k_ffn128<136, true>), grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_ffn128<0, true>), grid, block, 0, s, a); break;
+    }
+    g_last_kernel = "k_ffn128<0, true>";
+    return;
   }
-  g_last_kernel = "k_ffn128<0>";
+  switch (ablate) {
+    case 8: hipLaunchKernelGGL((k_ffn128<8, false>), grid, block, 0, s, a); break;
+    case 136: hipLaunchKernelGGL((k_ffn128<136, false>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_ffn128<0, false>), grid, block, 0, s, a); break;
+  }
+  g_last_kernel = "k_ffn128<0, false>";
 }
 
 }  // namespace gn
