@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgisnav_amd.so")
-SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_ffn128.hip", "gn_qkv.hip", "gn_attention.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
+SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_ffn128.hip", "gn_qkv.hip", "gn_attention.hip", "gn_attention_pw.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
 # SLP vectoriser: ON for every file except gn_qkv.hip.  With it, hipcc (ROCm 7.2) packs the second rotary pair of k_qkv's epilogue
 # (o.z = v.z cos' - v.w sin', o.w = v.w cos' + v.z sin') into `v_pk_fma_f32 D, A, B, C op_sel:[0,1,0]` -- the LOW lane multiplies by the HIGH
 # register of B -- and on the MI355X that instruction, in this kernel, intermittently returns C alone in the low lane (the product is dropped)
@@ -34,6 +34,8 @@ EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # (and is one straight line of ~17 k instructions: the default size limit of `#pragma unroll` would silently leave a loop rolled, and its
                # register arrays in scratch memory)
                "gn_ffn128.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
+               # k_attn_pw: the same style (one wave per SIMD, pinned order); accumulators in AGPRs (the default MFMA form)
+               "gn_attention_pw.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
                # SIFT: no fused multiply-adds -- every float operation rounds separately, as in the oracle (and in OpenCV's scalar code)
                "gn_sift.hip": ["-ffp-contract=off"]}
 

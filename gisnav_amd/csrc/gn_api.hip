@@ -509,6 +509,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
   const int np = c->npad_run, T = B * 2 * np, BS = B * 2;
   const bool bf16v2 = c->precision != GN_PREC_F32 && c->attn_variant >= 1;
   gn::g_attn_variant = c->attn_variant;
+  gn::g_attn_stamps = ((c->attn_variant == 73 || c->attn_variant >= 1000) && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;
   const int vt_perm = (bf16v2 ? 1 : 0) | (c->dbg_vt_skip ? 2 : 0);   // k_attn_bf16_v5 reads V^T with keys permuted inside 16-groups   // k_attn_bf16_v4 reads permuted V^T
   const bool attn_planes = c->planes_mode && bf16v2;   // k_attn_bf16_v5 writes the hm16 rows itself
   c->launch_count = 0;
@@ -1658,6 +1659,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
     launch_pack_attn_bf16(a, ctx->qkb, ctx->vtb, (hipStream_t)stream);
     a.qb = ctx->qkb; a.kb = ctx->qkb + kDim; a.ldqb = a.ldkb = 2 * kDim; a.vt = ctx->vtb;
     gn::g_attn_variant = ctx->attn_variant;
+    gn::g_attn_stamps = ((ctx->attn_variant == 73 || ctx->attn_variant >= 1000) && ctx->sim) ? reinterpret_cast<long long*>(ctx->sim) : nullptr;
     attn_split(ctx, a);
     launch_attention_bf16_v2(a, (hipStream_t)stream);
   } else {
@@ -1676,7 +1678,7 @@ int gn_sp_set_arithmetic(gn_ctx* ctx, int mode) {
 
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   if (!ctx) return GN_ERR_ARG;
-  if ((which == 12 && (value & 8)) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value) || (which == 20 && value)) {   // these developer paths use the similarity buffer
+  if ((which == 1 && (value == 73 || value >= 1000)) || (which == 12 && (value & 8)) || (which == 15 && value) || (which == 16 && !value) || (which == 17 && value) || (which == 20 && value)) {   // these developer paths use the similarity buffer
     GN_HIP(hipSetDevice(ctx->device));
     const int rc = ensure_sim(ctx); if (rc != GN_OK) return rc;
   }

@@ -754,8 +754,11 @@ void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipS
   hipLaunchKernelGGL(k_pack_attn_bf16, dim3((unsigned)((ntok * 32 + 255) / 256)), dim3(256), 0, s, a.q, a.ldq, a.k, a.ldk, a.v, a.ldv, a.qscale,
                      qkb, qkb + kDim, 2 * kDim, vtb, ntok, a.npad, a.half_fmt);
 }
+thread_local long long* g_attn_stamps = nullptr;
 thread_local int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
+  if (((g_attn_variant >= 70 && g_attn_variant <= 73) || g_attn_variant >= 1000) && !(a.nsplit > 1 && a.part != nullptr) &&
+      launch_attention_pw(a, g_attn_variant >= 1000 ? g_attn_variant - 900 : g_attn_variant - 70, s)) return;
   g_last_kernel = "k_attn16_v5<0, 4, 3, 1, false, false>";   // the name rocprofv3 prints (profiles up to r02m: "k_attn_bf16_v5<0, 4, 3, 1, false>")
   if (a.half_fmt) {   // fp16 operands (GN_PREC_F16X2_F16_ATTN)
     if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr) {

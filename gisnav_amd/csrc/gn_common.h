@@ -181,7 +181,9 @@ struct AttnArgs {
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);
+bool launch_attention_pw(const AttnArgs& a, int ablate, hipStream_t s);   // k_attn_pw (gn_attention_pw.hip): bulk grids, npad % 256 == 0; false = not applicable
 void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipStream_t s);   // (a.half_fmt selects bf16 / fp16)   // f32 rows -> the bf16 layouts k_attn_bf16_v5 reads (test entry)
+extern thread_local long long* g_attn_stamps;   // developer (knob 1 = 73): k_attn_pw writes s_memtime phase stamps here (the idle sim buffer)
 extern thread_local int g_attn_variant;  // developer knob: 4 = k_attn_bf16_v5 (default), 41 / 42 = its timing-only ablations
 
 // ---- elementwise / small kernels ----------------------------------------------------------------
