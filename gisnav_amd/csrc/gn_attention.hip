@@ -757,8 +757,12 @@ void launch_pack_attn_bf16(const AttnArgs& a, uint16_t* qkb, uint16_t* vtb, hipS
 thread_local long long* g_attn_stamps = nullptr;
 thread_local int g_attn_variant = 4;  // developer knob: 4 = k_attn_bf16_v5 (4 waves per block, default), 48 = 8 waves per block, 43 = 4-deep rings, 41 / 42 = timing-only ablations
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
-  if (((g_attn_variant >= 70 && g_attn_variant <= 73) || g_attn_variant >= 1000) && !(a.nsplit > 1 && a.part != nullptr) &&
-      launch_attention_pw(a, g_attn_variant >= 1000 ? g_attn_variant - 900 : g_attn_variant - 70, s)) return;
+  // fp16 mode, grids of at least one 256-query workgroup per CU: k_attn_pw (one wave per SIMD, pinned instruction stream; 31 vs 36 us at 8 pairs x
+  // 1024 keypoints, 112 vs 125 us at 32, 224 vs 244 us at 64; below that k_attn16_v5's two workgroups per CU and its key splits win: 27 vs 24 us at 4
+  // pairs).  Knob 1: 4 = this choice, 5 = k_attn16_v5 always, 70 = k_attn_pw whenever npad % 256 == 0, 71.. / 1000.. = its timing variants.
+  const bool pw_auto = g_attn_variant == 4 && a.half_fmt && a.npad % 256 == 0 && (long long)(a.npad / 256) * kHeads * a.BS >= 256;
+  if ((pw_auto || (g_attn_variant >= 70 && g_attn_variant <= 73) || g_attn_variant >= 1000) && !(a.nsplit > 1 && a.part != nullptr) &&
+      launch_attention_pw(a, pw_auto ? 0 : g_attn_variant >= 1000 ? g_attn_variant - 900 : g_attn_variant - 70, s)) return;
   g_last_kernel = "k_attn16_v5<0, 4, 3, 1, false, false>";   // the name rocprofv3 prints (profiles up to r02m: "k_attn_bf16_v5<0, 4, 3, 1, false>")
   if (a.half_fmt) {   // fp16 operands (GN_PREC_F16X2_F16_ATTN)
     if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr) {

@@ -154,32 +154,39 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
   float mloc[NQ];
   bool grow = false;
 
-  // maximum search of one query tile of a sub-tile (keys key0 .. key0 + 31), in two steps of four v_max3; masked keys become -inf first
-  auto m_step = [&](f32x16 (&S)[NQ], int qi, int hf, int key0, auto mask_tag) __attribute__((always_inline)) {
-    if constexpr (decltype(mask_tag)::value) {
-      const int lim = nkv - key0 - 4 * hh;
+  // maximum search of one query tile of a sub-tile (keys key0 .. key0 + 31) in three steps: five independent v_max3 over the lane's 16 scores
+  // (st 0), their merge (st 1: a dependent chain of v_max3 costs a lone wave ~9 cycles per link), the test against the reference (st 2).
+  // A lane holds half of a query's keys (hh): the test is made per half -- the wave-wide ballot sees either -- and the halves only meet in the
+  // rescale itself (rare), so the tile loop has no cross-lane operation.  Masked keys become -inf first.
+  float mt[NQ][5];
+  auto m_step = [&](f32x16 (&S)[NQ], int qi, int st, int key0, auto mask_tag) __attribute__((always_inline)) {
+    if (st == 0) {
+      if constexpr (decltype(mask_tag)::value) {
+        const int lim = nkv - key0 - 4 * hh;
 #pragma unroll
-      for (int r = 8 * hf; r < 8 * hf + 8; ++r)
-        if ((r & 3) + 8 * (r >> 2) >= lim) S[qi][r] = -INFINITY;
+        for (int r = 0; r < 16; ++r)
+          if ((r & 3) + 8 * (r >> 2) >= lim) S[qi][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) mt[qi][i] = __builtin_fmaxf(__builtin_fmaxf(S[qi][3 * i], S[qi][3 * i + 1]), S[qi][3 * i + 2]);
+    } else if (st == 1) {
+      const float x = __builtin_fmaxf(__builtin_fmaxf(mt[qi][0], mt[qi][1]), mt[qi][2]);
+      const float y = __builtin_fmaxf(__builtin_fmaxf(mt[qi][3], mt[qi][4]), S[qi][15]);
+      mloc[qi] = __builtin_fmaxf(x, y);
+    } else {
+      grow = grow || (mloc[qi] - m_run[qi]) * kLog2e > 8.0f;
     }
-    float m = hf == 0 ? S[qi][0] : mloc[qi];
-#pragma unroll
-    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, S[qi][r]), S[qi][r + 1]);
-    mloc[qi] = m;
-  };
-  auto m_final = [&](int qi) __attribute__((always_inline)) {
-    const unsigned mu = __float_as_uint(mloc[qi]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);     // {low half in both halves, high half in both halves}
-    const unsigned lo = sw[0], hi = sw[1];     // (by value: __builtin_bit_cast of the vector's elements read element 0 twice with this compiler)
-    mloc[qi] = __builtin_fmaxf(__uint_as_float(lo), __uint_as_float(hi));
-    grow = grow || (mloc[qi] - m_run[qi]) * kLog2e > 8.0f;
   };
   // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8 (probabilities stay <= 256)
   auto rescale = [&]() __attribute__((always_inline)) {
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+    if (ABL & 524288) { asm volatile("" ::"v"(grow ? 1 : 0)); }     // timing: the test without the branch
+    else if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        const float m_new = fmaxf(m_run[qi], mloc[qi]);
+        const unsigned mu = __float_as_uint(mloc[qi]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);     // {low half in both halves, high half in both halves}
+        const unsigned lo = sw[0], hi = sw[1];     // (by value: __builtin_bit_cast of the vector's elements read element 0 twice with this compiler)
+        const float m_new = fmaxf(m_run[qi], __builtin_fmaxf(__uint_as_float(lo), __uint_as_float(hi)));
         const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * kLog2e);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[qi][0][r] *= alpha; o[qi][1][r] *= alpha; ol[qi][r] *= alpha; }
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
     // the compiler does not know the latency of an MFMA written in assembly: the wait carries the accumulators, or the first reads are scheduled in front of it
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(Sa[0]), "+v"(Sa[1]));
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) { m_step(Sa, qi, 0, 0, std::true_type{}); m_step(Sa, qi, 1, 0, std::true_type{}); m_final(qi); }
+    for (int qi = 0; qi < NQ; ++qi) { m_step(Sa, qi, 0, 0, std::true_type{}); m_step(Sa, qi, 1, 0, std::true_type{}); m_step(Sa, qi, 2, 0, std::true_type{}); }
     rescale();
     kf[0] = k_frag(0, 1, 0);
     kf[1] = k_frag(0, 1, 1);
@@ -281,11 +288,9 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
 #pragma unroll
           for (int st = (10 * m) / 6; st < (10 * (m + 1)) / 6; ++st) if (!(ABL & 32)) e_step(SC, 2 + st / 5, st % 5);
         } else {
-          // maximum search of the next sub-tile: 4 steps + 2 final steps over 6 slots
+          // maximum search of the next sub-tile: 2 x 3 steps over 6 slots
           const int mm = m - 6;
-          if (ABL & 16) { }
-          else if (mm < 4) m_step(SN, mm >> 1, mm & 1, next_key0, mask);
-          else m_final(mm - 4);
+          if (!(ABL & 16)) m_step(SN, mm & 1, mm >> 1, next_key0, mask);
         }
         GN_PIN();
       }
@@ -407,7 +412,7 @@ bool launch_attention_pw(const AttnArgs& a, int ablate, hipStream_t s) {
 #define GN_PW_ABL(x) case x: hipLaunchKernelGGL((k_attn_pw<true, (x) | 8>), grid, block, 0, s, b); break;
       switch (ablate >= 100 ? ablate - 100 : 0) {
         GN_PW_ABL(0) GN_PW_ABL(1) GN_PW_ABL(2) GN_PW_ABL(4) GN_PW_ABL(16) GN_PW_ABL(32) GN_PW_ABL(64) GN_PW_ABL(128) GN_PW_ABL(256) GN_PW_ABL(6)
-        GN_PW_ABL(192) GN_PW_ABL(48) GN_PW_ABL(310) GN_PW_ABL(198) GN_PW_ABL(454) GN_PW_ABL(134) GN_PW_ABL(70) GN_PW_ABL(512) GN_PW_ABL(1024) GN_PW_ABL(2048) GN_PW_ABL(3584) GN_PW_ABL(6144) GN_PW_ABL(10240) GN_PW_ABL(18432) GN_PW_ABL(34816) GN_PW_ABL(65536)
+        GN_PW_ABL(192) GN_PW_ABL(48) GN_PW_ABL(310) GN_PW_ABL(198) GN_PW_ABL(454) GN_PW_ABL(134) GN_PW_ABL(70) GN_PW_ABL(512) GN_PW_ABL(1024) GN_PW_ABL(2048) GN_PW_ABL(3584) GN_PW_ABL(6144) GN_PW_ABL(10240) GN_PW_ABL(18432) GN_PW_ABL(34816) GN_PW_ABL(65536) GN_PW_ABL(524288) GN_PW_ABL(524320)
         default: return false;
       }
 #undef GN_PW_ABL

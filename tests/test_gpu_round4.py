@@ -202,3 +202,93 @@ def test_length_bucketing_scheduler_returns_the_padded_call_s_results(state_dict
     assert one["ok"].sum() >= 10
     assert np.abs(got["R"] - one["R"]).max() < 1e-8 and np.abs(got["t"] - one["t"]).max() < 1e-6
     assert stats["groups"] == 3 and stats["padded_tokens_bucketed"] < stats["padded_tokens_one_call"] and stats["real_tokens"] == int((n_q + n_r).sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# k_attn_pw (gn_attention_pw.hip): the attention kernel of bulk grids in the fp16-attention mode
+@pytest.fixture(scope="module")
+def eng_f16x2_f16attn(state_dict_np):
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=8, max_kpts=2048, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    return eng
+
+
+def _attn_ref64(q, k, v, nkv, cross):
+    q, k, v = (t.half().double().cpu() for t in (q, k, v))
+    out = torch.zeros_like(q)
+    for bs in range(q.shape[0]):
+        kv = bs ^ 1 if cross else bs
+        n = int(nkv[kv])
+        for h in range(4):
+            sl = slice(64 * h, 64 * h + 64)
+            out[bs, :, sl] = torch.softmax((q[bs, :, sl] * 0.125) @ k[kv, :n, sl].T, dim=-1) @ v[kv, :n, sl]
+    return out
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_attn_pw_ragged_key_counts_against_fp64_and_the_two_waves_per_simd_kernel(eng_f16x2_f16attn, cross):
+    """Every masking case of the 32-key sub-tile pipeline (key counts 1, 5, 32, 33, 64, 65, 130, 219, 250, 256: empty second sub-tile, partial
+    first / second sub-tile of the last tile, one to four tiles) against fp64 on the fp16-rounded operands, against k_attn16_v5 (same operands,
+    probabilities relative to a reference searched per 64 instead of per 32 keys: not bit-identical), and twice for bitwise repeatability."""
+    eng = eng_f16x2_f16attn
+    dev = eng.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nk = [256, 192, 128, 64, 32, 219, 130, 5, 65, 33, 1, 250]
+    q, k, v = (torch.randn(len(nk), 256, 256, generator=g).to(dev) for _ in range(3))
+    nkv = torch.tensor(nk, dtype=torch.int32, device=dev)
+    try:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 70)
+        a = eng.debug_attention(q, k, v, nkv, cross, 0.125)
+        b = eng.debug_attention(q, k, v, nkv, cross, 0.125)
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 5)
+        old = eng.debug_attention(q, k, v, nkv, cross, 0.125)
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+    assert torch.equal(a, b)
+    ref = _attn_ref64(q, k, v, nkv, cross)
+    a, old = a.double().cpu(), old.double().cpu()
+    err = {bs: float((a[bs] - ref[bs]).abs().max() / ref[bs].abs().max()) for bs in range(len(nk))}
+    _report(f"attn_pw_rel_err_vs_fp64_cross{int(cross)}", {"max": max(err.values()), "vs_v5": float((a - old).abs().max() / ref.abs().max())})
+    assert max(err.values()) < 1.5e-3, err
+    assert float((a - old).abs().max() / ref.abs().max()) < 1.5e-3
+
+
+def test_attn_pw_long_sequences_bitwise_repeatable_and_exact_running_maximum(eng_f16x2_f16attn):
+    """2048 keys (32 tiles) x 8 slots, late keys boosted so that the lazy reference has to move: 12 launches bit-identical (the kernel's score MFMAs
+    are written in assembly -- a register-recycling race in front of them changed one 64 x 32 output tile in ~1 launch of 12 before it was fixed),
+    result against fp64."""
+    eng = eng_f16x2_f16attn
+    dev = eng.device
+    g = torch.Generator(device="cpu").manual_seed(9)
+    q, k, v = (torch.randn(8, 2048, 256, generator=g).to(dev) for _ in range(3))
+    k[:, 1500:] *= 3.0
+    nkv = torch.tensor([2048, 2011, 2048, 1999, 1024, 2048, 1500, 2048], dtype=torch.int32, device=dev)
+    try:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 70)
+        first = eng.debug_attention(q, k, v, nkv, False, 0.125)
+        for _ in range(12):
+            assert torch.equal(first, eng.debug_attention(q, k, v, nkv, False, 0.125))
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+    ref = _attn_ref64(q, k, v, nkv, False)
+    assert float((first.double().cpu() - ref).abs().max() / ref.abs().max()) < 1.5e-3
+
+
+def test_attn_pw_is_the_default_of_bulk_grids_and_leaves_the_correspondences_unchanged(state_dict_np):
+    """8 pairs x 1024 keypoints = 256 workgroups of 256 queries: the default (knob 1 = 4) launches k_attn_pw; forcing k_attn16_v5 (knob 1 = 5) gives the
+    same correspondences and final features within the fp16-probability rounding."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=8, max_kpts=1024, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    inp = eng.stage_inputs([make_pair(i) for i in range(8)])
+    args = (inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+    res = {}
+    try:
+        for var in (4, 5):
+            eng.lib.gn_debug_set_variant(eng.ctx, 1, var)
+            idx, score, n = (t.cpu().numpy().copy() for t in eng.match(*args))
+            res[var] = (idx, n, eng.debug_read("x", 8 * 2 * 1024 * 256).copy(), None)
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+    (i0, n0, x0, _), (i1, n1, x1, _) = res[4], res[5]
+    assert np.array_equal(n0, n1) and all(np.array_equal(i0[b, : n0[b]], i1[b, : n1[b]]) for b in range(8))
+    assert np.abs(x0 - x1).max() / np.abs(x1).max() < 1e-4
