@@ -51,8 +51,8 @@ template <bool F16> __device__ __forceinline__ void mfma_v(f32x16& s, const bf16
 }
 
 // ABL (timing only, wrong results): 1 no exponentials, 2 no LDS-DMA in the loop, 4 no barrier in the loop, 16 no maximum search, 32 no probability steps,
-// 64 no score MFMAs, 128 no V^T P^T / denominator MFMAs, 256 no fragment reads; 8 = s_memtime stamps into a.part (results stay valid);
-// debugging (results stay valid): 512 every ring wait is vmcnt(0), 1024 a second barrier behind the DMA issue, 2048 s_nop 7 x 2 behind every score MFMA
+// 64 no score MFMAs, 256 no fragment reads, 524288 the rescale test without its branch; 8 = s_memtime stamps into a.part (results stay valid).
+// (Removing the V^T P^T MFMAs is not a usable probe: the probabilities become dead code and the compiler deletes their steps.)
 template <bool F16, int ABL>
 __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
   constexpr int NDK = 4, NDV = 3, NW = 4, NQ = 2, IPW = 8 / NW;
@@ -251,7 +251,6 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
                      auto mask, bool live) __attribute__((always_inline)) {
     bf16x8 vf[2][2];
     if (ABL & 256) vf[0][0] = vf[0][1] = vf[1][0] = vf[1][1] = ones;
-    const bool keep = !(ABL & 65536);
     // ---- slots 0..7: scores of the next sub-tile
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -259,8 +258,6 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
       for (int qi = 0; qi < NQ; ++qi) {
         const int m = 2 * c + qi;
         if (!(ABL & 64)) { if (c == 0) mfma_v0<F16>(SN[qi], kf[c % 3], qf[qi][c]); else mfma_v<F16>(SN[qi], kf[c % 3], qf[qi][c]); }
-        if ((ABL & 2048) && (!(ABL & 4096) || c == 0) && (!(ABL & 8192) || c == 3) && (!(ABL & 16384) || (c == 3 && qi == 1)) && (!(ABL & 32768) || (c == 1 || c == 2)))
-          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         // steps [10 m / 8, 10 (m + 1) / 8) of the 10 steps of fragments (qi = 0, u = 0), (1, 0)
 #pragma unroll
         for (int st = (10 * m) / 8; st < (10 * (m + 1)) / 8; ++st) if (!(ABL & 32)) e_step(SC, st / 5, st % 5);
@@ -280,8 +277,7 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
         const int qi = i & 1, m = 6 * u + i;
         if (u == 1 && i == 0 && !(ABL & 256)) kf[0] = k_frag(kst2, kt2, 0);      // fragments of the sub-tile after the next one
         if (u == 1 && i == 2 && !(ABL & 256)) kf[1] = k_frag(kst2, kt2, 1);
-        if (ABL & 128) { }
-        else if (i < 2) ol[qi] = mfma16<F16>(ones, pf[qi][u], ol[qi]);
+        if (i < 2) ol[qi] = mfma16<F16>(ones, pf[qi][u], ol[qi]);
         else o[qi][(i - 2) >> 1] = mfma16<F16>(vf[(i - 2) >> 1][u], pf[qi][u], o[qi][(i - 2) >> 1]);
         if (m < 6) {
           // probabilities of the second 16 keys: 10 steps over 6 slots
@@ -300,7 +296,7 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
     // fragment read in the next instruction -- and the MFMA, 8 passes later, wrote its result over the fragment (one 32-wide output tile of a wave
     // without its last 16 keys in about one launch of twelve; tools/probes/mfma_war.hip shows the opposite order, overwriting an operand behind the
     // MFMA that reads it, is safe)
-    if (keep) asm volatile("" ::"v"(SN[0]), "v"(SN[1]));
+    asm volatile("" ::"v"(SN[0]), "v"(SN[1]));
     if (live) rescale(); else grow = false;
   };
 
@@ -310,13 +306,12 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
     // K(t+1) and V^T(t) have landed once everything but the newest DMA group ({K(t+2), V^T(t+1)}) is complete; lgkmcnt(0): this wave's fragment
     // reads of the stages refilled below have returned; the barrier publishes all waves' shares and proves those stages are no longer being read
     if (ABL & 4) { }
-    else if (t + 2 < ntiles && !(ABL & 512)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (!(ABL & 2)) {
       if (t + 3 < ntiles) GN_DMA_K(k3, t + 3);        // the stage K(t-1) was read from (its second half one sub-tile ago)
       if (t + 2 < ntiles) GN_DMA_V(v2, t + 2);        // the stage V^T(t-1) was read from
     }
-    if (ABL & 1024) asm volatile("s_barrier" ::: "memory");
     const unsigned ks0 = 2 * kRing * k0, ks1 = 2 * kRing * k1, vs0 = 2 * kRing * (NDK + v0);
     GN_PIN();
     // sub-tile 2 t: scores of keys 32..63 of tile t; prefetch the first fragments of keys 0..31 of tile t + 1
@@ -411,8 +406,7 @@ bool launch_attention_pw(const AttnArgs& a, int ablate, hipStream_t s) {
       AttnArgs b = a; b.part = reinterpret_cast<float*>(g_attn_stamps);
 #define GN_PW_ABL(x) case x: hipLaunchKernelGGL((k_attn_pw<true, (x) | 8>), grid, block, 0, s, b); break;
       switch (ablate >= 100 ? ablate - 100 : 0) {
-        GN_PW_ABL(0) GN_PW_ABL(1) GN_PW_ABL(2) GN_PW_ABL(4) GN_PW_ABL(16) GN_PW_ABL(32) GN_PW_ABL(64) GN_PW_ABL(128) GN_PW_ABL(256) GN_PW_ABL(6)
-        GN_PW_ABL(192) GN_PW_ABL(48) GN_PW_ABL(310) GN_PW_ABL(198) GN_PW_ABL(454) GN_PW_ABL(134) GN_PW_ABL(70) GN_PW_ABL(512) GN_PW_ABL(1024) GN_PW_ABL(2048) GN_PW_ABL(3584) GN_PW_ABL(6144) GN_PW_ABL(10240) GN_PW_ABL(18432) GN_PW_ABL(34816) GN_PW_ABL(65536) GN_PW_ABL(524288) GN_PW_ABL(524320)
+        GN_PW_ABL(0) GN_PW_ABL(1) GN_PW_ABL(2) GN_PW_ABL(4) GN_PW_ABL(6) GN_PW_ABL(16) GN_PW_ABL(32) GN_PW_ABL(48) GN_PW_ABL(64) GN_PW_ABL(256) GN_PW_ABL(524288) GN_PW_ABL(524320)
         default: return false;
       }
 #undef GN_PW_ABL
