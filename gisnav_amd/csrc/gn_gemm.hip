@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] + bias;
         const float hi = slab[(t0 + 1) * ES + lane] + bias;
-        w[e] = pack_bf16(lo, hi);
+        w[e] = pack16_rt(lo, hi, a.half_fmt);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = pack_bf16(v.x, v.y);
-      pk.y = pack_bf16(v.z, v.w);
+      pk.x = pack16_rt(v.x, v.y, a.half_fmt);
+      pk.y = pack16_rt(v.z, v.w, a.half_fmt);
       *reinterpret_cast<uint2*>(a.Yb + (size_t)row * a.ldyb + col) = pk;
     } else {
       *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] + bias;
         const float hi = slab[(t0 + 1) * ES + lane] + bias;
-        w[e] = pack_bf16(lo, hi);
+        w[e] = pack16_rt(lo, hi, a.half_fmt);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32x3(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = pack_bf16(v.x, v.y);
-      pk.y = pack_bf16(v.z, v.w);
+      pk.x = pack16_rt(v.x, v.y, a.half_fmt);
+      pk.y = pack16_rt(v.z, v.w, a.half_fmt);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
         const int t0 = a.vt_perm ? 16 * (c >> 1) + 4 * (c & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : 8 * c + 2 * e;
         const float lo = slab[t0 * ES + lane] * a.acc_scale + bias;
         const float hi = slab[(t0 + 1) * ES + lane] * a.acc_scale + bias;
-        w[e] = pack_bf16(lo, hi);
+        w[e] = pack16_rt(lo, hi, a.half_fmt);
       }
       *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
     if (kBf16Out) {
       if (col < a.q_cols) v *= a.qscale;
       uint2 pk;
-      pk.x = pack_bf16(v.x, v.y);
-      pk.y = pack_bf16(v.z, v.w);
+      pk.x = pack16_rt(v.x, v.y, a.half_fmt);
+      pk.y = pack16_rt(v.z, v.w, a.half_fmt);
       vals[it].x = __uint_as_float(pk.x); vals[it].y = __uint_as_float(pk.y);
     } else {
       vals[it] = v;

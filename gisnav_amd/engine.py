@@ -90,7 +90,12 @@ class RecordStager:
 
         self._next = (self._next + 1) % self.depth
         if slot["used"]:
-            slot["consumed"].synchronize()           # the batch that last used this slot has been read by its kernels (and its H2D is long done)
+            slot["uploaded"].synchronize()           # the pinned host buffer is free again: its H2D copy has finished
+            if slot.get("released", False):
+                slot["consumed"].synchronize()       # the batch that last used this slot has been read by its kernels
+            else:
+                torch.cuda.synchronize(self.eng.device)   # release() was never called for it: wait for everything rather than overwrite a batch in use
+        slot["released"] = False
 
         def copy_pair(b):
             q, r, dem = msgs[b]
@@ -119,6 +124,7 @@ class RecordStager:
 
     def release(self, inputs: dict) -> None:
         inputs["_slot"]["consumed"].record(torch.cuda.current_stream(self.eng.device))
+        inputs["_slot"]["released"] = True
 
     def close(self) -> None:
         """Stop the copy threads (the pinned buffers and device slots go with the object)."""
@@ -151,10 +157,6 @@ class PoseEngine:
         self.device = torch.device("cuda", device)
         self.max_batch, self.precision = max_batch, precision
         self._n_layers, self._filter_threshold, self._state_dict = n_layers, filter_threshold, None
-        # sticky context state set through this object: replayed onto the new context by grow()
-        self._image_size = (None, None)
-        self._substreams, self._deferred_join, self._overlap = 1, False, False
-        self._sp_state_dict, self._sp_arithmetic = None, None
         self._guard = {"off": 0, "flag": 1, "sync": 2}[guard]
         self.feature = feature
         self._feature = {"sift": _lib.GN_FEATURE_SIFT, "superpoint": _lib.GN_FEATURE_SUPERPOINT}[feature]
@@ -192,10 +194,9 @@ class PoseEngine:
         self.kmax = self.lib.gn_kmax(self.ctx)
         self._sift = None
 
-    # SuperPoint weights / arithmetic live in the context too (gn_sp_*); kept here so that grow() can replay them
+    # SuperPoint weights / arithmetic live in the context (gn_sp_*) and survive gn_resize
     def sp_set_arithmetic(self, mode: int) -> None:
         _lib.check(self.ctx, self.lib.gn_sp_set_arithmetic(self.ctx, int(mode)), "gn_sp_set_arithmetic")
-        self._sp_arithmetic = int(mode)
 
     def sp_load_state_dict(self, sd) -> None:
         for name, arr in sd.items():
@@ -205,7 +206,6 @@ class PoseEngine:
             shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
             rc = self.lib.gn_sp_load_tensor(self.ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, max(arr.ndim, 1))
             _lib.check(self.ctx, rc, f"gn_sp_load_tensor({name})")
-        self._sp_state_dict = sd
 
     def load_state_dict(self, sd) -> None:
         self._state_dict = sd
@@ -221,7 +221,6 @@ class PoseEngine:
     def set_image_size(self, wh_q=None, wh_r=None) -> None:
         """kornia LightGlueMatcher's hw1 / hw2 as (w, h): image sizes for the keypoint normalisation; None = keypoint extent (what
         PoseNode gets, pose_node.py:285-287)."""
-        self._image_size = (wh_q, wh_r)
         q, r = wh_q or (0.0, 0.0), wh_r or (0.0, 0.0)
         _lib.check(self.ctx, self.lib.gn_set_image_size(self.ctx, float(q[0]), float(q[1]), float(r[0]), float(r[1])), "gn_set_image_size")
 
@@ -352,14 +351,12 @@ class PoseEngine:
         """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
         before reading R / t / n_inliers / ok."""
         _lib.check(self.ctx, self.lib.gn_set_overlap(self.ctx, int(enable)), "gn_set_overlap")
-        self._overlap = bool(enable)
 
     def set_substreams(self, n: int, deferred_join: bool = False) -> None:
         """Throughput option: every estimate() call runs its pairs as n groups on internal streams (gn_set_substreams).  With
         deferred_join the groups are only joined by flush(): keep the input tensors of a call alive until then."""
         _lib.check(self.ctx, self.lib.gn_set_substreams(self.ctx, int(n)), "gn_set_substreams")
         _lib.check(self.ctx, self.lib.gn_set_deferred_join(self.ctx, int(bool(deferred_join))), "gn_set_deferred_join")
-        self._substreams, self._deferred_join = int(n), bool(deferred_join)
 
     def set_active_kpts(self, max_kpts_per_side: int) -> int:
         """Padded keypoint count the following match()/estimate() calls run at (gn_set_active_kpts): pass the largest keypoint

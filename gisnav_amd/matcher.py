@@ -93,7 +93,7 @@ class LightGlueMatcher:
         if max(d1.shape[1], d2.shape[1]) > self._engine.kmax:      # kornia's matcher takes any number of keypoints
             self._engine.grow(((max(d1.shape[1], d2.shape[1]) + 1023) // 1024) * 1024)
         # kornia: image_size = (w, h) from hw when given, else the keypoint extent -- PoseNode passes hw1 = hw2 = None (pose_node.py:285-287).
-        # Set AFTER a possible grow(): the re-created context must normalise THIS call's keypoints by the sizes given with it.
+        # Set on every call: the context normalises THIS call's keypoints by the sizes given with it.
         self._engine.set_image_size(None if hw1 is None else (hw1[1], hw1[0]), None if hw2 is None else (hw2[1], hw2[0]))
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
         n1 = torch.full((1,), d1.shape[1], dtype=torch.int32, device=dev)     # (a fill kernel on the stream, not a blocking pageable upload)

@@ -32,7 +32,7 @@ class SuperPoint:
             self.load_state_dict(state_dict)
 
     def load_state_dict(self, sd) -> None:
-        self._eng.sp_load_state_dict(sd)     # kept by the engine: PoseEngine.grow() replays it onto the re-created context
+        self._eng.sp_load_state_dict(sd)     # lives in the context (gn_resize keeps it)
 
     def detect_and_describe_device(self, images):
         """images: (B, H, W) uint8 (scaled by 1/255 like the published pre-processing) or float32 in [0, 1], numpy or device tensor;
