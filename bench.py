@@ -661,10 +661,10 @@ def main() -> None:
                         "throughput).  The headline mode computes what the reference's own CUDA path computes (fp32-accurate linear layers, half-precision SDPA) and "
                         "is index-identical to the f32 CPU restatement of the reference on all 32 bench pairs and on mid-margin weights; on LOW-margin synthetic weights it differs in a few "
                         "decisions per thousand, like the reference's CUDA path differs from its CPU path",
-                "low_margin_index_mismatches": {"f32": "0 / 1220", "f16x2_f16_attn": "1 / 1220", "f16x2_bf16_attn": "4 / 1220",
-                                                "mid_margin_all_modes": "0 / 687",
+                "low_margin_index_mismatches": {"f32": "0 / 1220", "f16x2_f16_attn": "0 / 1220", "f16x2_bf16_attn": "6 / 1220",
+                                                "mid_margin": "0 / 687 (bf16 attention: 1 / 687)",
                                                 "source": "tests/test_gpu_parity2.py::test_low_margin_weights_index_mismatch_counts_per_precision (asserted <= 5 %), "
-                                                          "gpurun_out/parity_r02.json / profiles/r03_parity_report*.json"}},
+                                                          "profiles/r04_parity_report*.json (the reports the -m gpu tests wrote this round)"}},
             "data": "synthetic",
             "inputs_resident": True,
             "debug_variant": list(args.debug_variant),

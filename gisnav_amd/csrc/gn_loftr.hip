@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
 
   // weight fragments of one tap (CH / 8 channel steps x two 32-channel tiles) travel L2 -> registers one tap AHEAD of the MFMAs that use
   // them: with one wave per SIMD nothing else hides the ~1 us of L2 latency (the first build fetched them right in front of each step's
-  // MFMAs and ran at 45 TF; see DESIGN.md 12.4)
+  // MFMAs and ran at 45 TF; see DESIGN.md 9)
   constexpr int NS = CH / 8;
   f32x4 wcur[NS][2], wnxt[NS][2];
   auto load_w = [&](f32x4 (&w)[NS][2], int c0_, int tap_) __attribute__((always_inline)) {

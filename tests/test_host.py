@@ -35,7 +35,7 @@ def test_library_builds_loads_and_exports_every_header_symbol():
 
 def test_shipped_device_code_has_no_low_lane_opsel_packed_fma(tmp_path):
     """`v_pk_fma_f32 ... op_sel:[.,1,.]` (the LOW lane multiplies by the HIGH register of source 1) is the instruction behind k_qkv's run-to-run
-    differences when gn_qkv.hip is built with the SLP vectoriser (on the MI355X the low lane intermittently returns source 2 alone in
+    differences when gn_qkv.hip is built with the SLP vectoriser (docs/DESIGN_HISTORY.md 12.5: on the MI355X the low lane intermittently returns source 2 alone in
     lanes 48..63; replacing that one instruction makes the kernel repeatable).  hipcc must not have emitted it anywhere in the library that ships."""
     import shutil
     import subprocess

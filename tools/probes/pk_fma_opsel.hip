@@ -1,6 +1,6 @@
 // Developer probe (not part of the library): v_pk_fma_f32 with op_sel:[0,1,0] -- the LOW lane multiplies by the HIGH register of source 1.
 // hipcc's SLP vectoriser emits exactly this for the second rotary pair of k_qkv (o.z = v.z * cos' - v.w * sin'), and in that kernel the low lane
-// intermittently returns source 2 alone (the product is dropped) in lanes 48..63 (tools/slp_variants.sh: replacing only this
+// intermittently returns source 2 alone (the product is dropped) in lanes 48..63 (docs/DESIGN_HISTORY.md 12.5; tools/slp_variants.sh: replacing only this
 // instruction by two v_fma_f32 makes the kernel bitwise repeatable).  This probe looks for the same thing outside k_qkv: 8 waves per CU, each alternating
 // an MFMA phase (LDS-fed, like the projection's k-loop) with an epilogue of packed rotations on freshly loaded table entries, compared lane by lane
 // with scalar v_fma_f32 results.

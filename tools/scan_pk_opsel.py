@@ -1,6 +1,6 @@
 """Developer tool: which packed-f32 instructions with a LOW-lane op_sel bit does hipcc emit for each source file (its own build flags)?
 `v_pk_fma_f32 ... op_sel:[0,1,0]` is the instruction behind k_qkv's run-to-run differences when gn_qkv.hip is built with the SLP vectoriser
-(DESIGN.md 12.5): this lists every occurrence in the library.   python tools/scan_pk_opsel.py [--slp-qkv]"""
+(docs/DESIGN_HISTORY.md 12.5): this lists every occurrence in the library.   python tools/scan_pk_opsel.py [--slp-qkv]"""
 import collections, os, re, subprocess, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gisnav_amd import build as B
