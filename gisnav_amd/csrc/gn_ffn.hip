@@ -31,6 +31,12 @@ namespace gn {
 namespace {
 // FOLD: the message is not read from memory but computed here, msg = out_proj(ctx) (kornia `self.out_proj` / `self.to_out`), from
 // the attention output rows -- the out_proj GEMM launch and the msg round trip through HBM disappear.
+// Shapes of the same kernel: NW waves x NJ token tiles of 32 per workgroup.  (8, 2) is the bulk shape (64 tokens, one workgroup per
+// CU); (8, 1) halves the tokens per workgroup for small grids (batch 1: 2048 tokens are 32 workgroups of 64 on 256 CUs).  (4, 1) --
+// two workgroups per CU, whose VALU and MFMA phases could overlap -- was measured SLOWER at every batch size (each wave then streams
+// twice the weight bytes with the same number of loads in flight) and is not instantiated.
+//   NJ            token tiles of 32 per workgroup (every wave covers all of them)
+//   NI = 16 / NW  hidden tiles of 32 per wave in GEMM 1;   NO = 8 / NW  output tiles of 32 per wave in GEMM 0 and GEMM 2
 template <int ABL = 0, bool FOLD = true, int NW = 8, int NJ = 2>   // ABL, timing-only ablations: 1 no weight loads inside the loops, 2 no second GEMM, 4 no GELU; 8 = s_memtime stamps per phase into a.dbg_ts
 __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
   constexpr int NI = 16 / NW, NO = 8 / NW;

@@ -22,6 +22,11 @@
 // The instruction order of every k-step is pinned (sched_barrier after each MFMA): one memory instruction or one VALU stage per MFMA
 // gap -- left alone the machine scheduler clumps the weight loads (each stalls the wave's issue for ~30 cycles) and runs the VALU
 // work of a GELU chunk as one dependent chain per value pair BETWEEN the MFMA groups.
+// Default form since round 4 (COMP = true): out_proj is folded into ffn.0 at load time -- ffn.0([x | Wo ctx + bo]) = [W1x | W1m Wo] [x | ctx] + (b1 + W1m bo),
+// gn_api.hip build_composed -- so there is no GEMM 0, no message tile and no round trip of it through LDS: the prologue stages the first token
+// tiles, the weight ring and the bias, and GEMM 1 runs over all sixteen [x | ctx] k-tiles (51.5 instead of 60.1 GFLOP per launch; 156-160 us
+// against 173-187 us).  The description above is the uncomposed form (COMP = false: knob 28 = 0, and every grid the composed weight was not
+// built for); the two share everything from the LayerNorm statistics on.
 // Weight fragments: the layouts of gn_ffn.hip (build_weight_fragments), unchanged.  Accumulation order per output element equals
 // k_ffn_fused's for GEMM 0 and GEMM 1 (bitwise the same message and pre-LayerNorm values); the LayerNorm statistics, the last
 // multiply of the GELU (one fma instead of mul + add + mul) and GEMM 2's k order differ at rounding level.

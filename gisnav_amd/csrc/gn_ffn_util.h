@@ -9,12 +9,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-// Shapes of the same kernel: NW waves x NJ token tiles of 32 per workgroup.  (8, 2) is the bulk shape (64 tokens, one workgroup per
-// CU); (8, 1) halves the tokens per workgroup for small grids (batch 1: 2048 tokens are 32 workgroups of 64 on 256 CUs).  (4, 1) --
-// two workgroups per CU, whose VALU and MFMA phases could overlap -- was measured SLOWER at every batch size (each wave then streams
-// twice the weight bytes with the same number of loads in flight) and is not instantiated.
-//   NJ            token tiles of 32 per workgroup (every wave covers all of them)
-//   NI = 16 / NW  hidden tiles of 32 per wave in GEMM 1;   NO = 8 / NW  output tiles of 32 per wave in GEMM 0 and GEMM 2
 constexpr int YP = 260;                 // float pitch of the output tile staged for the row-wise epilogue (aliases the hidden tile)
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
