@@ -301,7 +301,7 @@ def test_grow_replays_sticky_context_state(state_dict_np):
     a = [t.cpu().numpy().copy() if hasattr(t, "cpu") else t for t in sp.detect_and_describe_device(img)]
     eng.grow(512)
     b = [t.cpu().numpy() if hasattr(t, "cpu") else t for t in sp.detect_and_describe_device(img)]      # weights and arithmetic survived
-    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and eng._substreams == 2
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))        # (settings live in the context: gn_resize keeps them, nothing is replayed)
 
 
 # ------------------------------------------------------------------ configs[4] at its size: SuperPoint at 1920x1080
