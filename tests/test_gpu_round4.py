@@ -326,3 +326,31 @@ def test_loftr_superpoint_sift_are_bitwise_repeatable_over_many_runs():
     for _ in range(8):
         assert all(torch.equal(a, b) for a, b in zip(f_sp, snap(sp.detect_and_describe_device(img[None]))))
         assert all(torch.equal(a, b) for a, b in zip(f_si, snap(sift.detect_and_compute_device(img))))
+
+
+def test_attn_pw_bf16_operands(state_dict_np):
+    """The same kernel on bf16 operands (`k_attn_pw<false, 0>`; reachable through knob 1 = 70 in the bf16-attention modes, whose default stays the
+    optimistic k_attn16_v5): ragged key counts against fp64 on the bf16-rounded operands and against k_attn16_v5, bitwise repeatable."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=4, max_kpts=512, precision="f16x2_bf16_attn", state_dict=state_dict_np)
+    dev = eng.device
+    g = torch.Generator(device="cpu").manual_seed(6)
+    nk = [512, 431, 64, 97, 5, 320]
+    q, k, v = (torch.randn(len(nk), 512, 256, generator=g).to(dev) for _ in range(3))
+    nkv = torch.tensor(nk, dtype=torch.int32, device=dev)
+    try:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 70)
+        a = eng.debug_attention(q, k, v, nkv, True, 0.125)
+        assert torch.equal(a, eng.debug_attention(q, k, v, nkv, True, 0.125))
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+    old = eng.debug_attention(q, k, v, nkv, True, 0.125).double().cpu()
+    qb, kb, vb = (t.bfloat16().double().cpu() for t in (q, k, v))
+    ref = torch.zeros_like(qb)
+    for bs in range(len(nk)):
+        n = nk[bs ^ 1]
+        for h in range(4):
+            sl = slice(64 * h, 64 * h + 64)
+            ref[bs, :, sl] = torch.softmax((qb[bs, :, sl] * 0.125) @ kb[bs ^ 1, :n, sl].T, dim=-1) @ vb[bs ^ 1, :n, sl]
+    a = a.double().cpu()
+    assert float((a - ref).abs().max() / ref.abs().max()) < 1.2e-2 and float((a - old).abs().max() / ref.abs().max()) < 1.2e-2
