@@ -354,3 +354,29 @@ def test_attn_pw_bf16_operands(state_dict_np):
             ref[bs, :, sl] = torch.softmax((qb[bs, :, sl] * 0.125) @ kb[bs ^ 1, :n, sl].T, dim=-1) @ vb[bs ^ 1, :n, sl]
     a = a.double().cpu()
     assert float((a - ref).abs().max() / ref.abs().max()) < 1.2e-2 and float((a - old).abs().max() / ref.abs().max()) < 1.2e-2
+
+
+def test_attn_pw_on_a_ragged_batch_gives_the_small_grid_kernel_s_correspondences(state_dict_np):
+    """12 pairs padded to 1024 with very different keypoint counts per side (7 .. 1024: empty sub-tiles, partial last tiles, sides of one tile) through
+    the whole matcher + pose: the default (k_attn_pw on this grid) and k_attn16_v5 (knob 1 = 5) return the same correspondences and poses."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=12, max_kpts=1024, precision="f16x2_f16_attn", state_dict=state_dict_np)
+    rs = np.random.RandomState(11)
+    counts = [(1024, 1024), (7, 900), (1000, 33), (64, 64), (65, 129), (512, 1023), (300, 31), (1024, 5), (97, 1024), (640, 480), (33, 33), (959, 961)]
+    pairs = [make_pair(200 + i, n_q=nq, n_r=nr) for i, (nq, nr) in enumerate(counts)]
+    inp = eng.stage_inputs(pairs)
+    res = {}
+    try:
+        for var in (4, 5):
+            eng.lib.gn_debug_set_variant(eng.ctx, 1, var)
+            idx, score, n = (t.cpu().numpy().copy() for t in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+            out = eng.estimate(inp, K_MATRIX)
+            res[var] = (idx, n, out["ok"].cpu().numpy().copy(), out["R"].cpu().numpy().copy(), out["t"].cpu().numpy().copy())
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+    (i0, n0, ok0, R0, t0), (i1, n1, ok1, R1, t1) = res[4], res[5]
+    assert np.array_equal(n0, n1) and np.array_equal(ok0, ok1) and n0.max() > 300
+    for b in range(len(counts)):
+        assert np.array_equal(i0[b, : n0[b]], i1[b, : n1[b]]), b
+        if ok0[b]:
+            assert np.linalg.norm(R0[b] - R1[b]) < 1e-6 and np.linalg.norm(t0[b] - t1[b]) < 1e-5 * max(1.0, np.linalg.norm(t1[b]))
