@@ -109,6 +109,7 @@ struct gn_ctx {
   // internal streams, out of phase with each other (fork / join events around them on the caller's stream)
   int defer_join = 0, sub_last_B = 0, sub_last_np = 0;   // gn_set_deferred_join; shape of the last unjoined sub-stream call
   int sub_serial = 0;      // developer knob 26: the sub-batch groups run one after the other on ONE stream (a working set the size of the Infinity Cache) instead of concurrently
+  int cu_mask_mode = 0;    // developer knob 29
   int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
   int overlap = 0; unsigned long long calls = 0;
@@ -1118,7 +1119,18 @@ int gn_set_substreams(gn_ctx* ctx, int n) {
   if (n > 1 && !ctx->ev_fork) GN_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < n && n > 1; ++i)
     if (!ctx->sub_s[i]) {
-      GN_HIP(hipStreamCreateWithFlags(&ctx->sub_s[i], hipStreamNonBlocking));
+      if (ctx->cu_mask_mode != 0) {
+        // developer experiment (knob 29): every sub-batch stream on its own share of the CUs.  bit b of the mask = CU b of the device's enumeration:
+        // 1 = contiguous shares, 2 = interleaved (b % n), 3 = by XCD assuming b % 8 is the XCD (share g gets XCDs g, g + n, ...)
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < 256; ++b) {
+          const int share = ctx->cu_mask_mode == 1 ? b * n / 256 : ctx->cu_mask_mode == 2 ? b % n : (b % 8) % n;
+          if (share == i) mask[b >> 5] |= 1u << (b & 31);
+        }
+        GN_HIP(hipExtStreamCreateWithCUMask(&ctx->sub_s[i], 8, mask));
+      } else {
+        GN_HIP(hipStreamCreateWithFlags(&ctx->sub_s[i], hipStreamNonBlocking));
+      }
       GN_HIP(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
     }
   ctx->n_sub = n;
@@ -1710,6 +1722,12 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 26) ctx->sub_serial = value;
   else if (which == 27) gn::g_qkv_products = value;
   else if (which == 28) ctx->ffn_compose = value;
+  else if (which == 29) {   // CU shares for the sub-batch streams: takes effect for streams created afterwards
+    GN_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); ctx->sub_s[i] = nullptr; ctx->ev_join[i] = nullptr; }
+    ctx->cu_mask_mode = value;
+    if (ctx->n_sub > 1) { const int n = ctx->n_sub; ctx->n_sub = 1; return gn_set_substreams(ctx, n); }
+  }
   else return GN_ERR_ARG;
   return GN_OK;
 }
