@@ -13,7 +13,7 @@ from gisnav_amd.weights import synthetic_state_dict  # noqa: E402
 
 B = 32
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision="f16x2_bf16_attn", state_dict=synthetic_state_dict(0))
+eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision=os.environ.get("GN_PREC", "f16x2_f16_attn"), state_dict=synthetic_state_dict(0))
 inp = eng.stage_inputs([make_pair(i, n_q=1024 - (i % 5) * 17, n_r=1024 - (i % 3) * 29) for i in range(B)])
 args = (inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
 ref = None
