@@ -110,6 +110,8 @@ struct gn_ctx {
   int defer_join = 0, sub_last_B = 0, sub_last_np = 0;   // gn_set_deferred_join; shape of the last unjoined sub-stream call
   int sub_serial = 0;      // developer knob 26: the sub-batch groups run one after the other on ONE stream (a working set the size of the Infinity Cache) instead of concurrently
   int cu_mask_mode = 0;    // developer knob 29
+  int use_lists = 1;       // k_ffn128 / k_qkv / k_attn_pw walk the call's lists of tiles with valid tokens (developer knob 31 = 0: every tile, one workgroup each)
+  int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
   int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
   int overlap = 0; unsigned long long calls = 0;
@@ -380,6 +382,7 @@ bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int 
   q.rot4 = c->rot4; q.rot_stride = (long long)c->Tmax; q.qkb = c->qkb; q.ldyb = cross ? kDim : 2 * kDim; q.vt = c->vtb; q.npad = np;
   q.qscale = 0.125f; q.scale = 0.35355339059327373f; q.vt_perm = vt_perm; q.T = T;
   q.half_fmt = c->attn_f16; q.ovf = (c->attn_f16 && c->guard) ? c->ovf : nullptr;
+  q.tiles = (c->use_lists && c->lists && !c->qkv_stamps) ? c->lists : nullptr;
   q.dbg_ts = (c->qkv_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 20
   ++c->launch_count;
   if (c->stop_after && c->launch_count > c->stop_after) return true;
@@ -467,6 +470,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     const bool comp = fold && c->ffn_compose && blk.wfc && blk.b1c && !blk.comp_dirty;
     if (comp) { f.composed = 1; f.w1s = blk.wfc; f.w1_scale = blk.wfc_scale; f.b1 = blk.b1c; }
     f.ovf = c->guard ? c->ovf : nullptr;
+    f.tiles = (c->use_lists && c->lists && !(gn::g_ffn_ablate & 8)) ? c->lists : nullptr;
     f.dbg_ts = (gn::g_ffn_ablate & 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
     if (c->stop_after && c->launch_count > c->stop_after) return;
@@ -538,6 +542,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
       gemm(c, EPI_BIAS, g, s);
     }
   }
+  // the call's lists of tiles / query blocks that hold valid tokens (k_prep has written the per-slot counts)
+  if (c->use_lists && c->lists) launch_tile_lists(c->nvalid, BS, np, c->lists, s);
   for (int i = 0; i < c->n_layers; ++i) {
     {  // SelfBlock on both sides at once
       const Block& blk = c->self_blk[i];
@@ -559,7 +565,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16;
+        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -592,7 +598,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16;
+        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -676,6 +682,8 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
   GN_ALLOC(hyp_ws, B * 16);
   GN_ALLOC(ovf_base, 16);
   ctx->ovf = ctx->ovf_base;
+  ctx->lists_stride = gn::kTileListBase + 2 * (np / 128) + 8 * ((np + 255) / 256);
+  GN_ALLOC(lists, B * (size_t)ctx->lists_stride);
 #undef GN_ALLOC
   return GN_OK;
 }
@@ -1041,6 +1049,7 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   const long long km = c->npad;
   mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
   mv(c->mask_ws, km * 16); mv(c->hyp_ws, 16); mv(c->pts_ws, km * 5);
+  mv(c->lists, c->lists_stride);
 }
 
 int estimate_impl(gn_ctx* ctx, int B, int kpt_format,
@@ -1722,6 +1731,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 26) ctx->sub_serial = value;
   else if (which == 27) gn::g_qkv_products = value;
   else if (which == 28) ctx->ffn_compose = value;
+  else if (which == 31) ctx->use_lists = value;
   else if (which == 29) {   // CU shares for the sub-batch streams: takes effect for streams created afterwards
     GN_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); ctx->sub_s[i] = nullptr; ctx->ev_join[i] = nullptr; }

@@ -54,18 +54,25 @@ template <bool F16> __device__ __forceinline__ void mfma_v(f32x16& s, const bf16
 // 64 no score MFMAs, 256 no fragment reads, 524288 the rescale test without its branch; 8 = s_memtime stamps into a.part (results stay valid).
 // (Removing the V^T P^T MFMAs is not a usable probe: the probabilities become dead code and the compiler deletes their steps.)
 template <bool F16, int ABL>
-__global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a, int nitems) {
   constexpr int NDK = 4, NDV = 3, NW = 4, NQ = 2, IPW = 8 / NW;
   // K ring [NDK][64 keys][64], V^T ring [NDV][64 dims][64 keys], output slabs [NW][32 rows][kSlabPitch bytes]
   __shared__ __attribute__((aligned(1024))) unsigned short smem[(NDK + NDV) * kRing + NW * 32 * kSlabPitch / 2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // persistent form: one workgroup per CU walks the call's list of (slot, head, 256-query block) items that hold valid queries (or, without a list,
+  // every item).  XCD-aware order: workgroup L lives on XCD L & 7 and takes positions (L & 7) * (gridDim.x / 8) + (L >> 3) + gridDim.x * i of the list, so
+  // that the query blocks of one (slot, head) -- neighbours in the list -- run at the same time on the same L2.
+  const int gx = a.npad / (NW * 32 * NQ);
+  const int n_work = a.tiles != nullptr ? a.tiles[1] : nitems;
+  const int first = (int)(blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+#pragma unroll 1
+  for (int work = first; work < n_work; work += gridDim.x) {
+  int tid = threadIdx.x;      // opaque per iteration: nothing derived from it is hoisted out of the item loop (register budget)
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, ql = lane & 31;
   int qblk, h, bs;
-  {   // XCD-aware order: the query blocks of one (slot, head) share an L2
-    const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
-    const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+  {
+    const int v = a.tiles != nullptr ? a.tiles[kTileListBase + a.BS * (a.npad / 128) + work] : work;
     qblk = v % gx;
     const int g = v / gx;
     h = g % kHeads; bs = g / kHeads;
@@ -385,6 +392,9 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
         }
     }
   }
+  // the rings and the slab are free for the next item once every wave is here (and its LDS reads have returned)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!(ABL & 8)) continue;
   if (ABL & 8) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
@@ -394,31 +404,39 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a) {
       dst[6] = ntiles; dst[7] = 0;
     }
   }
+  }   // work
 }
 #undef GN_PIN
 }  // namespace
 
-// bulk grids only (npad % 256 == 0); false = not applicable, the caller launches k_attn16_v5
+// grids of whole 256-query blocks; false = not applicable, the caller launches k_attn16_v5
 bool launch_attention_pw(const AttnArgs& a, int ablate, hipStream_t s) {
   if (a.npad % 256 != 0 || a.qb == nullptr) return false;
-  const dim3 grid(a.npad / 256, kHeads, a.BS), block(256);
+  const int nitems = a.npad / 256 * kHeads * a.BS;
+  if (nitems < 8) return false;
+  static int ncu = 0;
+  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) ? pr.multiProcessorCount : 256; }
+  // one workgroup per CU (LDS and registers leave room for one) walks the work list; a multiple of the 8 XCDs.  The phase-stamp variants keep one
+  // workgroup per item (tools/attn_pw_ab.py reads one record per item).
+  const bool stamps = ablate == 3 || ablate >= 100;
+  const dim3 grid((unsigned)((stamps || nitems < ncu) ? (nitems & ~7) : (ncu & ~7))), block(256);
   if (a.half_fmt) {
-    if (ablate == 1) hipLaunchKernelGGL((k_attn_pw<true, 1>), grid, block, 0, s, a);
-    else if (ablate == 2) hipLaunchKernelGGL((k_attn_pw<true, 2>), grid, block, 0, s, a);
-    else if (ablate == 3 || ablate >= 100) {
+    if (ablate == 1) hipLaunchKernelGGL((k_attn_pw<true, 1>), grid, block, 0, s, a, nitems);
+    else if (ablate == 2) hipLaunchKernelGGL((k_attn_pw<true, 2>), grid, block, 0, s, a, nitems);
+    else if (stamps) {
       if (g_attn_stamps == nullptr) return false;
-      AttnArgs b = a; b.part = reinterpret_cast<float*>(g_attn_stamps);
-#define GN_PW_ABL(x) case x: hipLaunchKernelGGL((k_attn_pw<true, (x) | 8>), grid, block, 0, s, b); break;
+      AttnArgs b = a; b.part = reinterpret_cast<float*>(g_attn_stamps); b.tiles = nullptr;
+#define GN_PW_ABL(x) case x: hipLaunchKernelGGL((k_attn_pw<true, (x) | 8>), grid, block, 0, s, b, nitems); break;
       switch (ablate >= 100 ? ablate - 100 : 0) {
         GN_PW_ABL(0) GN_PW_ABL(1) GN_PW_ABL(2) GN_PW_ABL(4) GN_PW_ABL(6) GN_PW_ABL(16) GN_PW_ABL(32) GN_PW_ABL(48) GN_PW_ABL(64) GN_PW_ABL(256) GN_PW_ABL(524288) GN_PW_ABL(524320)
         default: return false;
       }
 #undef GN_PW_ABL
     }
-    else hipLaunchKernelGGL((k_attn_pw<true, 0>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_attn_pw<true, 0>), grid, block, 0, s, a, nitems);
     g_last_kernel = "k_attn_pw<true, 0>";
   } else {
-    hipLaunchKernelGGL((k_attn_pw<false, 0>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((k_attn_pw<false, 0>), grid, block, 0, s, a, nitems);
     g_last_kernel = "k_attn_pw<false, 0>";
   }
   return true;

@@ -129,6 +129,7 @@ struct FfnArgs {
   int T;                                   // tokens, a multiple of 64 (of 32 for the 4-wave shape)
   unsigned int* ovf;                       // f16x2 domain guard word, or nullptr
   long long* dbg_ts;                       // developer: [blocks][8 waves][8] s_memtime stamps (ablation 8), or nullptr
+  const int* tiles = nullptr;              // k_ffn128: work list of the call (launch_tile_lists), or nullptr = every 128-token tile of T
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s);   // gn_ffn128.hip: 128 tokens per workgroup (a.cp set, a.T % 128 == 0); ablate: developer knob 12
@@ -152,6 +153,7 @@ struct QkvArgs {
   int half_fmt;                       // 0: qkb / vt hold bf16; 1: fp16 (GN_PREC_F16X2_F16_ATTN)
   unsigned int* ovf;                  // half_fmt 1: domain guard word raised when a q / k / v value does not fit fp16, or nullptr
   long long* dbg_ts;                  // developer: nullptr, or [blocks][8 waves][8] s_memtime stamps
+  const int* tiles = nullptr;         // work list of the call (launch_tile_lists), or nullptr = every 128-token tile of T
 };
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
 extern int g_qkv_products;
@@ -177,7 +179,16 @@ struct AttnArgs {
   int nsplit = 1;            // k_attn_bf16_v5 on small grids: key ranges per (slot, head, query block), merged by the last workgroup to finish
   float* part = nullptr;     // [slot][head][query block][split][4 waves][34][64] partial results
   unsigned int* tickets = nullptr;   // [slot][head][query block], zero between launches
+  const int* tiles = nullptr;        // k_attn_pw: work list of the call (launch_tile_lists), or nullptr = every 256-query block of every (slot, head)
 };
+// Work lists of one matcher call (round 4): the 128-token tiles and the (slot, head, 256-query block) items that hold at least one valid token, in
+// ascending order.  Layout (ints): [0] number of tiles, [1] number of attention items, [kTileListBase ..) tile indices (token / 128), then at
+// [kTileListBase + T / 128 ..) the items ((slot * 4 + head) * (npad / 256) + block).  The kernels that take a list run as many workgroups as CUs and
+// walk it: tiles of padding cost nothing -- not even a workgroup dispatch (~40 ns each on this part, which is what skipping them inside the
+// workgroup still paid).  Rows of padding are never written by those kernels; they keep whatever finite values they had (the workspaces are
+// zero-initialised), and no valid token reads them (keys are masked, everything else is row-wise).
+constexpr int kTileListBase = 16;
+void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);

@@ -31,6 +31,7 @@
 // k_ffn_fused's for GEMM 0 and GEMM 1 (bitwise the same message and pre-LayerNorm values); the LayerNorm statistics, the last
 // multiply of the GELU (one fma instead of mul + add + mul) and GEMM 2's k order differ at rounding level.
 #include "gn_common.h"
+#include <algorithm>
 #include "gn_ffn_util.h"
 
 namespace gn {
@@ -57,9 +58,17 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   constexpr int CST = STAT + 4096;        // [2][512] floats: LayerNorm weight, LayerNorm bias
   constexpr int SMEM = 10 * KT;           // 163,840 B
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // persistent form: the workgroup walks the call's list of tiles that hold valid tokens (or, without a list, every gridDim.x-th tile of T)
+  const int n_work = a.tiles != nullptr ? a.tiles[0] : a.T / TM;
+#pragma unroll 1
+  for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+  // (the thread index is opaque per iteration: everything derived from it -- lane, wave, every address -- is then recomputed inside the body instead of
+  // being hoisted out of the loop, where it would live across the whole tile and push the kernel over its register budget)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
-  const int bm = blockIdx.x * TM;
+  const int bm = (a.tiles != nullptr ? a.tiles[kTileListBase + work] : work) * TM;
   long long ts[12], ts2[16];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (ABL & 8) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
@@ -677,12 +686,16 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
     if ((ABL & 128) && a.dbg_ts != nullptr && lane == 0)
       for (int k = 0; k < 16; ++k) a.dbg_ts[(size_t)gridDim.x * NW * 12 + ((size_t)blockIdx.x * NW + wave) * 16 + k] = ts2[k];
   }
+  __syncthreads();     // every wave is done with the tile store before the next tile is staged
+  }   // work
 }
 #undef GN_PIN
 }  // namespace
 
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
-  const dim3 grid(a.T / 128), block(256);
+  static int ncu = 0;
+  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  const dim3 grid(a.tiles != nullptr ? std::min(a.T / 128, ncu) : a.T / 128), block(256);     // one workgroup per CU walks the work list
   if (a.composed) {
     switch (ablate) {
       case 8: hipLaunchKernelGGL((k_ffn128<8, true>), grid, block, 0, s, a); break;

@@ -303,4 +303,36 @@ void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s
   hipLaunchKernelGGL(k_cast_bf16, dim3(2048), dim3(256), 0, s, in, out, n);
 }
 
+namespace {
+// one workgroup; BS <= a few hundred slots
+__global__ __launch_bounds__(256) void k_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists) {
+  __shared__ int off_t[1025], off_a[1025];
+  const int gx = npad / 256, tps = npad / 128;
+  if (threadIdx.x == 0) {
+    int t = 0, a = 0;
+    for (int s = 0; s < BS; ++s) {
+      off_t[s] = t; off_a[s] = a;
+      const int n = min(max(nvalid[s], 0), npad);
+      t += (n + 127) / 128;
+      a += gx > 0 && npad % 256 == 0 ? 4 * ((n + 255) / 256) : 0;
+    }
+    off_t[BS] = t; off_a[BS] = a;
+    lists[0] = t; lists[1] = a;
+  }
+  __syncthreads();
+  int* const tl = lists + kTileListBase;
+  int* const al = tl + BS * tps;
+  for (int s = threadIdx.x; s < BS; s += 256) {
+    const int nt = off_t[s + 1] - off_t[s];
+    for (int i = 0; i < nt; ++i) tl[off_t[s] + i] = s * tps + i;
+    const int nb = (off_a[s + 1] - off_a[s]) / 4;
+    for (int h = 0; h < 4; ++h)
+      for (int i = 0; i < nb; ++i) al[off_a[s] + h * nb + i] = (s * 4 + h) * gx + i;
+  }
+}
+}  // namespace
+void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, hipStream_t s) {
+  hipLaunchKernelGGL(k_tile_lists, dim3(1), dim3(256), 0, s, nvalid, BS, npad, lists);
+}
+
 }  // namespace gn

@@ -13,6 +13,7 @@
 // 8 waves x 128 tokens per workgroup; wave w owns feature tile w of every pass (see below).  Arithmetic: hm16 scheme, three
 // v_mfma_f32_32x32x16_f16 per block.
 #include "gn_common.h"
+#include <algorithm>
 
 namespace gn {
 
@@ -43,9 +44,16 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   constexpr int NQK = CROSS ? kDim : 2 * kDim;      // q | k (or qk) features
   constexpr int NPASS = CROSS ? 2 : 3;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * KT + (CROSS ? 0 : 32768)];   // token tile (128 KB) + the self block's rotary entries
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_work = a.tiles != nullptr ? a.tiles[0] : a.T / TM;     // persistent form: see k_ffn128
+#pragma unroll 1
+  for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+  // (the thread index is opaque per iteration: everything derived from it -- lane, wave, every address -- is then recomputed inside the body instead of
+  // being hoisted out of the loop, where it would live across the whole tile and push the kernel over its register budget)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
-  const int bm = blockIdx.x * TM;
+  const int bm = (a.tiles != nullptr ? a.tiles[kTileListBase + work] : work) * TM;
   long long ts[8];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg_ts) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
@@ -222,6 +230,8 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
   if (a.dbg_ts && lane == 0) {   // developer: s_memtime phase stamps per wave
     for (int k = 0; k < 8; ++k) a.dbg_ts[((size_t)blockIdx.x * 8 + wave) * 8 + k] = ts[k];
   }
+  __syncthreads();     // the token tile is free again
+  }   // work
 }
 }  // namespace
 
@@ -232,7 +242,9 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
 // Developer knob 27 = 3 restores the third product.  (The block tail and the match head keep all three: their outputs are f32-accurate values.)
 int g_qkv_products = 2;
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s) {
-  const dim3 grid(a.T / TM), block(512);
+  static int ncu = 0;
+  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  const dim3 grid(a.tiles != nullptr ? std::min(a.T / TM, ncu) : a.T / TM), block(512);
   const int sel = (a.half_fmt ? 4 : 0) | (cross ? 2 : 0) | (g_qkv_products == 2 ? 1 : 0);
   switch (sel) {
     case 7: hipLaunchKernelGGL((k_qkv<true, true, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, true, 2>"; break;

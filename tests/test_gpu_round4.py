@@ -139,6 +139,10 @@ def test_ffn128_matches_the_64_token_tail_and_is_bitwise_repeatable(state_dict_n
             idx, score, n = (v.cpu().numpy().copy() for v in eng.match(*args))
             x = eng.debug_read("x", T * 256).copy()
             out.setdefault(shape, []).append((idx, score, n, x))
+        # rows of VALID tokens only: tiles that hold nothing but padding are not processed by the list-walking kernels (their rows keep older values)
+        nv = np.concatenate([[len(p.kp_q), len(p.kp_r)] for p in pairs])
+        valid = (np.arange(1024)[None, :] < nv[:, None]).reshape(-1)
+        out = {k: [(i, sc, n, x.reshape(T, 256)[valid]) for (i, sc, n, x) in v] for k, v in out.items()}
         (i1, s1, n1, x1), (i0, s0, n0, x0) = out[128][0], out[64][0]
         assert np.array_equal(n0, n1) and (n0 > 200).all()
         for b in range(8):
@@ -380,3 +384,13 @@ def test_attn_pw_on_a_ragged_batch_gives_the_small_grid_kernel_s_correspondences
         assert np.array_equal(i0[b, : n0[b]], i1[b, : n1[b]]), b
         if ok0[b]:
             assert np.linalg.norm(R0[b] - R1[b]) < 1e-6 and np.linalg.norm(t0[b] - t1[b]) < 1e-5 * max(1.0, np.linalg.norm(t1[b]))
+    # the work lists (k_ffn128 / k_qkv / k_attn_pw walk the tiles that hold valid tokens; knob 31 = 0: every tile): bit-identical results
+    try:
+        eng.lib.gn_debug_set_variant(eng.ctx, 31, 0)
+        idx, score, n = (t.cpu().numpy().copy() for t in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+        out = eng.estimate(inp, K_MATRIX)
+        R2, t2 = out["R"].cpu().numpy().copy(), out["t"].cpu().numpy().copy()
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 31, 1)
+    assert np.array_equal(n, n0) and all(np.array_equal(idx[b, : n[b]], i0[b, : n0[b]]) for b in range(len(counts)))
+    assert all(np.array_equal(R2[b], R0[b]) and np.array_equal(t2[b], t0[b]) for b in range(len(counts)) if ok0[b])
