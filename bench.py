@@ -201,6 +201,7 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / steps
 
+    eng.set_ragged(True)       # the caller of a ragged batch knows it is one (it holds the counts): block tail as a walk over the non-empty tiles
     eng.set_active_kpts(int(max(n_q.max(), n_r.max())))
     t_one = timed(lambda: eng.estimate(inp, K_MATRIX, out=out_a))
     eng.set_active_kpts(eng.kmax)

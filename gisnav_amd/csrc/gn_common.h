@@ -130,6 +130,9 @@ struct FfnArgs {
   unsigned int* ovf;                       // f16x2 domain guard word, or nullptr
   long long* dbg_ts;                       // developer: [blocks][8 waves][8] s_memtime stamps (ablation 8), or nullptr
   const int* tiles = nullptr;              // k_ffn128: work list of the call (launch_tile_lists), or nullptr = every 128-token tile of T
+  int walk = 0;                            // 1: one workgroup per CU walks `tiles`; 0: one workgroup per tile of T, which leaves at once when `tiles` says (through
+                                           // nvalid / npad) that its tile holds only padding
+  const int32_t* nvalid = nullptr; int npad = 0;
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s);   // gn_ffn128.hip: 128 tokens per workgroup (a.cp set, a.T % 128 == 0); ablate: developer knob 12

@@ -49,8 +49,8 @@ __device__ __forceinline__ float resid_hi(unsigned int h, float y) { float r; as
 
 // COMP: out_proj is composed into ffn.0 at load time (W1' = [W1_x | W1_m Wo], b1' = b1 + W1_m bo: gn_api.hip build_composed) -- no GEMM 0, no message
 // tile: GEMM 1 runs over [x | ctx], all sixteen k-tiles through the ring
-template <int ABL, bool COMP>   // timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
-__global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
+template <int ABL, bool COMP, bool LOOP = false>   // LOOP: the workgroup walks the work list (one workgroup per CU); timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
+__global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
   constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
   constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 128 token rows (hm16: 128 B per row)
   constexpr int RING = 8 * KT;            // two staging slots behind the message tile
@@ -59,9 +59,21 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   constexpr int SMEM = 10 * KT;           // 163,840 B
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   // persistent form: the workgroup walks the call's list of tiles that hold valid tokens (or, without a list, every gridDim.x-th tile of T)
-  const int n_work = a.tiles != nullptr ? a.tiles[0] : a.T / TM;
+  // LOOP = false is the one-tile kernel: the loop below is left after its first pass, and the compiler keeps nothing alive around it (the walking
+  // form holds the arguments and the loop state in scalar registers through the weight streams: a few spills, ~5 % slower per tile)
+  const int n_work = a_in.tiles != nullptr ? a_in.tiles[0] : a_in.T / TM;
 #pragma unroll 1
   for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the walking form reads its arguments from the kernel-argument segment again for every tile (through a pointer the compiler cannot see through), so
+  // that they are not held in scalar registers across the loop
+  typedef __attribute__((address_space(4))) const FfnArgs* karg_t;
+  karg_t ap = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  if (LOOP) asm volatile("" : "+s"(ap));
+  const FfnArgs a = *ap;
+#else
+  const FfnArgs a = a_in;
+#endif
   // (the thread index is opaque per iteration: everything derived from it -- lane, wave, every address -- is then recomputed inside the body instead of
   // being hoisted out of the loop, where it would live across the whole tile and push the kernel over its register budget)
   int tid = threadIdx.x;
@@ -72,6 +84,19 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
   long long ts[12], ts2[16];
   auto stamp = [&](int k) __attribute__((always_inline)) { if (ABL & 8) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
   stamp(0);
+  if (!LOOP && a.nvalid != nullptr) {
+    // one-tile form: a tile that holds only padding (tokens at or behind its slot's valid count) leaves at once -- its rows of the residual stream
+    // stay as they are (finite; no valid token reads them: keys are masked, everything else is row-wise); only an f32 copy wanted by the caller
+    // (the last block's, read by the match head) is defined: zeros.  (Still one workgroup dispatch per skipped tile, ~40 ns each.)
+    const int slot = bm / a.npad;
+    if (bm - slot * a.npad >= a.nvalid[slot]) {
+      if (a.y != nullptr) {
+        float4* dst = reinterpret_cast<float4*>(a.y + (size_t)bm * kDim);
+        for (int i = tid; i < TM * kDim / 4; i += 256) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+  }
   f32x4 b1q = {0.f, 0.f, 0.f, 0.f};      // ffn.0's bias, requested first: it is needed after GEMM 0 (see below)
   if (tid < 128) b1q = *reinterpret_cast<const f32x4*>(a.b1 + 4 * tid);
 
@@ -686,6 +711,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
     if ((ABL & 128) && a.dbg_ts != nullptr && lane == 0)
       for (int k = 0; k < 16; ++k) a.dbg_ts[(size_t)gridDim.x * NW * 12 + ((size_t)blockIdx.x * NW + wave) * 16 + k] = ts2[k];
   }
+  if (!LOOP) break;
   __syncthreads();     // every wave is done with the tile store before the next tile is staged
   }   // work
 }
@@ -695,22 +721,26 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a) {
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
   static int ncu = 0;
   if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-  const dim3 grid(a.tiles != nullptr ? std::min(a.T / 128, ncu) : a.T / 128), block(256);     // one workgroup per CU walks the work list
+  const bool walk = a.tiles != nullptr && a.walk && ablate == 0;
+  const dim3 grid(walk ? std::min(a.T / 128, ncu) : a.T / 128), block(256);     // walking form: one workgroup per CU
+  FfnArgs b = a;
+  if (!walk) b.tiles = nullptr;
+  if (walk || ablate != 0) b.nvalid = nullptr;
   if (a.composed) {
     switch (ablate) {
-      case 8: hipLaunchKernelGGL((k_ffn128<8, true>), grid, block, 0, s, a); break;
-      case 136: hipLaunchKernelGGL((k_ffn128<136, true>), grid, block, 0, s, a); break;
-      default: hipLaunchKernelGGL((k_ffn128<0, true>), grid, block, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((k_ffn128<8, true>), grid, block, 0, s, b); break;
+      case 136: hipLaunchKernelGGL((k_ffn128<136, true>), grid, block, 0, s, b); break;
+      default: if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true>), grid, block, 0, s, b); break;
     }
-    g_last_kernel = "k_ffn128<0, true>";
+    g_last_kernel = walk ? "k_ffn128<0, true, true>" : "k_ffn128<0, true, false>";
     return;
   }
   switch (ablate) {
-    case 8: hipLaunchKernelGGL((k_ffn128<8, false>), grid, block, 0, s, a); break;
-    case 136: hipLaunchKernelGGL((k_ffn128<136, false>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_ffn128<0, false>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_ffn128<8, false>), grid, block, 0, s, b); break;
+    case 136: hipLaunchKernelGGL((k_ffn128<136, false>), grid, block, 0, s, b); break;
+    default: if (walk) hipLaunchKernelGGL((k_ffn128<0, false, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, false>), grid, block, 0, s, b); break;
   }
-  g_last_kernel = "k_ffn128<0, false>";
+  g_last_kernel = walk ? "k_ffn128<0, false, true>" : "k_ffn128<0, false, false>";
 }
 
 }  // namespace gn

@@ -347,6 +347,12 @@ class PoseEngine:
         r = io["host_np"]
         return (r[0:72].view(np.float64).reshape(3, 3).copy(), r[72:96].view(np.float64).reshape(3, 1).copy(), int(r[100:104].view(np.int32)[0]), bool(r[104]))
 
+    def set_ragged(self, ragged: bool) -> None:
+        """Workload hint.  The big kernels skip tiles that hold only padding either way; with `ragged=True` the block tail also runs as one workgroup
+        per CU walking the list of non-empty tiles (no dispatch per skipped tile): ~20 % faster on batches whose keypoint counts differ a lot
+        (an unbounded cv2.SIFT_create(), pose_node.py:122), 3 % slower per launch on batches without padding -- hence a hint, not the default."""
+        _lib.check(self.ctx, self.lib.gn_debug_set_variant(self.ctx, 31, 2 if ragged else 1), "gn_debug_set_variant(31)")
+
     def set_overlap(self, enable: bool) -> None:
         """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
         before reading R / t / n_inliers / ok."""

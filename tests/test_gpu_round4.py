@@ -385,12 +385,14 @@ def test_attn_pw_on_a_ragged_batch_gives_the_small_grid_kernel_s_correspondences
         if ok0[b]:
             assert np.linalg.norm(R0[b] - R1[b]) < 1e-6 and np.linalg.norm(t0[b] - t1[b]) < 1e-5 * max(1.0, np.linalg.norm(t1[b]))
     # the work lists (k_ffn128 / k_qkv / k_attn_pw walk the tiles that hold valid tokens; knob 31 = 0: every tile): bit-identical results
-    try:
-        eng.lib.gn_debug_set_variant(eng.ctx, 31, 0)
-        idx, score, n = (t.cpu().numpy().copy() for t in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
-        out = eng.estimate(inp, K_MATRIX)
-        R2, t2 = out["R"].cpu().numpy().copy(), out["t"].cpu().numpy().copy()
-    finally:
-        eng.lib.gn_debug_set_variant(eng.ctx, 31, 1)
-    assert np.array_equal(n, n0) and all(np.array_equal(idx[b, : n[b]], i0[b, : n0[b]]) for b in range(len(counts)))
-    assert all(np.array_equal(R2[b], R0[b]) and np.array_equal(t2[b], t0[b]) for b in range(len(counts)) if ok0[b])
+    # (knob 31 = 2 = PoseEngine.set_ragged(True): the block tail walks the list as well, one workgroup per CU)
+    for lists in (0, 2):
+        try:
+            eng.lib.gn_debug_set_variant(eng.ctx, 31, lists)
+            idx, score, n = (t.cpu().numpy().copy() for t in eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"]))
+            out = eng.estimate(inp, K_MATRIX)
+            R2, t2 = out["R"].cpu().numpy().copy(), out["t"].cpu().numpy().copy()
+        finally:
+            eng.lib.gn_debug_set_variant(eng.ctx, 31, 1)
+        assert np.array_equal(n, n0) and all(np.array_equal(idx[b, : n[b]], i0[b, : n0[b]]) for b in range(len(counts))), lists
+        assert all(np.array_equal(R2[b], R0[b]) and np.array_equal(t2[b], t0[b]) for b in range(len(counts)) if ok0[b]), lists
