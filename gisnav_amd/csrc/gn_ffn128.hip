@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
             acc2[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[c % RG][o][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc2[o][j], 0, 0, 0);
             // the VALU stage of the next quarter's fragment (token tile w4, k-step ks) that shares this MFMA's gap
             if (fill && m < 22) gelu_stage(m, q + 1, w4, ks);
-            if (q == 3 && m == 2) res_load(cc);
+            if (q == 3 && m == 2 && !LOOP) res_load(cc);      // (walking form: the registers are not there, all residual rows are requested in the epilogue)
             if (!(ABL & 1) && m % 6 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 6) >> 1, (m / 6) & 1);
             GN_PIN();
           }
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
   // (the hidden buffers are dead: their space becomes the [128 tokens][256 features] f32 tile of the row-wise epilogue)
   float* const yt = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int it = RW / 4; it < RW / 2; ++it) res_load(it);     // second half of the residual rows (the first was requested during quarter 3)
+  for (int it = LOOP ? 0 : RW / 4; it < RW / 2; ++it) res_load(it);     // second half of the residual rows (the first was requested during quarter 3)
 #pragma unroll
   for (int o = 0; o < NO; ++o)
 #pragma unroll
