@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
 
   // wave w: output features 64 w ..; k-steps are visited quarter by quarter: sequence number c = 8 q + 2 w' + ks -> weight k-step 8 w' + 2 q + ks
   const __amdgpu_buffer_rsrc_t w2b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w2s) + (size_t)(NO * wave) * 32 * 2 * 512, 0, NO * 32 * 2 * 1024, 0x00020000);        // output tile NO w + o: 1 KB block ((tile * 32 + kstep) * 2 + term)
-  constexpr int RG = LOOP ? 5 : 6;      // (walking form: one slot less -- 16 registers -- keeps the LayerNorm constants of the last two quarters out of scratch)
+  constexpr int RG = 5;      // W2 k-tiles in flight.  (Six cost 16 more registers: the LayerNorm constants of the last two quarters then went to scratch and their
+                             // reload in the middle of GEMM 2 drained the ring: 164 -> 162 us with five, same bits.)
   f16x8 ga[RG][NO][2];
   auto load_g = [&](int slot, int c, int o, int pl) __attribute__((always_inline)) {
     const int kstep = 8 * ((c >> 1) & 3) + 2 * (c >> 3) + (c & 1);
