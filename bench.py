@@ -201,7 +201,7 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / steps
 
-    eng.set_ragged(True)       # the caller of a ragged batch knows it is one (it holds the counts): block tail as a walk over the non-empty tiles
+    # (no set_ragged hint: the library picks the block tail's form from the padding its previous call saw -- the warm-up calls -- DESIGN 12)
     eng.set_active_kpts(int(max(n_q.max(), n_r.max())))
     t_one = timed(lambda: eng.estimate(inp, K_MATRIX, out=out_a))
     eng.set_active_kpts(eng.kmax)
@@ -405,6 +405,45 @@ def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, gra
     return res
 
 
+def precision_guarantee(precision: str) -> dict:
+    """Index-mismatch counts of the precision mode against the CPU restatement of the reference -- READ from the report the -m gpu parity tests wrote
+    (tests/test_gpu_round5.py -> gpurun_out/parity_r05.json, committed as profiles/r05_parity_report.json), never typed in: the report carries the
+    digest of the sources it was measured on and `same_build` says whether that is the library this run loaded."""
+    from gisnav_amd.build import source_digest
+    out = {"mode": precision, "index_exact": "guaranteed" if precision == "f32" else "tolerance mode",
+           "note": "north_star asks for bit-exact correspondence indices: GN_PREC_F32 guarantees them (f32 MFMA everywhere; extra_configs carries its batch-32 "
+                   "throughput).  The headline mode computes in the reference's CUDA arithmetic class (fp32-accurate linear layers except the two-product q/k/v "
+                   "projections named in `dtype`, half-precision SDPA); counts below are symmetric differences of the match sets, headline KERNELS "
+                   "(k_qkv<.,.,2> + k_attn_pw + composed k_ffn128, asserted from the launch table), against the oracle",
+           "library_source_digest": source_digest()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_parity_report.json")
+    try:
+        with open(path) as f:
+            rep = json.load(f)
+    except (OSError, ValueError) as exc:
+        out["report"] = f"not available ({exc.__class__.__name__}): no counts are claimed for this run"
+        return out
+    out["report"] = "profiles/r05_parity_report.json"
+    out["report_source_digest"] = rep.get("source_digest")
+    out["same_build"] = rep.get("source_digest") == out["library_source_digest"]
+
+    def frac(row):
+        return f"{row['index_mismatches']} / {row['oracle_matches']}" if isinstance(row, dict) and "index_mismatches" in row else None
+    counts = {}
+    for key in ("forced_4x512_low_margin", "forced_4x512_mid_margin"):
+        t = rep.get(key) or {}
+        counts[key] = {k: frac(v) for k, v in t.items() if frac(v)}
+    for key in ("bulk_16x1024_low_margin", "bulk_16x1024_mid_margin"):
+        counts[key] = frac(rep.get(key))
+    rag = rep.get("ragged_16_pairs_u400_2500") or {}
+    counts["ragged_16_pairs_u400_2500_margin_built_weights"] = {k: frac(v) for k, v in rag.items() if frac(v)}
+    out["index_mismatches_vs_oracle"] = counts
+    out["source"] = "tests/test_gpu_round5.py (asserted: f32 = 0; headline kernels <= 1 % on low- / mid-margin weights, <= 0.1 % on the ragged bulk batch)"
+    if not out["same_build"]:
+        out["warning"] = "the report was measured on other sources than the library this run loaded: re-run `pytest -m gpu tests/test_gpu_round5.py` and copy gpurun_out/parity_r05.json"
+    return out
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -417,39 +456,50 @@ def _cpu_model() -> str:
 
 
 def cpu_baseline(state_dict, kpts: int, seconds_budget: float = 20.0):
-    """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a
-    bounded sample of the same workload."""
+    """The oracle (restated reference: torch-CPU LightGlue-sift + numpy solvePnPRansac) timed on this box's host cores, on a bounded sample of the
+    same workload -- twice: with every hardware thread the process may use (`torch.set_num_threads(os.cpu_count())`) and with a
+    32-thread cap (the 1024 x 256-sized CPU GEMMs of one pair stop scaling long before 256 threads).  `value` is the FASTER of the two (the baseline
+    gets the benefit of the doubt); both are printed."""
     from oracle import lightglue_sift as lg
     from oracle import pnp_ransac as pr
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, 32)))   # beyond 32 threads the 1024x256-sized CPU GEMMs of one pair only lose time to synchronisation
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in state_dict.items()}
     tq = torch.from_numpy
-    times, poses = [], 0
-    i = 0
-    t_start = time.perf_counter()
-    while True:
-        p = make_pair(10_000 + i, n_q=kpts, n_r=kpts)
-        t0 = time.perf_counter()
-        mq, mr, _, _ = lg.pose_node_match(sd, tq(p.kp_q), tq(p.desc_q), tq(p.size_q), tq(p.angle_q),
-                                          tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r))
-        if len(mq) >= 15:
-            poses += pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem) is not None
-        dt = time.perf_counter() - t0
-        if i >= 1:  # first pair is warm-up
-            times.append(dt)
-        i += 1
-        if (len(times) >= 3 and time.perf_counter() - t_start > seconds_budget) or time.perf_counter() - t_start > 6 * seconds_budget:
-            break
-    med = float(np.median(times))
-    res = {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{len(times)} synthetic 640x480 pairs ({kpts} kpts/side) after 1 warm-up pair, median; "
-                     f"torch-CPU fp32 LightGlue-sift restatement + numpy solvePnPRansac restatement (oracle/); "
+
+    def leg(threads, budget):
+        torch.set_num_threads(max(1, threads))
+        times, poses, i = [], 0, 0
+        t_start = time.perf_counter()
+        while True:
+            p = make_pair(10_000 + i, n_q=kpts, n_r=kpts)
+            t0 = time.perf_counter()
+            mq, mr, _, _ = lg.pose_node_match(sd, tq(p.kp_q), tq(p.desc_q), tq(p.size_q), tq(p.angle_q),
+                                              tq(p.kp_r), tq(p.desc_r), tq(p.size_r), tq(p.angle_r))
+            if len(mq) >= 15:
+                poses += pr.compute_pose(K_MATRIX.reshape(-1), mq.numpy(), mr.numpy(), p.dem) is not None
+            dt = time.perf_counter() - t0
+            if i >= 1:  # first pair is warm-up
+                times.append(dt)
+            i += 1
+            if (len(times) >= 3 and time.perf_counter() - t_start > budget) or time.perf_counter() - t_start > 6 * budget:
+                break
+        med = float(np.median(times))
+        return {"threads": torch.get_num_threads(), "value": round(1.0 / med, 4), "unit": "pairs/s", "pairs_timed": len(times), "median_s_per_pair": round(med, 4)}
+
+    legs = [leg(avail, seconds_budget / 2)]
+    if avail > 32:
+        legs.append(leg(32, seconds_budget / 2))
+    best = max(legs, key=lambda r: r["value"])
+    torch.set_num_threads(best["threads"])
+    res = {"value": best["value"], "unit": "pairs/s", "cores": best["threads"], "kind": "port",
+           "sample": f"{best['pairs_timed']} synthetic 640x480 pairs ({kpts} kpts/side) after 1 warm-up pair, median, at {best['threads']} threads (the faster of "
+                     f"the thread counts in by_threads); torch-CPU fp32 LightGlue-sift restatement + numpy solvePnPRansac restatement (oracle/); "
                      f"cpu={_cpu_model()}",
-           "cpu_model": _cpu_model(), "threads_used": torch.get_num_threads(), "threads_available": avail}
+           "by_threads": legs,
+           "cpu_model": _cpu_model(), "threads_used": best["threads"], "threads_available": avail, "os_cpu_count": os.cpu_count()}
     try:   # the same host cores on configs[1] as worded (the LoFTR restatement, oracle/loftr.py): one warm-up forward, one timed
         from oracle import loftr as olf
         sdl = olf.synthetic_state_dict(0)
@@ -649,23 +699,16 @@ def main() -> None:
                       "bf16_attn": "f32 projections/FFN/match-head + bf16 MFMA attention (f32 accumulate)",
                       "f32x3_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split exactly into 3 bf16 terms, "
                                          "6 bf16 MFMA partial products, f32 accumulate) + bf16 MFMA attention (f32 accumulate)",
-                      "f16x2_bf16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
-                                         "significant bits, 3 fp16 MFMA partial products, f32 accumulate; error vs fp64 <= the f32 "
-                                         "MFMA path's; fp16-range guard active) + bf16 MFMA attention (f32 accumulate)",
-                      "f16x2_f16_attn": "f32-accurate projections/FFN/match-head (each f32 operand split into 2 fp16 terms = 22 "
-                                        "significant bits, 3 fp16 MFMA partial products, f32 accumulate; fp16-range guard active) + "
+                      "f16x2_bf16_attn": "f32-accurate FFN / out-projection / match-head GEMMs (each f32 operand split into 2 fp16 terms = 22 significant bits, 3 fp16 MFMA "
+                                         "partial products, f32 accumulate; fp16-range guard active); attention INPUT projections (q, k, v: 18 of 66 launches) on 2 partial "
+                                         "products -- the fp16 high term of the activations (11 bits) times the 22-bit weights, outputs rounded to bf16 for the attention; "
+                                         "bf16 MFMA attention (f32 softmax / accumulate)",
+                      "f16x2_f16_attn": "f32-accurate FFN / out-projection / match-head GEMMs (each f32 operand split into 2 fp16 terms = 22 significant bits, 3 fp16 MFMA "
+                                        "partial products, f32 accumulate; fp16-range guard active); attention INPUT projections (q, k, v: 18 of 66 launches) on 2 partial "
+                                        "products -- the fp16 high term of the activations (11 bits) times the 22-bit weights, one rounding more than half(fp32 Linear(x)); "
+                                        "their outputs are rounded to fp16 for the attention either way (10.5 % of the q/k/v values move by one fp16 ulp, DESIGN 10.3) --; "
                                         "fp16 MFMA attention (q, k, v, p rounded to fp16 like the reference's CUDA SDPA; f32 softmax / accumulate)"}[args.precision],
-            "precision_guarantee": {
-                "mode": args.precision,
-                "index_exact": "guaranteed" if args.precision == "f32" else "tolerance mode",
-                "note": "north_star asks for bit-exact correspondence indices: GN_PREC_F32 guarantees them (f32 MFMA everywhere; extra_configs carries its batch-32 "
-                        "throughput).  The headline mode computes what the reference's own CUDA path computes (fp32-accurate linear layers, half-precision SDPA) and "
-                        "is index-identical to the f32 CPU restatement of the reference on all 32 bench pairs and on mid-margin weights; on LOW-margin synthetic weights it differs in a few "
-                        "decisions per thousand, like the reference's CUDA path differs from its CPU path",
-                "low_margin_index_mismatches": {"f32": "0 / 1220", "f16x2_f16_attn": "0 / 1220", "f16x2_bf16_attn": "6 / 1220",
-                                                "mid_margin": "0 / 687 (bf16 attention: 1 / 687)",
-                                                "source": "tests/test_gpu_parity2.py::test_low_margin_weights_index_mismatch_counts_per_precision (asserted <= 5 %), "
-                                                          "profiles/r04_parity_report*.json (the reports the -m gpu tests wrote this round)"}},
+            "precision_guarantee": precision_guarantee(args.precision),
             "data": "synthetic",
             "inputs_resident": True,
             "debug_variant": list(args.debug_variant),

@@ -54,6 +54,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_digest() -> str:
+    """16 hex digits over everything that decides the device code: every csrc/*.hip and *.h, the public header, and the compile flags.  The -m gpu
+    parity tests stamp their report with it and bench.py prints the report's mismatch counts only as belonging to the build whose digest matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join("..", "..", "include", "gisnav_amd.h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read() + b"\0")
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, "gn_common.h"), os.path.join(HERE, "..", "include", "gisnav_amd.h")]
     objs = []

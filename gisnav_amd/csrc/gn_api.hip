@@ -110,8 +110,13 @@ struct gn_ctx {
   int defer_join = 0, sub_last_B = 0, sub_last_np = 0;   // gn_set_deferred_join; shape of the last unjoined sub-stream call
   int sub_serial = 0;      // developer knob 26: the sub-batch groups run one after the other on ONE stream (a working set the size of the Infinity Cache) instead of concurrently
   int cu_mask_mode = 0;    // developer knob 29
-  int use_lists = 1;       // knob 31.  1: k_qkv / k_attn_pw walk the call's lists of tiles with valid tokens, k_ffn128 keeps one workgroup per tile (padding-only tiles
-                           // leave at once); 2: k_ffn128 walks the list too (3 % slower per tile on a batch without padding, 20 % faster on a ragged one); 0: every tile
+  int use_lists = 1;       // knob 31.  0: every tile.  1 (default): k_qkv / k_attn_pw walk the call's lists of tiles with valid tokens, and the block tail k_ffn128
+                           // chooses its form from the padding the SAME group's previous call had (tile_feedback): one workgroup per tile (padding-only tiles leave
+                           // at once) while >= 90 % of the tiles hold tokens, else one workgroup per CU walking the list (3 % slower per tile on a batch without
+                           // padding, 20 % faster on a ragged one; identical bits).  2: always walk.  3: never walk.
+  int ncu = 256;           // compute units of ctx->device (grids of the walking kernels)
+  int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
+  unsigned long long* tile_feedback = nullptr;   // pinned host [8]: (all tiles << 32 | valid tiles) written by k_tile_lists of sub-batch group g's last call
   int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
   int n_sub = 1; hipStream_t sub_s[8] = {}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[8] = {}; bool sub_pending[8] = {};
   // overlapped pose stage (gn_set_overlap): PnP of call n runs on an internal stream beside the matcher of call n+1
@@ -384,6 +389,7 @@ bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int 
   q.qscale = 0.125f; q.scale = 0.35355339059327373f; q.vt_perm = vt_perm; q.T = T;
   q.half_fmt = c->attn_f16; q.ovf = (c->attn_f16 && c->guard) ? c->ovf : nullptr;
   q.tiles = (c->use_lists && c->lists && !c->qkv_stamps) ? c->lists : nullptr;
+  q.products = c->qkv_products == 3 ? 3 : 2; q.ncu = c->ncu;
   q.dbg_ts = (c->qkv_stamps && c->sim) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer knob 20
   ++c->launch_count;
   if (c->stop_after && c->launch_count > c->stop_after) return true;
@@ -460,6 +466,17 @@ bool tail_folds_out_proj(const gn_ctx* c, const Block& blk, int T) {
          T % 64 == 0 && c->precision != GN_PREC_F32 && c->attn_variant >= 1;   // needs the attention kernel's hm16 output rows (ctx_p)
 }
 
+// The block tail's form on this call, predicted from the same sub-batch group's previous call (k_tile_lists leaves (all tiles, valid tiles) in pinned
+// host memory; read without synchronisation, so the word is from some earlier call -- workloads are stationary, and both forms give the same bits).
+bool tail_should_walk(const gn_ctx* c) {
+  if (!c->tile_feedback) return false;
+  const int g = (int)(c->ovf - c->ovf_base);
+  if (g < 0 || g >= 8) return false;
+  const unsigned long long w = __atomic_load_n(&c->tile_feedback[g], __ATOMIC_RELAXED);
+  const unsigned all = (unsigned)(w >> 32), valid = (unsigned)w;
+  return all > 0 && (unsigned long long)valid * 10u < (unsigned long long)all * 9u;
+}
+
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
 void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
   if (c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && blk.ffn0.wf && blk.ffn3.wf && T % 64 == 0) {   // the whole tail in one launch
@@ -472,7 +489,8 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     if (comp) { f.composed = 1; f.w1s = blk.wfc; f.w1_scale = blk.wfc_scale; f.b1 = blk.b1c; }
     f.ovf = c->guard ? c->ovf : nullptr;
     f.tiles = (c->use_lists && c->lists && !(gn::g_ffn_ablate & 8)) ? c->lists : nullptr;
-    f.walk = c->use_lists >= 2;
+    f.walk = c->use_lists == 2 || (c->use_lists == 1 && tail_should_walk(c));
+    f.ncu = c->ncu;
     if (c->use_lists) { f.nvalid = c->nvalid; f.npad = c->npad_run; }
     f.dbg_ts = (gn::g_ffn_ablate & 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
@@ -546,7 +564,10 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     }
   }
   // the call's lists of tiles / query blocks that hold valid tokens (k_prep has written the per-slot counts)
-  if (c->use_lists && c->lists) launch_tile_lists(c->nvalid, BS, np, c->lists, s);
+  if (c->use_lists && c->lists) {
+    const int g = (int)(c->ovf - c->ovf_base);
+    launch_tile_lists(c->nvalid, BS, np, c->lists, (c->tile_feedback && g >= 0 && g < 8) ? c->tile_feedback + g : nullptr, s);
+  }
   for (int i = 0; i < c->n_layers; ++i) {
     {  // SelfBlock on both sides at once
       const Block& blk = c->self_blk[i];
@@ -568,7 +589,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 3 * kDim; a.k = c->qkv + kDim; a.ldk = 3 * kDim; a.v = c->qkv + 2 * kDim; a.ldv = 3 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 0; a.qscale = 0.125f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr;
+        a.qb = c->qkb; a.ldqb = 2 * kDim; a.kb = c->qkb + kDim; a.ldkb = 2 * kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr; a.ncu = c->ncu;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -601,7 +622,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         a.q = c->qkv; a.ldq = 2 * kDim; a.k = c->qkv; a.ldk = 2 * kDim; a.v = c->qkv + kDim; a.ldv = 2 * kDim;
         a.out = c->ctx; a.ldo = kDim; a.nvalid = c->nvalid; a.npad = np; a.cross = 1; a.qscale = 1.0f; a.BS = BS;
         a.outp = attn_planes ? c->ctx_p : nullptr; a.ovf = (attn_planes && c->guard) ? c->ovf : nullptr;
-        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr;
+        a.qb = c->qkb; a.ldqb = kDim; a.kb = c->qkb; a.ldkb = kDim; a.vt = c->vtb; a.half_fmt = c->attn_f16; a.tiles = (c->use_lists && c->lists) ? c->lists : nullptr; a.ncu = c->ncu;
         if (bf16v2) attn_split(c, a);
         timed_attention(c, a, bf16v2, s);
         if (c->planes_mode && !attn_planes) launch_split_hm16(c->ctx, c->ctx_p, T, kDim, 1.0f, s);
@@ -739,8 +760,10 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   ctx->gemm_variant = precision == GN_PREC_F16X2_BF16_ATTN ? 6 : precision == GN_PREC_F32X3_BF16_ATTN ? 5 : 3;
   { const int rc_ws = alloc_workspace(ctx, max_kpts); if (rc_ws != GN_OK) { gn_destroy(ctx); return rc_ws; } }
   // pinned host words: [0, 16) guard words, [16, 16 + 4096) the per-image counters the SIFT / SuperPoint calls read back (up to 1024 images per call)
-  if (hipHostMalloc((void**)&ctx->ovf_host, (16 + 4096) * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
-  memset(ctx->ovf_host, 0, (16 + 4096) * sizeof(unsigned int));
+  if (hipHostMalloc((void**)&ctx->ovf_host, (16 + 4096 + 16) * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  memset(ctx->ovf_host, 0, (16 + 4096 + 16) * sizeof(unsigned int));
+  ctx->tile_feedback = reinterpret_cast<unsigned long long*>(ctx->ovf_host + 16 + 4096);   // [8] x 8 bytes behind the counters (8-byte aligned)
+  ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
   // required tensor names
@@ -1732,7 +1755,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 23) ctx->attn_split = value;
   else if (which == 25) ctx->dbg_trip_group = value;
   else if (which == 26) ctx->sub_serial = value;
-  else if (which == 27) gn::g_qkv_products = value;
+  else if (which == 27) ctx->qkv_products = value == 3 ? 3 : 2;
   else if (which == 28) ctx->ffn_compose = value;
   else if (which == 31) ctx->use_lists = value;
   else if (which == 29) {   // CU shares for the sub-batch streams: takes effect for streams created afterwards

@@ -348,23 +348,28 @@ __global__ __launch_bounds__(256) void k_attn_pw(AttnArgs a, int nitems) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     unsigned char* const slab = reinterpret_cast<unsigned char*>(smem) + 2 * (NDK + NDV) * kRing + wave * 32 * kSlabPitch;
+    // the guard only looks at rows of VALID queries: with work lists the q rows of a padding-only 128-token tile inside a partly valid 256-query block
+    // are whatever an earlier call left there (k_qkv skips such tiles) -- after a call that overflowed, possibly inf -- and must not trip later calls
+    const int nq = a.nvalid[bs];
     float amax = 0.f;
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
       const float l = ol[qi][0];
       const float inv = l > 0.f ? 1.0f / l : 0.f;
+      float amq = 0.f;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4v w = {o[qi][d][4 * g + 0] * inv, o[qi][d][4 * g + 1] * inv, o[qi][d][4 * g + 2] * inv, o[qi][d][4 * g + 3] * inv};
-          ovf_track(amax, w.x, w.y); ovf_track(amax, w.z, w.w);
+          ovf_track(amq, w.x, w.y); ovf_track(amq, w.z, w.w);
           const f16x4 hv = __builtin_convertvector(w, f16x4);
           const f16x4 mv = __builtin_convertvector(w - __builtin_convertvector(hv, f32x4v), f16x4);
           unsigned char* pp = slab + ql * kSlabPitch + (2 * d + (g >> 1)) * 64 + (8 * (g & 1) + 4 * hh) * 2;   // dims d * 32 + 8 g + 4 hh ..
           *reinterpret_cast<f16x4*>(pp) = hv;
           *reinterpret_cast<f16x4*>(pp + 32) = mv;
         }
+      if (q0 + 32 * qi + ql < nq) amax = fmaxf(amax, amq);
       // (the same wave wrote the slab: the LDS operations of a wave complete in order)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -414,8 +419,7 @@ bool launch_attention_pw(const AttnArgs& a, int ablate, hipStream_t s) {
   if (a.npad % 256 != 0 || a.qb == nullptr) return false;
   const int nitems = a.npad / 256 * kHeads * a.BS;
   if (nitems < 8) return false;
-  static int ncu = 0;
-  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) ? pr.multiProcessorCount : 256; }
+  const int ncu = a.ncu >= 8 ? a.ncu : std::max(device_cu_count(), 8);
   // one workgroup per CU (LDS and registers leave room for one) walks the work list; a multiple of the 8 XCDs.  The phase-stamp variants keep one
   // workgroup per item (tools/attn_pw_ab.py reads one record per item).
   const bool stamps = ablate == 3 || ablate >= 100;

@@ -133,6 +133,7 @@ struct FfnArgs {
   int walk = 0;                            // 1: one workgroup per CU walks `tiles`; 0: one workgroup per tile of T, which leaves at once when `tiles` says (through
                                            // nvalid / npad) that its tile holds only padding
   const int32_t* nvalid = nullptr; int npad = 0;
+  int ncu = 0;                             // compute units of the context's device (walking form: one workgroup per CU); 0 = ask the current device
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s);   // gn_ffn128.hip: 128 tokens per workgroup (a.cp set, a.T % 128 == 0); ablate: developer knob 12
@@ -157,9 +158,12 @@ struct QkvArgs {
   unsigned int* ovf;                  // half_fmt 1: domain guard word raised when a q / k / v value does not fit fp16, or nullptr
   long long* dbg_ts;                  // developer: nullptr, or [blocks][8 waves][8] s_memtime stamps
   const int* tiles = nullptr;         // work list of the call (launch_tile_lists), or nullptr = every 128-token tile of T
+  int products = 2;                   // fp16 partial products per output: 2 = x_h w_h + x_h w_m (the outputs are rounded to 16 bits anyway), 3 = + x_m w_h
+                                      // (per context: gn_debug_set_variant(ctx, 27, .))
+  int ncu = 0;                        // compute units of the context's device; 0 = ask the current device
 };
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
-extern int g_qkv_products;
+int device_cu_count();                // multiProcessorCount of the CURRENT device (no caching across devices)
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {
@@ -183,6 +187,7 @@ struct AttnArgs {
   float* part = nullptr;     // [slot][head][query block][split][4 waves][34][64] partial results
   unsigned int* tickets = nullptr;   // [slot][head][query block], zero between launches
   const int* tiles = nullptr;        // k_attn_pw: work list of the call (launch_tile_lists), or nullptr = every 256-query block of every (slot, head)
+  int ncu = 0;                       // compute units of the context's device; 0 = ask the current device
 };
 // Work lists of one matcher call (round 4): the 128-token tiles and the (slot, head, 256-query block) items that hold at least one valid token, in
 // ascending order.  Layout (ints): [0] number of tiles, [1] number of attention items, [kTileListBase ..) tile indices (token / 128), then at
@@ -191,7 +196,7 @@ struct AttnArgs {
 // workgroup still paid).  Rows of padding are never written by those kernels; they keep whatever finite values they had (the workspaces are
 // zero-initialised), and no valid token reads them (keys are masked, everything else is row-wise).
 constexpr int kTileListBase = 16;
-void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, hipStream_t s);
+void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, unsigned long long* feedback /* pinned host word or nullptr */, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s);

@@ -720,8 +720,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
 }  // namespace
 
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
-  static int ncu = 0;
-  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  const int ncu = a.ncu > 0 ? a.ncu : device_cu_count();
   const bool walk = a.tiles != nullptr && a.walk && ablate == 0;
   const dim3 grid(walk ? std::min(a.T / 128, ncu) : a.T / 128), block(256);     // walking form: one workgroup per CU
   FfnArgs b = a;

@@ -304,35 +304,50 @@ void launch_cast_bf16(const float* in, uint16_t* out, long long n, hipStream_t s
 }
 
 namespace {
-// one workgroup; BS <= a few hundred slots
-__global__ __launch_bounds__(256) void k_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists) {
-  __shared__ int off_t[1025], off_a[1025];
-  const int gx = npad / 256, tps = npad / 128;
-  if (threadIdx.x == 0) {
-    int t = 0, a = 0;
-    for (int s = 0; s < BS; ++s) {
-      off_t[s] = t; off_a[s] = a;
-      const int n = min(max(nvalid[s], 0), npad);
-      t += (n + 127) / 128;
-      a += gx > 0 && npad % 256 == 0 ? 4 * ((n + 255) / 256) : 0;
-    }
-    off_t[BS] = t; off_a[BS] = a;
-    lists[0] = t; lists[1] = a;
-  }
-  __syncthreads();
+// one workgroup; any number of slots: the per-slot tile / item counts are prefix-summed 256 slots at a time (block-wide scan, running base), so
+// nothing is sized by BS (the fixed 1025-entry arrays of round 4 were overrun by contexts of more than 512 pairs per call)
+__global__ __launch_bounds__(256) void k_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, unsigned long long* feedback) {
+  __shared__ int sc_t[256], sc_a[256], base[2];
+  const int gx = npad / 256, tps = npad / 128, tid = threadIdx.x;
+  const bool items = gx > 0 && npad % 256 == 0;
   int* const tl = lists + kTileListBase;
   int* const al = tl + BS * tps;
-  for (int s = threadIdx.x; s < BS; s += 256) {
-    const int nt = off_t[s + 1] - off_t[s];
-    for (int i = 0; i < nt; ++i) tl[off_t[s] + i] = s * tps + i;
-    const int nb = (off_a[s + 1] - off_a[s]) / 4;
+  if (tid == 0) { base[0] = 0; base[1] = 0; }
+  __syncthreads();
+  for (int s0 = 0; s0 < BS; s0 += 256) {
+    const int s = s0 + tid;
+    int nt = 0, nb = 0;
+    if (s < BS) {
+      const int n = min(max(nvalid[s], 0), npad);
+      nt = (n + 127) / 128;
+      nb = items ? (n + 255) / 256 : 0;
+    }
+    sc_t[tid] = nt; sc_a[tid] = 4 * nb;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int vt = tid >= d ? sc_t[tid - d] : 0, va = tid >= d ? sc_a[tid - d] : 0;
+      __syncthreads();
+      sc_t[tid] += vt; sc_a[tid] += va;
+      __syncthreads();
+    }
+    const int ot = base[0] + sc_t[tid] - nt, oa = base[1] + sc_a[tid] - 4 * nb;
+    for (int i = 0; i < nt; ++i) tl[ot + i] = s * tps + i;
     for (int h = 0; h < 4; ++h)
-      for (int i = 0; i < nb; ++i) al[off_a[s] + h * nb + i] = (s * 4 + h) * gx + i;
+      for (int i = 0; i < nb; ++i) al[oa + h * nb + i] = (s * 4 + h) * gx + i;
+    __syncthreads();
+    if (tid == 255) { base[0] += sc_t[255]; base[1] += sc_a[255]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    lists[0] = base[0]; lists[1] = base[1];
+    // (valid tiles, all tiles) of this call as ONE 8-byte store into pinned host memory: the library reads it -- whenever it has arrived, no
+    // synchronisation -- to choose the block tail's form for the NEXT call of the same group (a hint only: both forms give the same bits)
+    if (feedback) __hip_atomic_store(feedback, ((unsigned long long)(unsigned)(BS * tps) << 32) | (unsigned)base[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 }  // namespace
-void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, hipStream_t s) {
-  hipLaunchKernelGGL(k_tile_lists, dim3(1), dim3(256), 0, s, nvalid, BS, npad, lists);
+void launch_tile_lists(const int32_t* nvalid, int BS, int npad, int* lists, unsigned long long* feedback, hipStream_t s) {
+  hipLaunchKernelGGL(k_tile_lists, dim3(1), dim3(256), 0, s, nvalid, BS, npad, lists, feedback);
 }
 
 }  // namespace gn

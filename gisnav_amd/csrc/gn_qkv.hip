@@ -240,12 +240,14 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
 // the low-margin index-mismatch count against the oracle is 2 / 7173 (three products: 5 / 7173), mid-margin 0 / 3954 both ways, the 32 bench
 // pairs are index-identical, and the launches drop from 87 / 62 us to 72 / 53 us (tools/qkv2_study.py, profiles/r04_qkv2_study.json).
 // Developer knob 27 = 3 restores the third product.  (The block tail and the match head keep all three: their outputs are f32-accurate values.)
-int g_qkv_products = 2;
+int device_cu_count() {
+  int dev = 0; hipDeviceProp_t pr;
+  return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+}
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s) {
-  static int ncu = 0;
-  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  const int ncu = a.ncu > 0 ? a.ncu : device_cu_count();
   const dim3 grid(a.tiles != nullptr ? std::min(a.T / TM, ncu) : a.T / TM), block(512);
-  const int sel = (a.half_fmt ? 4 : 0) | (cross ? 2 : 0) | (g_qkv_products == 2 ? 1 : 0);
+  const int sel = (a.half_fmt ? 4 : 0) | (cross ? 2 : 0) | (a.products == 2 ? 1 : 0);
   switch (sel) {
     case 7: hipLaunchKernelGGL((k_qkv<true, true, 2>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, true, 2>"; break;
     case 6: hipLaunchKernelGGL((k_qkv<true, true, 3>), grid, block, 0, s, a); g_last_kernel = "k_qkv<true, true, 3>"; break;

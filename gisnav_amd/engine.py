@@ -347,11 +347,12 @@ class PoseEngine:
         r = io["host_np"]
         return (r[0:72].view(np.float64).reshape(3, 3).copy(), r[72:96].view(np.float64).reshape(3, 1).copy(), int(r[100:104].view(np.int32)[0]), bool(r[104]))
 
-    def set_ragged(self, ragged: bool) -> None:
-        """Workload hint.  The big kernels skip tiles that hold only padding either way; with `ragged=True` the block tail also runs as one workgroup
-        per CU walking the list of non-empty tiles (no dispatch per skipped tile): ~20 % faster on batches whose keypoint counts differ a lot
-        (an unbounded cv2.SIFT_create(), pose_node.py:122), 3 % slower per launch on batches without padding -- hence a hint, not the default."""
-        _lib.check(self.ctx, self.lib.gn_debug_set_variant(self.ctx, 31, 2 if ragged else 1), "gn_debug_set_variant(31)")
+    def set_ragged(self, ragged: Optional[bool]) -> None:
+        """Override of a choice the library makes by itself.  The big kernels skip tiles that hold only padding either way; the block tail has two
+        forms (one workgroup per tile, or one per CU walking the list of non-empty tiles: ~20 % faster on batches whose keypoint counts differ a lot --
+        an unbounded cv2.SIFT_create(), pose_node.py:122 --, 3 % slower per launch on batches without padding; identical bits).  By default
+        (`None`) the library picks the form per call from the fraction of padding-only tiles its previous call saw; True / False force one."""
+        _lib.check(self.ctx, self.lib.gn_debug_set_variant(self.ctx, 31, 1 if ragged is None else 2 if ragged else 3), "gn_debug_set_variant(31)")
 
     def set_overlap(self, enable: bool) -> None:
         """Batch-serving option: PnP of call n overlaps the matcher of call n+1 (see gn_set_overlap); call flush()
@@ -420,6 +421,9 @@ class PoseEngine:
                 self.estimate(grp, K, min_matches, out={k: v[a:b] for k, v in tmp.items()})
         finally:
             self.set_active_kpts(self.kmax)
+        # with set_overlap / set_substreams(deferred_join=True) the PnP stage or the groups may still run on the library's internal streams:
+        # join them before `tmp` is read on the caller's stream and before the index_select'ed copies in `srt` are released
+        self.flush()
         for k in out:
             out[k].index_copy_(0, perm, tmp[k])
         real = int((n_q_host + n_r_host).sum())

@@ -2,7 +2,7 @@
 
 Mirror of ros/gisnav/gisnav/core/_shared.py:89-125 (also used by TwistNode with a zero DEM,
 core/twist_node.py:289): numpy in, `(R (3,3) f64, t (3,1) f64)` out.  The DEM lookup is the
-reference's own host-side marshalling (`_compute_3d_points`); RANSAC, EPnP, the iterative refinement
+host-side marshalling of the reference's `_compute_3d_points`; RANSAC, EPnP, the iterative refinement
 and Rodrigues run in `gn_pnp_ransac` on the GPU.  Returns None where the reference would fail
 (cv2 returning no model).
 """
@@ -36,18 +36,17 @@ def init(device: int = 0, max_points: int = 4096) -> PoseEngine:
 
 def compute_pose(camera_info, mkp_qry: np.ndarray, mkp_ref: np.ndarray, elevation: Optional[np.ndarray],
                  engine: Optional[PoseEngine] = None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
-    def _compute_3d_points(mkp_ref, elevation):
-        if elevation is None:
-            return np.hstack((mkp_ref, np.zeros((len(mkp_ref), 1))))
-        x, y = np.transpose(np.floor(mkp_ref).astype(int))
-        z_values = elevation[y, x].reshape(-1, 1)
-        return np.hstack((mkp_ref, z_values))
-
     n = len(mkp_qry)
     if n < 4:                     # cv2.solvePnPRansac asserts npoints >= 4 (the reference would raise); the shim reports "no pose"
         return None
     eng = engine or _engine(n)
-    obj = np.ascontiguousarray(_compute_3d_points(mkp_ref, elevation), dtype=np.float32)
+    # object points = reference keypoint + the DEM cell under it (z = 0 without a raster: TwistNode), marshalled straight into the f32 [n][3]
+    # array gn_pnp_ransac reads -- the host-side twin of gn_gather_points' lift (reference: _shared.py:95-102)
+    obj = np.zeros((n, 3), np.float32)
+    obj[:, :2] = mkp_ref
+    if elevation is not None:
+        cell = np.floor(np.asarray(mkp_ref)).astype(np.intp)
+        obj[:, 2] = np.asarray(elevation)[cell[:, 1], cell[:, 0]]
     img = np.ascontiguousarray(mkp_qry, dtype=np.float32)
     k_matrix = np.asarray(camera_info.k, dtype=np.float64).reshape((3, 3))
     R, t, _, ok = eng.pnp_ransac_host(obj, img, k_matrix, RANSAC_ITERATIONS, min_pts=4)   # n == 4: OpenCV's P3P branch

@@ -60,6 +60,99 @@ def test_shipped_device_code_has_no_low_lane_opsel_packed_fma(tmp_path):
     assert bad == 0, f"{bad} v_pk_fma_f32 read a VGPR source through a low-lane op_sel bit"
 
 
+def _disassemble_kernels(tmp_path, wanted):
+    """{mangled kernel name: (metadata dict, [(opcode, [operands])])} for the kernels of the SHIPPED library whose mangled name contains one of `wanted`."""
+    import shutil
+    import subprocess
+    from gisnav_amd import build
+    build.build(verbose=False)
+    llvm = "/opt/rocm/lib/llvm/bin"
+    assert os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf"), "the ROCm image's llvm tools are needed to check the shipped code"
+    so = shutil.copy(os.path.join(ROOT, "gisnav_amd", "libgisnav_amd.so"), tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", os.path.basename(so)], cwd=tmp_path, check=True, capture_output=True)
+    out = {}
+    for f in sorted(f for f in os.listdir(tmp_path) if "hipv4" in f):
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        if not any(w in notes for w in wanted):
+            continue
+        meta = {}
+        for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+            kv = dict(re.findall(r"\.(agpr_count|name|private_segment_fixed_size|sgpr_spill_count|vgpr_count|vgpr_spill_count):\s*(\S+)", ".agpr_count:" + blk))
+            if "name" in kv:
+                meta[kv["name"]] = {k: (v if k == "name" else int(v)) for k, v in kv.items()}
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        parts = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", dis)
+        for i in range(1, len(parts), 2):
+            name = parts[i]
+            if not any(w in name for w in wanted) or name not in meta:
+                continue
+            ins = []
+            for ln in parts[i + 1].split("\n"):
+                ln = ln.split("//")[0].strip()
+                m = re.match(r"^(\S+)\s*(.*)$", ln)
+                if m:
+                    ins.append((m.group(1), [o.strip() for o in re.split(r",\s*(?![^\[]*\])", m.group(2))] if m.group(2) else []))
+            out[name] = (meta[name], ins)
+    return out
+
+
+def _reg_range(op):
+    m = re.match(r"^([va])\[(\d+):(\d+)\]$", op) or re.match(r"^([va])(\d+)()$", op)
+    if not m:
+        return None
+    lo = int(m.group(2))
+    return m.group(1), lo, int(m.group(3)) if m.group(3) else lo
+
+
+def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
+    """VERDICT r4 item 5.  `k_attn_pw` and `k_ffn128` are correct only as long as hipcc keeps allocating registers the way their hand-placed
+    instruction streams assume (gn_attention_pw.hip: score MFMAs written in assembly with VGPR accumulators, dead accumulators kept allocated so that
+    a late MFMA write-back cannot land on a recycled V^T fragment; gn_ffn128.hip: a straight line of ~17 k instructions that is 15 x slower when a
+    register array falls into scratch memory).  Both are pinned by build flags only (build.py) -- so the disassembly of the library that SHIPS is
+    checked here, on the CPU, before a GPU box ever sees a compiler upgrade:
+      * k_attn_pw<F16, 0> (and the bf16 twin): no scratch instruction, no spill, 96 accumulation registers, exactly 128 MFMAs in the code;
+        56 of them deliver the score tiles into VGPRs, and in the 16 instructions behind each of those no memory-return instruction
+        (ds_read / buffer_load / global_load / scratch_load) writes a register of its destination block -- the hardware does not interlock
+        an LDS return against an MFMA still in flight, which is the bug of DESIGN 10.2 (b) -- and no VALU instruction touches the block within
+        the first 6 instructions (the hand-counted wait);
+      * k_ffn128<0, composed, one tile per workgroup> (the bench's dominant kernel): 512 registers (256 + 256 accumulators), 2304 MFMAs, at most
+        the two spilled VGPRs / five scratch instructions of round 4's build, none of them inside GEMM 1's stream of 1536 MFMAs."""
+    ks = _disassemble_kernels(tmp_path, ["k_attn_pwILb1ELi0E", "k_attn_pwILb0ELi0E", "k_ffn128ILi0ELb1ELb0E", "k_ffn128ILi0ELb1ELb1E"])
+    pw = [n for n in ks if "k_attn_pw" in n]
+    assert len(pw) == 2, sorted(ks)
+    for name in pw:
+        meta, ins = ks[name]
+        assert meta["agpr_count"] == 96 and meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0, meta
+        assert not any(op.startswith("scratch_") for op, _ in ins), name
+        mf = [j for j, (op, _) in enumerate(ins) if op.startswith("v_mfma")]
+        assert len(mf) == 128, (name, len(mf))
+        score = [(j, _reg_range(ins[j][1][0])) for j in mf if _reg_range(ins[j][1][0]) and _reg_range(ins[j][1][0])[0] == "v"]
+        assert len(score) == 56 and all(hi - lo == 15 for _, (_, lo, hi) in score), (name, len(score))
+        for j, (_, lo, hi) in score:
+            for k in range(j + 1, min(j + 17, len(ins))):
+                op, ops = ins[k]
+                if op.startswith("v_mfma") or not ops:
+                    continue
+                d = _reg_range(ops[0])
+                hit = d is not None and d[0] == "v" and not (d[2] < lo or d[1] > hi)
+                if op.startswith(("ds_read", "ds_load", "buffer_load", "global_load", "scratch_load", "flat_load")):
+                    assert not hit, f"{name}: {op} {ops[0]} lands in the destination v[{lo}:{hi}] of the score MFMA {k - j} instructions earlier"
+                elif op.startswith("v_") and not op.startswith("v_cmp") and k - j <= 6:
+                    touched = hit or any((r := _reg_range(o)) is not None and r[0] == "v" and not (r[2] < lo or r[1] > hi) for o in ops[1:])
+                    assert not touched, f"{name}: {op} touches v[{lo}:{hi}] {k - j} instructions behind the score MFMA that writes it"
+    for tag, spills, scratch in (("k_ffn128ILi0ELb1ELb0E", 2, 5), ("k_ffn128ILi0ELb1ELb1E", 22, 21)):
+        (name,) = [n for n in ks if tag in n]
+        meta, ins = ks[name]
+        assert meta["agpr_count"] == 256 and meta["vgpr_count"] == 512, meta
+        assert meta["vgpr_spill_count"] <= spills and meta["sgpr_spill_count"] == 0, meta
+        mf = [j for j, (op, _) in enumerate(ins) if op.startswith("v_mfma")]
+        assert len(mf) == 2304, (name, len(mf))
+        sc = [j for j, (op, _) in enumerate(ins) if op.startswith("scratch_")]
+        assert len(sc) <= scratch, (name, len(sc))
+        if tag.endswith("Lb0E"):     # the shipped default: nothing from scratch memory inside the first GEMM's weight stream
+            assert not any(mf[0] < j < mf[1535] for j in sc), (name, sc, mf[0], mf[1535])
+
+
 def test_product_path_has_no_cpu_fallback():
     from gisnav_amd import _lib
     from gisnav_amd.engine import PoseEngine
