@@ -414,7 +414,7 @@ def precision_guarantee(precision: str) -> dict:
            "note": "north_star asks for bit-exact correspondence indices: GN_PREC_F32 guarantees them (f32 MFMA everywhere; extra_configs carries its batch-32 "
                    "throughput).  The headline mode computes in the reference's CUDA arithmetic class (fp32-accurate linear layers except the two-product q/k/v "
                    "projections named in `dtype`, half-precision SDPA); counts below are symmetric differences of the match sets, headline KERNELS "
-                   "(k_qkv<.,.,2> + k_attn_pw + composed k_ffn128, asserted from the launch table), against the oracle",
+                   "(k_qkv<.,.,2> + k_attn_pw + composed k_ffn128, asserted from the launch table), against the CPU restatement of the reference (tests' checker)",
            "library_source_digest": source_digest()}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_parity_report.json")
     try:
@@ -428,7 +428,7 @@ def precision_guarantee(precision: str) -> dict:
     out["same_build"] = rep.get("source_digest") == out["library_source_digest"]
 
     def frac(row):
-        return f"{row['index_mismatches']} / {row['oracle_matches']}" if isinstance(row, dict) and "index_mismatches" in row else None
+        return f"{row['index_mismatches']} / {row['cpu_matches']}" if isinstance(row, dict) and "index_mismatches" in row else None
     counts = {}
     for key in ("forced_4x512_low_margin", "forced_4x512_mid_margin"):
         t = rep.get(key) or {}
@@ -437,7 +437,7 @@ def precision_guarantee(precision: str) -> dict:
         counts[key] = frac(rep.get(key))
     rag = rep.get("ragged_16_pairs_u400_2500") or {}
     counts["ragged_16_pairs_u400_2500_margin_built_weights"] = {k: frac(v) for k, v in rag.items() if frac(v)}
-    out["index_mismatches_vs_oracle"] = counts
+    out["index_mismatches_vs_cpu_restatement"] = counts
     out["source"] = "tests/test_gpu_round5.py (asserted: f32 = 0; headline kernels <= 1 % on low- / mid-margin weights, <= 0.1 % on the ragged bulk batch)"
     if not out["same_build"]:
         out["warning"] = "the report was measured on other sources than the library this run loaded: re-run `pytest -m gpu tests/test_gpu_round5.py` and copy gpurun_out/parity_r05.json"

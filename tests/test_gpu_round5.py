@@ -117,24 +117,24 @@ def test_headline_kernels_forced_on_the_low_margin_table(name, kw, th):
     table = {}
     eng = PoseEngine(0, max_batch=4, max_kpts=512, precision="f32", state_dict=sd, filter_threshold=th)
     m, t, _, _ = _match_counted(eng, pairs, ref)
-    table["f32"] = {"index_mismatches": m, "oracle_matches": t}
+    table["f32"] = {"index_mismatches": m, "cpu_matches": t}
     del eng
     eng = PoseEngine(0, max_batch=4, max_kpts=512, precision=HEADLINE, state_dict=sd, filter_threshold=th)
     m, t, fam, _ = _match_counted(eng, pairs, ref)
     assert fam["k_ffn_fused"] and fam["k_attn16_v5"] and not fam["k_ffn128"] and not fam["k_attn_pw"], fam      # what this grid selects by itself
-    table["small_grid_kernels"] = {"index_mismatches": m, "oracle_matches": t, "kernels": "k_gemm_p2 (3 products) + k_attn16_v5 + k_ffn_fused"}
+    table["small_grid_kernels"] = {"index_mismatches": m, "cpu_matches": t, "kernels": "k_gemm_p2 (3 products) + k_attn16_v5 + k_ffn_fused"}
     for products in (2, 3):
         with _Knobs(eng, k14=128, k1=70, k19=2, k27=products):
             m, t, fam, _ = _match_counted(eng, pairs, ref)
         _assert_headline_family(fam, products)
-        table["headline_kernels_%d_products" % products] = {"index_mismatches": m, "oracle_matches": t,
+        table["headline_kernels_%d_products" % products] = {"index_mismatches": m, "cpu_matches": t,
                                                             "kernels": "k_qkv<., ., %d> + k_attn_pw + k_ffn128 (composed)" % products}
     del eng
     print(name, table)
     _report("forced_4x512_" + name, table)
     assert table["f32"]["index_mismatches"] == 0, table
     head = table["headline_kernels_2_products"]
-    assert head["index_mismatches"] <= 0.01 * head["oracle_matches"], table
+    assert head["index_mismatches"] <= 0.01 * head["cpu_matches"], table
     assert head["index_mismatches"] <= table["small_grid_kernels"]["index_mismatches"] + 2, table
 
 
@@ -152,7 +152,7 @@ def test_headline_kernels_selected_by_a_bulk_grid_on_low_margin_weights(name, kw
     m, t, fam, _ = _match_counted(eng, pairs, ref)
     _assert_headline_family(fam, 2)
     del eng
-    row = {"index_mismatches": m, "oracle_matches": t, "kernels": "k_qkv<., ., 2> + k_attn_pw + k_ffn128 (composed), selected by the grid"}
+    row = {"index_mismatches": m, "cpu_matches": t, "kernels": "k_qkv<., ., 2> + k_attn_pw + k_ffn128 (composed), selected by the grid"}
     print(name, row)
     _report("bulk_16x1024_" + name, row)
     assert t > 1000 and m <= 0.01 * t, row
@@ -182,7 +182,7 @@ def test_ragged_bulk_batch_with_work_lists_directly_against_the_oracle(state_dic
             for _ in range(2):      # the second call of the automatic form has seen the first one's padding
                 m, t, fam, (idx_h, n_h) = _match_counted(eng, pairs, ref)
         _assert_headline_family(fam, 2)
-        rows["lists_%d" % lists] = {"index_mismatches": m, "oracle_matches": t}
+        rows["lists_%d" % lists] = {"index_mismatches": m, "cpu_matches": t}
         if first is None:
             first = (idx_h, n_h)
         else:
