@@ -350,7 +350,7 @@ GemmArgs gemm_args(const float* A, int lda, const Linear& L, float* Y, int ldy, 
 static void attn_split(gn_ctx* c, AttnArgs& a) {
   const int blocks = a.npad / 128 * kHeads * a.BS;
   int S = 1;
-  while (S < 4 && S < c->attn_split && blocks * S * 2 <= 256 && a.npad / 64 >= 4 * S) S *= 2;
+  while (S < 4 && S < c->attn_split && blocks * S * 2 <= (c->attn_split >= 8 ? 512 : 256) && a.npad / 64 >= 4 * S) S *= 2;   // (knob 23 >= 8: up to 256 partial results = the buffer; 4: at most 128)
   // (sub-batch streams would share the partial-result buffer)
   if (c->attn_part && c->attn_tickets && c->attn_split && c->n_sub <= 1 && S > 1) { a.nsplit = S; a.part = c->attn_part; a.tickets = c->attn_tickets; }
 }
