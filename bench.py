@@ -101,6 +101,10 @@ def kernel_rows(table, steps, precision):
         peak = PEAK_F32_MFMA_TFLOPS if f32_pipe else PEAK_16BIT_MFMA_TFLOPS
         two = r["name"].startswith("k_qkv") and r["name"].rstrip(">").endswith(", 2")         # attention input projections: two partial products (gn_qkv.hip)
         mult = 1 if (attn or f32_pipe) else 6 if r["name"].startswith("k_gemm_f32x3") else 2 if two else 3   # matrix-pipe flops issued per algorithmic flop
+        if r["name"].startswith("k_ffn128") and r["name"].rstrip(">").endswith((", 1", ", 2")):      # block tail (3 products) + the next block's projection (2 products) in one launch
+            tail = 2.0 * (512 * 512 + 256 * 512)
+            proj = 2.0 * 256 * (768 if r["name"].rstrip(">").endswith(", 1") else 512)
+            mult = round((3 * tail + 2 * proj) / (tail + proj), 4)
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
         rows.append({"name": r["name"], "launches_per_step": round(n / steps, 2), "avg_launch_us": round(r["ms"] * 1e3 / n, 2),
                      "share_of_timed_kernel_time": round(r["ms"] / total_ms, 4),
@@ -670,6 +674,10 @@ def main() -> None:
 
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
     n_match_mean = float(out["n_match"].float().mean().item())
+    # the synthetic pairs are built so that every one yields a pose: a step that produced (almost) none has run a broken hot path, and its time is not a measurement
+    if not args.debug_variant and n_ok_all < 0.9 * args.batch * world:
+        raise SystemExit("bench.py: only %d of %d pairs of the last step produced a pose (mean matches %.1f) -- refusing to print a line for a broken hot path"
+                         % (int(n_ok_all), args.batch * world, n_match_mean))
     # the LAST timed step worked on batch (steps - 1) mod nres: its result records, gathered over RCCL, must contain this rank's block
     last = (args.steps - 1) % nres
     mine_rec = gdist.pack_records(last * args.batch * world + shard.start, out)

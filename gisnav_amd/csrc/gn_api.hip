@@ -115,6 +115,8 @@ struct gn_ctx {
                            // at once) while >= 90 % of the tiles hold tokens, else one workgroup per CU walking the list (3 % slower per tile on a batch without
                            // padding, 20 % faster on a ragged one; identical bits).  2: always walk.  3: never walk.
   int ncu = 256;           // compute units of ctx->device (grids of the walking kernels)
+  int qkv_in_tail = 1;     // knob 32.  1 (default): on bulk grids the block tail k_ffn128 also computes the NEXT block's attention input projection from the rows
+                           // it has just produced (k_ffn128<., ., ., 1 / 2>: no k_qkv launch, no read-back of the residual stream); 0: separate k_qkv launches
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
   unsigned long long* tile_feedback = nullptr;   // pinned host [8]: (all tiles << 32 | valid tiles) written by k_tile_lists of sub-batch group g's last call
   int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
@@ -379,10 +381,13 @@ void timed_attention(gn_ctx* c, const AttnArgs& a, bool bf16v2, hipStream_t s) {
 
 // q | k | v (or qk | v) projection of one block straight into the attention kernel's bf16 layouts; false when the shape / mode
 // needs the general GEMM
-bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
+bool qkv_projection_applies(const gn_ctx* c, const Block& blk, int T, int np, int vt_perm) {
   // (small batches keep the tiled GEMM: T / 128 workgroups would leave most of the chip idle)
-  if (!(c->planes_mode && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && T % 128 == 0 && np % 128 == 0 && (vt_perm & 1) &&
-        (T / 128 >= 128 || c->qkv_fused == 2))) return false;
+  return c->planes_mode && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && T % 128 == 0 && np % 128 == 0 && (vt_perm & 1) &&
+         (T / 128 >= 128 || c->qkv_fused == 2);
+}
+bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
+  if (!qkv_projection_applies(c, blk, T, np, vt_perm)) return false;
   QkvArgs q;
   q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
   q.rot4 = c->rot4; q.rot_stride = (long long)c->Tmax; q.qkb = c->qkb; q.ldyb = cross ? kDim : 2 * kDim; q.vt = c->vtb; q.npad = np;
@@ -478,7 +483,9 @@ bool tail_should_walk(const gn_ctx* c) {
 }
 
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
-void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
+// next / next_cross: the block whose attention input projection follows this tail (nullptr: none) -- when the tail runs as the composed k_ffn128 and that
+// projection is a k_qkv<., true, 2> launch, it is computed inside the tail instead; returns true when it was (the caller then skips the projection)
+bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const Block* next = nullptr, bool next_cross = false, int np = 0, int vt_perm = 0) {
   if (c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && blk.ffn0.wf && blk.ffn3.wf && T % 64 == 0) {   // the whole tail in one launch
     FfnArgs f;
     const bool fold = tail_folds_out_proj(c, blk, T);                     // out_proj computed inside the kernel from the attention output
@@ -491,10 +498,20 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     f.tiles = (c->use_lists && c->lists && !(gn::g_ffn_ablate & 8)) ? c->lists : nullptr;
     f.walk = c->use_lists == 2 || (c->use_lists == 1 && tail_should_walk(c));
     f.ncu = c->ncu;
+    f.composed = comp ? 1 : 0;
+    const bool fuse_qkv = next != nullptr && c->qkv_in_tail && comp && ffn_selects_128(f) && gn::g_ffn_ablate == 0 && c->attn_f16 && c->qkv_products != 3 && !c->qkv_stamps &&
+                          c->precision != GN_PREC_F32 && c->attn_variant >= 1 && qkv_projection_applies(c, *next, T, np, vt_perm) && !(vt_perm & 2);
+    if (fuse_qkv) {
+      f.qkv = next_cross ? 2 : 1;
+      f.q_wf = next->proj_in.wf; f.q_acc_scale = next->proj_in.acc_scale; f.q_bias = next->proj_in.b;
+      f.q_rot4 = c->rot4; f.q_rot_stride = (long long)c->Tmax; f.q_qkb = c->qkb; f.q_vt = c->vtb;
+      f.q_qscale = 0.125f; f.q_scale = 0.35355339059327373f;
+      f.npad = np;
+    }
     if (c->use_lists) { f.nvalid = c->nvalid; f.npad = c->npad_run; }
     f.dbg_ts = (gn::g_ffn_ablate & 8) ? reinterpret_cast<long long*>(c->sim) : nullptr;   // developer: phase stamps land in the (idle) sim buffer
     ++c->launch_count;
-    if (c->stop_after && c->launch_count > c->stop_after) return;
+    if (c->stop_after && c->launch_count > c->stop_after) return false;
     const bool rec = c->ktiming && c->kused < c->kflops.size();
     if (rec) hipEventRecord(c->kev[2 * c->kused], s);
     launch_ffn_fused(f, s);
@@ -502,11 +519,16 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
       hipEventRecord(c->kev[2 * c->kused + 1], s);
       c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + ((fold && !comp) ? 256.0 * 256.0 : 0.0));   // composed: the flops the kernel's own formulation needs
       c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
+      if (fuse_qkv) {     // + the projection (k_qkv's figures without its read of the rows)
+        const double N = next_cross ? 2.0 * kDim : 3.0 * kDim;
+        c->kflops[c->kused] += 2.0 * T * N * kDim;
+        c->kbytes[c->kused] += 2.0 * T * N + 4.0 * N * kDim + (next_cross ? 0.0 : 2.0 * 4.0 * T * kFreq);
+      }
       c->kclass[c->kused] = 0;
       c->kname[c->kused] = gn::g_last_kernel;
       ++c->kused;
     }
-    return;
+    return fuse_qkv;
   }
   GemmArgs g = gemm_args(c->x, kDim, blk.ffn0, c->h, 2 * kDim, T);
   g.A2 = c->msg; g.lda2 = kDim; g.K1 = kDim;
@@ -526,6 +548,7 @@ void ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32) {
     if (planes_of(c, c->x, &xp)) { g3.residp = xp; g3.ldrp = kDim; g3.resid = nullptr; g3.drop_f32 = keep_f32 ? 0 : 1; }
   }
   gemm(c, EPI_RESIDUAL, g3, s);
+  return false;
 }
 
 int run_matcher(gn_ctx* c, int B, int kpt_format,
@@ -568,10 +591,11 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     const int g = (int)(c->ovf - c->ovf_base);
     launch_tile_lists(c->nvalid, BS, np, c->lists, (c->tile_feedback && g >= 0 && g < 8) ? c->tile_feedback + g : nullptr, s);
   }
+  bool qkv_done = false;      // the previous tail has already computed this block's attention input projection
   for (int i = 0; i < c->n_layers; ++i) {
     {  // SelfBlock on both sides at once
       const Block& blk = c->self_blk[i];
-      {
+      if (!qkv_done) {
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 3 * kDim, T);
         g.cos_t = c->cos_t; g.sin_t = c->sin_t; g.rot_cols = 2 * kDim;
@@ -599,11 +623,11 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
       }
-      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s, false); }
+      { StageTimer tm(c, s, ST_FFN); qkv_done = ffn(c, blk, T, s, false, bf16v2 ? &c->cross_blk[i] : nullptr, true, np, vt_perm); }
     }
     {  // CrossBlock
       const Block& blk = c->cross_blk[i];
-      {
+      if (!qkv_done) {
         StageTimer tm(c, s, ST_PROJ);
         GemmArgs g = gemm_args(c->x, kDim, blk.proj_in, c->qkv, 2 * kDim, T);
         g.scale = 0.35355339059327373f;  // (dim_head ** -0.5) ** 0.5 applied to both qk sides
@@ -632,7 +656,7 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
         GemmArgs g = gemm_args(c->ctx, kDim, blk.proj_out, c->msg, kDim, T);
         gemm(c, EPI_BIAS, g, s);
       }
-      { StageTimer tm(c, s, ST_FFN); ffn(c, blk, T, s, i == c->n_layers - 1); }   // the last block leaves f32 x for the match head
+      { StageTimer tm(c, s, ST_FFN); qkv_done = ffn(c, blk, T, s, i == c->n_layers - 1, (bf16v2 && i + 1 < c->n_layers) ? &c->self_blk[i + 1] : nullptr, false, np, vt_perm); }   // the last block leaves f32 x for the match head
     }
   }
   {
@@ -1758,6 +1782,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 27) ctx->qkv_products = value == 3 ? 3 : 2;
   else if (which == 28) ctx->ffn_compose = value;
   else if (which == 31) ctx->use_lists = value;
+  else if (which == 32) ctx->qkv_in_tail = value ? 1 : 0;
   else if (which == 29) {   // CU shares for the sub-batch streams: takes effect for streams created afterwards
     GN_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); ctx->sub_s[i] = nullptr; ctx->ev_join[i] = nullptr; }

@@ -134,8 +134,17 @@ struct FfnArgs {
                                            // nvalid / npad) that its tile holds only padding
   const int32_t* nvalid = nullptr; int npad = 0;
   int ncu = 0;                             // compute units of the context's device (walking form: one workgroup per CU); 0 = ask the current device
+  // k_ffn128 with the NEXT block's attention input projection fused behind the tail (round 5): the tile's new residual rows go from the epilogue's
+  // registers into LDS as the projection's token operand (no 64 MB round trip through HBM, no second launch).  Same arithmetic, operand order and
+  // outputs as k_qkv<., true, 2> (gn_qkv.hip: fp16 outputs, two partial products): bit-identical q | k rows and V^T panels.
+  int qkv = 0;                             // 0: none; 1: the self block's Wqkv + rotary; 2: the cross block's to_qk | to_v
+  const uint16_t* q_wf = nullptr; float q_acc_scale = 1.f; const float* q_bias = nullptr;   // QkvArgs::wf / acc_scale / bias
+  const float* q_rot4 = nullptr; long long q_rot_stride = 0;                               // QkvArgs::rot4 / rot_stride (qkv == 1)
+  uint16_t* q_qkb = nullptr; uint16_t* q_vt = nullptr;                                     // fp16 q | k (ld 512) or qk (ld 256) rows; V^T panels [slot][4][64][npad]
+  float q_qscale = 1.f, q_scale = 1.f;                                                     // QkvArgs::qscale (self) / scale (cross)
 };
 void launch_ffn_fused(const FfnArgs& a, hipStream_t s);
+bool ffn_selects_128(const FfnArgs& a);   // true when launch_ffn_fused(a) dispatches k_ffn128 (the caller may then ask for the fused projection: a.qkv)
 void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s);   // gn_ffn128.hip: 128 tokens per workgroup (a.cp set, a.T % 128 == 0); ablate: developer knob 12
 extern int g_ffn_ablate;
 extern int g_ffn_shape;

@@ -402,6 +402,9 @@ __global__ __launch_bounds__(NW * 64) void k_ffn_fused(FfnArgs a) {
 
 int g_ffn_ablate = 0;   // developer knob 12: timing-only ablations of k_ffn_fused (wrong results)
 int g_ffn_shape = 0;    // developer knob 14: 0 = automatic, 64 / 32 = force the 64-token / 32-token workgroup shape
+bool ffn_selects_128(const FfnArgs& a) {
+  return a.cp != nullptr && a.T % 128 == 0 && (g_ffn_shape == 128 || (g_ffn_shape == 0 && a.T / 128 >= 256));
+}
 void launch_ffn_fused(const FfnArgs& a_in, hipStream_t s) {
   FfnArgs a = a_in;
   if (a.composed && !(a.T % 128 == 0 && (g_ffn_shape == 128 || (g_ffn_shape == 0 && a.T / 128 >= 256)))) {

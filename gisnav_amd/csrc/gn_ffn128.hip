@@ -49,7 +49,8 @@ __device__ __forceinline__ float resid_hi(unsigned int h, float y) { float r; as
 
 // COMP: out_proj is composed into ffn.0 at load time (W1' = [W1_x | W1_m Wo], b1' = b1 + W1_m bo: gn_api.hip build_composed) -- no GEMM 0, no message
 // tile: GEMM 1 runs over [x | ctx], all sixteen k-tiles through the ring
-template <int ABL, bool COMP, bool LOOP = false>   // LOOP: the workgroup walks the work list (one workgroup per CU); timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
+// QKV (round 5): 1 / 2 = the NEXT block's attention input projection (self: Wqkv + rotary; cross: to_qk | to_v) runs on the tile's new rows behind the epilogue
+template <int ABL, bool COMP, bool LOOP = false, int QKV = 0>   // LOOP: the workgroup walks the work list (one workgroup per CU); timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
 __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
   constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
   constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 128 token rows (hm16: 128 B per row)
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
   __syncthreads();
   stamp(8);
   float amax2 = 0.f;
+  uint4 xh[QKV != 0 ? RW / 2 : 1];
 #pragma unroll
   for (int it = 0; it < RW / 2; ++it) {
     const int rowl = RW * wave + 2 * it;      // (+ hh: in the lane offsets)
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
     for (int k = 0; k < 4; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
     __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){hw[0], hw[1], hw[2], hw[3]}, yrs, roff, rowl * 1024, 0);
     __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){mw[0], mw[1], mw[2], mw[3]}, yrs, roff + 32, rowl * 1024, 0);
+    if constexpr (QKV != 0) xh[it] = make_uint4(hw[0], hw[1], hw[2], hw[3]);     // the fp16 HIGH terms of the new rows: the fused projection's token operand
     if (a.y != nullptr) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v[0][0], v[0][1], v[1][0], v[1][1]}), frs, foff, rowl * 1024, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v[2][0], v[2][1], v[3][0], v[3][1]}), frs, foff + 16, rowl * 1024, 0);
@@ -705,6 +708,185 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
     GN_PIN();
   }
   ovf_commit(a.ovf, amax2);
+  if constexpr (QKV != 0) {
+    // ================================================================ the NEXT block's attention input projection on this tile's new rows (round 5)
+    // k_qkv<CROSS, true, 2> (gn_qkv.hip) with 4 waves instead of 8: the same two partial products per block (W_m X_h, then W_h X_h) in the same k
+    // order, the same epilogue expressions -> the same bits.  Token operand = the fp16 HIGH terms the row-wise epilogue just produced (xh[]), written
+    // into the k-tile layout the other GEMMs of this kernel read; weights register-fed through a ring; wave w owns feature tiles 8 pass + 2 w + {0, 1}
+    // of every pass (64 features x 128 tokens = 128 accumulator registers), i.e. one head of q, of k and of v.
+    constexpr bool CROSS = QKV == 2;
+    constexpr int NPASS = CROSS ? 2 : 3;
+    constexpr int NQK = CROSS ? kDim : 2 * kDim;      // q | k (or qk) features = the pitch of the fp16 rows
+    constexpr int ROT = 8 * KT;                       // [16 feature groups][128 tokens] f32x4 rotary entries behind the token tile (32 KB)
+    constexpr int RQ = 4;                             // weight k-steps in flight (4 KB per wave each)
+    const int slot = bm / a.npad, i0 = bm - slot * a.npad;
+    f32x4 rq[CROSS ? 1 : 8];
+    if constexpr (!CROSS) {      // the tile's rotary entries: thread -> entries tid + 256 k of [fg][token] (consecutive threads = consecutive tokens)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        rq[k] = reinterpret_cast<const f32x4*>(a.q_rot4)[(size_t)(e >> 7) * a.q_rot_stride + (size_t)(bm + (e & 127))];
+      }
+    }
+    __syncthreads();          // every wave has read its rows of the f32 tile: the space becomes the projection's token tile
+    {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int oc = l_ & 31, rp = l_ >> 5;
+      const int ch = 4 * ((oc >> 1) & 1) + (oc & 1);       // chunk of the k-tile's 128-byte row segment: 4 (k-step & 1) + 2 term + half
+#pragma unroll
+      for (int it = 0; it < RW / 2; ++it) {
+        const int row = RW * wave + 2 * it + rp;
+        *reinterpret_cast<uint4*>(smem + (oc >> 2) * KT + row * 128 + ((ch ^ swz(row)) * 16)) = xh[it];
+      }
+    }
+    if constexpr (!CROSS) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(smem + ROT + (tid + 256 * k) * 16) = rq[k];
+    }
+    window(0);
+    window(1);
+    f16x8 qa[RQ][2][2];
+    f16x8 qb[3][2];          // token fragments of one pair of token tiles (j = 2 jp, 2 jp + 1), high terms only
+    auto read_q = [&](int gp) __attribute__((always_inline)) {      // pair-step gp = 2 ks + jp
+      const int ks = gp >> 1, jp = gp & 1;
+      const int off = (ks >> 1) * KT + jp * 8192;
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) qb[gp % 3][jl] = *reinterpret_cast<const f16x8*>(smem + bo[off >> 16][jl][2 * (ks & 1)] + (off & 65535));
+    };
+    const float ascale = a.q_acc_scale;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(a.q_qkb + (size_t)bm * NQK, 0, TM * NQK * 2, 0x00020000);
+    float amaxq = 0.f;
+    __syncthreads();          // token tile (and rotary entries) visible
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const bool vpass = pass == NPASS - 1;
+      const __amdgpu_buffer_rsrc_t wq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.q_wf) + (size_t)(8 * pass + 2 * wave) * 16 * 2 * 512, 0, 2 * 16 * 2 * 1024, 0x00020000);
+      auto load_q = [&](int slot_, int ks, int i2, int pl) __attribute__((always_inline)) { qa[slot_][i2][pl] = ldw(wq, ((i2 * 16 + ks) * 2 + pl) * 1024); };
+#pragma unroll
+      for (int q = 0; q < RQ; ++q)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) load_q(q, q, i2, pl);
+      f32x4 bias4[2][4];
+      if (!vpass) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bias4[i2][g] = *reinterpret_cast<const f32x4*>(a.q_bias + 32 * (8 * pass + 2 * wave + i2) + 8 * g + 4 * hh);
+      }
+      f32x16 qacc[2][NJ];
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) qacc[i2][j][r] = 0.f;
+      read_q(0);
+      read_q(1);
+      GN_PIN();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int gp = 2 * ks + jp;
+          if (gp + 2 < 32) read_q(gp + 2);
+          // products: W_m X_h, then W_h X_h (k_qkv's order per accumulator); the four accumulators of the pair round-robin
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+              for (int i2 = 0; i2 < 2; ++i2) {
+                const int j = 2 * jp + jl, m = 8 * jp + 4 * p + 2 * jl + i2;
+                const f16x8 w = qa[ks % RQ][i2][p == 0 ? 1 : 0], x = qb[gp % 3][jl];
+                qacc[i2][j] = vpass ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, qacc[i2][j], 0, 0, 0)     // rows = tokens, columns = features
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, qacc[i2][j], 0, 0, 0);    // rows = features, columns = tokens
+                if (m % 4 == 1 && ks >= 1 && ks + RQ - 1 < 16) load_q((ks - 1) % RQ, ks + RQ - 1, (m / 4) >> 1, (m / 4) & 1);
+                GN_PIN();
+              }
+        }
+      }
+      if (!vpass) {
+        // register r of tile (i2, j) <-> feature 32 tile + (r & 3) + 8 (r >> 2) + 4 hh, token 32 j + ql (k_qkv's q / k epilogue, expression for expression)
+        const unsigned int qlo = (unsigned int)((ql * NQK + 8 * hh) * 2);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int tile = 8 * pass + 2 * wave + i2;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            uint2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 v = {qacc[i2][j][4 * g], qacc[i2][j][4 * g + 1], qacc[i2][j][4 * g + 2], qacc[i2][j][4 * g + 3]};
+              // SCALAR f32 arithmetic, component by component, each result pinned: written on the f32x4 vectors (k_qkv's source) hipcc emits
+              // `v_pk_mul_f32 D, s[n:n+1], V op_sel_hi:[0,1]` for the scale factors, and in THIS kernel's company (one-tile form, self block) the
+              // q rows then came back with garbage in (o.z, o.w) of two of the four feature groups in lanes 12..15 / 28..31 -- deterministic, moving
+              // with every unrelated edit (K before Q: gone; a barrier in front: other positions), the LDS rotary entries and the accumulators
+              // verified intact (tools/dbg_fused_qkv.py).  The same class as build.py's note on v_pk_fma_f32 in k_qkv.  The
+              // products and their order are unchanged: (acc * s + b), the rotation's mul + fma pairs, * qscale -- same bits as k_qkv.
+              v.x = v.x * ascale; v.y = v.y * ascale; v.z = v.z * ascale; v.w = v.w * ascale;
+              asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+              v.x += bias4[i2][g].x; v.y += bias4[i2][g].y; v.z += bias4[i2][g].z; v.w += bias4[i2][g].w;
+              asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+              if (CROSS) {
+                v.x *= a.q_scale; v.y *= a.q_scale; v.z *= a.q_scale; v.w *= a.q_scale;
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+              } else {
+                const f32x4 rot = *reinterpret_cast<const f32x4*>(smem + ROT + ((8 * i2 + 2 * g + hh) * 128 + 32 * j + ql) * 16);
+                f32x4 o;
+                o.x = v.x * rot.x + (-v.y) * rot.z;
+                o.y = v.y * rot.x + v.x * rot.z;
+                o.z = v.z * rot.y + (-v.w) * rot.w;
+                o.w = v.w * rot.y + v.z * rot.w;
+                v = o;
+                if (pass == 0) { v.x *= a.q_qscale; v.y *= a.q_qscale; v.z *= a.q_qscale; v.w *= a.q_qscale; asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+              }
+              pk[g].x = pack16<true>(v.x, v.y);
+              pk[g].y = pack16<true>(v.z, v.w);
+              ovf_track(amaxq, v.x, v.y); ovf_track(amaxq, v.z, v.w);
+            }
+            // the half-waves trade every other group of 4 features: a lane stores 8 consecutive features (16 bytes)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const uint2 give = hh ? pk[2 * gp] : pk[2 * gp + 1];
+              uint2 got;
+              got.x = __shfl_xor(give.x, 32); got.y = __shfl_xor(give.y, 32);
+              const uint2 own = hh ? pk[2 * gp + 1] : pk[2 * gp];
+              const u32x4_t out = hh ? (u32x4_t){got.x, got.y, own.x, own.y} : (u32x4_t){own.x, own.y, got.x, got.y};
+              __builtin_amdgcn_raw_buffer_store_b128(out, qrs, qlo, (32 * j * NQK + 32 * tile + 16 * gp) * 2, 0);
+            }
+          }
+        }
+      } else {
+        // register r of tile (i2, j) <-> token 32 j + (r & 3) + 8 (r >> 2) + 4 hh, feature 32 (2 w + i2) + ql of the V panel = head w, dim 32 i2 + ql;
+        // registers 8 m .. 8 m + 7 are the keys 16 m + 4 hh + {0..3, 8..11}: group 2 m + hh of the permuted V^T layout
+        const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.q_vt + ((size_t)(slot * kHeads + wave) * kHeadDim) * a.npad + i0, 0, kHeadDim * a.npad * 2, 0x00020000);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const float bias = a.q_bias[NQK + 32 * (2 * wave + i2) + ql];
+          const unsigned int vlo = (unsigned int)(((32 * i2 + ql) * a.npad + 8 * hh) * 2);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              unsigned int w4[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = qacc[i2][j][8 * m + 2 * e] * ascale + bias;
+                const float hi = qacc[i2][j][8 * m + 2 * e + 1] * ascale + bias;
+                w4[e] = pack16<true>(lo, hi);
+                ovf_track(amaxq, lo, hi);
+              }
+              __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){w4[0], w4[1], w4[2], w4[3]}, vrs, vlo, (32 * j + 16 * m) * 2, 0);
+            }
+        }
+      }
+      GN_PIN();
+    }
+    ovf_commit(a.ovf, amaxq);
+  }
   if (ABL & 8) {
     stamp(9);
     if (a.dbg_ts != nullptr && lane == 0)
@@ -726,13 +908,23 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
   FfnArgs b = a;
   if (!walk) b.tiles = nullptr;
   if (walk || ablate != 0) b.nvalid = nullptr;
+  if (a.composed && a.qkv != 0 && ablate == 0) {      // the next block's attention input projection behind the tail (a.qkv: 1 self, 2 cross)
+    if (a.qkv == 1) {
+      if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, 1>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true, false, 1>), grid, block, 0, s, b);
+      g_last_kernel = walk ? "k_ffn128<0, true, true, 1>" : "k_ffn128<0, true, false, 1>";
+    } else {
+      if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, 2>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true, false, 2>), grid, block, 0, s, b);
+      g_last_kernel = walk ? "k_ffn128<0, true, true, 2>" : "k_ffn128<0, true, false, 2>";
+    }
+    return;
+  }
   if (a.composed) {
     switch (ablate) {
       case 8: hipLaunchKernelGGL((k_ffn128<8, true>), grid, block, 0, s, b); break;
       case 136: hipLaunchKernelGGL((k_ffn128<136, true>), grid, block, 0, s, b); break;
       default: if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true>), grid, block, 0, s, b); break;
     }
-    g_last_kernel = walk ? "k_ffn128<0, true, true>" : "k_ffn128<0, true, false>";
+    g_last_kernel = walk ? "k_ffn128<0, true, true, 0>" : "k_ffn128<0, true, false, 0>";
     return;
   }
   switch (ablate) {
@@ -740,7 +932,7 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
     case 136: hipLaunchKernelGGL((k_ffn128<136, false>), grid, block, 0, s, b); break;
     default: if (walk) hipLaunchKernelGGL((k_ffn128<0, false, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, false>), grid, block, 0, s, b); break;
   }
-  g_last_kernel = walk ? "k_ffn128<0, false, true>" : "k_ffn128<0, false, false>";
+  g_last_kernel = walk ? "k_ffn128<0, false, true, 0>" : "k_ffn128<0, false, false, 0>";
 }
 
 }  // namespace gn

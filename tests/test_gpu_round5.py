@@ -76,7 +76,7 @@ class _Knobs:
 
     def __init__(self, eng, **kv):
         self.eng, self.kv = eng, {int(k[1:]): v for k, v in kv.items()}
-        self.default = {14: 0, 1: 4, 19: 1, 27: 2, 31: 1}
+        self.default = {14: 0, 1: 4, 19: 1, 27: 2, 31: 1, 32: 1}
 
     def __enter__(self):
         for k, v in self.kv.items():
@@ -245,4 +245,54 @@ def test_estimate_bucketed_with_overlapped_pose_stage_and_deferred_joins(state_d
             assert float((got["R"] - want["R"]).abs().max()) < 1e-9 and float((got["t"] - want["t"]).abs().max()) < 1e-6, mode
     eng.set_substreams(1)
     eng.flush()
+    del eng
+
+
+def test_projection_fused_into_the_block_tail_gives_the_bits_of_the_separate_launches(state_dict_np, state_dict_t):
+    """Round 5: on bulk grids k_ffn128 computes the NEXT block's attention input projection from the rows its epilogue has just produced
+    (k_ffn128<0, true, ., 1 / 2>; knob 32).  Same partial products in the same order and the same epilogue expressions as k_qkv<., true, 2>:
+    everything downstream -- match descriptors, scores, correspondence indices, poses -- is BITWISE what the separate launches give; the launch
+    table shows 17 fused tails + 1 plain one and ONE k_qkv launch (the first block's) instead of 18.  Checked on a full batch (16 x 1024), on a
+    ragged one (work lists; the walking and the one-tile form of the tail), and the full batch against the oracle."""
+    from gisnav_amd.engine import PoseEngine
+    _threads()
+    rs = np.random.default_rng(3)
+    full = [make_pair(8800 + i, n_q=1024, n_r=1024 - 7 * (i % 4)) for i in range(16)]
+    rag = [make_pair(8900 + i, n_q=int(rs.integers(60, 1025)), n_r=int(rs.integers(60, 1025))) for i in range(16)]
+    eng = PoseEngine(0, max_batch=16, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+    for label, pairs, forms in (("full", full, (1,)), ("ragged", rag, (2, 3))):
+        inp = eng.stage_inputs(pairs)
+        for lists in forms:
+            got = {}
+            for fused in (1, 0):
+                with _Knobs(eng, k31=lists):
+                    eng.lib.gn_debug_set_variant(eng.ctx, 32, fused)
+                    eng.set_kernel_timing(400)
+                    idx, score, n = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+                    torch.cuda.synchronize()
+                    tab = {r["name"]: int(r["launches"]) for r in eng.kernel_table()}
+                    eng.set_kernel_timing(0)
+                    md = eng.debug_read("md", 2 * 16 * 1024 * 256).copy()
+                    out = eng.estimate(inp, K_MATRIX)
+                    torch.cuda.synchronize()
+                    got[fused] = (idx.cpu().numpy().copy(), score.cpu().numpy().copy(), n.cpu().numpy().copy(), md, out["R"].cpu().numpy().copy(), tab)
+            eng.lib.gn_debug_set_variant(eng.ctx, 32, 1)
+            a, b = got[1], got[0]
+            nf = sum(v for k, v in a[5].items() if k.startswith("k_ffn128") and k.rstrip(">").endswith((", 1", ", 2")))
+            assert nf == 17 and sum(v for k, v in a[5].items() if k.startswith("k_qkv")) == 1, a[5]
+            assert sum(v for k, v in b[5].items() if k.startswith("k_qkv")) == 18 and not any(k.rstrip(">").endswith((", 1", ", 2")) for k in b[5] if k.startswith("k_ffn128")), b[5]
+            assert np.array_equal(a[2], b[2]) and a[2].max() > 300, (label, lists)
+            for p in range(16):
+                k = int(a[2][p])
+                assert np.array_equal(a[0][p, :k], b[0][p, :k]) and np.array_equal(a[1][p, :k].view(np.uint32), b[1][p, :k].view(np.uint32)), (label, lists, p)
+                nq, nr = len(pairs[p].kp_q), len(pairs[p].kp_r)
+                for side, nv in ((0, nq), (1, nr)):        # the match descriptors of the VALID tokens, bit for bit
+                    lo = (2 * p + side) * 1024 * 256
+                    assert np.array_equal(a[3][lo: lo + nv * 256].view(np.uint32), b[3][lo: lo + nv * 256].view(np.uint32)), (label, lists, p, side)
+            assert np.array_equal(a[4], b[4]), (label, lists)
+        if label == "full":
+            ref = [oracle_match(state_dict_t, p) for p in pairs]
+            m, t, fam, _ = _match_counted(eng, pairs, ref)
+            assert fam["k_ffn128"] and fam["k_attn_pw"] and m == 0 and t > 8000, (m, t, fam)
+            _report("fused_tail_projection_16x1024_margin_built", {"index_mismatches": m, "cpu_matches": t})
     del eng

@@ -117,7 +117,7 @@ def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
         the first 6 instructions (the hand-counted wait);
       * k_ffn128<0, composed, one tile per workgroup> (the bench's dominant kernel): 512 registers (256 + 256 accumulators), 2304 MFMAs, at most
         the two spilled VGPRs / five scratch instructions of round 4's build, none of them inside GEMM 1's stream of 1536 MFMAs."""
-    ks = _disassemble_kernels(tmp_path, ["k_attn_pwILb1ELi0E", "k_attn_pwILb0ELi0E", "k_ffn128ILi0ELb1ELb0E", "k_ffn128ILi0ELb1ELb1E"])
+    ks = _disassemble_kernels(tmp_path, ["k_attn_pwILb1ELi0E", "k_attn_pwILb0ELi0E", "k_ffn128ILi0ELb1ELb0ELi", "k_ffn128ILi0ELb1ELb1ELi0E"])
     pw = [n for n in ks if "k_attn_pw" in n]
     assert len(pw) == 2, sorted(ks)
     for name in pw:
@@ -140,17 +140,27 @@ def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
                 elif op.startswith("v_") and not op.startswith("v_cmp") and k - j <= 6:
                     touched = hit or any((r := _reg_range(o)) is not None and r[0] == "v" and not (r[2] < lo or r[1] > hi) for o in ops[1:])
                     assert not touched, f"{name}: {op} touches v[{lo}:{hi}] {k - j} instructions behind the score MFMA that writes it"
-    for tag, spills, scratch in (("k_ffn128ILi0ELb1ELb0E", 2, 5), ("k_ffn128ILi0ELb1ELb1E", 22, 21)):
+    # (tag, MFMAs in the code, spilled VGPRs at most, scratch instructions at most): the one-tile tail alone, with the self / cross projection fused behind it
+    # (round 5: + 768 / 512 MFMAs), and the walking form
+    for tag, nmf, spills, scratch in (("k_ffn128ILi0ELb1ELb0ELi0E", 2304, 2, 5), ("k_ffn128ILi0ELb1ELb0ELi1E", 3072, 3, 5), ("k_ffn128ILi0ELb1ELb0ELi2E", 2816, 19, 12),
+                                      ("k_ffn128ILi0ELb1ELb1ELi0E", 2304, 22, 21)):
         (name,) = [n for n in ks if tag in n]
         meta, ins = ks[name]
         assert meta["agpr_count"] == 256 and meta["vgpr_count"] == 512, meta
         assert meta["vgpr_spill_count"] <= spills and meta["sgpr_spill_count"] == 0, meta
         mf = [j for j, (op, _) in enumerate(ins) if op.startswith("v_mfma")]
-        assert len(mf) == 2304, (name, len(mf))
+        assert len(mf) == nmf, (name, len(mf))
         sc = [j for j, (op, _) in enumerate(ins) if op.startswith("scratch_")]
         assert len(sc) <= scratch, (name, len(sc))
-        if tag.endswith("Lb0E"):     # the shipped default: nothing from scratch memory inside the first GEMM's weight stream
+        if "Lb0ELi" in tag:     # the one-tile forms the bench runs: nothing from scratch memory inside the first GEMM's weight stream, nor inside the projection's
             assert not any(mf[0] < j < mf[1535] for j in sc), (name, sc, mf[0], mf[1535])
+            assert not any(j > mf[2304] for j in sc if nmf > 2304), (name, sc, mf[2304])
+        if nmf > 2304:
+            # round 5: the fused projection's epilogue is written component by component -- with the f32x4 expressions of k_qkv hipcc
+            # emitted `v_pk_mul_f32 D, s[n:n+1], V op_sel_hi:[0,1]`, and the one-tile self form then stored garbage in (o.z, o.w) of lanes 12..15 /
+            # 28..31 (deterministic; gone with scalar arithmetic).  No packed f32 arithmetic behind the projection's first MFMA (the tail's own row-wise epilogue, in front of it, keeps its v_pk_fma_f32).
+            packed = [(j, op) for j, (op, _) in enumerate(ins) if j > mf[2304] and op.startswith("v_pk_") and op.endswith("_f32")]
+            assert not packed, (name, packed[:8])
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -21,3 +21,19 @@ for b in batches:
     elapsed, _ = bench.timed_steps(eng, inp, out, 300, 30, dev)
     print(f"batch {b} knobs {knobs}: {elapsed / 300 * 1e3:.4f} ms per call, {b * 300 / elapsed:.1f} pairs/s, poses ok {int(out['ok'].sum().item())}", flush=True)
     del eng
+    if "--table" in args:      # per-kernel HIP-event table of one call (launch gaps excluded) + the stage split
+        eng = PoseEngine(0, max_batch=b, max_kpts=1024, precision="f16x2_f16_attn", state_dict=sd)
+        for w, v in knobs:
+            eng.lib.gn_debug_set_variant(eng.ctx, w, v)
+        for _ in range(3):
+            eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        eng.set_kernel_timing(400)
+        eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        torch.cuda.synchronize()
+        tot = 0.0
+        for r in sorted(eng.kernel_table(), key=lambda r: -r["ms"]):
+            tot += r["ms"]
+            print(f"   {r['name']:44s} x{int(r['launches']):3d}  {r['ms'] * 1e3 / r['launches']:8.2f} us each  {r['ms'] * 1e3:9.1f} us total")
+        print(f"   recorded launches: {tot * 1e3:.1f} us")
+        eng.set_kernel_timing(0)
+        del eng
