@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgisnav_amd.so")
-SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_ffn128.hip", "gn_qkv.hip", "gn_attention.hip", "gn_attention_pw.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
+SOURCES = ["gn_api.hip", "gn_gemm.hip", "gn_gemm_p2.hip", "gn_ffn.hip", "gn_ffn128.hip", "gn_qkv.hip", "gn_skinny.hip", "gn_attention.hip", "gn_attention_pw.hip", "gn_prep.hip", "gn_match_head.hip", "gn_knn.hip", "gn_warp.hip", "gn_geo.hip", "gn_sift.hip", "gn_superpoint.hip", "gn_pnp.hip", "gn_loftr.hip"]
 # SLP vectoriser: ON for every file except gn_qkv.hip.  With it, hipcc (ROCm 7.2) packs the second rotary pair of k_qkv's epilogue
 # (o.z = v.z cos' - v.w sin', o.w = v.w cos' + v.z sin') into `v_pk_fma_f32 D, A, B, C op_sel:[0,1,0]` -- the LOW lane multiplies by the HIGH
 # register of B -- and on the MI355X that instruction, in this kernel, intermittently returns C alone in the low lane (the product is dropped)
@@ -30,6 +30,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # with the default AGPR form each tile paid ~255 v_accvgpr_read/write moves on the VALU, the kernel's bottleneck)
 EXTRA_FLAGS = {"gn_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "gn_qkv.hip": ["-fno-slp-vectorize"],
+               "gn_skinny.hip": ["-fno-slp-vectorize"],     # k_qkv's epilogue expressions (same bits): same flag
                # k_ffn128 places its VALU work instruction by instruction beside the MFMAs: packed f32 arithmetic is an anti-lever there
                # (and is one straight line of ~17 k instructions: the default size limit of `#pragma unroll` would silently leave a loop rolled, and its
                # register arrays in scratch memory)

@@ -15,7 +15,8 @@ thread_local std::string g_err;
 
 struct Linear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; uint16_t* wp = nullptr; float acc_scale = 1.f;
                 uint16_t* wf = nullptr; int frag_order = -1;       // frag_order: -1 none, else the k order of build_weight_fragments
-                uint16_t* wf2 = nullptr; };                         // ffn.0 only: order 2 (message half permuted) for the folded out_proj   // wf: the scaled fp16 pair in MFMA fragment order (gn_ffn.hip), same scale as wp
+                uint16_t* wf2 = nullptr;
+                uint16_t* wfn = nullptr; };                         // ffn.3 only: NATURAL k order (gn_skinny.hip reads GELU rows from memory, not from registers)                         // ffn.0 only: order 2 (message half permuted) for the folded out_proj   // wf: the scaled fp16 pair in MFMA fragment order (gn_ffn.hip), same scale as wp
 // wp: pre-split planes, [3][out][in] bf16 (f32x3) or [2][out][in] fp16 of w / acc_scale (f16x2; acc_scale a power of two)
 
 struct Block {       // one SelfBlock or CrossBlock
@@ -117,6 +118,8 @@ struct gn_ctx {
   int ncu = 256;           // compute units of ctx->device (grids of the walking kernels)
   int qkv_in_tail = 1;     // knob 32.  1 (default): on bulk grids the block tail k_ffn128 also computes the NEXT block's attention input projection from the rows
                            // it has just produced (k_ffn128<., ., ., 1 / 2>: no k_qkv launch, no read-back of the residual stream); 0: separate k_qkv launches
+  int skinny = 1;          // knob 33.  1 (default): calls of at most 4096 tokens (one or two pairs of 1024 keypoints) run the attention input projections and the block
+                           // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
   unsigned long long* tile_feedback = nullptr;   // pinned host [8]: (all tiles << 32 | valid tiles) written by k_tile_lists of sub-batch group g's last call
   int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
@@ -325,6 +328,11 @@ int build_planes(gn_ctx* ctx, Linear& L) {
       build_weight_fragments(host.data(), L.out, L.in, scale, L.frag_order, frag.data());
       if (!L.wf) { int rc = dalloc(ctx, &L.wf, 2 * n); if (rc != GN_OK) return rc; }
       GN_HIP(hipMemcpy(L.wf, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      if (L.frag_order == 1) {   // ffn.3: also in natural k order for the small-grid tail (gn_skinny.hip)
+        build_weight_fragments(host.data(), L.out, L.in, scale, 0, frag.data());
+        if (!L.wfn) { int rc = dalloc(ctx, &L.wfn, 2 * n); if (rc != GN_OK) return rc; }
+        GN_HIP(hipMemcpy(L.wfn, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
       if (L.out == 2 * kDim && L.in == 2 * kDim) {   // ffn.0: also the variant whose message half is fed from registers
         build_weight_fragments(host.data(), L.out, L.in, scale, 2, frag.data());
         if (!L.wf2) { int rc = dalloc(ctx, &L.wf2, 2 * n); if (rc != GN_OK) return rc; }
@@ -386,8 +394,12 @@ bool qkv_projection_applies(const gn_ctx* c, const Block& blk, int T, int np, in
   return c->planes_mode && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && T % 128 == 0 && np % 128 == 0 && (vt_perm & 1) &&
          (T / 128 >= 128 || c->qkv_fused == 2);
 }
+bool skinny_applies(const gn_ctx* c, int T) {
+  return (c->skinny & 15) && c->planes_mode && c->x_planes_only && T % 32 == 0 && ((c->skinny & 15) == 2 || T <= 4096);
+}
 bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
-  if (!qkv_projection_applies(c, blk, T, np, vt_perm)) return false;
+  const bool skinny = skinny_applies(c, T) && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && np % 32 == 0 && vt_perm == 1 && !c->qkv_stamps;
+  if (!skinny && !qkv_projection_applies(c, blk, T, np, vt_perm)) return false;
   QkvArgs q;
   q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
   q.rot4 = c->rot4; q.rot_stride = (long long)c->Tmax; q.qkb = c->qkb; q.ldyb = cross ? kDim : 2 * kDim; q.vt = c->vtb; q.npad = np;
@@ -400,7 +412,7 @@ bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int 
   if (c->stop_after && c->launch_count > c->stop_after) return true;
   const bool rec = c->ktiming && c->kused < c->kflops.size();
   if (rec) hipEventRecord(c->kev[2 * c->kused], s);
-  launch_qkv(q, cross, s);
+  if (skinny) launch_skinny_qkv(q, cross, s); else launch_qkv(q, cross, s);
   if (rec) {
     const double N = cross ? 2.0 * kDim : 3.0 * kDim;
     hipEventRecord(c->kev[2 * c->kused + 1], s);
@@ -485,7 +497,33 @@ bool tail_should_walk(const gn_ctx* c) {
 // x += ffn3(gelu(ln(ffn0([x | msg]))))
 // next / next_cross: the block whose attention input projection follows this tail (nullptr: none) -- when the tail runs as the composed k_ffn128 and that
 // projection is a k_qkv<., true, 2> launch, it is computed inside the tail instead; returns true when it was (the caller then skips the projection)
+// one recorded launch of the matcher schedule (kernel class 0): stop_after bookkeeping + optional HIP events around it
+template <typename F> bool timed_launch(gn_ctx* c, hipStream_t s, double flops, double bytes, F&& launch) {
+  ++c->launch_count;
+  if (c->stop_after && c->launch_count > c->stop_after) return false;
+  const bool rec = c->ktiming && c->kused < c->kflops.size();
+  if (rec) hipEventRecord(c->kev[2 * c->kused], s);
+  launch();
+  if (rec) {
+    hipEventRecord(c->kev[2 * c->kused + 1], s);
+    c->kflops[c->kused] = flops; c->kbytes[c->kused] = bytes; c->kclass[c->kused] = 0; c->kname[c->kused] = gn::g_last_kernel;
+    ++c->kused;
+  }
+  return true;
+}
+
 bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const Block* next = nullptr, bool next_cross = false, int np = 0, int vt_perm = 0) {
+  if (skinny_applies(c, T) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
+      c->h && c->ctx_p && gn::g_ffn_ablate == 0 && gn::g_ffn_shape == 0) {
+    // small grid: the weight stream split across CUs -- two launches (gn_skinny.hip)
+    SkinnyTailArgs a;
+    a.xp = c->x_p; a.cp = c->ctx_p; a.w1 = blk.wfc; a.w1_scale = blk.wfc_scale; a.b1 = blk.b1c; a.h = c->h; a.ln_g = blk.ln_g; a.ln_b = blk.ln_b;
+    a.w2 = blk.ffn3.wfn; a.w2_scale = blk.ffn3.acc_scale; a.b2 = blk.ffn3.b; a.xp_out = c->x_p; a.y = keep_f32 ? c->x : nullptr;
+    a.ovf = c->guard ? c->ovf : nullptr; a.T = T;
+    if (!timed_launch(c, s, 2.0 * T * 512.0 * 512.0, 4.0 * T * (256.0 + 256.0 + 512.0) + 4.0 * 512.0 * 512.0, [&] { launch_skinny_h(a, s, c->skinny >> 4); })) return false;
+    timed_launch(c, s, 2.0 * T * 256.0 * 512.0, 4.0 * T * (512.0 + 256.0 + 256.0) + 4.0 * 256.0 * 512.0, [&] { launch_skinny_out(a, s, c->skinny >> 4); });
+    return false;
+  }
   if (c->planes_mode && c->x_planes_only && c->ffn_fused == 3 && blk.ffn0.wf && blk.ffn3.wf && T % 64 == 0) {   // the whole tail in one launch
     FfnArgs f;
     const bool fold = tail_folds_out_proj(c, blk, T);                     // out_proj computed inside the kernel from the attention output
@@ -1783,6 +1821,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 28) ctx->ffn_compose = value;
   else if (which == 31) ctx->use_lists = value;
   else if (which == 32) ctx->qkv_in_tail = value ? 1 : 0;
+  else if (which == 33) ctx->skinny = value;
   else if (which == 29) {   // CU shares for the sub-batch streams: takes effect for streams created afterwards
     GN_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); ctx->sub_s[i] = nullptr; ctx->ev_join[i] = nullptr; }

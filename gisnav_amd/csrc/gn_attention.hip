@@ -712,6 +712,175 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 2 : 1) void k_attn16_v5(AttnArgs
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// k_attn_ks (round 5): attention of ONE or TWO pairs -- the reference's own operating point (one pair per message, pose_node.py:178-184).
+// k_attn16_v5 gives a wave 32 queries and ALL keys: at one pair that is 64 workgroups on a quarter of the chip, each wave walking 16 key tiles one
+// after the other (21 us per launch, of which ~4 us are MFMAs).  Here the four waves of a workgroup share the SAME 32 queries and take every fourth
+// 64-key tile each; the partial results (running reference, denominator, 64 x 32 output tile per wave) are merged through LDS, in a fixed order.
+// 8 x the workgroups (npad / 32 per (slot, head)), a quarter of the serial tile chain per wave.  No LDS ring and no barrier in the tile loop: the
+// K rows and V^T panels of a (slot, head) are 256 KB and stay in L2, every wave reads its own fragments straight into registers (16-byte loads:
+// a K row's 64 dims and a V^T row's 64 keys are one 128-byte line each), one tile ahead.  Same operands, operand rounding and per-tile arithmetic
+// as k_attn16_v5's exact path (maximum searched in every tile, lazy reference, denominators from the rounded probabilities on the matrix pipe);
+// the partial sums are combined in another order, so context rows differ from k_attn16_v5's in the last bits (as between any two attention
+// kernels of this library; correspondences: tests/test_gpu_round5.py).
+// NW = 8 (the shipped form): eight waves, two per SIMD, every eighth tile each (two tiles at 1024 keys: 128 registers of fragments) -- one
+// wave's probability arithmetic runs under the other's MFMAs; NW = 4: one wave per SIMD, four tiles each.
+template <bool F16, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_ks(AttnArgs a) {
+  constexpr int TP = 16 / NW;      // tiles of a wave per pass, all requested up front
+  __shared__ __attribute__((aligned(16))) float part[NW][34][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, bs = blockIdx.z;
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = blockIdx.x * 32;
+  const int ntiles = (nkv + KT - 1) / KT;
+
+  bf16x8 qf[4];
+  {
+    const unsigned short* qp = a.qb + ((size_t)bs * a.npad + q0 + ql) * a.ldqb + h * 64 + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+  }
+  f32x16 o[2], ol;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)(F16 ? 0x3c00 : 0x3f80);
+  float m_run = -INFINITY;
+
+  // fragments of key tile t: K rows 32 kt + ql, dims 16 c + 8 hh ..; V^T rows (dims) 32 d + ql, keys 8 (4 kt + 2 u + hh) ..
+  const unsigned short* const kbase = a.kb + ((size_t)kvs * a.npad + ql) * a.ldkb + h * 64 + 8 * hh;
+  const unsigned short* const vbase = a.vt + (((size_t)kvs * kHeads + h) * kHeadDim + ql) * a.npad + 8 * hh;
+  // ALL of a wave's tiles are requested before the first one is used (up to four per pass: 64 KB of fragments, 256 registers of a lone wave's 512).
+  // A (slot, head)'s K rows and V^T panels were written by the projection launch just before, from other XCDs: every first touch is an L2 miss,
+  // and with one tile of look-ahead the four tiles of a wave cost four miss latencies one behind the other (12.0 -> 9.x us per launch).
+  bf16x8 kf[TP][2][4], vf[TP][2][2][2];     // [tile of the pass][kt][c], [tile of the pass][kt][u][d]
+  auto load_tile = [&](int buf, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) kf[buf][kt][c] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)(t * KT + 32 * kt) * a.ldkb + 16 * c);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) vf[buf][kt][u][d] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)(32 * d) * a.npad + t * KT + 8 * (4 * kt + 2 * u));
+  };
+  auto tile = [&](int buf, int t) __attribute__((always_inline)) {
+    f32x16 S[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) S[kt] = mfma16<F16>(kf[buf][kt][c], qf[c], S[kt]);
+    if (t * KT + KT > nkv) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= nkv) S[kt][r] = -INFINITY;
+        }
+    }
+    float m = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) m = fmaxf(fmaxf(m, S[kt][r]), S[kt][(r + 1) & 15]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    // lazy maximum: keep the stale reference unless some query's maximum grew by more than 2^8 (k_attn16_v5's exact path)
+    if (__builtin_amdgcn_ballot_w64((m - m_run) * kLog2e > 8.0f) != 0) {
+      const float m_new = fmaxf(m_run, m);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
+      m_run = m_new;
+    }
+    const float mneg = -m_run * kLog2e;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][8 * u + 2 * e], kLog2e, mneg));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][8 * u + 2 * e + 1], kLog2e, mneg));
+          pw[e] = pack16<F16>(p0, p1);
+        }
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        ol = mfma16<F16>(ones, pf, ol);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) o[d] = mfma16<F16>(vf[buf][kt][u][d], pf, o[d]);
+      }
+  };
+  // wave w takes tiles w, w + NW, ...: passes of up to TP tiles, all requested up front
+#pragma unroll 1
+  for (int t0 = wave; t0 < ntiles; t0 += 16) {
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+      if (t0 + NW * i < ntiles) load_tile(i, t0 + NW * i);
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+      if (t0 + NW * i < ntiles) tile(i, t0 + NW * i);
+  }
+  // ---- merge the four waves' partial results: [34][64] floats per wave = o[0][0..15], o[1][0..15], reference, denominator of lane l at [.][l]
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][16 * d + r][lane] = o[d][r];
+  part[wave][32][lane] = m_run;
+  part[wave][33][lane] = ol[0];
+  __syncthreads();
+  float al[NW], M = -INFINITY, L = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) M = fmaxf(M, part[i][33][lane] > 0.f ? part[i][32][lane] : -INFINITY);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const float li = part[i][33][lane];
+    al[i] = li > 0.f ? __builtin_amdgcn_exp2f((part[i][32][lane] - M) * kLog2e) : 0.f;     // (a wave without keys has l = 0)
+    L += li * al[i];
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  // the NW waves share the 2 x 4 groups of four output registers: wave w finishes groups GP w .. GP w + GP - 1 (half d = group >> 2, g = group & 3)
+  constexpr int GP = 8 / NW;
+  float amax = 0.f;
+#pragma unroll
+  for (int gg = 0; gg < GP; ++gg) {
+    const int d = (GP * wave + gg) >> 2, g = (GP * wave + gg) & 3;
+    float w4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) acc += part[i][16 * d + 4 * g + e][lane] * al[i];
+      w4[e] = acc * inv;
+    }
+    const size_t row = (size_t)bs * a.npad + q0 + ql;
+    if (a.outp != nullptr) {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const f32x4v w = {w4[0], w4[1], w4[2], w4[3]};
+      ovf_track(amax, w.x, w.y); ovf_track(amax, w.z, w.w);
+      const f16x4 hv = __builtin_convertvector(w, f16x4);
+      const f16x4 mv = __builtin_convertvector(w - __builtin_convertvector(hv, f32x4v), f16x4);
+      uint16_t* pp = a.outp + hm16_off(row, a.ldo, h * 64 + d * 32 + 8 * g + 4 * hh);
+      *reinterpret_cast<f16x4*>(pp) = hv;
+      *reinterpret_cast<f16x4*>(pp + 16) = mv;
+    } else {
+      *reinterpret_cast<float4*>(a.out + row * a.ldo + h * 64 + 4 * hh + d * 32 + 8 * g) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+    }
+  }
+  if (a.outp != nullptr) ovf_commit(a.ovf, amax);
+}
 }  // namespace
 
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
@@ -763,6 +932,24 @@ void launch_attention_bf16_v2(const AttnArgs& a, hipStream_t s) {
   const bool pw_auto = g_attn_variant == 4 && a.half_fmt && a.npad % 256 == 0 && (long long)(a.npad / 256) * kHeads * a.BS >= 256;
   if ((pw_auto || (g_attn_variant >= 70 && g_attn_variant <= 73) || g_attn_variant >= 1000) && !(a.nsplit > 1 && a.part != nullptr) &&
       launch_attention_pw(a, pw_auto ? 0 : g_attn_variant >= 1000 ? g_attn_variant - 900 : g_attn_variant - 70, s)) return;
+  // ONE pair (k_attn16_v5's grid leaves three quarters of the CUs idle; measured 14.4 vs 21.1 us per launch at 1024 keypoints; at two pairs the
+  // two kernels tie): the four waves of a workgroup split the KEYS of 32 queries (k_attn_ks).  The choice depends on the number of pairs only,
+  // never on the padded length: gn_set_active_kpts must not change a result bit (test_active_kpts_padding_does_not_change_results).
+  // Knob 1: 80 = always, 81 = always in the four-wave form, 5 = never.
+  {
+    const bool ks_auto = g_attn_variant == 4 && a.BS <= 2;
+    if ((ks_auto || g_attn_variant == 80 || g_attn_variant == 81) && !(a.nsplit > 1 && a.part != nullptr) && a.npad % 64 == 0) {
+      const dim3 grid(a.npad / 32, kHeads, a.BS);
+      if (g_attn_variant == 81) {
+        if (a.half_fmt) { hipLaunchKernelGGL((k_attn_ks<true, 4>), grid, dim3(256), 0, s, a); g_last_kernel = "k_attn_ks<true, 4>"; }
+        else { hipLaunchKernelGGL((k_attn_ks<false, 4>), grid, dim3(256), 0, s, a); g_last_kernel = "k_attn_ks<false, 4>"; }
+      } else {
+        if (a.half_fmt) { hipLaunchKernelGGL((k_attn_ks<true, 8>), grid, dim3(512), 0, s, a); g_last_kernel = "k_attn_ks<true, 8>"; }
+        else { hipLaunchKernelGGL((k_attn_ks<false, 8>), grid, dim3(512), 0, s, a); g_last_kernel = "k_attn_ks<false, 8>"; }
+      }
+      return;
+    }
+  }
   g_last_kernel = "k_attn16_v5<0, 4, 3, 1, false, false>";   // the name rocprofv3 prints (profiles up to r02m: "k_attn_bf16_v5<0, 4, 3, 1, false>")
   if (a.half_fmt) {   // fp16 operands (GN_PREC_F16X2_F16_ATTN)
     if (a.nsplit > 1 && a.part != nullptr && a.tickets != nullptr) {

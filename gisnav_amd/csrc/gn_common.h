@@ -172,6 +172,21 @@ struct QkvArgs {
   int ncu = 0;                        // compute units of the context's device; 0 = ask the current device
 };
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s);
+// small grids (one or two pairs; gn_skinny.hip): 32 tokens x 128 features per workgroup, no LDS -- a.tiles / a.vt_perm / a.dbg_ts are not used
+void launch_skinny_qkv(const QkvArgs& a, bool cross, hipStream_t s);
+// the block tail of a small grid as two launches (gn_skinny.hip): h = composed ffn.0 over [x | ctx] (f32 rows); LayerNorm + GELU of the workgroup's
+// rows into LDS, x += ffn.3(g) + b2 in place (hm16 rows, optional f32 copy)
+struct SkinnyTailArgs {
+  const uint16_t* xp = nullptr; const uint16_t* cp = nullptr;       // [T][256] hm16 residual stream and attention output
+  const uint16_t* w1 = nullptr; float w1_scale = 1.f; const float* b1 = nullptr;   // composed ffn.0 [512][512], fragment order (natural k), and its bias
+  float* h = nullptr;                                               // [T][512] f32 hidden rows (k_skinny_h out, k_skinny_out in)
+  const float* ln_g = nullptr; const float* ln_b = nullptr;         // LayerNorm(512) weight / bias
+  const uint16_t* w2 = nullptr; float w2_scale = 1.f; const float* b2 = nullptr;   // ffn.3 [256][512], fragment order with NATURAL k
+  uint16_t* xp_out = nullptr; float* y = nullptr;                   // hm16 output rows (may be xp) and optional f32 copy
+  unsigned int* ovf = nullptr; int T = 0;
+};
+void launch_skinny_h(const SkinnyTailArgs& a, hipStream_t s, int variant = 0);
+void launch_skinny_out(const SkinnyTailArgs& a, hipStream_t s, int variant = 0);
 int device_cu_count();                // multiProcessorCount of the CURRENT device (no caching across devices)
 
 // ---- attention --------------------------------------------------------------------------------

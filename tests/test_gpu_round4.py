@@ -139,6 +139,7 @@ def test_ffn128_matches_the_64_token_tail_and_is_bitwise_repeatable(state_dict_n
             idx, score, n = (v.cpu().numpy().copy() for v in eng.match(*args))
             x = eng.debug_read("x", T * 256).copy()
             out.setdefault(shape, []).append((idx, score, n, x))
+        eng.lib.gn_debug_set_variant(eng.ctx, 14, 0)      # (the shape knob is process-wide: back to automatic for the tests that follow)
         # rows of VALID tokens only: tiles that hold nothing but padding are not processed by the list-walking kernels (their rows keep older values)
         nv = np.concatenate([[len(p.kp_q), len(p.kp_r)] for p in pairs])
         valid = (np.arange(1024)[None, :] < nv[:, None]).reshape(-1)

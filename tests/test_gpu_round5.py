@@ -296,3 +296,73 @@ def test_projection_fused_into_the_block_tail_gives_the_bits_of_the_separate_lau
             assert fam["k_ffn128"] and fam["k_attn_pw"] and m == 0 and t > 8000, (m, t, fam)
             _report("fused_tail_projection_16x1024_margin_built", {"index_mismatches": m, "cpu_matches": t})
     del eng
+
+
+def _attn_ref64(q, k, v, nkv, cross, cast):
+    BS, n, _ = q.shape
+    outs = []
+    for bs in range(BS):
+        kvs = bs ^ 1 if cross else bs
+        m = int(nkv[kvs])
+        qq = cast(q[bs] * 0.125).double().cpu().reshape(n, 4, 64).transpose(0, 1)
+        kk = cast(k[kvs, :m]).double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        vv = cast(v[kvs, :m]).double().cpu().reshape(m, 4, 64).transpose(0, 1)
+        outs.append((torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(n, 256).numpy())
+    return outs
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_key_split_attention_of_one_pair_against_fp64(state_dict_np, cross):
+    """k_attn_ks (round 5; the reference's operating point is ONE pair per message, pose_node.py:178-184): the four waves of a workgroup share
+    32 queries and split the key tiles, partial results merged through LDS.  One pair x 1024 tokens per side with ragged key counts (a side
+    with 5 keys: three waves of every workgroup have no tile; 833: a masked last tile), against fp64 on the fp16-rounded operands (only the
+    rounding of the probabilities is left: same bound as k_attn16_v5's test) and against k_attn16_v5 itself; selected by the grid on its own."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=1, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(17)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())      # noqa: E731
+    worst = 0.0
+    for nk in ((1024, 833), (5, 1000), (64, 65)):
+        q, k, v = (torch.randn(2, 1024, 256, generator=g).to(dev) for _ in range(3))
+        k[1, 7] *= 6.0
+        nkv = torch.tensor(nk, dtype=torch.int32, device=dev)
+        eng.set_kernel_timing(8)
+        out = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+        names = [r["name"] for r in eng.kernel_table()]
+        eng.set_kernel_timing(0)
+        eng.lib.gn_debug_set_variant(eng.ctx, 1, 5)
+        try:
+            v5 = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+        finally:
+            eng.lib.gn_debug_set_variant(eng.ctx, 1, 4)
+        ref = _attn_ref64(q, k, v, nkv, cross, lambda t: t.half())
+        assert np.isfinite(out).all()
+        for bs in range(2):
+            worst = max(worst, rel(out[bs], ref[bs]))
+            assert rel(out[bs], ref[bs]) < 1.5e-3 and rel(out[bs], v5[bs]) < 1.5e-3, (nk, bs, rel(out[bs], ref[bs]), rel(out[bs], v5[bs]))
+    _report("attn_ks_rel_err_vs_fp64_cross%d" % int(cross), worst)
+    del eng
+
+
+def test_one_pair_runs_the_small_grid_kernels_and_matches_the_oracle(state_dict_np, state_dict_t):
+    """Batch 1 (the reference's operating point): the launch table shows k_attn_ks, and the correspondences of full-size pairs are the oracle's."""
+    from gisnav_amd.engine import PoseEngine
+    _threads()
+    eng = PoseEngine(0, max_batch=1, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+    m_all = t_all = 0
+    for seed, nq, nr in ((9100, 1024, 1024), (9101, 1000, 777), (9102, 333, 1024)):
+        p = make_pair(seed, n_q=nq, n_r=nr)
+        ref = [oracle_match(state_dict_t, p)]
+        inp = eng.stage_inputs([p])
+        eng.set_kernel_timing(200)
+        idx, score, n = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        torch.cuda.synchronize()
+        names = [r["name"] for r in eng.kernel_table()]
+        eng.set_kernel_timing(0)
+        assert any(nm.startswith("k_attn_ks") for nm in names), names
+        d, t = _mismatches(idx.cpu().numpy()[0], int(n.cpu().numpy()[0]), ref[0][3].numpy())
+        m_all += d; t_all += t
+    assert m_all == 0 and t_all > 600, (m_all, t_all)
+    _report("one_pair_small_grid_kernels_margin_built", {"index_mismatches": m_all, "cpu_matches": t_all})
+    del eng
