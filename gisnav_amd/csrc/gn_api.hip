@@ -119,7 +119,8 @@ struct gn_ctx {
   int qkv_in_tail = 1;     // knob 32.  1 (default): on bulk grids the block tail k_ffn128 also computes the NEXT block's attention input projection from the rows
                            // it has just produced (k_ffn128<., ., ., 1 / 2>: no k_qkv launch, no read-back of the residual stream); 0: separate k_qkv launches
   int skinny = 1;          // knob 33.  1 (default): calls of at most 4096 tokens (one or two pairs of 1024 keypoints) run the attention input projections and the block
-                           // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow
+                           // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow; + 4: not the projections; + 8: not the tail;
+                           // >> 4: kernel variant (tools/skinny_ab.py)
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
   unsigned long long* tile_feedback = nullptr;   // pinned host [8]: (all tiles << 32 | valid tiles) written by k_tile_lists of sub-batch group g's last call
   int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
@@ -395,10 +396,10 @@ bool qkv_projection_applies(const gn_ctx* c, const Block& blk, int T, int np, in
          (T / 128 >= 128 || c->qkv_fused == 2);
 }
 bool skinny_applies(const gn_ctx* c, int T) {
-  return (c->skinny & 15) && c->planes_mode && c->x_planes_only && T % 32 == 0 && ((c->skinny & 15) == 2 || T <= 4096);
+  return (c->skinny & 3) && c->planes_mode && c->x_planes_only && T % 32 == 0 && ((c->skinny & 3) == 2 || T <= 4096);
 }
 bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
-  const bool skinny = skinny_applies(c, T) && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && np % 32 == 0 && vt_perm == 1 && !c->qkv_stamps;
+  const bool skinny = skinny_applies(c, T) && !(c->skinny & 4) && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && np % 32 == 0 && vt_perm == 1 && !c->qkv_stamps;
   if (!skinny && !qkv_projection_applies(c, blk, T, np, vt_perm)) return false;
   QkvArgs q;
   q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
@@ -513,7 +514,7 @@ template <typename F> bool timed_launch(gn_ctx* c, hipStream_t s, double flops, 
 }
 
 bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const Block* next = nullptr, bool next_cross = false, int np = 0, int vt_perm = 0) {
-  if (skinny_applies(c, T) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
+  if (skinny_applies(c, T) && !(c->skinny & 8) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
       c->h && c->ctx_p && gn::g_ffn_ablate == 0 && gn::g_ffn_shape == 0) {
     // small grid: the weight stream split across CUs -- two launches (gn_skinny.hip)
     SkinnyTailArgs a;

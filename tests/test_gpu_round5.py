@@ -366,3 +366,48 @@ def test_one_pair_runs_the_small_grid_kernels_and_matches_the_oracle(state_dict_
     assert m_all == 0 and t_all > 600, (m_all, t_all)
     _report("one_pair_small_grid_kernels_margin_built", {"index_mismatches": m_all, "cpu_matches": t_all})
     del eng
+
+
+def test_small_grid_projections_give_the_bits_of_the_bulk_kernel_and_the_small_grid_tail_its_features(state_dict_np):
+    """gn_skinny.hip (one pair per call): k_skinny_qkv forms k_qkv's partial products in k_qkv's order with k_qkv's epilogue expressions, so with
+    the block tail held fixed (knob 33 = 9: projections only) EVERYTHING downstream of the 18 projections is bitwise what the bulk kernel (forced by
+    knob 19 = 2) gives; the two-launch tail (knob 33 = 5: tail only) uses k_ln_gelu's row arithmetic and one accumulator per output like k_ffn_fused,
+    but another k order inside the composed ffn.0 (natural instead of register-fed), so the final residual stream agrees to f32 rounding and the
+    correspondences are identical."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=1, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+    eng.lib.gn_debug_set_variant(eng.ctx, 19, 2)          # the bulk k_qkv also on this small grid
+    p = make_pair(9200, n_q=1024, n_r=901)
+    inp = eng.stage_inputs([p])
+    got = {}
+    for knob in (0, 9, 5, 1):
+        eng.lib.gn_debug_set_variant(eng.ctx, 33, knob)
+        eng.set_kernel_timing(400)
+        idx, score, n = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+        torch.cuda.synchronize()
+        names = {r["name"].split("<")[0] for r in eng.kernel_table()}
+        eng.set_kernel_timing(0)
+        got[knob] = (idx.cpu().numpy()[0].copy(), score.cpu().numpy()[0].copy(), int(n.cpu().numpy()[0]), eng.debug_read("x", 2 * 1024 * 256).copy(), names)   # the residual stream behind the last block
+    eng.lib.gn_debug_set_variant(eng.ctx, 33, 1); eng.lib.gn_debug_set_variant(eng.ctx, 19, 1)
+    assert "k_qkv" in got[0][4] and "k_skinny_qkv" not in got[0][4] and "k_skinny_h" not in got[0][4], got[0][4]
+    assert "k_skinny_qkv" in got[9][4] and "k_qkv" not in got[9][4] and "k_skinny_h" not in got[9][4], got[9][4]
+    assert "k_skinny_h" in got[5][4] and "k_skinny_out" in got[5][4] and "k_skinny_qkv" not in got[5][4], got[5][4]
+    assert {"k_skinny_qkv", "k_skinny_h", "k_skinny_out"} <= got[1][4], got[1][4]
+    a, b = got[0], got[9]
+    assert a[2] == b[2] and a[2] > 200
+    assert np.array_equal(a[0][:a[2]], b[0][:a[2]]) and np.array_equal(a[1][:a[2]].view(np.uint32), b[1][:a[2]].view(np.uint32))
+    for side, nv in ((0, 1024), (1, 901)):
+        lo = side * 1024 * 256
+        assert np.array_equal(a[3][lo: lo + nv * 256].view(np.uint32), b[3][lo: lo + nv * 256].view(np.uint32)), side
+    worst = 0.0
+    for knob in (5, 1):
+        c = got[knob]
+        assert c[2] == a[2] and np.array_equal(c[0][:a[2]], a[0][:a[2]]), knob
+        for side, nv in ((0, 1024), (1, 901)):
+            lo = side * 1024 * 256
+            d = float(np.abs(c[3][lo: lo + nv * 256] - a[3][lo: lo + nv * 256]).max() / np.abs(a[3][lo: lo + nv * 256]).max())
+            worst = max(worst, d)
+            assert d < 2e-5, (knob, side, d)
+    assert np.abs(a[3]).max() > 0.1
+    _report("small_grid_tail_vs_k_ffn_fused_final_features_rel", worst)
+    del eng

@@ -15,6 +15,8 @@ for b in batches:
     eng = PoseEngine(0, max_batch=b, max_kpts=1024, precision="f16x2_f16_attn", state_dict=sd)
     for w, v in knobs:
         eng.lib.gn_debug_set_variant(eng.ctx, w, v)
+    if "--overlap" in args:
+        eng.set_overlap(True)
     inp = eng.stage_inputs([make_pair(i, n_q=1024, n_r=1024) for i in range(b)])
     out = eng.alloc_outputs(b)
     torch.cuda.synchronize()
