@@ -118,7 +118,7 @@ struct gn_ctx {
   int ncu = 256;           // compute units of ctx->device (grids of the walking kernels)
   int qkv_in_tail = 1;     // knob 32.  1 (default): on bulk grids the block tail k_ffn128 also computes the NEXT block's attention input projection from the rows
                            // it has just produced (k_ffn128<., ., ., 1 / 2>: no k_qkv launch, no read-back of the residual stream); 0: separate k_qkv launches
-  int skinny = 1;          // knob 33.  1 (default): calls of at most 4096 tokens (one or two pairs of 1024 keypoints) run the attention input projections and the block
+  int skinny = 1;          // knob 33.  1 (default): calls of one or two pairs run the attention input projections and the block
                            // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow; + 4: not the projections; + 8: not the tail;
                            // >> 4: kernel variant (tools/skinny_ab.py)
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
@@ -395,11 +395,13 @@ bool qkv_projection_applies(const gn_ctx* c, const Block& blk, int T, int np, in
   return c->planes_mode && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && T % 128 == 0 && np % 128 == 0 && (vt_perm & 1) &&
          (T / 128 >= 128 || c->qkv_fused == 2);
 }
-bool skinny_applies(const gn_ctx* c, int T) {
-  return (c->skinny & 3) && c->planes_mode && c->x_planes_only && T % 32 == 0 && ((c->skinny & 3) == 2 || T <= 4096);
+// The choice depends on the number of pairs of the call only (at most two), never on the padded length: gn_set_active_kpts must not change a result
+// bit (test_active_kpts_padding_does_not_change_results), and the small-grid tail rounds differently from the bulk kernels.
+bool skinny_applies(const gn_ctx* c, int T, int np) {
+  return (c->skinny & 3) && c->planes_mode && c->x_planes_only && T % 32 == 0 && np > 0 && ((c->skinny & 3) == 2 || T / np <= 4);
 }
 bool qkv_projection(gn_ctx* c, const Block& blk, bool cross, int T, int np, int vt_perm, hipStream_t s) {
-  const bool skinny = skinny_applies(c, T) && !(c->skinny & 4) && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && np % 32 == 0 && vt_perm == 1 && !c->qkv_stamps;
+  const bool skinny = skinny_applies(c, T, np) && !(c->skinny & 4) && c->qkv_fused && blk.proj_in.wf && c->x_p && c->qkb && c->vtb && c->rot4 && np % 32 == 0 && vt_perm == 1 && !c->qkv_stamps;
   if (!skinny && !qkv_projection_applies(c, blk, T, np, vt_perm)) return false;
   QkvArgs q;
   q.xp = c->x_p; q.wf = blk.proj_in.wf; q.acc_scale = blk.proj_in.acc_scale; q.bias = blk.proj_in.b;
@@ -514,7 +516,7 @@ template <typename F> bool timed_launch(gn_ctx* c, hipStream_t s, double flops, 
 }
 
 bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const Block* next = nullptr, bool next_cross = false, int np = 0, int vt_perm = 0) {
-  if (skinny_applies(c, T) && !(c->skinny & 8) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
+  if (skinny_applies(c, T, np) && !(c->skinny & 8) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
       c->h && c->ctx_p && gn::g_ffn_ablate == 0 && gn::g_ffn_shape == 0) {
     // small grid: the weight stream split across CUs -- two launches (gn_skinny.hip)
     SkinnyTailArgs a;
