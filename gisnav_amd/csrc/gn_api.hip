@@ -41,6 +41,11 @@ struct gn_ctx {
   int qkv_fused = 1;       // attention input projections by k_qkv (gn_qkv.hip) instead of the LDS-staged GEMM (developer knob 19)
   int sp_split = 1;        // gn_sp_set_arithmetic (developer knob 21): 0 exact f32, 1 split-fp16 operands (contexts of the f16x2 mode), 2 one fp16 product
   long long sp_split_trips = 0;
+  int sp_stop = 0;
+  int sp_ts_layer = 0;          // developer knob 35: the layer (1..11) whose k_sp_conv_s launch writes phase stamps into sp_ts (gn_debug_read("sp_ts"))
+  long long* sp_ts = nullptr;   // [8192 workgroups][32] s_memtime stamps
+  void* sp_allocs_dbg = nullptr;
+  bool sp_enc_hm16 = false;   // the last pass left the encoder output (sp_y) as hm16 records (gn_debug_read("sp_enc") converts)
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
@@ -881,6 +886,7 @@ void gn_destroy(gn_ctx* ctx) {
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
   for (void* p : ctx->sp_allocs) hipFree(p);
+  if (ctx->sp_allocs_dbg) hipFree(ctx->sp_allocs_dbg);
   if (ctx->ev_fork) {
     for (int i = 0; i < 8; ++i) if (ctx->sub_s[i]) { hipStreamSynchronize(ctx->sub_s[i]); hipEventDestroy(ctx->ev_join[i]); hipStreamDestroy(ctx->sub_s[i]); }
     hipEventDestroy(ctx->ev_fork);
@@ -1634,18 +1640,27 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
   bool split = ctx->sp_split && ctx->sp[1].wfh != nullptr;
   // GN_SP_FP16: the activations of the layers above 1 / 8 resolution (layers 0 .. 6: 95 % of the extractor's bytes) travel as fp16;
   // layer 6 writes f32 again, the 1 / 8-resolution layers and the heads read and write f32 as in the other modes
+  bool hm16_io = false;
   auto conv = [&](int i, const float* in, float* out, int n, int hh, int ww, int relu, int pool = 0) {
+    if (ctx->sp_stop > 0 && i > ctx->sp_stop) return;      // developer knob 39: the layers behind layer sp_stop are skipped (their outputs are garbage)
     const bool hm = split && ctx->sp[i].wfh != nullptr;
     const bool half_io = hm && ctx->sp_split == 2;
+    // split mode (round 5): every activation between the layers travels as hm16 records (k_sp_conv_s); the two head outputs stay f32
+    const int in_fmt = hm16_io ? 2 : (half_io && i >= 1 && i <= 6 ? 1 : 0);
+    const int out_fmt = hm16_io ? (i == 9 || i == 11 ? 0 : 2) : (half_io && i >= 1 && i <= 5 ? 1 : 0);
     sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
-            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf_base + 8, pool, ctx->sp_split == 2,
-            half_io && i >= 1 && i <= 6, half_io && i >= 1 && i <= 5);
+            hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf_base + 8, pool, ctx->sp_split == 2, in_fmt, out_fmt,
+            (ctx->sp_ts_layer == i && ctx->sp_ts != nullptr) ? ctx->sp_ts : nullptr);
   };
   std::vector<int> counts((size_t)chunk * 4);
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
     if (split) GN_HIP(hipMemsetAsync(ctx->ovf_base + 8, 0, sizeof(unsigned int), s));
-    sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s, split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr);
+    hm16_io = split && ctx->sp_split == 1 && gn::g_sp_conv_s != 0;
+    for (int i = 1; i < 12; ++i) hm16_io = hm16_io && ctx->sp[i].wfh != nullptr;
+    ctx->sp_enc_hm16 = hm16_io;
+    sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s,
+             hm16_io ? 2 : (split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr ? 1 : 0), ctx->ovf_base + 8);
     // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
     // block 0 alone is 0.5 GB per 1080p image: writing it and reading it back was a quarter of the extractor's HBM traffic)
     conv(1, X, Y, n, H, W, 1, 1);                                                                   // block 0 -> Y [H/2][W/2][64]
@@ -1690,6 +1705,9 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"sp_enc", ctx->sp_y, ctx->sp_y ? (size_t)ctx->sp_chunk * (ctx->sp_h / 8) * (ctx->sp_w / 8) * 128 : 0},          // SuperPoint: encoder output of the last pass, NHWC
       {"sp_scores", ctx->sp_maps[0], ctx->sp_maps[0] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},             // softmax + depth-to-space scores
       {"sp_nms", ctx->sp_maps[5], ctx->sp_maps[5] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},                // after simple_nms
+      {"sp_x", ctx->sp_x, ctx->sp_x ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w * 64 : 0},                         // raw words of the two activation buffers
+      {"sp_y", ctx->sp_y, ctx->sp_y ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w * 64 : 0},
+      {"sp_ts", ctx->sp_ts, ctx->sp_ts ? (size_t)8192 * 32 * 2 : 0},                                                     // phase stamps (knob 35), int64 pairs of 4-byte words
       {"x_p", ctx->x_p, ctx->x_p ? T * kDim : 0}, {"msg_p", ctx->msg_p, ctx->msg_p ? T * kDim : 0},   // hm16 rows, raw (4 bytes per value)
       {"qkb", ctx->qkb, ctx->qkb ? T * kDim : 0}, {"rot4", ctx->rot4, ctx->rot4 ? T * 2 * kFreq : 0}, {"vtb", ctx->vtb, ctx->vtb ? T * kDim / 2 : 0}};
   for (const Ent& e : tab)
@@ -1698,6 +1716,15 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       if ((int64_t)(count * 4) > max_bytes) count = (size_t)max_bytes / 4;
       if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GN_ERR_HIP;
       if (hipMemcpy(host_out, e.p, count * 4, hipMemcpyDeviceToHost) != hipSuccess) return GN_ERR_HIP;
+      if (strcmp(name, "sp_enc") == 0 && ctx->sp_enc_hm16) {
+        // hm16 records (per 16 channels: 16 high halfs, 16 residual halfs) -> f32 values in channel order, in place
+        uint16_t rec[32];
+        for (size_t g = 0; g + 16 <= count; g += 16) {
+          memcpy(rec, (const char*)host_out + g * 4, 64);
+          float* dst = (float*)host_out + g;
+          for (int c = 0; c < 16; ++c) dst[c] = (float)__builtin_bit_cast(_Float16, rec[c]) + (float)__builtin_bit_cast(_Float16, rec[16 + c]);
+        }
+      }
       return (int64_t)count;
     }
   if (strcmp(name, "e_idx") == 0) {
@@ -1817,6 +1844,14 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 20) ctx->qkv_stamps = value;
   else if (which == 21) ctx->sp_split = value;
   else if (which == 24) gn::g_sp_conv_h = value;
+  else if (which == 34) gn::g_sp_conv_s = value;
+  else if (which == 36) gn::g_sp_nms_fused = value;
+  else if (which == 39) ctx->sp_stop = value;
+  else if (which == 35) {
+    ctx->sp_ts_layer = value;
+    if (value > 0 && ctx->sp_ts == nullptr) { void* q = nullptr; if (hipMalloc(&q, (size_t)8192 * 32 * sizeof(long long)) == hipSuccess) { ctx->sp_ts = (long long*)q; ctx->sp_allocs_dbg = q; } }
+    if (ctx->sp_ts != nullptr) hipMemset(ctx->sp_ts, 0, (size_t)8192 * 32 * sizeof(long long));
+  }
   else if (which == 23) ctx->attn_split = value;
   else if (which == 25) ctx->dbg_trip_group = value;
   else if (which == 26) ctx->sub_serial = value;

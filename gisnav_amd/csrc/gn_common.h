@@ -339,12 +339,13 @@ void sift_sort_dedup(int B, SiftKeypoint* kp, long long kp_stride, int* counters
 
 // ---- SuperPoint extractor (gn_superpoint.hip) ------------------------------------------------------------------
 void sp_weight_fragments(const float* w, int Cout, int Cin, int taps, int Cout_pad, float* out);   // host arrays
-void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half = 0);
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half = 0, unsigned int* ovf = nullptr);   // out_half: 0 f32, 1 fp16, 2 hm16 records (guarded by ovf)
+extern int g_sp_conv_s, g_sp_nms_fused;
 void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int Cout_pad, float scale, uint16_t* out);   // host arrays; out: 2 * Cout_pad * taps * Cin halfs
 void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,
              const uint16_t* wfh = nullptr, float acc_scale = 1.f, unsigned int* ovf = nullptr, int pool = 0,
-             int single_product = 0, int in_half = 0, int out_half = 0);   // single_product: one fp16 product per block instead of three (GN_SP_FP16);
-                                                                                 // in_half / out_half: fp16 NHWC activations   // wfh != nullptr: split-fp16 arithmetic; pool: fused 2 x 2 max-pool, out is [H/2][W/2]
+             int single_product = 0, int in_half = 0, int out_half = 0, long long* dbg_ts = nullptr);   // single_product: one fp16 product per block instead of three (GN_SP_FP16);
+                                                                                 // in_half / out_half: 1 = fp16 NHWC activations, 2 = hm16 records (k_sp_conv_s)   // wfh != nullptr: split-fp16 arithmetic; pool: fused 2 x 2 max-pool, out is [H/2][W/2]
 void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 void sp_scores(const float* logits, int cp, float* scores, int B, int h, int w, hipStream_t s);
 void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, float* tmp, float* mask, float* supp, float* aux, hipStream_t s);

@@ -19,6 +19,7 @@
 // The convolutions are f32-exact (no reduced-precision operand anywhere), so keypoints agree with an f32 CPU run except where two
 // scores tie to the last bit.
 #include "gn_common.h"
+#include "gn_ffn_util.h"
 
 #include <cmath>
 
@@ -30,8 +31,9 @@ constexpr int TW = 32;                   // output tile of k_sp_conv: (4 RPW) ro
                                          // pipe); RPW = 2 for the layers whose 2 x 2 max-pool is fused into the epilogue (row pairs in one lane)
 constexpr int CH = 32;                   // input channels staged per pass (128 B per pixel in LDS)
 
-template <bool OUT_HALF>   // OUT_HALF: the 64-channel map leaves as fp16 (GN_SP_FP16)
-__global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W) {
+template <int OUT_FMT>   // 0: f32 NHWC; 1: the 64-channel map leaves as fp16 (GN_SP_FP16); 2: as hm16 records (16 high terms, 16 residual terms per 16 channels:
+                         // what k_sp_conv_s stages without touching it; the thread's 16 channels are one record group, 64 contiguous bytes)
+__global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W, unsigned int* ovf) {
   // the 576 weights + 64 biases sit in LDS: a lane's channel group differs from its neighbours', so reading them from memory was
   // 144 vector loads per thread (the layer ran at 1.5 TB/s of output instead of the HBM rate)
   __shared__ float ws[64 * 9 + 64];
@@ -50,8 +52,11 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
   }
+  float amax = 0.f;
   float* o = out + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
   _Float16* oh = reinterpret_cast<_Float16*>(out) + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
+  typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+  h16x4_t hq[4], mq[4];
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) {
     f32x4 r;
@@ -63,13 +68,26 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
       for (int t = 0; t < 9; ++t) acc = fmaf(ws[c * 9 + t], v[t], acc);
       r[e] = fmaxf(acc, 0.f);
     }
-    if (OUT_HALF) {
-      typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+    if (OUT_FMT == 1) {
       *reinterpret_cast<h16x4_t*>(oh + c4 * 4) = __builtin_convertvector(r, h16x4_t);
+    } else if (OUT_FMT == 2) {
+      ovf_track(amax, r.x, r.y); ovf_track(amax, r.z, r.w);
+      hq[c4] = __builtin_convertvector(r, h16x4_t);
+      mq[c4] = __builtin_convertvector(r - __builtin_convertvector(hq[c4], f32x4), h16x4_t);
     } else {
       *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
     }
   }
+  if (OUT_FMT == 2) {
+    // the thread's record group: 16 high terms, 16 residual terms = four 16-byte stores, 64 contiguous bytes (a pixel's four threads: 256)
+    typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+    _Float16* const og = reinterpret_cast<_Float16*>(out) + ((long long)blockIdx.z * H * W + pix) * 128 + grp * 32;
+    *reinterpret_cast<h16x8_t*>(og) = __builtin_shufflevector(hq[0], hq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<h16x8_t*>(og + 8) = __builtin_shufflevector(hq[2], hq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<h16x8_t*>(og + 16) = __builtin_shufflevector(mq[0], mq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<h16x8_t*>(og + 24) = __builtin_shufflevector(mq[2], mq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  if (OUT_FMT == 2) ovf_commit(ovf, amax);
 }
 
 struct ConvArgs {
@@ -80,6 +98,7 @@ struct ConvArgs {
   int relu;
   const uint16_t* wfh; float acc_scale;      // HM variant: weights as fp16 pairs in fragment order (sp_weight_fragments_hm16), scaled by 1 / acc_scale
   unsigned int* ovf;                         // HM variant: raised when an input activation does not fit fp16 (the caller re-runs the exact path)
+  long long* dbg_ts;                         // developer: s_memtime stamps of k_sp_conv_s's phases, [workgroup][32] (tools/sp_phases.py), or nullptr
   int in_half, out_half;                     // GN_SP_FP16 only: the layer reads / writes its NHWC activations as fp16 (half the HBM traffic of the full-resolution layers)
 };
 
@@ -89,6 +108,7 @@ struct ConvArgs {
 // GEMMs (gn_gemm_p2.hip: error <= the f32 pipe's) at 5 x the matrix-pipe rate.  The activations stay f32 in memory: the halo tile is
 // split while it is staged (hm16 row format: 16 high terms, 16 residual terms per 16 channels -- the same 128 bytes per pixel).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_sp __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // 16-byte chunk c of halo pixel (ly, lx) sits at position c ^ psw(lx): pixels lx, lx + 8, lx + 16, lx + 24 of a wave's fragment read
 // must not share a chunk position (a plain lx & 7 made every ds_read_b128 a 4-way bank conflict: the LDS port, not the matrix
@@ -518,6 +538,273 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_h(ConvArgs a) {   // two wor
   ovf_commit(a.ovf, amax);
 }
 
+// Split-fp16 convolution on hm16 activations (round 5).  What the counters said about k_sp_conv<., 1, ...> (tools/sp_pmc.sh): matrix pipe busy
+// 0.47-0.50 on every layer, 4.5 VALU instructions per MFMA -- the split of the f32 halo tile into fp16 terms while it is staged (~35
+// instructions per 16-byte chunk, once per channel slice, per output-channel group and per halo overlap) and the fragment addresses of a
+// run-time tap (dy, dx), none of it in the shadow of an MFMA (a wave's VALU work overlaps the matrix pipe only inside its own instruction
+// stream).  Here the activations TRAVEL as hm16 records -- per pixel and 16 channels: 16 high terms, 16 residual terms (64 B; the same 4 bytes
+// per value as f32, and exactly the terms the staging pass computed: h = fp16(v), m = fp16(v - h)) -- written once by the producer's
+// epilogue, so that
+//  * the halo tile of a 32-channel slice is the pixel records' bytes as they are: staged by LDS-DMA (`buffer_load_dwordx4 ... lds`: 1 KB = 8
+//    pixels per instruction and wave, no register round trip, no VALU; the chunk swizzle is applied on the global side, pixels outside the
+//    image are out-of-range offsets of the buffer descriptor and arrive as zeros: tools/probes/buf_lds.hip);
+//  * the weight fragments of a tap (8 KB) are handed over the same way, one tap ahead;
+//  * the nine taps are unrolled: every fragment read is `one of 12 base registers + immediate`;
+//  * the fp16-range guard moves to the producer (the values it checked are the producer's outputs).
+// Arithmetic: identical to k_sp_conv<., 1, ...> product for product (same terms, same order of the three products and of the k-steps), so the
+// results are bitwise the same.  Tiles, accumulator layout and the fused 2 x 2 max-pool are k_sp_conv's.
+//
+// What the phase stamps of the first version said (tools/sp_phases.py; two workgroups per CU): with the co-resident workgroup in its MFMA
+// stream, a VALU instruction of this one issues about once per 16-20 cycles (the dense MFMA stream of the other wave holds the SIMD's VALU
+// port), so the ~420 VALU instructions of the per-lane staging offsets cost 6.8 k cycles and the ~900 of the epilogue 26 k, of a workgroup's
+// 72 k -- against 21 k cycles of MFMAs.  Hence the VALU diet: a staging instruction covers 8 pixels of ONE halo row (row validity and row
+// offset are scalar: SALU; five per-lane offset registers per tile; the two-pixel tail of a 34-pixel row is an EXEC-masked instruction), the
+// epilogue is 16 instructions per four values (packed fma, max3 for the range guard, v_fma_mix for the residual term), the rows leave as
+// whole 256-byte record segments through a per-wave LDS slab and buffer stores whose descriptor ends at the image border.
+typedef __attribute__((address_space(3))) void* sp_lptr_t;
+// Two wait states behind a 16-byte buffer store with an SGPR soffset, before anything may rewrite its data registers (hipcc's hazard recogniser
+// pads that case only for an immediate soffset; cheap insurance: the stores are the last thing a row does).
+__device__ __forceinline__ void sp_store_guard() { asm volatile("s_nop 1" ::: "memory"); }
+__device__ __forceinline__ float sp_resid_lo(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+__device__ __forceinline__ float sp_resid_hi(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
+template <int TAPS, int RPW, bool POOL, bool OUTHM>   // OUTHM: the output leaves as hm16 records (else f32: the two head outputs)
+__global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
+  constexpr int TH = 4 * RPW;
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
+  constexpr int NSEG = (LW + 7) / 8;                // staging instructions per halo row (8 pixels = 1 KB each)
+  constexpr int TAIL = LW - 8 * (NSEG - 1);         // pixels of the last one
+  constexpr int NROW = (LH + 3) / 4;                // halo rows per wave (row q * 4 + wave)
+  constexpr int TILE_B = ((LH * LW * 128 + 1023) / 1024) * 1024;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TILE_B + 2 * 8192];
+  unsigned char* const tb = smem;
+  unsigned char* const wbuf = smem + TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = a.Cout / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const unsigned int rec = (unsigned int)a.Cin * 4u;                       // bytes of a pixel record
+  unsigned char* const ibase = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.in)) + (size_t)img * a.H * a.W * rec;
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, (unsigned int)((size_t)a.H * a.W * rec), 0x00020000);
+  const __amdgpu_buffer_rsrc_t irs0 = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, 0, 0x00020000);      // rows outside the image: every lane out of range = zeros
+  // weights: block (((tile * TAPS + tap) * (Cin / 16) + kstep) * 2 + term) of 1 KB; this workgroup's tiles are 2 og, 2 og + 1
+  const unsigned int ksteps = (unsigned int)a.Cin / 16u;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.wfh) + (size_t)(2 * og) * TAPS * ksteps * 1024, 0, 2u * TAPS * ksteps * 2048u, 0x00020000);
+  const unsigned int lds_tile = (unsigned int)(size_t)(sp_lptr_t)tb, lds_w = (unsigned int)(size_t)(sp_lptr_t)wbuf;
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+  const int wg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  long long* const ts = (a.dbg_ts != nullptr && wg_lin < 8192 && tid == 0) ? a.dbg_ts + (size_t)wg_lin * 32 : nullptr;
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (ts != nullptr && k < 32) ts[k] = (long long)__builtin_amdgcn_s_memtime(); };
+  stamp(0);
+  // the bias of the lane's 32 output channels, requested first (read in the epilogue)
+  f32x4 b4[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[i][g] = *reinterpret_cast<const f32x4*>(a.bias + 64 * og + 32 * i + 8 * g + 4 * hh);
+
+  // staging: instruction (row r, segment sg) covers halo pixels lx = 8 sg .. 8 sg + 7 of row r: lane -> (pixel lane >> 3, position lane & 7);
+  // the piece that belongs at position pos of pixel lx is pos ^ psw(lx).  Per-lane part of the offset (column + piece), one register per segment;
+  // the row part (and the channel slice) is the instruction's scalar offset
+  unsigned int lanepart[NSEG];
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg) {
+    const int lx = 8 * sg + (lane >> 3), gx = x0 + lx - HALO;
+    lanepart[sg] = (gx >= 0 && gx < a.W) ? (unsigned int)gx * rec + (unsigned int)(((lane & 7) ^ psw(lx)) * 16) : 0x80000000u;
+  }
+  // the wave's two 1 KB weight blocks of a tap: block 4 e + wave = (i * 2 + s) * 2 + pl  ->  source block ((i * TAPS + tap) * ksteps + c0 / 16 + s) * 2 + pl
+  auto weights_dma = [&](int tap, int c0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int blk = 4 * e + wave, i = blk >> 2, ks = (blk >> 1) & 1, pl = blk & 1;
+      const unsigned int src = ((((unsigned int)i * TAPS + tap) * ksteps + (unsigned int)(c0 / 16 + ks)) * 2u + pl) * 1024u;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lane16), "s"(wrs), "s"(lds_w + (unsigned int)(buf * 8192 + blk * 1024)), "s"(src) : "memory");
+    }
+  };
+  auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  auto stage_issue = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int r = q * 4 + wave;
+      if (r < LH) {
+        const int gy = y0 + r - HALO;
+        const bool rv = gy >= 0 && gy < a.H;
+        const __amdgpu_buffer_rsrc_t rs = rv ? irs : irs0;
+        const unsigned int soff = rv ? (unsigned int)(gy * a.W) * rec + (unsigned int)(c0 * 4) : 0u;
+        const unsigned int dst = lds_tile + (unsigned int)(r * LW * 128);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+          if (sg + 1 < NSEG || TAIL == 8)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff) : "memory");
+          else     // the row's last TAIL pixels: the other lanes must not write (their slots are the next row's first pixels)
+            asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\ts_mov_b64 exec, -1" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff), "n"((1ull << (8 * TAIL)) - 1ull) : "memory");
+        }
+      }
+    }
+    weights_dma(0, c0, 0);
+  };
+  stage_issue(0);
+  stamp(1);
+  // (behind the first requests, in the shadow of their latency)
+  // fragment addresses: pixel (RPW wave + j + dy, ql + dx), piece 4 s + 2 pl + hh -> base[dx][2 s + pl] + (j + dy) * LW * 128
+  unsigned int fbase[TAPS == 9 ? 3 : 1][4];
+#pragma unroll
+  for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int lx = ql + dx;
+      fbase[dx][c] = (unsigned int)((RPW * wave * LW + lx) * 128 + (((2 * c + hh) ^ psw(lx)) * 16));
+    }
+
+  f32x16 acc[2][RPW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+    if (c0 > 0) {
+      __syncthreads();      // every wave is done with the previous slice's tile and weight buffers
+      stage_issue(c0);
+      stamp(12);
+    }
+    dma_wait();
+    __syncthreads();
+    stamp(c0 == 0 ? 2 : 13);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+      if (tap + 1 < TAPS) weights_dma(tap + 1, c0, (tap + 1) & 1);      // (that buffer's last readers passed the barrier in front of this tap)
+      const unsigned char* const wb = wbuf + (tap & 1) * 8192;
+#pragma unroll
+      for (int s = 0; s < CH / 16; ++s) {
+        h16x8 fa[2][2], fb[RPW][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + ((i * 2 + s) * 2 + pl) * 1024 + lane16);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + fbase[dx][2 * s + pl] + (j + dy) * LW * 128);
+        // products: W_m X_h, W_h X_m, W_h X_h (small terms first) -- the order of k_sp_conv
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+      }
+      if (tap + 1 < TAPS) { dma_wait(); __syncthreads(); }
+      stamp((c0 == 0 ? 3 : 14) + tap);       // slices beyond the second overwrite the second's stamps
+    }
+  }
+  stamp(24);
+
+  // epilogue: lane = pixel (row RPW wave + j, column ql); registers 4 g + c = output channels 32 i + 8 g + 4 hh + c.  hm16 output: channel
+  // 32 i + 8 g + 4 hh + c of the workgroup's 64 sits in record group 2 i + (g >> 1) of the 256-byte segment, halfs 8 (g & 1) + 4 hh + c (high) and
+  // 16 + that (residual).  Final bytes go into the wave's LDS slab (the tile is dead), 16-byte chunks come out: lane -> (pixel it * 4 + lane >> 4,
+  // chunk lane & 15), one store instruction = four whole record segments; the store descriptor ends where the image row does.
+  const float ascale = a.acc_scale;
+  float amax = 0.f;
+  constexpr bool out_hm = OUTHM;
+  const float relu_lo = a.relu ? 0.f : -INFINITY;     // ReLU as one v_max_f32 per value, whatever the flag
+  constexpr int PSTR = 256 + 16;                      // slab bytes per pixel (the pad spreads the lanes' pieces over the banks)
+  constexpr int SLAB = 32 * PSTR;
+  static_assert(4 * SLAB <= TILE_B, "the slabs alias the halo tile");
+  unsigned char* const slab = smem + wave * SLAB;
+  __syncthreads();                                    // every wave is done with the tile and the weight buffers
+  stamp(26);
+  auto put4 = [&](int p, int i, int g, f32x2v v0, f32x2v v1) __attribute__((always_inline)) {      // v0, v1: scaled + biased (+ ReLU'd) values of channels c .. c + 3
+    const int cl = 32 * i + 8 * g + 4 * hh;
+    if (out_hm) {
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v0[0]), __builtin_fabsf(v0[1])));
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v1[0]), __builtin_fabsf(v1[1])));
+      const unsigned int h0 = pack16<true>(v0[0], v0[1]), h1 = pack16<true>(v1[0], v1[1]);
+      const unsigned int m0 = pack16<true>(sp_resid_lo(h0, v0[0]), sp_resid_hi(h0, v0[1])), m1 = pack16<true>(sp_resid_lo(h1, v1[0]), sp_resid_hi(h1, v1[1]));
+      unsigned char* o = slab + p * PSTR + (cl >> 4) * 64 + (cl & 15) * 2;
+      *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(o + 32) = make_uint2(m0, m1);
+    } else {
+      *reinterpret_cast<f32x4*>(slab + p * PSTR + cl * 4) = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+    }
+  };
+  const size_t orec = (size_t)a.Cout * 4;             // bytes of an output pixel record (f32 and hm16 alike)
+  unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)og * 256;
+  const unsigned int rd = (unsigned int)((lane >> 4) * PSTR + (lane & 15) * 16);                     // read-back address inside the slab
+  const unsigned int so = (unsigned int)(lane >> 4) * (unsigned int)orec + (unsigned int)(lane & 15) * 16u;   // ... and inside the output row
+  if (POOL) {
+    static_assert(!POOL || RPW == 2, "the fused pool pairs the two rows of a wave");
+    const int gy = y0 + RPW * wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v m[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const f32x2v bk = {b4[i][g][2 * k], b4[i][g][2 * k + 1]};
+          // (ascale is a power of two: the fused multiply-add rounds like the multiplication followed by the addition)
+          const f32x2v v0 = pair(acc[i][0], 4 * g + 2 * k) * splat2(ascale) + bk, v1 = pair(acc[i][RPW - 1], 4 * g + 2 * k) * splat2(ascale) + bk;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float mv = fmaxf(fmaxf(v0[e], v1[e]), relu_lo);      // max(relu(a), relu(b)) = relu(max(a, b))
+            mv = fmaxf(mv, __shfl_xor(mv, 1));
+            m[k][e] = mv;
+          }
+        }
+        if (!(ql & 1)) put4(ql >> 1, i, g, m[0], m[1]);
+      }
+    if (out_hm) ovf_commit(a.ovf, amax);
+    const size_t prow = ((size_t)img * (a.H / 2) + (gy >> 1)) * (a.W / 2) + (x0 >> 1);
+    const int npix = gy + 1 < a.H ? min(16, (a.W - x0) / 2) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + 256) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * 4 * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * 4) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+    stamp(25);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int gy = y0 + RPW * wave + j;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const f32x2v bk = {b4[i][g][2 * k], b4[i][g][2 * k + 1]};
+          v[k] = pair(acc[i][j], 4 * g + 2 * k) * splat2(ascale) + bk;      // (ascale is a power of two: rounds like multiplication, then addition)
+          v[k][0] = fmaxf(v[k][0], relu_lo); v[k][1] = fmaxf(v[k][1], relu_lo);
+        }
+        put4(ql, i, g, v[0], v[1]);
+      }
+    const size_t prow = ((size_t)img * a.H + gy) * a.W + x0;
+    const int npix = gy < a.H ? min(32, a.W - x0) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + 256) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * 4 * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * 4) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+  }
+  if (out_hm) ovf_commit(a.ovf, amax);
+  stamp(25);
+}
+
 // 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
 __global__ __launch_bounds__(256) void k_sp_pool(const float* in, float* out, int H, int W, int C, long long total4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -590,15 +877,141 @@ __global__ __launch_bounds__(256) void k_sp_nms_step(int mode, const float* scor
   else { /* mode 3: final scores = mask ? scores : 0, in place into aux */ aux[i] = mask[i] != 0.f ? scores[i] : 0.f; }
 }
 
+// simple_nms(scores, 4) in ONE kernel (round 5; the 16 launches above moved 50 full-resolution maps through HBM per call: 0.69 ms per four 1080p
+// frames).  The five 9 x 9 max-pools of the algorithm reach 4 + 2 x 8 = 20 pixels: a workgroup computes a 64 x 32 output tile from the
+// 104 x 72 region around it, every intermediate in LDS; values within 4 k pixels of the region's edge are wrong after k pools and are never
+// read by the tile.  A pool is a row pass and a column pass; one work item = 8 consecutive outputs of a row (column) from 16 inputs held in
+// registers (window maxima by doubling: 45 maximum operations per 8 outputs).  Pixels outside the image are -inf (F.max_pool2d's padding),
+// carry no mask and never become maxima.  Comparisons, selections and their order are those of k_sp_nms_step: identical output.
+constexpr int NMS_TX = 64, NMS_TY = 32, NMS_HL = 20, NMS_RW = NMS_TX + 2 * NMS_HL, NMS_RH = NMS_TY + 2 * NMS_HL;
+constexpr int NMS_LP = 8, NMS_PITCH = NMS_RW + 2 * NMS_LP;      // 8 pad columns of -inf on either side (16-byte aligned row segments)
+__device__ __forceinline__ void nms_window9(const float (&v)[16], float (&o)[8]) {
+  float m2[15], m4[13], m8[9];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) m2[i] = fmaxf(v[i], v[i + 1]);
+#pragma unroll
+  for (int i = 0; i < 13; ++i) m4[i] = fmaxf(m2[i], m2[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m8[i] = fmaxf(m4[i], m4[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaxf(m8[i], v[i + 8]);
+}
+__global__ __launch_bounds__(1024) void k_sp_nms_fused(const float* scores, float* out, int H, int W) {
+  constexpr int NP = NMS_RH * NMS_PITCH;
+  __shared__ __attribute__((aligned(16))) float S[NP], A[NP], M[NP], P[NP];
+  __shared__ unsigned char U[NMS_RH * NMS_RW];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * NMS_TX - NMS_HL, y0 = blockIdx.y * NMS_TY - NMS_HL;      // image coordinates of region pixel (0, 0)
+  const float* img = scores + (long long)blockIdx.z * H * W;
+  float* oimg = out + (long long)blockIdx.z * H * W;
+  const float NINF = -INFINITY;
+  // scores -> S (-inf outside the image and in the pad columns); pads of A and M
+  for (int i = tid; i < NP; i += 1024) {
+    const int ry = i / NMS_PITCH, cx = i - ry * NMS_PITCH, rx = cx - NMS_LP;
+    const int gy = y0 + ry, gx = x0 + rx;
+    const bool in = rx >= 0 && rx < NMS_RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    S[i] = in ? img[(long long)gy * W + gx] : NINF;
+    if (rx < 0 || rx >= NMS_RW) { A[i] = NINF; M[i] = NINF; }
+  }
+  __syncthreads();
+  const bool active = tid < NMS_RH * (NMS_RW / 8);       // 936 items per pass, both passes
+  // row item: row rr, outputs 8 rs .. 8 rs + 7
+  const int rr = tid / (NMS_RW / 8), rs = tid - rr * (NMS_RW / 8);
+  auto row_pass = [&](const float* X) __attribute__((always_inline)) {
+    if (active) {
+      float v[16], o[8];
+      const f32x4* src = reinterpret_cast<const f32x4*>(X + rr * NMS_PITCH + NMS_LP + 8 * rs - 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const f32x4 t = src[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+      nms_window9(v, o);
+      f32x4* dst = reinterpret_cast<f32x4*>(P + rr * NMS_PITCH + NMS_LP + 8 * rs);
+      dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
+      dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
+    }
+    __syncthreads();
+  };
+  // column item: column cc, outputs rows 8 cs .. 8 cs + 7 (consecutive threads = consecutive columns)
+  const int cs = tid / NMS_RW, cc = tid - cs * NMS_RW;
+  const int gxc = x0 + cc;
+  auto col_pool = [&](float (&o)[8]) __attribute__((always_inline)) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ry = 8 * cs - 4 + k;
+      const int ryc = min(max(ry, 0), NMS_RH - 1);
+      const float t = P[ryc * NMS_PITCH + NMS_LP + cc];
+      v[k] = (ry >= 0 && ry < NMS_RH) ? t : NINF;
+    }
+    nms_window9(v, o);
+  };
+  auto in_image = [&](int k) __attribute__((always_inline)) { const int gy = y0 + 8 * cs + k; return gy >= 0 && gy < H && gxc >= 0 && gxc < W; };
+
+  row_pass(S);
+  if (active) {
+    float o[8];
+    col_pool(o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = (8 * cs + k) * NMS_PITCH + NMS_LP + cc;
+      M[i] = (in_image(k) && S[i] == o[k]) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < 2; ++it) {
+    row_pass(M);
+    if (active) {
+      float o[8];
+      col_pool(o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = (8 * cs + k) * NMS_PITCH + NMS_LP + cc;
+        const bool supp = o[k] > 0.f;
+        U[(8 * cs + k) * NMS_RW + cc] = supp ? 1 : 0;
+        A[i] = in_image(k) ? (supp ? 0.f : S[i]) : NINF;
+      }
+    }
+    __syncthreads();
+    row_pass(A);
+    if (active) {
+      float o[8];
+      col_pool(o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = (8 * cs + k) * NMS_PITCH + NMS_LP + cc;
+        if (in_image(k) && A[i] == o[k] && U[(8 * cs + k) * NMS_RW + cc] == 0) M[i] = 1.f;
+      }
+    }
+    __syncthreads();
+  }
+  // the tile: mask ? scores : 0
+  for (int i = tid; i < NMS_TX * NMS_TY; i += 1024) {
+    const int ty = i / NMS_TX, tx = i - ty * NMS_TX;
+    const int gy = blockIdx.y * NMS_TY + ty, gx = blockIdx.x * NMS_TX + tx;
+    if (gy < H && gx < W) {
+      const int j = (NMS_HL + ty) * NMS_PITCH + NMS_LP + NMS_HL + tx;
+      oimg[(long long)gy * W + gx] = M[j] != 0.f ? S[j] : 0.f;
+    }
+  }
+}
+
 // candidates: score > threshold, y >= border, x >= border (transformers tests the far borders against 8 x the map size, i.e. never)
 __global__ __launch_bounds__(256) void k_sp_candidates(const float* nms, int H, int W, float thr, int border, int* cand /*[B][cap] raster index*/, int* counts /*[B][4]*/, int cap) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.z;
-  if (i >= (long long)H * W) return;
+  if (i >= (long long)H * W) return;      // (H * W is a multiple of 64: whole waves leave)
   const float s = nms[(long long)b * H * W + i];
   const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  if (s > thr && y >= border && x >= border) {
-    const int slot = atomicAdd(&counts[4 * b], 1);
+  // one atomic per wave (untrained weights make almost every NMS survivor a candidate: one atomic per candidate was 0.2 ms per call); the order
+  // of the list is immaterial (k_sp_select ranks by score and raster index)
+  const bool c = s > thr && y >= border && x >= border;
+  const unsigned long long bal = __ballot(c);
+  if (bal == 0ull) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(&counts[4 * b], __popcll(bal));
+  base = __shfl(base, leader);
+  if (c) {
+    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
     if (slot < cap) cand[(long long)b * cap + slot] = (int)i;
   }
 }
@@ -757,19 +1170,30 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
 }
 
 int g_sp_conv_h = 1;   // developer knob 24: 0 = GN_SP_FP16 3 x 3 layers through k_sp_conv<9, 2, ...> (the first single-product kernel)
-void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half) {
+int g_sp_conv_s = 1;   // developer knob 34: 0 = the split-fp16 mode on f32 activations through k_sp_conv<., 1, ...> (the round-2 kernel); 1 = hm16 activations, k_sp_conv_s
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half, unsigned int* ovf) {
   const long long n = (long long)H * W * 4;
-  if (out_half) hipLaunchKernelGGL(k_sp_conv1<true>, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
-  else hipLaunchKernelGGL(k_sp_conv1<false>, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, s, in, w, bias, out, H, W);
+  const dim3 grid((unsigned)((n + 255) / 256), 1, B);
+  if (out_half == 2) hipLaunchKernelGGL(k_sp_conv1<2>, grid, dim3(256), 0, s, in, w, bias, out, H, W, ovf);
+  else if (out_half) hipLaunchKernelGGL(k_sp_conv1<1>, grid, dim3(256), 0, s, in, w, bias, out, H, W, ovf);
+  else hipLaunchKernelGGL(k_sp_conv1<0>, grid, dim3(256), 0, s, in, w, bias, out, H, W, ovf);
 }
 void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,
-             const uint16_t* wfh, float acc_scale, unsigned int* ovf, int pool, int single_product, int in_half, int out_half) {
+             const uint16_t* wfh, float acc_scale, unsigned int* ovf, int pool, int single_product, int in_half, int out_half, long long* dbg_ts) {
   ConvArgs a; a.in = in; a.H = H; a.W = W; a.Cin = Cin; a.wf = wf; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = relu;
-  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf; a.in_half = in_half; a.out_half = out_half;
+  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf; a.in_half = in_half; a.out_half = out_half; a.dbg_ts = dbg_ts;
   const int th = pool ? 8 : 12;
   const dim3 grid((W + TW - 1) / TW, (H + th - 1) / th, B * (Cout_pad / 64));
   const bool hm = wfh != nullptr;
   const bool single = hm && single_product;
+  if (hm && !single && in_half == 2) {   // split fp16 on hm16 activations
+    if (pool) hipLaunchKernelGGL((k_sp_conv_s<9, 2, true, true>), grid, dim3(256), 0, s, a);      // (the pooled layers are inner layers)
+    else if (taps == 9 && out_half == 2) hipLaunchKernelGGL((k_sp_conv_s<9, 3, false, true>), grid, dim3(256), 0, s, a);
+    else if (taps == 9) hipLaunchKernelGGL((k_sp_conv_s<9, 3, false, false>), grid, dim3(256), 0, s, a);
+    else if (out_half == 2) hipLaunchKernelGGL((k_sp_conv_s<1, 3, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv_s<1, 3, false, false>), grid, dim3(256), 0, s, a);
+    return;
+  }
   if (single && taps == 9 && g_sp_conv_h) {
     const dim3 grid4((W + TW - 1) / TW, (H + TH4 - 1) / TH4, B * (Cout_pad / 64));
     if (pool) hipLaunchKernelGGL((k_sp_conv_h<true>), grid4, dim3(256), 0, s, a);
@@ -804,7 +1228,12 @@ void sp_scores(const float* logits, int cp, float* scores, int B, int h, int w, 
   hipLaunchKernelGGL(k_sp_scores, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, logits, cp, scores, h, w, cells);
 }
 // simple_nms(scores, r) -> `aux` (the suppressed score map); scratch: pooled, tmp, mask, supp (each B*H*W floats)
+int g_sp_nms_fused = 1;   // developer knob 36: 0 = simple_nms as 16 full-resolution launches (the round-1 form)
 void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, float* tmp, float* mask, float* supp, float* aux, hipStream_t s) {
+  if (g_sp_nms_fused && r == 4) {
+    hipLaunchKernelGGL(k_sp_nms_fused, dim3((W + NMS_TX - 1) / NMS_TX, (H + NMS_TY - 1) / NMS_TY, B), dim3(1024), 0, s, scores, aux, H, W);
+    return;
+  }
   const long long total = (long long)B * H * W;
   const dim3 g((unsigned)((total + 255) / 256)), blk(256);
   auto pool = [&](const float* src) {

@@ -282,3 +282,43 @@ def test_oracle_reproduces_the_transformers_extractor_fixture_at_1080p():
     kp, sc, d = osp.detect_and_describe(osp.synthetic_state_dict(0), torch.from_numpy(u8.astype(np.float32) * np.float32(1.0 / 255.0)), int(z["k"]))
     assert np.array_equal(kp.numpy().astype(np.int16), z["keypoints"])
     assert np.abs(sc.numpy() - z["scores"]).max() < 1e-6 and np.abs(d.numpy()[::4] - z["desc_every4"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 1080, 1920), (1, 480, 1920), (3, 136, 200)])
+def test_superpoint_round5_kernels_bitwise_against_the_forms_they_replace(shape):
+    """Round 5's extractor kernels compute what the kernels they replace computed, bit for bit: k_sp_conv_s (hm16 activation records staged by
+    LDS-DMA, knob 34 = 1) against k_sp_conv<., 1, ...> (f32 activations split while they are staged, knob 34 = 0) -- same terms, same product
+    and k order, so the score map is identical; k_sp_nms_fused (knob 36 = 1) against the 16-launch simple_nms (knob 36 = 0); and the whole
+    pass is repeatable run to run at the bench's frame size (a 16-channel-slice variant of the convolution that was not -- four workgroups per
+    CU, one word of four pixels per ~10^4 tiles -- was removed: DESIGN 12.4)."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_f16_attn", feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0))
+    img = torch.from_numpy(np.random.default_rng(11).random(shape, dtype=np.float32)).cuda()
+    npx = shape[0] * shape[1] * shape[2]
+
+    def run(conv, nms):
+        eng.lib.gn_debug_set_variant(eng.ctx, 34, conv)
+        eng.lib.gn_debug_set_variant(eng.ctx, 36, nms)
+        out = sp.detect_and_describe_device(img)
+        torch.cuda.synchronize()
+        return (eng.debug_read("sp_scores", npx).copy(), eng.debug_read("sp_nms", npx).copy(), [o.cpu().numpy().copy() if hasattr(o, "cpu") else np.asarray(o) for o in out])
+
+    try:
+        old = run(0, 0)
+        new = run(1, 1)
+        assert np.array_equal(old[0], new[0]), "score map of the hm16 convolutions differs from the round-2 kernels'"
+        assert np.array_equal(old[1], new[1]), "fused simple_nms differs from the 16-launch form"
+        assert int((new[1] > 0).sum()) > 100
+        for a, b in zip(old[2], new[2]):
+            assert np.array_equal(a, b)
+        for _ in range(6 if shape[1] >= 480 else 2):
+            again = run(1, 1)
+            assert np.array_equal(new[0], again[0]) and np.array_equal(new[1], again[1])
+            assert all(np.array_equal(a, b) for a, b in zip(new[2], again[2]))
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 34, 1)
+        eng.lib.gn_debug_set_variant(eng.ctx, 36, 1)
