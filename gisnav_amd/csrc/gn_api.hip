@@ -1628,7 +1628,7 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     ctx->sp_z = (float*)alloc((size_t)chunk * h * w * 256 * sizeof(float));
     bool ok = ctx->sp_x && ctx->sp_y && ctx->sp_z;
     for (int k = 0; k < 6; ++k) { ctx->sp_maps[k] = (float*)alloc(full * sizeof(float)); ok = ok && ctx->sp_maps[k]; }
-    ctx->sp_cand = (int*)alloc((size_t)chunk * cap * sizeof(int));
+    ctx->sp_cand = (int*)alloc((size_t)chunk * cap * 2 * sizeof(int));      // (raster index, score bits) pairs
     ctx->sp_counts = (int*)alloc((size_t)chunk * 4 * sizeof(int));
     ctx->sp_index = (int*)alloc((size_t)chunk * 2048 * sizeof(int));
     if (!ok || !ctx->sp_cand || !ctx->sp_counts || !ctx->sp_index) return fail(ctx, GN_ERR_HIP, "SuperPoint workspace allocation failed");

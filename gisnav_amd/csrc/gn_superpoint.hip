@@ -35,57 +35,80 @@ template <int OUT_FMT>   // 0: f32 NHWC; 1: the 64-channel map leaves as fp16 (G
                          // what k_sp_conv_s stages without touching it; the thread's 16 channels are one record group, 64 contiguous bytes)
 __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* w /*[64][9]*/, const float* bias, float* out, int H, int W, unsigned int* ovf) {
   // the 576 weights + 64 biases sit in LDS: a lane's channel group differs from its neighbours', so reading them from memory was
-  // 144 vector loads per thread (the layer ran at 1.5 TB/s of output instead of the HBM rate)
+  // 144 vector loads per thread (the layer ran at 1.5 TB/s of output instead of the HBM rate).  Round 5: a thread owns FOUR horizontally
+  // adjacent pixels of its 16-channel group -- one pixel per thread spent 160 LDS reads and 144 FMAs per 64 output bytes and was bound
+  // by exactly that (0.78 ms per four 1080p frames for 2.1 GB of output); now a weight read feeds four FMAs.  Per output the FMA chain is
+  // the same (bias, then the nine taps in order): same bits.
   __shared__ float ws[64 * 9 + 64];
   for (int q = threadIdx.x; q < 64 * 9 + 64; q += 256) ws[q] = q < 576 ? w[q] : bias[q - 576];
   __syncthreads();
-  // thread -> (pixel, 16-channel group); image index in blockIdx.z
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int grp = (int)(idx & 3);
-  const long long pix = idx >> 2;
-  if (pix >= (long long)H * W) return;
-  const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+  const long long quad = idx >> 2;
+  const int wq = W >> 2;
+  if (quad >= (long long)H * wq) return;
+  const int y = (int)(quad / wq), x = 4 * (int)(quad - (long long)y * wq);
   const float* img = in + (long long)blockIdx.z * H * W;
-  float v[9];
+  float v[3][6];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
-  }
-  float amax = 0.f;
-  float* o = out + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
-  _Float16* oh = reinterpret_cast<_Float16*>(out) + ((long long)blockIdx.z * H * W + pix) * 64 + grp * 16;
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int yy = y + r - 1, xx = x + c - 1;
+      v[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
+    }
   typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
-  h16x4_t hq[4], mq[4];
+  typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+  float amax = 0.f;
+  float r[4][16];
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) {
-    f32x4 r;
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = grp * 16 + cc;
+    float wt[9];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = grp * 16 + c4 * 4 + e;
-      float acc = ws[576 + c];
+    for (int t = 0; t < 9; ++t) wt[t] = ws[c * 9 + t];
+    const float bs = ws[576 + c];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc = fmaf(ws[c * 9 + t], v[t], acc);
-      r[e] = fmaxf(acc, 0.f);
-    }
-    if (OUT_FMT == 1) {
-      *reinterpret_cast<h16x4_t*>(oh + c4 * 4) = __builtin_convertvector(r, h16x4_t);
-    } else if (OUT_FMT == 2) {
-      ovf_track(amax, r.x, r.y); ovf_track(amax, r.z, r.w);
-      hq[c4] = __builtin_convertvector(r, h16x4_t);
-      mq[c4] = __builtin_convertvector(r - __builtin_convertvector(hq[c4], f32x4), h16x4_t);
-    } else {
-      *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+    for (int p = 0; p < 4; ++p) {
+      float acc = bs;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(wt[t], v[t / 3][p + t % 3], acc);
+      r[p][cc] = fmaxf(acc, 0.f);
     }
   }
-  if (OUT_FMT == 2) {
-    // the thread's record group: 16 high terms, 16 residual terms = four 16-byte stores, 64 contiguous bytes (a pixel's four threads: 256)
-    typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
-    _Float16* const og = reinterpret_cast<_Float16*>(out) + ((long long)blockIdx.z * H * W + pix) * 128 + grp * 32;
-    *reinterpret_cast<h16x8_t*>(og) = __builtin_shufflevector(hq[0], hq[1], 0, 1, 2, 3, 4, 5, 6, 7);
-    *reinterpret_cast<h16x8_t*>(og + 8) = __builtin_shufflevector(hq[2], hq[3], 0, 1, 2, 3, 4, 5, 6, 7);
-    *reinterpret_cast<h16x8_t*>(og + 16) = __builtin_shufflevector(mq[0], mq[1], 0, 1, 2, 3, 4, 5, 6, 7);
-    *reinterpret_cast<h16x8_t*>(og + 24) = __builtin_shufflevector(mq[2], mq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const long long pix = (long long)blockIdx.z * H * W + (long long)y * W + x + p;
+    if (OUT_FMT == 1) {
+      _Float16* oh = reinterpret_cast<_Float16*>(out) + pix * 64 + grp * 16;
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {
+        h16x8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)r[p][8 * c8 + e];
+        *reinterpret_cast<h16x8_t*>(oh + 8 * c8) = h;
+      }
+    } else if (OUT_FMT == 2) {
+      // the thread's record group of this pixel: 16 high terms, 16 residual terms = four 16-byte stores, 64 contiguous bytes
+      _Float16* const og = reinterpret_cast<_Float16*>(out) + pix * 128 + grp * 32;
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {
+        h16x8_t h, m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = r[p][8 * c8 + e];
+          amax = fmaxf(amax, f);          // (ReLU'd: no sign)
+          h[e] = (_Float16)f;
+          m[e] = (_Float16)(f - (float)h[e]);
+        }
+        *reinterpret_cast<h16x8_t*>(og + 8 * c8) = h;
+        *reinterpret_cast<h16x8_t*>(og + 16 + 8 * c8) = m;
+      }
+    } else {
+      float* o = out + pix * 64 + grp * 16;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<f32x4*>(o + c4 * 4) = (f32x4){r[p][4 * c4], r[p][4 * c4 + 1], r[p][4 * c4 + 2], r[p][4 * c4 + 3]};
+    }
   }
   if (OUT_FMT == 2) ovf_commit(ovf, amax);
 }
@@ -994,35 +1017,52 @@ __global__ __launch_bounds__(1024) void k_sp_nms_fused(const float* scores, floa
   }
 }
 
-// candidates: score > threshold, y >= border, x >= border (transformers tests the far borders against 8 x the map size, i.e. never)
-__global__ __launch_bounds__(256) void k_sp_candidates(const float* nms, int H, int W, float thr, int border, int* cand /*[B][cap] raster index*/, int* counts /*[B][4]*/, int cap) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.z;
-  if (i >= (long long)H * W) return;      // (H * W is a multiple of 64: whole waves leave)
-  const float s = nms[(long long)b * H * W + i];
-  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  // one atomic per wave (untrained weights make almost every NMS survivor a candidate: one atomic per candidate was 0.2 ms per call); the order
-  // of the list is immaterial (k_sp_select ranks by score and raster index)
-  const bool c = s > thr && y >= border && x >= border;
-  const unsigned long long bal = __ballot(c);
-  if (bal == 0ull) return;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(&counts[4 * b], __popcll(bal));
-  base = __shfl(base, leader);
-  if (c) {
-    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-    if (slot < cap) cand[(long long)b * cap + slot] = (int)i;
+// candidates: score > threshold, y >= border, x >= border (transformers tests the far borders against 8 x the map size, i.e. never).  A list entry
+// is (raster index, score bits): k_sp_select streams the list instead of gathering the scores behind the indices.  One atomic per WORKGROUP of
+// 2048 pixels (untrained weights make almost every NMS survivor a candidate: one atomic per candidate, then per wave, on the image's single counter
+// was 0.2 ms per call); the order of the list is immaterial (k_sp_select ranks by score and raster index).
+__global__ __launch_bounds__(256) void k_sp_candidates(const float* nms, int H, int W, float thr, int border, int2* cand /*[B][cap]*/, int* counts /*[B][4]*/, int cap) {
+  const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long hw = (long long)H * W, base = (long long)blockIdx.x * 2048;
+  __shared__ int wsum[4];
+  __shared__ int wgbase;
+  float sv[8];
+  unsigned long long bal[8];
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const long long i = base + it * 256 + tid;
+    const bool in = i < hw;
+    sv[it] = in ? nms[(long long)b * hw + i] : 0.f;
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    bal[it] = __ballot(in && sv[it] > thr && y >= border && x >= border);
+    cnt += __popcll(bal[it]);
+  }
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    wgbase = total > 0 ? atomicAdd(&counts[4 * b], total) : 0;
+  }
+  __syncthreads();
+  int slot0 = wgbase;
+  for (int w = 0; w < wave; ++w) slot0 += wsum[w];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    if ((bal[it] >> lane) & 1ull) {
+      const int slot = slot0 + __popcll(bal[it] & ((1ull << lane) - 1ull));
+      if (slot < cap) cand[(long long)b * cap + slot] = make_int2((int)(base + it * 256 + tid), __float_as_int(sv[it]));
+    }
+    slot0 += __popcll(bal[it]);
   }
 }
 
 // top-k by score, one workgroup per image: radix select of the k-th largest score over the candidates, survivors compacted into
 // LDS and rank-sorted by (score descending, raster index ascending).  Outputs GN_KPT_XYSA keypoint records and scores.
-__global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int W, const int* cand, int* counts, int cap, int k,
+__global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* cand, int* counts, int cap, int k,
                                                       float* kpt_xy, float* score_out, int* kp_index, long long out_stride) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* sc = nms + (long long)b * H * W;
-  const int* cd = cand + (long long)b * cap;
+  const int2* cd = cand + (long long)b * cap;
   const int n = min(counts[4 * b], cap);
   __shared__ int s_hist[256];
   __shared__ unsigned int s_prefix;
@@ -1037,9 +1077,14 @@ __global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int
       if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
       const unsigned int prefix = s_prefix;
-      for (int i = tid; i < n; i += 1024) {
-        const unsigned int bits = __float_as_uint(sc[cd[i]]);
-        if (shift == 24 || ((bits ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(bits >> shift) & 255u], 1);
+      // (four independent list reads per step: the loop is a chain of memory latencies otherwise)
+      for (int i0 = tid; i0 < n; i0 += 4096) {
+        unsigned int bits[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bits[u] = i0 + 1024 * u < n ? (unsigned int)cd[i0 + 1024 * u].y : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 1024 * u < n && (shift == 24 || ((bits[u] ^ prefix) >> (shift + 8)) == 0u)) atomicAdd(&s_hist[(bits[u] >> shift) & 255u], 1);
       }
       __syncthreads();
       if (tid == 0) {
@@ -1061,10 +1106,16 @@ __global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int
       if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
       const unsigned int prefix = s_prefix;
-      for (int i = tid; i < n; i += 1024) {
-        const unsigned int ci = (unsigned int)cd[i];
-        if (__float_as_uint(sc[ci]) != tbits) continue;
-        if (shift == 24 || ((ci ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(ci >> shift) & 255u], 1);
+      for (int i0 = tid; i0 < n; i0 += 4096) {
+        int2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = i0 + 1024 * u < n ? cd[i0 + 1024 * u] : make_int2(0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned int ci = (unsigned int)e[u].x;
+          if (i0 + 1024 * u >= n || (unsigned int)e[u].y != tbits) continue;
+          if (shift == 24 || ((ci ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(ci >> shift) & 255u], 1);
+        }
       }
       __syncthreads();
       if (tid == 0) {
@@ -1080,9 +1131,10 @@ __global__ __launch_bounds__(1024) void k_sp_select(const float* nms, int H, int
   __syncthreads();
   // survivors: score > T, plus the ties with a raster index up to the one found above
   for (int i = tid; i < n; i += 1024) {
-    const int ci = cd[i];
-    const unsigned int bits = __float_as_uint(sc[ci]);
-    if (n <= kk || bits > tbits || (bits == tbits && (unsigned int)ci <= ithr)) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = sc[ci]; } }
+    const int2 e = cd[i];
+    const int ci = e.x;
+    const unsigned int bits = (unsigned int)e.y;
+    if (n <= kk || bits > tbits || (bits == tbits && (unsigned int)ci <= ithr)) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = __int_as_float(e.y); } }
   }
   __syncthreads();
   const int m = min(s_cnt, min(kk, 2048));
@@ -1172,7 +1224,7 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
 int g_sp_conv_h = 1;   // developer knob 24: 0 = GN_SP_FP16 3 x 3 layers through k_sp_conv<9, 2, ...> (the first single-product kernel)
 int g_sp_conv_s = 1;   // developer knob 34: 0 = the split-fp16 mode on f32 activations through k_sp_conv<., 1, ...> (the round-2 kernel); 1 = hm16 activations, k_sp_conv_s
 void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half, unsigned int* ovf) {
-  const long long n = (long long)H * W * 4;
+  const long long n = (long long)H * W;      // threads: (quad of pixels, 16-channel group) = H * W / 4 * 4
   const dim3 grid((unsigned)((n + 255) / 256), 1, B);
   if (out_half == 2) hipLaunchKernelGGL(k_sp_conv1<2>, grid, dim3(256), 0, s, in, w, bias, out, H, W, ovf);
   else if (out_half) hipLaunchKernelGGL(k_sp_conv1<1>, grid, dim3(256), 0, s, in, w, bias, out, H, W, ovf);
@@ -1253,8 +1305,8 @@ void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, floa
 void sp_select(const float* nms, int B, int H, int W, float thr, int border, int* cand, int* counts, int cap, int k,
                float* kpt_xy, float* score, int* kp_index, long long out_stride, hipStream_t s) {
   hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int), s);
-  hipLaunchKernelGGL(k_sp_candidates, dim3((unsigned)(((long long)H * W + 255) / 256), 1, B), dim3(256), 0, s, nms, H, W, thr, border, cand, counts, cap);
-  hipLaunchKernelGGL(k_sp_select, dim3(B), dim3(1024), 0, s, nms, H, W, cand, counts, cap, k, kpt_xy, score, kp_index, out_stride);
+  hipLaunchKernelGGL(k_sp_candidates, dim3((unsigned)(((long long)H * W + 2047) / 2048), 1, B), dim3(256), 0, s, nms, H, W, thr, border, reinterpret_cast<int2*>(cand), counts, cap);
+  hipLaunchKernelGGL(k_sp_select, dim3(B), dim3(1024), 0, s, H, W, reinterpret_cast<const int2*>(cand), counts, cap, k, kpt_xy, score, kp_index, out_stride);
 }
 void sp_describe(const float* dmap, int B, int h, int w, const float* kpt_xy, const int* counts, long long out_stride, int max_k, float* desc, hipStream_t s) {
   hipLaunchKernelGGL(k_sp_describe, dim3((max_k + 3) / 4, B), dim3(256), 0, s, dmap, h, w, kpt_xy, counts, out_stride, desc);
