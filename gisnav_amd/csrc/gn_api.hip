@@ -1705,6 +1705,8 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"sp_enc", ctx->sp_y, ctx->sp_y ? (size_t)ctx->sp_chunk * (ctx->sp_h / 8) * (ctx->sp_w / 8) * 128 : 0},          // SuperPoint: encoder output of the last pass, NHWC
       {"sp_scores", ctx->sp_maps[0], ctx->sp_maps[0] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},             // softmax + depth-to-space scores
       {"sp_nms", ctx->sp_maps[5], ctx->sp_maps[5] ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w : 0},                // after simple_nms
+      {"sp_counts", ctx->sp_counts, ctx->sp_counts ? (size_t)ctx->sp_chunk * 4 : 0},                                    // per image: candidates, keypoints, candidates seen by the select
+      {"sp_cand", ctx->sp_cand, ctx->sp_cand ? (size_t)ctx->sp_chunk * ctx->sp_cap * 2 : 0},                            // (raster index, score bits) pairs, [image][cap]
       {"sp_x", ctx->sp_x, ctx->sp_x ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w * 64 : 0},                         // raw words of the two activation buffers
       {"sp_y", ctx->sp_y, ctx->sp_y ? (size_t)ctx->sp_chunk * ctx->sp_h * ctx->sp_w * 64 : 0},
       {"sp_ts", ctx->sp_ts, ctx->sp_ts ? (size_t)8192 * 32 * 2 : 0},                                                     // phase stamps (knob 35), int64 pairs of 4-byte words

@@ -587,6 +587,11 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_h(ConvArgs a) {   // two wor
 typedef __attribute__((address_space(3))) void* sp_lptr_t;
 // Two wait states behind a 16-byte buffer store with an SGPR soffset, before anything may rewrite its data registers (hipcc's hazard recogniser
 // pads that case only for an immediate soffset; cheap insurance: the stores are the last thing a row does).
+// acc * scale + bias as ONE scalar v_fma_f32 per value, pinned so that nothing re-packs it: written on two-wide vectors hipcc emits
+// `v_pk_fma_f32 D, V, s[n:n+1], V op_sel_hi:[1,0,1]` (the scale in an SGPR pair), and that instruction intermittently returned garbage for one
+// quad of lanes (20..23 / 28..31) in this epilogue -- ReLU turned it into zeros: one word of four pixels in about one tile per 10^4, found with
+// tools/sp_race.py.  The same class as gn_ffn128.hip's note on v_pk_mul_f32 with an SGPR scale and build.py's on k_qkv's v_pk_fma_f32.
+__device__ __forceinline__ float sp_scale_bias(float a, float s, float b) { float r = __builtin_fmaf(a, s, b); asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ void sp_store_guard() { asm volatile("s_nop 1" ::: "memory"); }
 __device__ __forceinline__ float sp_resid_lo(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
 __device__ __forceinline__ float sp_resid_hi(unsigned int h, float y) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y)); return r; }
@@ -775,7 +780,8 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
         for (int k = 0; k < 2; ++k) {
           const f32x2v bk = {b4[i][g][2 * k], b4[i][g][2 * k + 1]};
           // (ascale is a power of two: the fused multiply-add rounds like the multiplication followed by the addition)
-          const f32x2v v0 = pair(acc[i][0], 4 * g + 2 * k) * splat2(ascale) + bk, v1 = pair(acc[i][RPW - 1], 4 * g + 2 * k) * splat2(ascale) + bk;
+          const f32x2v v0 = {sp_scale_bias(acc[i][0][4 * g + 2 * k], ascale, bk[0]), sp_scale_bias(acc[i][0][4 * g + 2 * k + 1], ascale, bk[1])};
+          const f32x2v v1 = {sp_scale_bias(acc[i][RPW - 1][4 * g + 2 * k], ascale, bk[0]), sp_scale_bias(acc[i][RPW - 1][4 * g + 2 * k + 1], ascale, bk[1])};
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float mv = fmaxf(fmaxf(v0[e], v1[e]), relu_lo);      // max(relu(a), relu(b)) = relu(max(a, b))
@@ -809,8 +815,9 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const f32x2v bk = {b4[i][g][2 * k], b4[i][g][2 * k + 1]};
-          v[k] = pair(acc[i][j], 4 * g + 2 * k) * splat2(ascale) + bk;      // (ascale is a power of two: rounds like multiplication, then addition)
-          v[k][0] = fmaxf(v[k][0], relu_lo); v[k][1] = fmaxf(v[k][1], relu_lo);
+          // (ascale is a power of two: the fused multiply-add rounds like multiplication, then addition)
+          v[k][0] = fmaxf(sp_scale_bias(acc[i][j][4 * g + 2 * k], ascale, bk[0]), relu_lo);
+          v[k][1] = fmaxf(sp_scale_bias(acc[i][j][4 * g + 2 * k + 1], ascale, bk[1]), relu_lo);
         }
         put4(ql, i, g, v[0], v[1]);
       }
@@ -826,6 +833,223 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
   }
   if (out_hm) ovf_commit(a.ovf, amax);
   stamp(25);
+}
+
+// The same convolution with 16-channel slices (3 x 3 layers): the halo tile of an 8 x 32 output tile is 22 KB and a tap's weight fragments 4 KB --
+// 35 KB per workgroup, accumulators for two rows per wave -> up to four workgroups (16 waves) per CU, so that a staging workgroup leaves others on
+// the matrix pipe (with two per CU the full-resolution layer ran at HBM time PLUS MFMA time).  The weight fragments run two taps ahead through
+// three 4 KB buffers, across the slice boundaries (they do not depend on the tile), and are waited for with a counted vmcnt.  LDS pixel layout:
+// 64 bytes = pieces 2 pl + hh at position piece ^ ((lx >> 2) & 3) (k_sp_conv_h's).  Same products, but the k order is (slice of 16, tap) instead
+// of (slice of 32, tap, k-step): results equal k_sp_conv_s's to f32 rounding, not bitwise.
+template <bool POOL, bool OUTHM>
+__global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
+  constexpr int RPW = 2, TH = 8, LW = TW + 2, LH = TH + 2, TAPS = 9;
+  constexpr int NSEG = 3, TAIL = 2;                 // 16 pixels per staging instruction; 34 = 16 + 16 + 2
+  constexpr int NROW = (LH + 3) / 4;
+  constexpr int TILE_B = ((LH * LW * 64 + 1023) / 1024) * 1024;
+  constexpr int PSTR = 256 + 16, SLAB = (POOL ? 16 : 32) * PSTR;
+  constexpr int SMEM = TILE_B + 3 * 4096 > 4 * SLAB ? TILE_B + 3 * 4096 : 4 * SLAB;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+  unsigned char* const tb = smem;
+  unsigned char* const wbuf = smem + TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = a.Cout / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const unsigned int rec = (unsigned int)a.Cin * 4u;
+  unsigned char* const ibase = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.in)) + (size_t)img * a.H * a.W * rec;
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, (unsigned int)((size_t)a.H * a.W * rec), 0x00020000);
+  const __amdgpu_buffer_rsrc_t irs0 = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, 0, 0x00020000);
+  const unsigned int ksteps = (unsigned int)a.Cin / 16u;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.wfh) + (size_t)(2 * og) * TAPS * ksteps * 1024, 0, 2u * TAPS * ksteps * 2048u, 0x00020000);
+  const unsigned int lds_tile = (unsigned int)(size_t)(sp_lptr_t)tb, lds_w = (unsigned int)(size_t)(sp_lptr_t)wbuf;
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+  auto fsw = [](int lx) { return (lx >> 2) & 3; };
+  // staging: instruction (row r, segment sg) covers halo pixels 16 sg .. 16 sg + 15 of row r: lane -> (pixel lane >> 2, position lane & 3)
+  unsigned int lanepart[NSEG];
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg) {
+    const int lx = 16 * sg + (lane >> 2), gx = x0 + lx - 1;
+    lanepart[sg] = (gx >= 0 && gx < a.W) ? (unsigned int)gx * rec + (unsigned int)(((lane & 3) ^ fsw(lx)) * 16) : 0x80000000u;
+  }
+  // the wave's 1 KB weight block of a (tap, slice): block wave = i * 2 + pl  ->  source block ((i * TAPS + tap) * ksteps + c0 / 16) * 2 + pl
+  const unsigned int wsrc0 = (((unsigned int)(wave >> 1) * TAPS) * ksteps * 2u + (unsigned int)(wave & 1)) * 1024u;
+  auto weights_dma = [&](int tap, int c0, int buf) __attribute__((always_inline)) {
+    const unsigned int src = wsrc0 + ((unsigned int)tap * ksteps + (unsigned int)(c0 >> 4)) * 2048u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lane16), "s"(wrs), "s"(lds_w + (unsigned int)(buf * 4096) + (unsigned int)wave * 1024u), "s"(src) : "memory");
+  };
+  auto stage_issue = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int r = q * 4 + wave;
+      if (r < LH) {
+        const int gy = y0 + r - 1;
+        const bool rv = gy >= 0 && gy < a.H;
+        const __amdgpu_buffer_rsrc_t rs = rv ? irs : irs0;
+        const unsigned int soff = rv ? (unsigned int)(gy * a.W) * rec + (unsigned int)(c0 * 4) : 0u;
+        const unsigned int dst = lds_tile + (unsigned int)(r * LW * 64);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+          if (sg + 1 < NSEG)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff) : "memory");
+          else     // the row's last two pixels: the other lanes must not write (their slots are the next row's first pixels)
+            asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\ts_mov_b64 exec, -1" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff), "n"((1ull << (4 * TAIL)) - 1ull) : "memory");
+        }
+      }
+    }
+  };
+  stage_issue(0);
+  weights_dma(0, 0, 0);
+  weights_dma(1, 0, 1);
+  // (behind the first requests, in the shadow of their latency)
+  // fragment addresses: pixel (RPW wave + j + dy, ql + dx), piece 2 pl + hh -> fbase[dx][pl] + (j + dy) * LW * 64
+  unsigned int fbase[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int lx = ql + dx;
+      fbase[dx][pl] = (unsigned int)((RPW * wave * LW + lx) * 64 + (((2 * pl + hh) ^ fsw(lx)) * 16));
+    }
+  f32x16 acc[2][RPW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 16) {
+    const bool more = c0 + 16 < a.Cin;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      // weights two taps ahead, into the buffer tap - 1 has released (its readers passed the barrier in front of this tap)
+      const bool issue = tap + 2 < TAPS || more;
+      if (tap + 2 < TAPS) weights_dma(tap + 2, c0, (tap + 2) % 3);
+      else if (more) weights_dma(tap + 2 - TAPS, c0 + 16, (tap + 2) % 3);
+      const unsigned char* const wb = wbuf + (tap % 3) * 4096;
+      h16x8 fa[2][2], fb[RPW][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + (i * 2 + pl) * 1024 + lane16);
+#pragma unroll
+      for (int j = 0; j < RPW; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + fbase[dx][pl] + (j + dy) * LW * 64);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < RPW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][p == 0 ? 1 : 0], fb[j][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+      if (tap + 1 < TAPS) {
+        // the next tap's weights (requested a tap ago) must have landed; the request of this tap may stay in flight
+        if (issue) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    if (more) {
+      __syncthreads();      // every wave is done with this slice's tile
+      stage_issue(c0 + 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // epilogue: k_sp_conv_s's (bias requested here: no request of this wave is in flight any more)
+  f32x4 b4[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[i][g] = *reinterpret_cast<const f32x4*>(a.bias + 64 * og + 32 * i + 8 * g + 4 * hh);
+  const float ascale = a.acc_scale;
+  float amax = 0.f;
+  constexpr bool out_hm = OUTHM;
+  const float relu_lo = a.relu ? 0.f : -INFINITY;
+  unsigned char* const slab = smem + wave * SLAB;
+  __syncthreads();                                    // every wave is done with the tile and the weight buffers
+  auto put4 = [&](int p, int i, int g, f32x2v v0, f32x2v v1) __attribute__((always_inline)) {
+    const int cl = 32 * i + 8 * g + 4 * hh;
+    if (out_hm) {
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v0[0]), __builtin_fabsf(v0[1])));
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v1[0]), __builtin_fabsf(v1[1])));
+      const unsigned int h0 = pack16<true>(v0[0], v0[1]), h1 = pack16<true>(v1[0], v1[1]);
+      const unsigned int m0 = pack16<true>(sp_resid_lo(h0, v0[0]), sp_resid_hi(h0, v0[1])), m1 = pack16<true>(sp_resid_lo(h1, v1[0]), sp_resid_hi(h1, v1[1]));
+      unsigned char* o = slab + p * PSTR + (cl >> 4) * 64 + (cl & 15) * 2;
+      *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(o + 32) = make_uint2(m0, m1);
+    } else {
+      *reinterpret_cast<f32x4*>(slab + p * PSTR + cl * 4) = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+    }
+  };
+  const size_t orec = (size_t)a.Cout * 4;
+  unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)og * 256;
+  const unsigned int rd = (unsigned int)((lane >> 4) * PSTR + (lane & 15) * 16);
+  const unsigned int so = (unsigned int)(lane >> 4) * (unsigned int)orec + (unsigned int)(lane & 15) * 16u;
+  if (POOL) {
+    const int gy = y0 + RPW * wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v m[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float bk = b4[i][g][2 * k + e];
+            float mv = fmaxf(fmaxf(sp_scale_bias(acc[i][0][4 * g + 2 * k + e], ascale, bk), sp_scale_bias(acc[i][1][4 * g + 2 * k + e], ascale, bk)), relu_lo);
+            mv = fmaxf(mv, __shfl_xor(mv, 1));
+            m[k][e] = mv;
+          }
+        if (!(ql & 1)) put4(ql >> 1, i, g, m[0], m[1]);
+      }
+    if (out_hm) ovf_commit(a.ovf, amax);
+    const size_t prow = ((size_t)img * (a.H / 2) + (gy >> 1)) * (a.W / 2) + (x0 >> 1);
+    const int npix = gy + 1 < a.H ? min(16, (a.W - x0) / 2) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + 256) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * 4 * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * 4) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int gy = y0 + RPW * wave + j;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) v[k][e] = fmaxf(sp_scale_bias(acc[i][j][4 * g + 2 * k + e], ascale, b4[i][g][2 * k + e]), relu_lo);
+        put4(ql, i, g, v[0], v[1]);
+      }
+    const size_t prow = ((size_t)img * a.H + gy) * a.W + x0;
+    const int npix = gy < a.H ? min(32, a.W - x0) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + 256) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * 4 * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * 4) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+  }
+  if (out_hm) ovf_commit(a.ovf, amax);
 }
 
 // 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
@@ -1095,6 +1319,9 @@ __global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* ca
       __syncthreads();
     }
     tbits = s_prefix; eq_budget = s_need;
+    __syncthreads();      // every thread has its copy before thread 0 re-uses the two words for the tie select (a fast thread 0 used to zero s_prefix
+                          // under slower waves: they selected with threshold 0 -- a whole image's keypoint list changed in ~1 of 10 runs once the
+                          // passes got faster; found by the repeat assertions of test_superpoint_round5_kernels_against_the_forms_they_replace)
   }
   // ties at the threshold are taken in raster order: a second radix select, over the raster index of the candidates whose score
   // equals T, finds the eq_budget-th SMALLEST index (a flat score map -- untrained weights -- makes almost every candidate a tie;
@@ -1222,7 +1449,8 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
 }
 
 int g_sp_conv_h = 1;   // developer knob 24: 0 = GN_SP_FP16 3 x 3 layers through k_sp_conv<9, 2, ...> (the first single-product kernel)
-int g_sp_conv_s = 1;   // developer knob 34: 0 = the split-fp16 mode on f32 activations through k_sp_conv<., 1, ...> (the round-2 kernel); 1 = hm16 activations, k_sp_conv_s
+int g_sp_conv_s = 2;   // developer knob 34: 0 = the split-fp16 mode on f32 activations through k_sp_conv<., 1, ...> (the round-2 kernel); 1 = hm16 activations, k_sp_conv_s
+                       // for every layer (bitwise the round-2 results); 2 = k_sp_conv_s16 for the 3 x 3 layers (5 % faster, another k order: f32 rounding)
 void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half, unsigned int* ovf) {
   const long long n = (long long)H * W;      // threads: (quad of pixels, 16-channel group) = H * W / 4 * 4
   const dim3 grid((unsigned)((n + 255) / 256), 1, B);
@@ -1239,6 +1467,13 @@ void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, con
   const bool hm = wfh != nullptr;
   const bool single = hm && single_product;
   if (hm && !single && in_half == 2) {   // split fp16 on hm16 activations
+    if (taps == 9 && g_sp_conv_s == 2) {   // 16-channel slices, 8 x 32 tiles
+      const dim3 g8((W + TW - 1) / TW, (H + 7) / 8, B * (Cout_pad / 64));
+      if (pool) hipLaunchKernelGGL((k_sp_conv_s16<true, true>), g8, dim3(256), 0, s, a);
+      else if (out_half == 2) hipLaunchKernelGGL((k_sp_conv_s16<false, true>), g8, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_sp_conv_s16<false, false>), g8, dim3(256), 0, s, a);
+      return;
+    }
     if (pool) hipLaunchKernelGGL((k_sp_conv_s<9, 2, true, true>), grid, dim3(256), 0, s, a);      // (the pooled layers are inner layers)
     else if (taps == 9 && out_half == 2) hipLaunchKernelGGL((k_sp_conv_s<9, 3, false, true>), grid, dim3(256), 0, s, a);
     else if (taps == 9) hipLaunchKernelGGL((k_sp_conv_s<9, 3, false, false>), grid, dim3(256), 0, s, a);

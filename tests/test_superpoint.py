@@ -286,12 +286,14 @@ def test_oracle_reproduces_the_transformers_extractor_fixture_at_1080p():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 1080, 1920), (1, 480, 1920), (3, 136, 200)])
-def test_superpoint_round5_kernels_bitwise_against_the_forms_they_replace(shape):
-    """Round 5's extractor kernels compute what the kernels they replace computed, bit for bit: k_sp_conv_s (hm16 activation records staged by
-    LDS-DMA, knob 34 = 1) against k_sp_conv<., 1, ...> (f32 activations split while they are staged, knob 34 = 0) -- same terms, same product
-    and k order, so the score map is identical; k_sp_nms_fused (knob 36 = 1) against the 16-launch simple_nms (knob 36 = 0); and the whole
-    pass is repeatable run to run at the bench's frame size (a 16-channel-slice variant of the convolution that was not -- four workgroups per
-    CU, one word of four pixels per ~10^4 tiles -- was removed: DESIGN 12.4)."""
+def test_superpoint_round5_kernels_against_the_forms_they_replace(shape):
+    """Round 5's extractor kernels against the kernels they replace.  k_sp_conv_s (hm16 activation records staged by LDS-DMA, knob 34 = 1) against
+    k_sp_conv<., 1, ...> (f32 activations split while they are staged, knob 34 = 0): same terms, same product and k order -> the score map is
+    IDENTICAL.  k_sp_nms_fused (knob 36 = 1) against the 16-launch simple_nms (knob 36 = 0): identical.  k_sp_conv_s16 (16-channel slices, four
+    workgroups per CU, the default: knob 34 = 2) sums the same products slice by slice instead of tap by tap: score map within f32 rounding, the
+    keypoint set the same up to last-bit ties.  And every form is repeatable run to run at the bench's frame size -- the first epilogue of these
+    kernels was not (a packed `v_pk_fma_f32` with the scale in an SGPR pair returned garbage for one quad of lanes in about one tile per 10^4
+    with 16 waves per CU: DESIGN 12.4); the arithmetic is scalar now and this test repeats the pass."""
     from gisnav_amd.engine import PoseEngine
     from gisnav_amd.superpoint import SuperPoint
     from oracle import superpoint as osp
@@ -315,10 +317,19 @@ def test_superpoint_round5_kernels_bitwise_against_the_forms_they_replace(shape)
         assert int((new[1] > 0).sum()) > 100
         for a, b in zip(old[2], new[2]):
             assert np.array_equal(a, b)
-        for _ in range(6 if shape[1] >= 480 else 2):
-            again = run(1, 1)
-            assert np.array_equal(new[0], again[0]) and np.array_equal(new[1], again[1])
-            assert all(np.array_equal(a, b) for a, b in zip(new[2], again[2]))
+        s16 = run(2, 1)
+        assert np.abs(s16[0] - new[0]).max() < 1e-5                 # (the bar of the oracle comparison above)
+        assert ((s16[1] > 0) != (new[1] > 0)).mean() < 1e-4
+        n_new, n_16 = new[2][3], s16[2][3]
+        for b in range(shape[0]):
+            ka = {(float(x), float(y)) for x, y in new[2][0][b, : int(n_new[b]), :2]}
+            kb = {(float(x), float(y)) for x, y in s16[2][0][b, : int(n_16[b]), :2]}
+            assert len(ka & kb) >= 0.99 * len(ka)
+        for conv, ref in ((2, s16), (1, new)):
+            for _ in range(6 if shape[1] >= 480 else 2):
+                again = run(conv, 1)
+                assert np.array_equal(ref[0], again[0]) and np.array_equal(ref[1], again[1]), f"knob 34 = {conv}: the pass is not repeatable"
+                assert all(np.array_equal(a, b) for a, b in zip(ref[2], again[2]))
     finally:
-        eng.lib.gn_debug_set_variant(eng.ctx, 34, 1)
+        eng.lib.gn_debug_set_variant(eng.ctx, 34, 2)
         eng.lib.gn_debug_set_variant(eng.ctx, 36, 1)

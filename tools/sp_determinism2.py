@@ -1,3 +1,4 @@
+"""Developer tool: run-to-run repeatability of the SuperPoint pass per convolution family (knob 34), several frame sizes."""
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from gisnav_amd.engine import PoseEngine
@@ -6,7 +7,8 @@ from oracle import superpoint as osp
 eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_f16_attn", feature="superpoint")
 sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0))
 rng = np.random.default_rng(0)
-def check(shape, tag, reps=12):
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+def check(shape, tag):
     img = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
     maps = []
     for rep in range(reps):
