@@ -40,13 +40,14 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
   // by exactly that (0.78 ms per four 1080p frames for 2.1 GB of output); now a weight read feeds four FMAs.  Per output the FMA chain is
   // the same (bias, then the nine taps in order): same bits.
   __shared__ float ws[64 * 9 + 64];
+  __shared__ __attribute__((aligned(16))) unsigned char slab[OUT_FMT == 2 ? 4 * 4096 : 16];
   for (int q = threadIdx.x; q < 64 * 9 + 64; q += 256) ws[q] = q < 576 ? w[q] : bias[q - 576];
   __syncthreads();
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int grp = (int)(idx & 3);
   const long long quad = idx >> 2;
   const int wq = W >> 2;
-  if (quad >= (long long)H * wq) return;
+  if (OUT_FMT != 2 && quad >= (long long)H * wq) return;      // (the hm16 form keeps whole waves: its rows leave through a wave-wide LDS exchange)
   const int y = (int)(quad / wq), x = 4 * (int)(quad - (long long)y * wq);
   const float* img = in + (long long)blockIdx.z * H * W;
   float v[3][6];
@@ -89,8 +90,11 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
         *reinterpret_cast<h16x8_t*>(oh + 8 * c8) = h;
       }
     } else if (OUT_FMT == 2) {
-      // the thread's record group of this pixel: 16 high terms, 16 residual terms = four 16-byte stores, 64 contiguous bytes
-      _Float16* const og = reinterpret_cast<_Float16*>(out) + pix * 128 + grp * 32;
+      // the thread's record group of this pixel: 16 high terms, 16 residual terms = 64 contiguous bytes.  Stored directly, an instruction wrote 64
+      // separate 16-byte pieces (16 of every 64 bytes, quads 1 KB apart); through the wave's LDS slab an instruction writes 1 KB in one piece
+      // (the wave's 16 quads x 4 groups of pixel p are 16 records 1 KB apart: slab [quad][256 B], read back as [quad][16 lanes x 16 B])
+      unsigned char* const sl = slab + (threadIdx.x >> 6) * 4096;
+      const int lane = threadIdx.x & 63;
 #pragma unroll
       for (int c8 = 0; c8 < 2; ++c8) {
         h16x8_t h, m;
@@ -101,8 +105,20 @@ __global__ __launch_bounds__(256) void k_sp_conv1(const float* in, const float* 
           h[e] = (_Float16)f;
           m[e] = (_Float16)(f - (float)h[e]);
         }
-        *reinterpret_cast<h16x8_t*>(og + 8 * c8) = h;
-        *reinterpret_cast<h16x8_t*>(og + 16 + 8 * c8) = m;
+        *reinterpret_cast<h16x8_t*>(sl + (lane >> 2) * 256 + grp * 64 + 16 * c8) = h;
+        *reinterpret_cast<h16x8_t*>(sl + (lane >> 2) * 256 + grp * 64 + 32 + 16 * c8) = m;
+      }
+      // read-back: instruction it covers quads 4 it .. 4 it + 3 of the wave: lane -> (quad 4 it + (lane >> 4), 16-byte chunk lane & 15) of pixel p's record
+      const long long wq0 = quad - (lane >> 2);          // the wave's first quad (consecutive quads of one row, or the tail of the grid)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int qq = 4 * it + (lane >> 4);
+        const uint4 v4 = *reinterpret_cast<const uint4*>(sl + qq * 256 + (lane & 15) * 16);
+        const long long qd = wq0 + qq;
+        if (qd < (long long)H * wq) {
+          const int yq = (int)(qd / wq), xq = 4 * (int)(qd - (long long)yq * wq);
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + (((long long)blockIdx.z * H + yq) * W + xq + p) * 256 + (lane & 15) * 16) = v4;
+        }
       }
     } else {
       float* o = out + pix * 64 + grp * 16;
