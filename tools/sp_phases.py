@@ -1,4 +1,4 @@
-"""Developer tool: phase stamps (s_memtime) of k_sp_conv_s for one SuperPoint layer, 4 x 1080p per call.   python tools/sp_phases.py [layer]"""
+"""Developer tool: phase stamps (s_memtime) of k_sp_conv_s (knob 34 = 1: the 32-channel-slice form carries the stamps) for SuperPoint layers, 4 x 1080p per call.   python tools/sp_phases.py [layers...]"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -11,6 +11,7 @@ eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_f16_attn", featu
 sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0))
 rng = np.random.default_rng(0)
 img = torch.from_numpy(rng.random((4, 1080, 1920), dtype=np.float32)).cuda()
+eng.lib.gn_debug_set_variant(eng.ctx, 34, 1)
 for _ in range(2):
     sp.detect_and_describe_device(img)
 torch.cuda.synchronize()
@@ -33,3 +34,4 @@ for layer in layers:
             print(f"  {names[k]:14s} {np.median(cur):9.0f} {np.median(cur - prev):8.0f}   (p10 {np.percentile(cur - prev, 10):7.0f}, p90 {np.percentile(cur - prev, 90):7.0f})")
             prev = cur
 eng.lib.gn_debug_set_variant(eng.ctx, 35, 0)
+eng.lib.gn_debug_set_variant(eng.ctx, 34, 2)
