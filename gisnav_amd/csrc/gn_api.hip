@@ -1656,7 +1656,9 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int n = std::min(chunk, B - b0);
     if (split) GN_HIP(hipMemsetAsync(ctx->ovf_base + 8, 0, sizeof(unsigned int), s));
-    hm16_io = split && ctx->sp_split == 1 && gn::g_sp_conv_s != 0;
+    // (k_sp_conv_s addresses a frame's activations with 32-bit buffer offsets, 0x80000000 marking a pixel outside the image: frames whose
+    // full-resolution 64-channel map reaches 2 GB -- beyond 8 Mpixel -- stay on the round-2 kernels)
+    hm16_io = split && ctx->sp_split == 1 && gn::g_sp_conv_s != 0 && (size_t)H * W * 256 < 0x7fffffffull;
     for (int i = 1; i < 12; ++i) hm16_io = hm16_io && ctx->sp[i].wfh != nullptr;
     ctx->sp_enc_hm16 = hm16_io;
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s,

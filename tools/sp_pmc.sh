@@ -25,7 +25,7 @@ for SET in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_L
 import json
 d = json.load(open("/tmp/pmc.json"))
 for k, v in sorted(d.items()):
-    if "k_sp_conv<" in k or "k_sp_conv_h" in k:
+    if "k_sp_conv" in k:
         print(k[:28], {c: (round(x["sum"] / x["dispatches"]), x["dispatches"]) for c, x in v.items()})
 PY
 done
