@@ -45,7 +45,7 @@ struct gn_ctx {
   int sp_ts_layer = 0;          // developer knob 35: the layer (1..11) whose k_sp_conv_s launch writes phase stamps into sp_ts (gn_debug_read("sp_ts"))
   long long* sp_ts = nullptr;   // [8192 workgroups][32] s_memtime stamps
   void* sp_allocs_dbg = nullptr;
-  bool sp_enc_hm16 = false;   // the last pass left the encoder output (sp_y) as hm16 records (gn_debug_read("sp_enc") converts)
+  bool sp_enc_hm16 = false, sp_enc_fp16 = false;   // the last pass left the encoder output (sp_y) as hm16 records (gn_debug_read("sp_enc") converts)
   int head_fused = 1;      // match head: 1 = two fused sweeps that recompute the similarity tiles (no sim buffer); 0 = sim GEMM + five passes (developer knob 16)
   int head_stamps = 0;     // developer knob 17: k_head_fused writes s_memtime phase stamps into the sim buffer
   int pnp_stamps = 0;      // developer knob 15: k_pnp_* write s_memtime phase stamps into the sim buffer
@@ -1646,8 +1646,11 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     const bool hm = split && ctx->sp[i].wfh != nullptr;
     const bool half_io = hm && ctx->sp_split == 2;
     // split mode (round 5): every activation between the layers travels as hm16 records (k_sp_conv_s); the two head outputs stay f32
-    const int in_fmt = hm16_io ? 2 : (half_io && i >= 1 && i <= 6 ? 1 : 0);
-    const int out_fmt = hm16_io ? (i == 9 || i == 11 ? 0 : 2) : (half_io && i >= 1 && i <= 5 ? 1 : 0);
+    // GN_SP_FP16 with k_sp_conv_h16 (knob 24 = 2): fp16 activations all the way to the two head outputs (the single-product staging rounds the same
+    // values to fp16 anyway); with the older kernels only layers 1 .. 6 read and layers 1 .. 5 write fp16
+    const bool h_all = gn::g_sp_conv_h == 2;
+    const int in_fmt = hm16_io ? 2 : (half_io && i >= 1 && (h_all || i <= 6) ? 1 : 0);
+    const int out_fmt = hm16_io ? (i == 9 || i == 11 ? 0 : 2) : (half_io && i >= 1 && (h_all ? (i != 9 && i != 11) : i <= 5) ? 1 : 0);
     sp_conv(in, n, hh, ww, ctx->sp[i].cin, ctx->sp[i].wf, ctx->sp[i].b, out, ctx->sp[i].cout_pad, ctx->sp[i].taps, relu, s,
             hm ? ctx->sp[i].wfh : nullptr, ctx->sp[i].acc_scale, ctx->ovf_base + 8, pool, ctx->sp_split == 2, in_fmt, out_fmt,
             (ctx->sp_ts_layer == i && ctx->sp_ts != nullptr) ? ctx->sp_ts : nullptr);
@@ -1661,6 +1664,7 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     hm16_io = split && ctx->sp_split == 1 && gn::g_sp_conv_s != 0 && (size_t)H * W * 256 < 0x7fffffffull;
     for (int i = 1; i < 12; ++i) hm16_io = hm16_io && ctx->sp[i].wfh != nullptr;
     ctx->sp_enc_hm16 = hm16_io;
+    ctx->sp_enc_fp16 = !hm16_io && split && ctx->sp_split == 2 && gn::g_sp_conv_h == 2 && ctx->sp[7].wfh != nullptr;
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s,
              hm16_io ? 2 : (split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr ? 1 : 0), ctx->ovf_base + 8);
     // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
@@ -1720,6 +1724,12 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       if ((int64_t)(count * 4) > max_bytes) count = (size_t)max_bytes / 4;
       if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GN_ERR_HIP;
       if (hipMemcpy(host_out, e.p, count * 4, hipMemcpyDeviceToHost) != hipSuccess) return GN_ERR_HIP;
+      if (strcmp(name, "sp_enc") == 0 && ctx->sp_enc_fp16) {
+        // fp16 NHWC values (the first half of the bytes read) -> f32, back to front in place
+        const uint16_t* hsrc = (const uint16_t*)host_out;
+        float* dst = (float*)host_out;
+        for (size_t g = count; g-- > 0;) dst[g] = (float)__builtin_bit_cast(_Float16, hsrc[g]);
+      }
       if (strcmp(name, "sp_enc") == 0 && ctx->sp_enc_hm16) {
         // hm16 records (per 16 channels: 16 high halfs, 16 residual halfs) -> f32 values in channel order, in place
         uint16_t rec[32];

@@ -1068,6 +1068,221 @@ __global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
   if (out_hm) ovf_commit(a.ovf, amax);
 }
 
+// GN_SP_FP16 (one fp16 product per block, fp16 NHWC activations: the arithmetic BASELINE configs[4] names) in k_sp_conv_s16's form, for the 3 x 3 layers
+// whose input already is fp16 (layers 1 .. 6: 85 % of the extractor's flops): a 32-channel slice of an fp16 pixel is the same 64 bytes as a
+// 16-channel slice of an hm16 record, so the halo tile, the LDS-DMA staging, the three-buffer weight pipeline (high-term blocks only: k-steps s = 0, 1
+// of the slice where k_sp_conv_s16 has the two terms) and the slab epilogue are that kernel's; per tap 8 MFMAs on 8 fragment reads.  Replaces
+// k_sp_conv_h there (fragment reuse across the taps of a kernel column, but staging through registers and run-time tap addressing: 0.12 of the
+// single-product issue ceiling).  A tolerance mode like k_sp_conv_h (another k order: f32 rounding).
+template <bool POOL, bool OUTH>   // OUTH: fp16 NHWC output (else f32)
+__global__ __launch_bounds__(256, 3) void k_sp_conv_h16(ConvArgs a) {
+  constexpr int RPW = 2, TH = 8, LW = TW + 2, LH = TH + 2, TAPS = 9;
+  constexpr int NSEG = 3, TAIL = 2;                 // 16 pixels per staging instruction; 34 = 16 + 16 + 2
+  constexpr int NROW = (LH + 3) / 4;
+  constexpr int TILE_B = ((LH * LW * 64 + 1023) / 1024) * 1024;
+  constexpr int SEG = OUTH ? 128 : 256;               // bytes of the workgroup's 64 channels in an output pixel record
+  constexpr int PSTR = SEG + 16, SLAB = (POOL ? 16 : 32) * PSTR;
+  constexpr int SMEM = TILE_B + 3 * 4096 > 4 * SLAB ? TILE_B + 3 * 4096 : 4 * SLAB;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+  unsigned char* const tb = smem;
+  unsigned char* const wbuf = smem + TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int ogroups = a.Cout / 64;
+  const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const unsigned int rec = (unsigned int)a.Cin * 2u;                       // fp16 NHWC: a 32-channel slice of a pixel is the same 64 bytes
+  unsigned char* const ibase = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.in)) + (size_t)img * a.H * a.W * rec;
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, (unsigned int)((size_t)a.H * a.W * rec), 0x00020000);
+  const __amdgpu_buffer_rsrc_t irs0 = __builtin_amdgcn_make_buffer_rsrc(ibase, 0, 0, 0x00020000);
+  const unsigned int ksteps = (unsigned int)a.Cin / 16u;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.wfh) + (size_t)(2 * og) * TAPS * ksteps * 1024, 0, 2u * TAPS * ksteps * 2048u, 0x00020000);
+  const unsigned int lds_tile = (unsigned int)(size_t)(sp_lptr_t)tb, lds_w = (unsigned int)(size_t)(sp_lptr_t)wbuf;
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+  auto fsw = [](int lx) { return (lx >> 2) & 3; };
+  // staging: instruction (row r, segment sg) covers halo pixels 16 sg .. 16 sg + 15 of row r: lane -> (pixel lane >> 2, position lane & 3)
+  unsigned int lanepart[NSEG];
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg) {
+    const int lx = 16 * sg + (lane >> 2), gx = x0 + lx - 1;
+    lanepart[sg] = (gx >= 0 && gx < a.W) ? (unsigned int)gx * rec + (unsigned int)(((lane & 3) ^ fsw(lx)) * 16) : 0x80000000u;
+  }
+  // the wave's 1 KB weight block of a (tap, slice): block wave = i * 2 + s  ->  HIGH-term source block ((i * TAPS + tap) * ksteps + c0 / 16 + s) * 2
+  const unsigned int wsrc0 = (((unsigned int)(wave >> 1) * TAPS) * ksteps * 2u + 2u * (unsigned int)(wave & 1)) * 1024u;
+  auto weights_dma = [&](int tap, int c0, int buf) __attribute__((always_inline)) {
+    const unsigned int src = wsrc0 + ((unsigned int)tap * ksteps + (unsigned int)(c0 >> 4)) * 2048u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lane16), "s"(wrs), "s"(lds_w + (unsigned int)(buf * 4096) + (unsigned int)wave * 1024u), "s"(src) : "memory");
+  };
+  auto stage_issue = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int r = q * 4 + wave;
+      if (r < LH) {
+        const int gy = y0 + r - 1;
+        const bool rv = gy >= 0 && gy < a.H;
+        const __amdgpu_buffer_rsrc_t rs = rv ? irs : irs0;
+        const unsigned int soff = rv ? (unsigned int)(gy * a.W) * rec + (unsigned int)(c0 * 2) : 0u;
+        const unsigned int dst = lds_tile + (unsigned int)(r * LW * 64);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+          if (sg + 1 < NSEG)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff) : "memory");
+          else     // the row's last two pixels: the other lanes must not write (their slots are the next row's first pixels)
+            asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\ts_mov_b64 exec, -1" ::"v"(lanepart[sg]), "s"(rs), "s"(dst + (unsigned int)(sg * 1024)), "s"(soff), "n"((1ull << (4 * TAIL)) - 1ull) : "memory");
+        }
+      }
+    }
+  };
+  stage_issue(0);
+  weights_dma(0, 0, 0);
+  weights_dma(1, 0, 1);
+  // (behind the first requests, in the shadow of their latency)
+  // fragment addresses: pixel (RPW wave + j + dy, ql + dx), piece 2 s + hh (k-step s of the slice) -> fbase[dx][s] + (j + dy) * LW * 64
+  unsigned int fbase[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int lx = ql + dx;
+      fbase[dx][pl] = (unsigned int)((RPW * wave * LW + lx) * 64 + (((2 * pl + hh) ^ fsw(lx)) * 16));
+    }
+  f32x16 acc[2][RPW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+    const bool more = c0 + 32 < a.Cin;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      // weights two taps ahead, into the buffer tap - 1 has released (its readers passed the barrier in front of this tap)
+      const bool issue = tap + 2 < TAPS || more;
+      if (tap + 2 < TAPS) weights_dma(tap + 2, c0, (tap + 2) % 3);
+      else if (more) weights_dma(tap + 2 - TAPS, c0 + 32, (tap + 2) % 3);
+      const unsigned char* const wb = wbuf + (tap % 3) * 4096;
+      h16x8 fa[2][2], fb[RPW][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *reinterpret_cast<const h16x8*>(wb + (i * 2 + pl) * 1024 + lane16);
+#pragma unroll
+      for (int j = 0; j < RPW; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const h16x8*>(tb + fbase[dx][pl] + (j + dy) * LW * 64);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < RPW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+      if (tap + 1 < TAPS) {
+        // the next tap's weights (requested a tap ago) must have landed; the request of this tap may stay in flight
+        if (issue) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    if (more) {
+      __syncthreads();      // every wave is done with this slice's tile
+      stage_issue(c0 + 32);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // epilogue: k_sp_conv_s16's, with fp16 (or f32) records instead of hm16
+  f32x4 b4[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[i][g] = *reinterpret_cast<const f32x4*>(a.bias + 64 * og + 32 * i + 8 * g + 4 * hh);
+  const float ascale = a.acc_scale;
+  float amax = 0.f;
+  constexpr bool out_h = OUTH;
+  const float relu_lo = a.relu ? 0.f : -INFINITY;
+  unsigned char* const slab = smem + wave * SLAB;
+  __syncthreads();                                    // every wave is done with the tile and the weight buffers
+  auto put4 = [&](int p, int i, int g, f32x2v v0, f32x2v v1) __attribute__((always_inline)) {
+    const int cl = 32 * i + 8 * g + 4 * hh;
+    if (out_h) {
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v0[0]), __builtin_fabsf(v0[1])));
+      amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v1[0]), __builtin_fabsf(v1[1])));
+      *reinterpret_cast<uint2*>(slab + p * PSTR + cl * 2) = make_uint2(pack16<true>(v0[0], v0[1]), pack16<true>(v1[0], v1[1]));
+    } else {
+      *reinterpret_cast<f32x4*>(slab + p * PSTR + cl * 4) = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+    }
+  };
+  const size_t orec = (size_t)a.Cout * (OUTH ? 2 : 4);
+  unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)og * SEG;
+  constexpr int CPP = SEG / 16, PPI = 64 / CPP;      // 16-byte chunks per pixel segment, pixels per read-back instruction
+  const unsigned int rd = (unsigned int)((lane / CPP) * PSTR + (lane % CPP) * 16);
+  const unsigned int so = (unsigned int)(lane / CPP) * (unsigned int)orec + (unsigned int)(lane % CPP) * 16u;
+  if (POOL) {
+    const int gy = y0 + RPW * wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v m[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float bk = b4[i][g][2 * k + e];
+            float mv = fmaxf(fmaxf(sp_scale_bias(acc[i][0][4 * g + 2 * k + e], ascale, bk), sp_scale_bias(acc[i][1][4 * g + 2 * k + e], ascale, bk)), relu_lo);
+            mv = fmaxf(mv, __shfl_xor(mv, 1));
+            m[k][e] = mv;
+          }
+        if (!(ql & 1)) put4(ql >> 1, i, g, m[0], m[1]);
+      }
+    if (out_h) ovf_commit(a.ovf, amax);
+    const size_t prow = ((size_t)img * (a.H / 2) + (gy >> 1)) * (a.W / 2) + (x0 >> 1);
+    const int npix = gy + 1 < a.H ? min(16, (a.W - x0) / 2) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + SEG) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 16 / PPI; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * PPI * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * PPI) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int gy = y0 + RPW * wave + j;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x2v v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) v[k][e] = fmaxf(sp_scale_bias(acc[i][j][4 * g + 2 * k + e], ascale, b4[i][g][2 * k + e]), relu_lo);
+        put4(ql, i, g, v[0], v[1]);
+      }
+    const size_t prow = ((size_t)img * a.H + gy) * a.W + x0;
+    const int npix = gy < a.H ? min(32, a.W - x0) : 0;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase + prow * orec, 0, npix > 0 ? (unsigned int)((npix - 1) * orec + SEG) : 0u, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 32 / PPI; ++it) {
+      const u32x4_sp v = *reinterpret_cast<const u32x4_sp*>(slab + rd + it * PPI * PSTR);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ors, so, (unsigned int)(it * PPI) * (unsigned int)orec, 0);
+      sp_store_guard();
+    }
+  }
+  if (out_h) ovf_commit(a.ovf, amax);
+}
+
 // 2x2 max-pool, NHWC; thread -> (output pixel, 4 channels)
 __global__ __launch_bounds__(256) void k_sp_pool(const float* in, float* out, int H, int W, int C, long long total4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1464,7 +1679,7 @@ void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int C
           }
 }
 
-int g_sp_conv_h = 1;   // developer knob 24: 0 = GN_SP_FP16 3 x 3 layers through k_sp_conv<9, 2, ...> (the first single-product kernel)
+int g_sp_conv_h = 2;   // developer knob 24: 2 = GN_SP_FP16 3 x 3 layers with fp16 input through k_sp_conv_h16 (round 5), 1 = all through k_sp_conv_h, 0 = through k_sp_conv<9, 2, ...> (the first single-product kernel)
 int g_sp_conv_s = 2;   // developer knob 34: 0 = the split-fp16 mode on f32 activations through k_sp_conv<., 1, ...> (the round-2 kernel); 1 = hm16 activations, k_sp_conv_s
                        // for every layer (bitwise the round-2 results); 2 = k_sp_conv_s16 for the 3 x 3 layers (5 % faster, another k order: f32 rounding)
 void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half, unsigned int* ovf) {
@@ -1495,6 +1710,13 @@ void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, con
     else if (taps == 9) hipLaunchKernelGGL((k_sp_conv_s<9, 3, false, false>), grid, dim3(256), 0, s, a);
     else if (out_half == 2) hipLaunchKernelGGL((k_sp_conv_s<1, 3, false, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_sp_conv_s<1, 3, false, false>), grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (single && taps == 9 && g_sp_conv_h == 2 && in_half == 1) {   // fp16 activations in: k_sp_conv_s16's form
+    const dim3 g8((W + TW - 1) / TW, (H + 7) / 8, B * (Cout_pad / 64));
+    if (pool) hipLaunchKernelGGL((k_sp_conv_h16<true, true>), g8, dim3(256), 0, s, a);     // (the pooled layers write fp16)
+    else if (out_half == 1) hipLaunchKernelGGL((k_sp_conv_h16<false, true>), g8, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_sp_conv_h16<false, false>), g8, dim3(256), 0, s, a);
     return;
   }
   if (single && taps == 9 && g_sp_conv_h) {
