@@ -1514,85 +1514,107 @@ __global__ __launch_bounds__(256) void k_sp_candidates(const float* nms, int H, 
 
 // top-k by score, one workgroup per image: radix select of the k-th largest score over the candidates, survivors compacted into
 // LDS and rank-sorted by (score descending, raster index ascending).  Outputs GN_KPT_XYSA keypoint records and scores.
-__global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* cand, int* counts, int cap, int k,
-                                                      float* kpt_xy, float* score_out, int* kp_index, long long out_stride) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int2* cd = cand + (long long)b * cap;
-  const int n = min(counts[4 * b], cap);
-  __shared__ int s_hist[256];
-  __shared__ unsigned int s_prefix;
-  __shared__ int s_need, s_cnt, s_eq;
-  __shared__ int s_idx[2048];
-  __shared__ float s_val[2048];
-  const int kk = min(k, 2048);
-  unsigned int tbits = 0u; int eq_budget = 0x7fffffff;
-  if (n > kk) {
-    if (tid == 0) { s_prefix = 0u; s_need = kk; }
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      if (tid < 256) s_hist[tid] = 0;
-      __syncthreads();
-      const unsigned int prefix = s_prefix;
-      // (four independent list reads per step: the loop is a chain of memory latencies otherwise)
-      for (int i0 = tid; i0 < n; i0 += 4096) {
-        unsigned int bits[4];
+// CACHED: the image's candidates fit the workgroup's registers (PT per thread, read ONCE with all loads in flight); the eight radix passes and the
+// survivor pass then run from registers -- streamed, each pass was a chain of list reads by one workgroup (0.24 ms per four 1080p frames).  Histogram
+// updates are aggregated per wave for the bin most lanes share (a flat score map puts every candidate of a pass into one or two bins: 64 serialised LDS
+// atomics per instruction otherwise).
+constexpr int kSelPT = 40;
+template <bool CACHED>
+__device__ __forceinline__ void sp_select_core(int W, const int2* cd, int n, int kk, int b, int* counts, float* kpt_xy, float* score_out, int* kp_index, long long out_stride,
+                                               int* s_hist, unsigned int& s_prefix, int& s_need, int& s_cnt, int* s_idx, float* s_val) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nu = (n + 1023) >> 10;               // list entries per thread (uniform)
+  int2 e[CACHED ? kSelPT : 1];
+  if constexpr (CACHED) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bits[u] = i0 + 1024 * u < n ? (unsigned int)cd[i0 + 1024 * u].y : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i0 + 1024 * u < n && (shift == 24 || ((bits[u] ^ prefix) >> (shift + 8)) == 0u)) atomicAdd(&s_hist[(bits[u] >> shift) & 255u], 1);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int need = s_need, bin = 255;
-        for (; bin > 0; --bin) { if (s_hist[bin] >= need) break; need -= s_hist[bin]; }
-        s_need = need; s_prefix = prefix | ((unsigned int)bin << shift);
-      }
-      __syncthreads();
-    }
-    tbits = s_prefix; eq_budget = s_need;
-    __syncthreads();      // every thread has its copy before thread 0 re-uses the two words for the tie select (a fast thread 0 used to zero s_prefix
-                          // under slower waves: they selected with threshold 0 -- a whole image's keypoint list changed in ~1 of 10 runs once the
-                          // passes got faster; found by the repeat assertions of test_superpoint_round5_kernels_against_the_forms_they_replace)
+    for (int u = 0; u < kSelPT; ++u) { const int i = tid + 1024 * u; e[u] = (u < nu && i < n) ? cd[i] : make_int2(-1, 0); }
   }
-  // ties at the threshold are taken in raster order: a second radix select, over the raster index of the candidates whose score
-  // equals T, finds the eq_budget-th SMALLEST index (a flat score map -- untrained weights -- makes almost every candidate a tie;
-  // counting, for each tie, the ties before it was O(ties x candidates): 3.7 ms per 1080p call)
-  unsigned int ithr = 0xffffffffu;
-  if (n > kk) {
-    if (tid == 0) { s_prefix = 0u; s_need = eq_budget; }
+  auto item = [&](int u) __attribute__((always_inline)) -> int2 {
+    if constexpr (CACHED) return e[u];
+    else { const int i = tid + 1024 * u; return i < n ? cd[i] : make_int2(-1, 0); }
+  };
+  auto hist_add = [&](bool on, int bin) __attribute__((always_inline)) {
+    const unsigned long long act = __ballot(on);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const int b0 = __shfl(bin, leader);
+    const unsigned long long same = __ballot(on && bin == b0);
+    if (lane == leader) atomicAdd(&s_hist[b0], __popcll(same));
+    if (on && bin != b0) atomicAdd(&s_hist[bin], 1);
+  };
+  // pass(key, accept): radix select over the keys of the accepted entries; largest = true finds the need-th LARGEST key, else the need-th smallest
+  auto radix = [&](int need0, bool largest, auto key, auto accept) __attribute__((always_inline)) {
+    if (tid == 0) { s_prefix = 0u; s_need = need0; }
     for (int shift = 24; shift >= 0; shift -= 8) {
       if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
       const unsigned int prefix = s_prefix;
-      for (int i0 = tid; i0 < n; i0 += 4096) {
-        int2 e[4];
+      if constexpr (CACHED) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = i0 + 1024 * u < n ? cd[i0 + 1024 * u] : make_int2(0, 0);
+        for (int u = 0; u < kSelPT; ++u)
+          if (u < nu) { const int2 it = item(u); const unsigned int kv = key(it); hist_add(it.x >= 0 && accept(it) && (shift == 24 || ((kv ^ prefix) >> (shift + 8)) == 0u), (int)((kv >> shift) & 255u)); }
+      } else {
+        for (int u = 0; u < nu; ++u) { const int2 it = item(u); const unsigned int kv = key(it); hist_add(it.x >= 0 && accept(it) && (shift == 24 || ((kv ^ prefix) >> (shift + 8)) == 0u), (int)((kv >> shift) & 255u)); }
+      }
+      __syncthreads();
+      // the bin that holds the need-th key, by one wave (thread 0 walking the 256 bins was 256 dependent LDS reads per pass: most of the kernel):
+      // lane l owns bins 4 l .. 4 l + 3; running sums from the top (largest) or the bottom, the bin is where they first reach `need`
+      if (tid < 64) {
+        const int need = s_need;
+        int c[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned int ci = (unsigned int)e[u].x;
-          if (i0 + 1024 * u >= n || (unsigned int)e[u].y != tbits) continue;
-          if (shift == 24 || ((ci ^ prefix) >> (shift + 8)) == 0u) atomicAdd(&s_hist[(ci >> shift) & 255u], 1);
+        for (int q = 0; q < 4; ++q) c[q] = s_hist[4 * lane + q];
+        const int t = c[0] + c[1] + c[2] + c[3];
+        int run = t;      // inclusive scan over the lanes: from the top lane down (largest) or from lane 0 up
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl(run, largest ? lane + d : lane - d);
+          if (largest ? lane + d < 64 : lane - d >= 0) run += o;
+        }
+        const int before = run - t;      // keys in the bins beyond this lane's (above it / below it)
+        int acc4[4];                     // running sum INCLUDING the bin, walking this lane's bins in the search direction
+        int below = 0;                   // bins of this lane whose running sum is still short of need
+        int sum = before;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int bq = largest ? 3 - q : q; sum += c[bq]; acc4[bq] = sum; below += sum < need ? 1 : 0; }
+        int nshort = below;              // bins (in search order) before the one that reaches need
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nshort += __shfl_xor(nshort, d);
+        nshort = min(nshort, 255);
+        const int bin = largest ? 255 - nshort : nshort;
+        if (lane == (bin >> 2)) {
+          const int incl = acc4[bin & 3];
+          s_need = need - (incl - c[bin & 3]);
+          s_prefix = prefix | ((unsigned int)bin << shift);
         }
       }
       __syncthreads();
-      if (tid == 0) {
-        int need = s_need, bin = 0;
-        for (; bin < 255; ++bin) { if (s_hist[bin] >= need) break; need -= s_hist[bin]; }
-        s_need = need; s_prefix = prefix | ((unsigned int)bin << shift);
-      }
-      __syncthreads();
     }
+  };
+  unsigned int tbits = 0u, ithr = 0xffffffffu;
+  if (n > kk) {
+    radix(kk, true, [](const int2& it) { return (unsigned int)it.y; }, [](const int2&) { return true; });
+    tbits = s_prefix;
+    const int eq_budget = s_need;
+    __syncthreads();      // every thread has its copies before thread 0 re-uses the two words (a fast thread 0 used to zero s_prefix under slower waves: they
+                          // selected with threshold 0 -- a whole image's keypoint list changed in ~1 of 10 runs once the passes got faster)
+    // ties at the threshold are taken in raster order: a second radix select, over the raster index of the candidates whose score equals T, finds the
+    // eq_budget-th SMALLEST index (a flat score map -- untrained weights -- makes almost every candidate a tie)
+    radix(eq_budget, false, [](const int2& it) { return (unsigned int)it.x; }, [tbits](const int2& it) { return (unsigned int)it.y == tbits; });
     ithr = s_prefix;
   }
-  if (tid == 0) { s_cnt = 0; s_eq = 0; }
+  if (tid == 0) s_cnt = 0;
   __syncthreads();
   // survivors: score > T, plus the ties with a raster index up to the one found above
-  for (int i = tid; i < n; i += 1024) {
-    const int2 e = cd[i];
-    const int ci = e.x;
-    const unsigned int bits = (unsigned int)e.y;
-    if (n <= kk || bits > tbits || (bits == tbits && (unsigned int)ci <= ithr)) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = ci; s_val[p] = __int_as_float(e.y); } }
+  auto keep = [&](const int2& it) __attribute__((always_inline)) {
+    const unsigned int bits = (unsigned int)it.y;
+    if (it.x >= 0 && (n <= kk || bits > tbits || (bits == tbits && (unsigned int)it.x <= ithr))) { const int p = atomicAdd(&s_cnt, 1); if (p < 2048) { s_idx[p] = it.x; s_val[p] = __int_as_float(it.y); } }
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int u = 0; u < kSelPT; ++u) if (u < nu) keep(item(u));
+  } else {
+    for (int u = 0; u < nu; ++u) keep(item(u));
   }
   __syncthreads();
   const int m = min(s_cnt, min(kk, 2048));
@@ -1607,6 +1629,20 @@ __global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* ca
     kp_index[(long long)b * out_stride + rank] = ci;
   }
   if (tid == 0) { counts[4 * b + 1] = m; counts[4 * b + 2] = n; }
+}
+__global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* cand, int* counts, int cap, int k,
+                                                      float* kpt_xy, float* score_out, int* kp_index, long long out_stride) {
+  const int b = blockIdx.x;
+  const int2* cd = cand + (long long)b * cap;
+  const int n = min(counts[4 * b], cap);
+  __shared__ int s_hist[256];
+  __shared__ unsigned int s_prefix;
+  __shared__ int s_need, s_cnt;
+  __shared__ int s_idx[2048];
+  __shared__ float s_val[2048];
+  const int kk = min(k, 2048);
+  if (n <= kSelPT * 1024) sp_select_core<true>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
+  else sp_select_core<false>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
 }
 
 // descriptors: one wave per keypoint; lane -> 4 of the 256 channels.  dmap [B][h][w][256] (conv_descriptor_b output, NOT yet normalised)
