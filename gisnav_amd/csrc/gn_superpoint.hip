@@ -1621,7 +1621,15 @@ __device__ __forceinline__ void sp_select_core(int W, const int2* cd, int n, int
   for (int i = tid; i < m; i += 1024) {
     const float v = s_val[i]; const int ci = s_idx[i];
     int rank = 0;
-    for (int j = 0; j < m; ++j) { const float vj = s_val[j]; if (vj > v || (vj == v && s_idx[j] < ci)) ++rank; }
+    // (four entries per step: two 16-byte LDS broadcasts instead of eight 4-byte ones; entries at and beyond m never outrank: score -1)
+    for (int j = 0; j < m; j += 4) {
+      const f32x4 vj = *reinterpret_cast<const f32x4*>(s_val + j);
+      const int4 ij = *reinterpret_cast<const int4*>(s_idx + j);
+      rank += (j + 0 < m && (vj.x > v || (vj.x == v && ij.x < ci))) ? 1 : 0;
+      rank += (j + 1 < m && (vj.y > v || (vj.y == v && ij.y < ci))) ? 1 : 0;
+      rank += (j + 2 < m && (vj.z > v || (vj.z == v && ij.z < ci))) ? 1 : 0;
+      rank += (j + 3 < m && (vj.w > v || (vj.w == v && ij.w < ci))) ? 1 : 0;
+    }
     const int y = ci / W, x = ci - y * W;
     float* kr = kpt_xy + ((long long)b * out_stride + rank) * 4;       // GN_KPT_XYSA record: x, y, size (unused: 1), angle (unused: 0)
     kr[0] = (float)x; kr[1] = (float)y; kr[2] = 1.f; kr[3] = 0.f;
@@ -1638,8 +1646,8 @@ __global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* ca
   __shared__ int s_hist[256];
   __shared__ unsigned int s_prefix;
   __shared__ int s_need, s_cnt;
-  __shared__ int s_idx[2048];
-  __shared__ float s_val[2048];
+  __shared__ __attribute__((aligned(16))) int s_idx[2048];
+  __shared__ __attribute__((aligned(16))) float s_val[2048];
   const int kk = min(k, 2048);
   if (n <= kSelPT * 1024) sp_select_core<true>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
   else sp_select_core<false>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
