@@ -712,6 +712,9 @@ def main() -> None:
         extras.append(run_extra_loftr(local_rank, 10, 2, dev, arithmetic="split_fp16"))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev, arithmetic="fp16"))
+        # the same two at configs[3]'s per-GPU batch (32 pairs: the extractor still runs four frames per pass, the matcher and the PnP stage run once)
+        extras.append(run_extra_superpoint(local_rank, 32, 2, 1, dev))
+        extras.append(run_extra_superpoint(local_rank, 32, 2, 1, dev, arithmetic="fp16"))
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps

@@ -1384,12 +1384,16 @@ __global__ __launch_bounds__(1024) void k_sp_nms_fused(const float* scores, floa
   float* oimg = out + (long long)blockIdx.z * H * W;
   const float NINF = -INFINITY;
   // scores -> S (-inf outside the image and in the pad columns); pads of A and M
-  for (int i = tid; i < NP; i += 1024) {
-    const int ry = i / NMS_PITCH, cx = i - ry * NMS_PITCH, rx = cx - NMS_LP;
+  // (four columns per load: x0 and W are multiples of 4, so a group of four is inside the image or outside it as a whole)
+  for (int i = tid; i < NMS_RH * (NMS_PITCH / 4); i += 1024) {
+    const int ry = i / (NMS_PITCH / 4), c4 = i - ry * (NMS_PITCH / 4), rx = 4 * c4 - NMS_LP;
     const int gy = y0 + ry, gx = x0 + rx;
-    const bool in = rx >= 0 && rx < NMS_RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    S[i] = in ? img[(long long)gy * W + gx] : NINF;
-    if (rx < 0 || rx >= NMS_RW) { A[i] = NINF; M[i] = NINF; }
+    const bool pad = rx < 0 || rx >= NMS_RW;
+    const bool in = !pad && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const f32x4 ninf4 = {NINF, NINF, NINF, NINF};
+    const int o = ry * NMS_PITCH + 4 * c4;
+    *reinterpret_cast<f32x4*>(S + o) = in ? *reinterpret_cast<const f32x4*>(img + (long long)gy * W + gx) : ninf4;
+    if (pad) { *reinterpret_cast<f32x4*>(A + o) = ninf4; *reinterpret_cast<f32x4*>(M + o) = ninf4; }
   }
   __syncthreads();
   const bool active = tid < NMS_RH * (NMS_RW / 8);       // 936 items per pass, both passes
