@@ -7,6 +7,11 @@
 //                     matrix instruction v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain): weights are the A operand, fetched
 //                     from L2 straight into registers in MFMA fragment order (re-laid-out once at load time, like gn_ffn.hip);
 //                     output pixels are the B operand, read from an LDS halo tile of 18 x 34 pixels x 32 input channels
+//   k_sp_conv_s       (round 5) the split-fp16 convolution on hm16 activation RECORDS: halo tile and weight fragments by LDS-DMA, unrolled taps,
+//                     scalar VALU-lean epilogue through an LDS slab; bitwise k_sp_conv<., 1, ...>'s results.  Runs the 1 x 1 head layers
+//   k_sp_conv_s16     (round 5) the same with 16-channel slices and four workgroups per CU: the 3 x 3 layers of the split mode (matrix pipe busy 0.72-0.81)
+//   k_sp_conv_h16     (round 5) k_sp_conv_s16's form for GN_SP_FP16 (fp16 activations, one product per block)
+//   k_sp_nms_fused    (round 5) simple_nms in one kernel (the five 9 x 9 pools of a 64 x 32 tile in LDS); k_sp_maxrow/col + k_sp_nms_step stay as knob 36 = 0
 //   k_sp_pool         2x2 max-pool
 //   k_sp_scores       65-way softmax per 8x8 cell, dustbin dropped, depth-to-space -> full-resolution score map
 //   k_sp_maxrow/col   separable (2 r + 1)^2 max-pool passes of simple_nms (restated exactly: -inf padding)
@@ -16,8 +21,8 @@
 //                     raster index ascending on ties) -- one workgroup per image
 //   k_sp_describe     per keypoint: bilinear sample (align_corners) of the L2-normalised 1/8-resolution descriptor map, L2 normalise
 //
-// The convolutions are f32-exact (no reduced-precision operand anywhere), so keypoints agree with an f32 CPU run except where two
-// scores tie to the last bit.
+// The convolutions of f32 contexts are f32-exact (no reduced-precision operand anywhere), so keypoints agree with an f32 CPU run except where
+// two scores tie to the last bit; f16x2 contexts run the f32-ACCURATE split-fp16 kernels.
 #include "gn_common.h"
 #include "gn_ffn_util.h"
 
