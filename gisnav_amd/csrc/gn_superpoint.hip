@@ -1648,7 +1648,7 @@ __device__ __forceinline__ void sp_select_core(int W, const int2* cd, int n, int
   if (tid == 0) { counts[4 * b + 1] = m; counts[4 * b + 2] = n; }
 }
 __global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* cand, int* counts, int cap, int k,
-                                                      float* kpt_xy, float* score_out, int* kp_index, long long out_stride) {
+                                                      float* kpt_xy, float* score_out, int* kp_index, long long out_stride, int force_stream) {
   const int b = blockIdx.x;
   const int2* cd = cand + (long long)b * cap;
   const int n = min(counts[4 * b], cap);
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(1024) void k_sp_select(int H, int W, const int2* ca
   __shared__ __attribute__((aligned(16))) int s_idx[2048];
   __shared__ __attribute__((aligned(16))) float s_val[2048];
   const int kk = min(k, 2048);
-  if (n <= kSelPT * 1024) sp_select_core<true>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
+  if (n <= kSelPT * 1024 && !force_stream) sp_select_core<true>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
   else sp_select_core<false>(W, cd, n, kk, b, counts, kpt_xy, score_out, kp_index, out_stride, s_hist, s_prefix, s_need, s_cnt, s_idx, s_val);
 }
 
@@ -1806,6 +1806,7 @@ void sp_scores(const float* logits, int cp, float* scores, int B, int h, int w, 
   hipLaunchKernelGGL(k_sp_scores, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, logits, cp, scores, h, w, cells);
 }
 // simple_nms(scores, r) -> `aux` (the suppressed score map); scratch: pooled, tmp, mask, supp (each B*H*W floats)
+int g_sp_select_stream = 0;   // developer knob 40: 1 = k_sp_select reads the candidate list from memory in every pass (the path of frames with more than 40 960 candidates)
 int g_sp_nms_fused = 1;   // developer knob 36: 0 = simple_nms as 16 full-resolution launches (the round-1 form)
 void sp_nms(const float* scores, int B, int H, int W, int r, float* pooled, float* tmp, float* mask, float* supp, float* aux, hipStream_t s) {
   if (g_sp_nms_fused && r == 4) {
@@ -1832,7 +1833,7 @@ void sp_select(const float* nms, int B, int H, int W, float thr, int border, int
                float* kpt_xy, float* score, int* kp_index, long long out_stride, hipStream_t s) {
   hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int), s);
   hipLaunchKernelGGL(k_sp_candidates, dim3((unsigned)(((long long)H * W + 2047) / 2048), 1, B), dim3(256), 0, s, nms, H, W, thr, border, reinterpret_cast<int2*>(cand), counts, cap);
-  hipLaunchKernelGGL(k_sp_select, dim3(B), dim3(1024), 0, s, H, W, reinterpret_cast<const int2*>(cand), counts, cap, k, kpt_xy, score, kp_index, out_stride);
+  hipLaunchKernelGGL(k_sp_select, dim3(B), dim3(1024), 0, s, H, W, reinterpret_cast<const int2*>(cand), counts, cap, k, kpt_xy, score, kp_index, out_stride, g_sp_select_stream);
 }
 void sp_describe(const float* dmap, int B, int h, int w, const float* kpt_xy, const int* counts, long long out_stride, int max_k, float* desc, hipStream_t s) {
   hipLaunchKernelGGL(k_sp_describe, dim3((max_k + 3) / 4, B), dim3(256), 0, s, dmap, h, w, kpt_xy, counts, out_stride, desc);

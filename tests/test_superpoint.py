@@ -325,6 +325,12 @@ def test_superpoint_round5_kernels_against_the_forms_they_replace(shape):
             ka = {(float(x), float(y)) for x, y in new[2][0][b, : int(n_new[b]), :2]}
             kb = {(float(x), float(y)) for x, y in s16[2][0][b, : int(n_16[b]), :2]}
             assert len(ka & kb) >= 0.99 * len(ka)
+        eng.lib.gn_debug_set_variant(eng.ctx, 40, 1)      # k_sp_select streaming its candidate list (frames with more than 40 960 candidates) = the register-cached form
+        try:
+            streamed = run(2, 1)
+        finally:
+            eng.lib.gn_debug_set_variant(eng.ctx, 40, 0)
+        assert all(np.array_equal(a, b) for a, b in zip(s16[2], streamed[2]))
         for conv, ref in ((2, s16), (1, new)):
             for _ in range(6 if shape[1] >= 480 else 2):
                 again = run(conv, 1)
