@@ -339,3 +339,38 @@ def test_superpoint_round5_kernels_against_the_forms_they_replace(shape):
     finally:
         eng.lib.gn_debug_set_variant(eng.ctx, 34, 2)
         eng.lib.gn_debug_set_variant(eng.ctx, 36, 1)
+
+
+@pytest.mark.gpu
+def test_superpoint_fp16_kernel_of_round5_against_the_one_it_replaces():
+    """GN_SP_FP16 at the bench's frame size: k_sp_conv_h16 + fp16 activations through every layer (knob 24 = 2, the default) against k_sp_conv_h
+    (knob 24 = 1: fp16 activations up to layer 6 only) -- a tolerance mode either way (every layer rounds its activations to fp16, so two summation orders differ by fp16 ulps that propagate): score maps
+    within 5e-3, >= 95 % of the keypoints in common (the bars of the oracle comparison of this mode) --
+    and the pass is repeatable run to run."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_f16_attn", feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=1024, state_dict=osp.synthetic_state_dict(0), arithmetic="fp16")
+    shape = (2, 1080, 1920)
+    img = torch.from_numpy(np.random.default_rng(12).random(shape, dtype=np.float32)).cuda()
+    npx = shape[0] * shape[1] * shape[2]
+
+    def run(knob):
+        eng.lib.gn_debug_set_variant(eng.ctx, 24, knob)
+        out = sp.detect_and_describe_device(img)
+        torch.cuda.synchronize()
+        return eng.debug_read("sp_scores", npx).copy(), [o.cpu().numpy().copy() if hasattr(o, "cpu") else np.asarray(o) for o in out]
+
+    try:
+        old, new = run(1), run(2)
+        assert np.abs(old[0] - new[0]).max() < 5e-3
+        for b in range(shape[0]):
+            ka = {(float(x), float(y)) for x, y in old[1][0][b, : int(old[1][3][b]), :2]}
+            kb = {(float(x), float(y)) for x, y in new[1][0][b, : int(new[1][3][b]), :2]}
+            assert len(ka & kb) >= 0.95 * len(ka), (len(ka & kb), len(ka))
+        for _ in range(6):
+            again = run(2)
+            assert np.array_equal(new[0], again[0]) and all(np.array_equal(a, b) for a, b in zip(new[1], again[1]))
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 24, 2)
