@@ -286,6 +286,119 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The exact-f32 GEMM on 64 x 128 tiles (round 5) for grids that leave most of the chip idle on 128 x 128 tiles: LoFTR's coarse cross halves
+// are M = 4864 rows x N = 256 / 512 columns = 76 / 152 workgroups of k_gemm_f32_v3 on 256 CUs, each a 17 us chain of MFMAs (29 us per launch for
+// 0.6 GFLOP: profiles/r05e_loftr_layers_exact_f32.txt).  Same operands, swizzle, LDS-DMA staging and k order as k_gemm_f32_v3 -- every output
+// element sums the same products in the same order: same bits --, half the rows per workgroup: wave w owns rows 32 (w >> 1) .. and columns
+// 64 (w & 1) ..; plain / bias / ReLU epilogues only (what the coarse transformer uses), compiler-scheduled.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
+  constexpr int BM2 = 64;
+  constexpr int TILE = (BM2 + BN) * BK;               // floats per buffer
+  constexpr int SLAB = 4 * 32 * ES;
+  __shared__ __attribute__((aligned(16))) float smem[(2 * TILE > SLAB) ? 2 * TILE : SLAB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * BM2, bn = blockIdx.x * BN;
+  const float* A = a.A + (long long)blockIdx.z * a.strideA;
+  const float* W = a.W + (long long)blockIdx.z * a.strideW;
+  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
+  const float* const A2 = a.A2;
+  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
+  // staging: wave w brings rows [16 w, 16 w + 16) of the A tile (2 instructions of 8 rows) and rows [32 w, 32 w + 32) of the B tile (4);
+  // lane -> (row offset lane >> 3, chunk position lane & 7) fetches source chunk pos ^ f(row), f(row) = (row ^ (row >> 3)) & 7
+  const int dpos = lane & 7;
+  const float* asrc[2]; const float* a2src[2]; const float* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + 8 * j + (lane >> 3);
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    asrc[j] = A + (size_t)(bm + row) * lda + c * 4;
+    a2src[j] = A2 ? A2 + (size_t)(bm + row) * lda2 + c * 4 - K1 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 32 + 8 * j + (lane >> 3);
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    wsrc[j] = W + (size_t)(bn + row) * ldw + c * 4;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int buf, int k0) __attribute__((always_inline)) {
+    const bool second = (A2 != nullptr) && (k0 >= K1);
+    float* la_ = smem + buf * TILE + (wave_u * 16) * BK;
+    float* lb_ = smem + buf * TILE + BM2 * BK + (wave_u * 32) * BK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) __builtin_amdgcn_global_load_lds((gptr_t)((second ? a2src[j] : asrc[j]) + k0), (lptr_t)(la_ + j * 8 * BK), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + k0), (lptr_t)(lb_ + j * 8 * BK), 16, 0, 0);
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int hh = lane >> 5;
+  const int ra_ = wr * 32 + (lane & 31);
+  const int arow = ra_ * BK, ga = hh ^ ((ra_ ^ (ra_ >> 3)) & 7);
+  int brow[2], gb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb_ = wc * 64 + 32 * j + (lane & 31);
+    brow[j] = BM2 * BK + rb_ * BK; gb[j] = hh ^ ((rb_ ^ (rb_ >> 3)) & 7);
+  }
+  const int nt = K / BK;
+  dma_tile(0, 0);
+  { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) dma_tile(cur ^ 1, (t + 1) * BK);
+    const float* b_ = smem + cur * TILE;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(b_ + arow + 4 * ((kc << 1) ^ ga));
+      f32x4 fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b_ + brow[j] + 4 * ((kc << 1) ^ gb[j]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[j], 0, 0, 0);
+      }
+    }
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+  }
+  // epilogue: the wave's 32 x 64 block through its LDS slab, read back row-wise (16 lanes x 16 bytes = one 256-byte row segment)
+  float* slab = smem + wave * 32 * ES;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      slab[row * ES + j * 32 + (lane & 31)] = acc[j][r];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 15) * 4;
+  const int col = bn + wc * 64 + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  f32x4 vals[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = bm + wr * 32 + it * 4 + (lane >> 4);
+    f32x4 v = vals[it];
+    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32x3: f32-accurate GEMM on the bf16 matrix pipe.  Every f32 operand is split exactly into three
 // bf16 terms (x = xh + xm + xl, 8 + 8 + 8 mantissa bits) while its fragment sits in registers, and each
 // 32x32x16 block is accumulated from the six products whose magnitude exceeds 2^-24 of the leading one
@@ -928,6 +1041,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
 }  // namespace
 
 thread_local int g_gemm_variant = 3;
+int g_gemm_m64 = 320;    // developer knob 41: the exact-f32 GEMM runs on 64-row tiles when its 128 x 128 grid has at most this many workgroups (0 = never)
 
 // Pure-MFMA ceiling probe: 4 waves per CU-resident block, 8 independent accumulators, no memory traffic.
 __global__ __launch_bounds__(256) void k_mfma_probe(float* out, int iters) {
@@ -1057,6 +1171,15 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
       default: GN_X3(EPI_PLAIN) break;
     }
 #undef GN_X3
+    return;
+  }
+  // small grids: 64-row tiles when 128 x 128 tiles would leave more than a third of the CUs without a workgroup (same bits: k_gemm_f32_m64)
+  if (g_gemm_m64 && (epi == EPI_BIAS || epi == EPI_PLAIN || epi == EPI_RELU) && (long long)grid.x * grid.y * grid.z <= g_gemm_m64) {
+    const dim3 g64(a.N / BN, a.M / 64, batch);
+    g_last_kernel = "k_gemm_f32_m64<";
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_BIAS>, g64, block, 0, s, a);
+    else if (epi == EPI_RELU) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_RELU>, g64, block, 0, s, a);
+    else hipLaunchKernelGGL(k_gemm_f32_m64<EPI_PLAIN>, g64, block, 0, s, a);
     return;
   }
   // exact-f32 MFMA (k_gemm_f32_v3: LDS-DMA, double-buffered, LDS-slab epilogue) -- GN_PREC_F32 / GN_PREC_BF16_ATTN and the VO matcher

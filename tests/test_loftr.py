@@ -251,3 +251,25 @@ def test_loftr_split_arithmetic_falls_back_when_activations_leave_fp16_range(sd)
     small = sp({"image0": i0.cuda(), "image1": i1.cuda()}, with_ids=True)       # the same context afterwards, in range: split arithmetic again
     ref = lf.loftr_forward(sd, i0, i1)
     assert torch.equal(small["i_ids"].cpu(), ref["i_ids"]) and torch.equal(small["j_ids"].cpu(), ref["j_ids"])
+
+
+@pytest.mark.gpu
+def test_exact_f32_gemm_on_64_row_tiles_equals_the_128_row_kernel_bitwise():
+    """k_gemm_f32_m64 (round 5: the exact-f32 GEMM on 64 x 128 tiles for grids that would leave most CUs without a workgroup -- LoFTR's coarse
+    cross halves) sums the same products in the same order as k_gemm_f32_v3: identical bits, with and without bias, at the coarse level's shapes
+    and at a shape whose 128-row grid is above the threshold (the 128-row kernel runs either way there)."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f32")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    try:
+        for (M, N, K) in ((4864, 256, 256), (4864, 512, 512), (9728, 256, 256), (256, 128, 64), (128 * 48, 1024, 96)):
+            A = torch.randn(M, K, generator=g).cuda(); Wt = torch.randn(N, K, generator=g).cuda(); b = torch.randn(N, generator=g).cuda()
+            outs = {}
+            for thr in (0, 320):
+                eng.lib.gn_debug_set_variant(eng.ctx, 41, thr)
+                outs[thr] = (eng.debug_gemm(A, Wt, b).cpu().numpy(), eng.debug_gemm(A, Wt, None).cpu().numpy())
+            assert np.array_equal(outs[0][0], outs[320][0]) and np.array_equal(outs[0][1], outs[320][1]), (M, N, K)
+            ref = (A.double() @ Wt.double().T + b.double()).cpu().numpy()
+            assert np.abs(outs[320][0] - ref).max() < 2e-6 * np.abs(ref).max() * np.sqrt(K)
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 41, 320)
