@@ -1862,6 +1862,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 36) gn::g_sp_nms_fused = value;
   else if (which == 40) gn::g_sp_select_stream = value;
   else if (which == 41) gn::g_gemm_m64 = value;
+  else if (which == 42) gn::g_lf_conv_knob = value;
   else if (which == 39) ctx->sp_stop = value;
   else if (which == 35) {
     ctx->sp_ts_layer = value;

@@ -109,6 +109,7 @@ void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // 
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
 void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s);
 extern int g_gemm_m64;
+extern int g_lf_conv_knob;   // developer knob 42 (gn_loftr.hip lf_conv)
 extern thread_local const char* g_last_kernel;   // bench facility: rocprof-style name of the kernel the last launch_* call of THIS host thread dispatched
 extern thread_local int g_gemm_variant;  // developer knob: kernel variant selector for A/B benchmarking (per host thread: every API entry sets it from its own context before it launches)
 extern int g_p2_wide;       // developer knob: 1 = k_gemm_p2 uses the 256x256 kernel when the shape allows

@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
 }  // namespace
 
 thread_local int g_gemm_variant = 3;
+int g_lf_conv_knob = 0;  // developer knob 42: bit 0 = LoFTR's convolutions stage their halo tiles the way rounds 3-4 did (no register prefetch); bits 8.. = the overhead term of lf_conv's cost model x 100
 int g_gemm_m64 = 320;    // developer knob 41: the exact-f32 GEMM runs on 64-row tiles when its 128 x 128 grid has at most this many workgroups (0 = never)
 
 // Pure-MFMA ceiling probe: 4 waves per CU-resident block, 8 independent accumulators, no memory traffic.

@@ -76,8 +76,11 @@ struct LfConvArgs {
 // grid (ceil(Wout / 32), ceil(Hout / (4 RPW)), N * ceil(Cout / 64)); 4 waves, wave w = output rows [RPW w, RPW w + RPW) of the tile,
 // 32 output columns, two 32-channel tiles.  Halo tile: ((4 RPW - 1) S + KS) x (31 S + KS) input pixels x CH channels, 16-byte chunk
 // c of pixel column lx at position c ^ sw(lx).
-template <int KS, int S, int RPW, int CH>
-__global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
+// PF (round 5): the halo tile of the NEXT channel slice is requested into registers behind the first tap of the current one and written to
+// LDS at the slice boundary -- with one or two workgroups per CU nothing else hid the global latency of the staging pass (~7 us per slice
+// beside ~17 us of MFMAs at RPW = 2; profiles/r05e_loftr_layers_exact_f32.txt); same values in the same LDS places: bitwise the same output
+template <int KS, int S, int RPW, int CH, bool PF>
+__global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_conv(LfConvArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TH = 4 * RPW, LH = (TH - 1) * S + KS, LW = 31 * S + KS, NCH = CH / 4;
   __shared__ __attribute__((aligned(16))) float tile[LH * LW * CH];
@@ -114,11 +117,37 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
     }
   };
   load_w(wcur, 0, 0);
+  constexpr int NP = LH * LW * NCH, NQ = (NP + 255) / 256, SB = 8;
+  f32x4 pre[PF ? NQ : 1];
+  auto fetch = [&](int c0_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = e * 256 + tid;
+      const int pix = q / NCH, chunk = q - pix * NCH;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int gy = gy0 + ly, gx = gx0 + lx;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pre[e] = z;
+      if (q < NP && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+        pre[e] = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.Win + gx) * a.Cin + c0_ + chunk * 4);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = e * 256 + tid;
+      if (q >= NP) continue;
+      const int pix = q / NCH, chunk = q - pix * NCH;
+      const int lx = pix % LW;
+      *reinterpret_cast<f32x4*>(tile + pix * CH + ((chunk ^ sw(lx)) * 4)) = pre[e];
+    }
+  };
+  if (PF) fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += CH) {
     __syncthreads();
-    constexpr int NP = LH * LW * NCH, NQ = (NP + 255) / 256, SB = 8;
+    if (PF) commit();
 #pragma unroll 1
-    for (int q0 = 0; q0 < NQ; q0 += SB) {
+    for (int q0 = 0; !PF && q0 < NQ; q0 += SB) {
       f32x4 v[SB];
 #pragma unroll
       for (int e = 0; e < SB; ++e) {
@@ -147,6 +176,7 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
       // next tap of this slice, or the first tap of the next slice (its request then also overlaps the staging of that slice)
       const bool last_tap = tap + 1 == TAPS;
       if (!last_tap || c0 + CH < a.Cin) load_w(wnxt, last_tap ? c0 + CH : c0, last_tap ? 0 : tap + 1);
+      if (PF && tap == 0 && c0 + CH < a.Cin) fetch(c0 + CH);     // behind the next tap's weights: it has two taps of MFMAs to land in
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         f32x4 fb[RPW];
@@ -201,8 +231,8 @@ __global__ __launch_bounds__(256) void k_lf_conv(LfConvArgs a) {
 // high terms then 16 residual terms); weights are pre-split at load time with a power-of-two scale (folded into the epilogue's affine map)
 // and, per tap, fetched ONCE per workgroup into a double-buffered LDS block (per-wave fetches would make the L2 -> CU ingest the bottleneck at
 // this MFMA rate).  An activation that does not fit fp16 raises a.ovf: the caller repeats the forward on the exact kernels.
-template <int KS, int S, int RPW, int CH>
-__global__ __launch_bounds__(256) void k_lf_conv_h(LfConvArgs a) {
+template <int KS, int S, int RPW, int CH, bool PF>      // PF: as in k_lf_conv
+__global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_conv_h(LfConvArgs a) {
   typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
   typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
   constexpr int TAPS = KS * KS, PAD = KS / 2;
@@ -243,11 +273,42 @@ __global__ __launch_bounds__(256) void k_lf_conv_h(LfConvArgs a) {
 #pragma unroll
   for (int e = 0; e < WPT; ++e) wnext[e] = wsrc(0, 0, e);
   int par = 0;
+  constexpr int NQF = LH * LW * (CH / 4), NQ = (NQF + 255) / 256, SB = 8;
+  f32x4 pre[PF ? NQ : 1];
+  auto fetch = [&](int c0_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = e * 256 + tid;
+      const int pix = q / (CH / 4), chunk = q - pix * (CH / 4);
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int gy = gy0 + ly, gx = gx0 + lx;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pre[e] = z;
+      if (q < NQF && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+        pre[e] = *reinterpret_cast<const f32x4*>(in + ((long long)gy * a.Win + gx) * a.Cin + c0_ + chunk * 4);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = e * 256 + tid;
+      if (q >= NQF) continue;
+      const int pix = q / (CH / 4), chunk = q - pix * (CH / 4);
+      const int lx = pix % LW;
+      const h16x4 h4 = __builtin_convertvector(pre[e], h16x4);
+      const h16x4 m4 = __builtin_convertvector(pre[e] - __builtin_convertvector(h4, f32x4), h16x4);
+      ovf_track(amax, pre[e].x, pre[e].y); ovf_track(amax, pre[e].z, pre[e].w);
+      const int piece = 4 * (chunk >> 2) + ((chunk & 3) >> 1), sub = (chunk & 1) * 8;
+      *reinterpret_cast<h16x4*>(tb + pix * (CH * 4) + ((piece ^ sw(lx)) * 16) + sub) = h4;
+      *reinterpret_cast<h16x4*>(tb + pix * (CH * 4) + (((piece + 2) ^ sw(lx)) * 16) + sub) = m4;
+    }
+  };
+  if (PF) fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += CH) {
     __syncthreads();
-    constexpr int NQF = LH * LW * (CH / 4), NQ = (NQF + 255) / 256, SB = 8;
+    if (PF) commit();
 #pragma unroll 1
-    for (int q0 = 0; q0 < NQ; q0 += SB) {
+    for (int q0 = 0; !PF && q0 < NQ; q0 += SB) {
       f32x4 v[SB];
 #pragma unroll
       for (int e = 0; e < SB; ++e) {
@@ -286,6 +347,7 @@ __global__ __launch_bounds__(256) void k_lf_conv_h(LfConvArgs a) {
 #pragma unroll
         for (int e = 0; e < WPT; ++e) wnext[e] = wsrc(last_tap ? c0 + CH : c0, last_tap ? 0 : tap + 1, e);
       }
+      if (PF && tap == 0 && c0 + CH < a.Cin) fetch(c0 + CH);
       __syncthreads();     // this tap's weights (and, at tap 0, the halo tile) are in LDS; the block written two taps ago is no longer read
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
@@ -869,15 +931,19 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   // ceil(workgroups / 256) rounds of RPW units each -- pick the RPW with the fewest units (layer1 at 240x320: 600 workgroups = 3 rounds of 4
   // against 1200 = 5 rounds of 2; the 1/8-resolution layers fill 96 CUs with RPW = 4 and 192 with 2)
   // (+ 0.75: the halo rows, the weight stream and the prologue a workgroup pays whatever its height -- without it RPW = 1 wins ties it loses on the GPU)
-  auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return (double)((wg + 255) / 256) * (rpw + 0.75); };
+  const bool pf = !(gn::g_lf_conv_knob & 1);                                   // developer knob 42, bit 0: the staging form of rounds 3-4
+  const double ovh = (gn::g_lf_conv_knob >> 8) ? (gn::g_lf_conv_knob >> 8) * 0.01 : (pf ? 0.25 : 0.75);    // bits 8..: the per-workgroup overhead of the cost model, in 1/100 units
+  auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return (double)((wg + 255) / 256) * (rpw + ovh); };
   const dim3 blk(256);
   auto grid = [&](int rpw) { return dim3((a.Wout + 31) / 32, (a.Hout + 4 * rpw - 1) / (4 * rpw), N * og); };
   if (stride == 1) {
     int rpw = 4;
     if (units(2) < units(rpw)) rpw = 2;
     if (units(1) < units(rpw)) rpw = 1;
-#define LF_LAUNCH(KS_, S_, R_, C_) do { if (hm) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_>), grid(R_), blk, 0, s, a); \
-                                        else hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_>), grid(R_), blk, 0, s, a); } while (0)
+#define LF_LAUNCH(KS_, S_, R_, C_) do { if (hm && pf) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_, true>), grid(R_), blk, 0, s, a); \
+                                        else if (hm) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_, false>), grid(R_), blk, 0, s, a); \
+                                        else if (pf) hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_, true>), grid(R_), blk, 0, s, a); \
+                                        else hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_, false>), grid(R_), blk, 0, s, a); } while (0)
     if (c.ks == 3) {
       if (rpw == 4) LF_LAUNCH(3, 1, 4, 32); else if (rpw == 2) LF_LAUNCH(3, 1, 2, 32); else LF_LAUNCH(3, 1, 1, 32);
     } else {
