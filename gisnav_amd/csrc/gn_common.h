@@ -103,6 +103,9 @@ struct GemmArgs {
   const uint16_t* A2p;                       // optional second source (k >= K1), same row pitch
   uint16_t* Yp; int ldyp;                    // optional hm16 output (Y may then be nullptr)
   unsigned int* ovf;                         // f16x2 domain guard word (see ovf_track), or nullptr
+  // optional row limit read on the DEVICE (LoFTR's fine level: the number of matches stays on the device, the buffers hold max_matches windows):
+  // a row tile whose first row r has (mlim_seg ? r % mlim_seg : r) >= mlim[0] * mlim_mul is skipped (its rows of Y keep what they held)
+  const int* mlim; int mlim_mul; int mlim_seg;
 };
 void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s);
 void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // fp16-plane operands (Ap, Wp)

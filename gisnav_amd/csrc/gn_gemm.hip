@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
     bx = v % gx; by = v / gx;
   }
   const int bm = by * BM, bn = bx * BN;
+  if (a.mlim != nullptr && (a.mlim_seg > 0 ? bm % a.mlim_seg : bm) >= a.mlim[0] * a.mlim_mul) return;     // GemmArgs::mlim: a tile of rows nobody will read
   const float* A = a.A + (long long)blockIdx.z * a.strideA;
   const float* W = a.W + (long long)blockIdx.z * a.strideW;
   float* Y = a.Y + (long long)blockIdx.z * a.strideY;
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int bm = blockIdx.y * BM2, bn = blockIdx.x * BN;
+  if (a.mlim != nullptr && (a.mlim_seg > 0 ? bm % a.mlim_seg : bm) >= a.mlim[0] * a.mlim_mul) return;     // GemmArgs::mlim: a tile of rows nobody will read
   const float* A = a.A + (long long)blockIdx.z * a.strideA;
   const float* W = a.W + (long long)blockIdx.z * a.strideW;
   float* Y = a.Y + (long long)blockIdx.z * a.strideY;
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
     bx = v % gx; by = v / gx;
   }
   const int bm = by * BM, bn = bx * BN;
+  if (a.mlim != nullptr && (a.mlim_seg > 0 ? bm % a.mlim_seg : bm) >= a.mlim[0] * a.mlim_mul) return;     // GemmArgs::mlim: a tile of rows nobody will read
   const float* A = a.A + (long long)blockIdx.z * a.strideA;
   const float* W = a.W + (long long)blockIdx.z * a.strideW;
   float* Y = a.Y + (long long)blockIdx.z * a.strideY;

@@ -523,9 +523,13 @@ __global__ __launch_bounds__(256) void k_lf_attn_apply(const float* q, int ldq, 
 // The fine level's linear attention in ONE launch: sequences of <= 32 tokens, 8 heads x 16 (d = 128).  One block per sequence; thread t -> (head
 // t >> 4, v = t & 15).  K^T V (values / S), sum K and the application to the block's own queries, all from LDS; the source is the sequence
 // itself or its partner seq ^ 1 (cross).  Same summation orders as k_lf_kv_partial<16> (one chunk) + k_lf_attn_apply<16>.
-__global__ __launch_bounds__(128) void k_lf_fine_attn(const float* qkv /*[nseq][S][384]*/, int S, int cross, float* out /*[nseq][S][128]*/) {
+// partner: the sequence attended to is seq ^ 1 (cross = 1, partner = 0: interleaved pairs), seq + partner (partner != 0: side-major buffers, the
+// other side's window of the same match) or seq itself; seq0: first sequence of the launch; nlim / per_side: sequences whose window index
+// (seq % per_side) is at or behind nlim[0] (the match count, on the device) are skipped
+__global__ __launch_bounds__(128) void k_lf_fine_attn(const float* qkv /*[nseq][S][384]*/, int S, int cross, float* out /*[nseq][S][128]*/, int seq0, int partner, const int* nlim, int per_side) {
   __shared__ float qs[32][128], ks[32][129], vs[32][128];
-  const int seq = blockIdx.x, src = cross ? (seq ^ 1) : seq, tid = threadIdx.x;
+  const int seq = seq0 + blockIdx.x, src = partner != 0 ? seq + partner : cross ? (seq ^ 1) : seq, tid = threadIdx.x;
+  if (nlim != nullptr && seq % per_side >= nlim[0]) return;
   const float vdiv = (float)S;
   for (int i = tid; i < S * 32; i += 128) {
     const int r = i >> 5, c = (i & 31) * 4;
@@ -561,10 +565,13 @@ __device__ inline float wsum(float v) {
 }
 // LayerNorm over rows of C (128 or 256; eps 1e-5, affine), optional residual: out = (resid ? resid : 0) + LN(in).  One wave per row.
 // mode 0: every row; 1 / 2: only rows of even / odd sequences (sequence = row / seq_rows) -- the two halves of a 'cross' layer.
-__global__ __launch_bounds__(256) void k_lf_layernorm(const float* in, const float* g, const float* b, const float* resid, float* out, long long rows, int C, int seq_rows, int mode) {
+// mlim / mlim_mul / mlim_seg: GemmArgs' row limit (rows r with (seg ? r % seg : r) >= mlim[0] * mul are skipped)
+__global__ __launch_bounds__(256) void k_lf_layernorm(const float* in, const float* g, const float* b, const float* resid, float* out, long long rows, int C, int seq_rows, int mode,
+                                                     const int* mlim = nullptr, int mlim_mul = 0, int mlim_seg = 0) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (mlim != nullptr && (mlim_seg > 0 ? row % mlim_seg : row) >= (long long)mlim[0] * mlim_mul) return;
   if (mode != 0 && (int)((row / seq_rows) & 1) != mode - 1) return;
   // a lane owns C / 64 = 2 or 4 CONSECUTIVE values: one 8- or 16-byte access each for the row, the affine pair and the residual
   float v[4], gg[4], bb[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -958,9 +965,12 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
 }
 
 thread_local int g_lf_gemm_variant = 3;   // set by lf_forward from the context it runs (per host thread)
-void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s, bool relu = false) {
+struct LfLimit { const int* n = nullptr; int mul = 0, seg = 0; };     // GemmArgs::mlim
+void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* Wt, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, hipStream_t s, bool relu = false,
+             LfLimit lim = LfLimit()) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.mlim = lim.n; g.mlim_mul = lim.mul; g.mlim_seg = lim.seg;
   g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = Wt; g.ldw = ldw; g.bias = bias; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.acc_scale = 1.f;
   const int saved = gn::g_gemm_variant;
   gn::g_gemm_variant = g_lf_gemm_variant;                   // 3 = the exact-f32 MFMA GEMM, whatever other contexts selected; 6 = every f32 operand split into two fp16 terms on the fly (gn_loftr_set_arithmetic)
@@ -973,9 +983,29 @@ void lf_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const f
 // cross = 0: every sequence attends to itself (mode 0 updates all).  cross = 1: sequence s attends to sequence s ^ 1; a 'cross' LAYER is
 // two calls, mode 1 (even sequences = side 0 updated from side 1) then mode 2 (odd sequences from the UPDATED even ones) -- the
 // sequential order of LocalFeatureTransformer.forward.  Projections run over the whole buffer (keeps M a multiple of 128).
+// lim (fine level only): the windows behind the match count are skipped (LfLimit; the buffers then hold the sides one behind the other:
+// side_seqs windows each, the cross partner of sequence q is q +- side_seqs)
 void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pad, int d, int cross, int mode,
-                float* qkv, float* att, float* msg, float* hid, float* kvpart, float* kv, hipStream_t s) {
+                float* qkv, float* att, float* msg, float* hid, float* kvpart, float* kv, hipStream_t s, LfLimit lim = LfLimit(), int side_seqs = 0) {
   const int heads = kLfHeads, hd = d / heads, nall = rows_pad / seq_rows;
+  if (side_seqs > 0 && cross) {
+    // the fine level's cross halves on side-major buffers (round 5; the same split as the coarse level's below): only side a = mode - 1 is updated,
+    // only side b is attended to -- q for a's rows, k | v for b's, merge / MLP / norms over a's rows: half of what the general path computes
+    const int a = mode - 1, b = 1 - a, half = side_seqs * seq_rows;
+    LfLimit hl = lim; hl.seg = 0;                                   // one side: rows [0, n * 25) are the valid ones
+    float* xa = x + (size_t)a * half * d; const float* xb = x + (size_t)b * half * d;
+    float* qa = qkv + (size_t)a * half * 3 * d; float* kvb = qkv + (size_t)b * half * 3 * d + d;
+    float* atta = att + (size_t)a * half * d; float* msga = msg + (size_t)a * half * d; float* hida = hid + (size_t)a * half * 2 * d;
+    lf_gemm(xa, d, nullptr, 0, 0, ly.qkv.w, d, nullptr, qa, 3 * d, half, d, d, s, false, hl);
+    lf_gemm(xb, d, nullptr, 0, 0, ly.qkv.w + (size_t)d * d, d, nullptr, kvb, 3 * d, half, 2 * d, d, s, false, hl);
+    hipLaunchKernelGGL(k_lf_fine_attn, dim3(side_seqs), dim3(128), 0, s, qkv, Lseq, 1, att, a * side_seqs, (b - a) * side_seqs, lim.n, side_seqs);
+    lf_gemm(atta, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msga, d, half, d, d, s, false, hl);
+    hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((half + 3) / 4)), dim3(256), 0, s, msga, ly.n1g, ly.n1b, (const float*)nullptr, msga, (long long)half, d, seq_rows, 0, hl.n, hl.mul, hl.seg);
+    lf_gemm(xa, d, msga, d, d, ly.mlp0.w, 2 * d, nullptr, hida, 2 * d, half, 2 * d, 2 * d, s, true, hl);
+    lf_gemm(hida, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, atta, d, half, d, 2 * d, s, false, hl);
+    hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((half + 3) / 4)), dim3(256), 0, s, atta, ly.n2g, ly.n2b, xa, xa, (long long)half, d, seq_rows, 0, hl.n, hl.mul, hl.seg);
+    return;
+  }
   if (cross && nall == 2 && hd == 32 && seq_rows % 128 == 0) {
     // the coarse level's cross halves: only sequence a = mode - 1 is updated, only sequence b = 1 - a is attended to -- project q for a's rows,
     // k | v for b's rows, and run merge / MLP / norms over a's rows alone (half the work of the general path below)
@@ -998,7 +1028,7 @@ void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pa
     hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((seq_rows + 3) / 4)), dim3(256), 0, s, atta, ly.n2g, ly.n2b, xa, xa, (long long)seq_rows, d, seq_rows, 0);
     return;
   }
-  lf_gemm(x, d, nullptr, 0, 0, ly.qkv.w, d, nullptr, qkv, 3 * d, rows_pad, 3 * d, d, s);
+  lf_gemm(x, d, nullptr, 0, 0, ly.qkv.w, d, nullptr, qkv, 3 * d, rows_pad, 3 * d, d, s, false, lim);
   const int chunk = Lseq <= 64 ? 64 : 192, nsplit = (Lseq + chunk - 1) / chunk;
   const long long per = (long long)heads * (hd + 1) * hd;
   const size_t smem = (size_t)(per + 8 * d) * sizeof(float);
@@ -1007,17 +1037,17 @@ void lf_encoder(const LfLayer& ly, float* x, int seq_rows, int Lseq, int rows_pa
     hipLaunchKernelGGL(k_lf_kv_reduce, dim3((unsigned)((per * nall + 255) / 256)), dim3(256), 0, s, kvpart, kv, nsplit, per, nall);
     hipLaunchKernelGGL(k_lf_attn_apply<32>, dim3((Lseq + 7) / 8, nall), dim3(256), smem, s, qkv, 3 * d, (long long)seq_rows * 3 * d, kv, cross, att, d, (long long)seq_rows * d, Lseq, (float)Lseq, heads);
   } else if (Lseq <= 32 && seq_rows == Lseq && d == 128) {
-    hipLaunchKernelGGL(k_lf_fine_attn, dim3(nall), dim3(128), 0, s, qkv, Lseq, cross, att);
+    hipLaunchKernelGGL(k_lf_fine_attn, dim3(nall), dim3(128), 0, s, qkv, Lseq, cross, att, 0, 0, lim.n, side_seqs > 0 ? side_seqs : nall);
   } else {
     hipLaunchKernelGGL(k_lf_kv_partial<16>, dim3(heads, nsplit, nall), dim3(256), 0, s, qkv + d, qkv + 2 * d, 3 * d, (long long)seq_rows * 3 * d, Lseq, chunk, (float)Lseq, kvpart, nsplit, heads);
     hipLaunchKernelGGL(k_lf_kv_reduce, dim3((unsigned)((per * nall + 255) / 256)), dim3(256), 0, s, kvpart, kv, nsplit, per, nall);
     hipLaunchKernelGGL(k_lf_attn_apply<16>, dim3((Lseq + 7) / 8, nall), dim3(256), smem, s, qkv, 3 * d, (long long)seq_rows * 3 * d, kv, cross, att, d, (long long)seq_rows * d, Lseq, (float)Lseq, heads);
   }
-  lf_gemm(att, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msg, d, rows_pad, d, d, s);
-  hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, msg, ly.n1g, ly.n1b, (const float*)nullptr, msg, (long long)rows_pad, d, seq_rows, 0);
-  lf_gemm(x, d, msg, d, d, ly.mlp0.w, 2 * d, nullptr, hid, 2 * d, rows_pad, 2 * d, 2 * d, s, true);
-  lf_gemm(hid, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, att, d, rows_pad, d, 2 * d, s);
-  hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, att, ly.n2g, ly.n2b, x, x, (long long)rows_pad, d, seq_rows, mode);
+  lf_gemm(att, d, nullptr, 0, 0, ly.merge.w, d, nullptr, msg, d, rows_pad, d, d, s, false, lim);
+  hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, msg, ly.n1g, ly.n1b, (const float*)nullptr, msg, (long long)rows_pad, d, seq_rows, 0, lim.n, lim.mul, lim.seg);
+  lf_gemm(x, d, msg, d, d, ly.mlp0.w, 2 * d, nullptr, hid, 2 * d, rows_pad, 2 * d, 2 * d, s, true, lim);
+  lf_gemm(hid, 2 * d, nullptr, 0, 0, ly.mlp2.w, 2 * d, nullptr, att, d, rows_pad, d, 2 * d, s, false, lim);
+  hipLaunchKernelGGL(k_lf_layernorm, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, s, att, ly.n2g, ly.n2b, x, x, (long long)rows_pad, d, seq_rows, mode, lim.n, lim.mul, lim.seg);
 }
 }  // namespace
 
@@ -1239,9 +1269,21 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
     // ---- fine level: windows of both sides as 2 Mp sequences of 25 tokens (side 0 first); cross pairs are (m, Mp + m)
     const int R = 2 * Mp * kLfWW;                       // token rows; 2 * Mp * 25 is a multiple of 128 (Mp is)
     hipLaunchKernelGGL(k_lf_coarse_gather, dim3((unsigned)((2LL * Mp * 64 + 255) / 256)), dim3(256), 0, s, ctx->tok, ctx->tok + (size_t)Lp * 256, ctx->i_ids, ctx->j_ids, ctx->n_dev, Mp, ctx->fc);
-    lf_gemm(ctx->fc, 256, nullptr, 0, 0, ctx->down_proj.w, 256, ctx->down_proj.b, ctx->fwin, 128, 2 * Mp, 128, 256, s);
+    // round 5 (developer knob 42, bit 1 = the form of rounds 3-4): the fine level works on the windows of the matches there ARE (the count stays on
+    // the device: row tiles, rows and sequences behind it leave at once -- kornia's fine level runs on exactly the M matched windows) and keeps
+    // the two sides one behind the other, so that a cross half projects, merges and normalises only the side it updates
+    const bool lean = !(gn::g_lf_conv_knob & 2);
+    LfLimit lim1, lim25;
+    if (lean) { lim1.n = ctx->n_dev; lim1.mul = 1; lim1.seg = Mp; lim25.n = ctx->n_dev; lim25.mul = kLfWW; lim25.seg = Mp * kLfWW; }
+    lf_gemm(ctx->fc, 256, nullptr, 0, 0, ctx->down_proj.w, 256, ctx->down_proj.b, ctx->fwin, 128, 2 * Mp, 128, 256, s, false, lim1);
     hipLaunchKernelGGL(k_lf_fine_gather, dim3((unsigned)((2LL * Mp * kLfWW * 64 + 255) / 256)), dim3(256), 0, s, ctx->x1_out, h2, w2, wc, ctx->i_ids, ctx->j_ids, ctx->n_dev, Mp, ctx->fwin, ctx->frows);
-    lf_gemm(ctx->frows, 256, nullptr, 0, 0, ctx->merge_feat.w, 256, ctx->merge_feat.b, ctx->ftok, 128, R, 128, 256, s);
+    lf_gemm(ctx->frows, 256, nullptr, 0, 0, ctx->merge_feat.w, 256, ctx->merge_feat.b, ctx->ftok, 128, R, 128, 256, s, false, lim25);
+    if (lean) {
+      // ftok [2][Mp][25][128] as it is: sequence q of side 0 pairs with q + Mp
+      lf_encoder(ctx->finel[0], ctx->ftok, kLfWW, kLfWW, R, kLfFine, 0, 0, ctx->fqkv, ctx->fatt, ctx->fmsg, ctx->fhid, ctx->fkvpart, ctx->fkv, s, lim25, Mp);
+      lf_encoder(ctx->finel[1], ctx->ftok, kLfWW, kLfWW, R, kLfFine, 1, 1, ctx->fqkv, ctx->fatt, ctx->fmsg, ctx->fhid, ctx->fkvpart, ctx->fkv, s, lim25, Mp);
+      lf_encoder(ctx->finel[1], ctx->ftok, kLfWW, kLfWW, R, kLfFine, 1, 2, ctx->fqkv, ctx->fatt, ctx->fmsg, ctx->fhid, ctx->fkvpart, ctx->fkv, s, lim25, Mp);
+    } else {
     // sequences: index q in [0, 2 Mp); its cross partner must be q ^ 1 for k_lf_attn_apply -> windows are stored INTERLEAVED? No: the
     // partner of window m of side 0 is window m of side 1, i.e. q + Mp.  The fine encoder therefore runs on a buffer re-ordered so that
     // sequence 2 m = side 0, 2 m + 1 = side 1 (fine_reorder below does it in place through frows).
@@ -1264,6 +1306,7 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
     for (int side = 0; side < 2; ++side)
       LF_HIP(hipMemcpy2DAsync(ctx->ftok + (size_t)side * Mp * kLfWW * 128, (size_t)kLfWW * 128 * sizeof(float), ft + (size_t)side * kLfWW * 128, 2 * (size_t)kLfWW * 128 * sizeof(float),
                               (size_t)kLfWW * 128 * sizeof(float), Mp, hipMemcpyDeviceToDevice, s));
+    }
     hipLaunchKernelGGL(k_lf_fine_match, dim3((M + 3) / 4), dim3(256), 0, s, ctx->ftok, ctx->ftok + (size_t)Mp * kLfWW * 128, ctx->n_dev, ctx->k1c, ctx->fc);
     if (ctx->arith == 1) { const long long n4 = (long long)M * 2 / 4; if (n4 > 0) hipLaunchKernelGGL(k_lf_check_finite, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ctx->fc, n4, ctx->ovf); }
   }
