@@ -26,10 +26,19 @@ thread_local std::string g_lf_err;
 constexpr int kLfDim = 256, kLfHeads = 8, kLfFine = 128, kLfWW = 25;
 
 // ------------------------------------------------------------------------------------------------ stem: 7x7 stride 2, 1 -> 128
-// thread -> (output pixel, 16-channel group); weights [128][49] + affine in LDS
+// thread -> (output pixel, 16-channel group); weights + affine in LDS.  Round 5: the weights sit TRANSPOSED there ([tap][channel]) and a thread reads
+// its 16 channels of a tap as four 16-byte pieces (the [channel][tap] form read one float per multiply-add through 4-way bank conflicts: the
+// kernel was LDS-bound at 181 us for 79 MB of output); every channel still accumulates its taps in the order 0 .. 48: the same bits.  OLD = the
+// form of rounds 3-4 (developer knob 42, bit 2)
+template <bool OLD>
 __global__ __launch_bounds__(256) void k_lf_conv1(const float* in, const float* w, const float* scale, const float* shift, float* out, int H, int W) {
-  __shared__ float ws[128 * 49 + 256];
-  for (int q = threadIdx.x; q < 128 * 49 + 256; q += 256) ws[q] = q < 128 * 49 ? w[q] : (q < 128 * 49 + 128 ? scale[q - 128 * 49] : shift[q - 128 * 49 - 128]);
+  __shared__ __attribute__((aligned(16))) float ws[128 * 49 + 256];
+  for (int q = threadIdx.x; q < 128 * 49 + 256; q += 256) {
+    float x;
+    if (q < 128 * 49) x = OLD ? w[q] : w[(q & 127) * 49 + (q >> 7)];
+    else x = q < 128 * 49 + 128 ? scale[q - 128 * 49] : shift[q - 128 * 49 - 128];
+    ws[q] = x;
+  }
   __syncthreads();
   const int Ho = H / 2, Wo = W / 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -45,18 +54,40 @@ __global__ __launch_bounds__(256) void k_lf_conv1(const float* in, const float* 
     v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : 0.f;
   }
   float* o = out + ((long long)blockIdx.z * Ho * Wo + pix) * 128 + grp * 16;
+  if (OLD) {
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) {
-    f32x4 r;
+    for (int c4 = 0; c4 < 4; ++c4) {
+      f32x4 r;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = grp * 16 + c4 * 4 + e;
-      float acc = 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int c = grp * 16 + c4 * 4 + e;
+        float acc = 0.f;
 #pragma unroll
-      for (int t = 0; t < 49; ++t) acc = fmaf(ws[c * 49 + t], v[t], acc);
-      r[e] = fmaxf(acc * ws[128 * 49 + c] + ws[128 * 49 + 128 + c], 0.f);
+        for (int t = 0; t < 49; ++t) acc = fmaf(ws[c * 49 + t], v[t], acc);
+        r[e] = fmaxf(acc * ws[128 * 49 + c] + ws[128 * 49 + 128 + c], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
     }
-    *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+  } else {
+    f32x4 acc[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) acc[c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 49; ++t)
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + t * 128 + grp * 16 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c4][e] = fmaf(w4[e], v[t], acc[c4][e]);
+      }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + grp * 16 + c4 * 4), sh = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + 128 + grp * 16 + c4 * 4);
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[c4][e] * sc[e] + sh[e], 0.f);
+      *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+    }
   }
 }
 
@@ -71,6 +102,7 @@ struct LfConvArgs {
   // split-fp16 arithmetic (k_lf_conv_h): weights as fp16 pairs in fragment order (sp_weight_fragments_hm16), the affine scale with the
   // inverse of the weights' power-of-two scale folded in, the fp16-range guard word
   const uint16_t* wfh; const float* scale_h; unsigned int* ovf;
+  int cin_real;                             // input channels that exist (196 of Cin = 224 in LoFTR's middle layers): 8- (k_lf_conv) / 16-channel (k_lf_conv_h) steps behind them multiply zeros and are skipped
 };
 
 // grid (ceil(Wout / 32), ceil(Hout / (4 RPW)), N * ceil(Cout / 64)); 4 waves, wave w = output rows [RPW w, RPW w + RPW) of the tile,
@@ -92,7 +124,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH;
   const int gy0 = y0 * S - PAD, gx0 = x0 * S - PAD;
   const float* in = a.in + (long long)img * a.Hin * a.Win * a.Cin;
-  const int csteps = a.Cin / 8;
+  const int csteps = a.Cin / 8, rsteps = (a.cin_real + 7) / 8;
   const f32x4* wf = reinterpret_cast<const f32x4*>(a.wf) + lane;
   auto sw = [](int lx) { const int u = lx / S; return (u ^ (u >> 3)) & (NCH - 1); };
 
@@ -112,6 +144,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
   auto load_w = [&](f32x4 (&w)[NS][2], int c0_, int tap_) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+      if (c0_ / 8 + s >= rsteps) continue;
       w[s][0] = wf[(size_t)(((2 * og) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
       if (two) w[s][1] = wf[(size_t)(((2 * og + 1) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
     }
@@ -179,6 +212,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
       if (PF && tap == 0 && c0 + CH < a.Cin) fetch(c0 + CH);     // behind the next tap's weights: it has two taps of MFMAs to land in
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
+        if (c0 / 8 + s >= rsteps) continue;
         f32x4 fb[RPW];
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
@@ -249,7 +283,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH;
   const int gy0 = y0 * S - PAD, gx0 = x0 * S - PAD;
   const float* in = a.in + (long long)img * a.Hin * a.Win * a.Cin;
-  const int ksteps = a.Cin / 16;
+  const int ksteps = a.Cin / 16, rsteps = (a.cin_real + 15) / 16;
   const uint4* wfh = reinterpret_cast<const uint4*>(a.wfh) + lane;
   auto sw = [](int lx) { const int u = lx / S; return (u ^ (u >> 3)) & (NP16 - 1); };
 
@@ -351,6 +385,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
       __syncthreads();     // this tap's weights (and, at tap 0, the halo tile) are in LDS; the block written two taps ago is no longer read
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
+        if (c0 / 16 + s >= rsteps) continue;
         h16x8 fa[2][2], fb[RPW][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -757,6 +792,7 @@ __global__ __launch_bounds__(256) void k_lf_fine_gather(const float* ff /*[2][Hf
   const int m2 = (int)t, side = m2 >= Mp ? 1 : 0, m = m2 - side * Mp;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   const int M = *n_match;
+  if (m * kLfWW + ww >= (M * kLfWW + 127) / 128 * 128) return;         // behind the last 128-row tile a GEMM of the fine level touches (GemmArgs::mlim)
   if (m < M) {
     if (c4 < 32) {
       const int cell = side ? j_ids[m] : i_ids[m];
@@ -932,6 +968,7 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   a.in = in; a.Hin = Hin; a.Win = Win; a.Cin = c.cin_p; a.wf = c.wf; a.scale = c.scale; a.shift = c.shift; a.resid = resid;
   a.out = out; a.Hout = Hin / stride; a.Wout = Win / stride; a.Cout = c.cout_p; a.act = act;
   a.wfh = c.wfh; a.scale_h = c.scale_h; a.ovf = ctx->ovf;
+  a.cin_real = (gn::g_lf_conv_knob & 8) ? c.cin_p : c.cin;        // developer knob 42, bit 3: multiply the zero padding like rounds 3-4 did
   const bool hm = ctx->arith == 1 && c.wfh != nullptr;
   const int og = (c.cout_p + 63) / 64;
   // rows per wave (RPW): the workgroup covers 4 RPW output rows x 32 columns x 64 channels and one workgroup fits a CU, so a launch takes
@@ -1209,7 +1246,8 @@ static int lf_forward(gn_loftr* ctx, hipStream_t s) {
   {
     const LfConv& c = ctx->conv["backbone.conv1"];
     const long long n = (long long)h2 * w2 * 8;
-    hipLaunchKernelGGL(k_lf_conv1, dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s, ctx->img, c.wf, c.scale, c.shift, ctx->x0, H, W);
+    if (gn::g_lf_conv_knob & 4) hipLaunchKernelGGL(k_lf_conv1<true>, dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s, ctx->img, c.wf, c.scale, c.shift, ctx->x0, H, W);
+    else hipLaunchKernelGGL(k_lf_conv1<false>, dim3((unsigned)((n + 255) / 256), 1, 2), dim3(256), 0, s, ctx->img, c.wf, c.scale, c.shift, ctx->x0, H, W);
   }
   auto block = [&](const std::string& p, const float* x, int Hin, int Win, int stride, float* tmp, float* ds, float* out) {
     // y = relu(bn1(conv1(x))); y = bn2(conv2(y)); x' = stride != 1 ? bn(conv1x1(x)) : x; out = relu(x' + y)
