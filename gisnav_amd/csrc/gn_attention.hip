@@ -148,6 +148,151 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnArgs a) {
     }
 }
 
+// k_attn_f32_ks (round 5): the exact-f32 attention of ONE or TWO pairs -- BASELINE configs[1] as SURVEY.md reads it, the reference's own operating
+// point in the guaranteed arithmetic.  k_attn_f32 puts 64 workgroups on 256 CUs there, each walking 16 key tiles whose loads nothing hides
+// (101 us per launch, 47 % of the call).  Here a workgroup owns 32 queries and its four waves split the KEYS (wave w: tiles w, w + 4, ..): 256
+// workgroups at one pair; a wave stages its tile in its OWN LDS region (no workgroup barrier inside the loop) and requests the next tile into
+// registers before it computes on the current one; the four partial results meet through LDS by the log-sum-exp identity.  The same MFMA
+// instruction and per-tile arithmetic as k_attn_f32; the order in which a query's keys enter its sums differs (rounding level).
+__global__ __launch_bounds__(256) void k_attn_f32_ks(AttnArgs a) {
+  constexpr int KT2 = 32;                                  // keys per tile here: the next tile waits in 64 registers (with 64-key tiles the kernel spilled)
+  constexpr int WREG = KT2 * KLS + KT2 * 64;               // floats of one wave's K | V region
+  __shared__ __attribute__((aligned(16))) float smem[4 * 32 * 64 + 8 * 64 > 4 * WREG ? 4 * 32 * 64 + 8 * 64 : 4 * WREG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, bs = blockIdx.z;
+  const int kvs = a.cross ? (bs ^ 1) : bs;
+  const int nkv = a.nvalid[kvs];
+  const int q0 = blockIdx.x * 32;
+  float* Ks = smem + wave * WREG;
+  float* Vs = Ks + KT2 * KLS;
+
+  float qf[8][4];
+  {
+    const float* qp = a.q + ((size_t)bs * a.npad + q0 + ql) * a.ldq + h * 64 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 8 * j);
+      qf[j][0] = t.x * a.qscale; qf[j][1] = t.y * a.qscale;
+      qf[j][2] = t.z * a.qscale; qf[j][3] = t.w * a.qscale;
+    }
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const float* kbase = a.k + (size_t)kvs * a.npad * a.ldk + h * 64;
+  const float* vbase = a.v + (size_t)kvs * a.npad * a.ldv + h * 64;
+  const int ntiles = (nkv + KT2 - 1) / KT2;
+  // the wave's share of a tile: lane -> (row lr + 4 p, 16-byte column lc), p = 0 .. 7
+  const int lr = lane >> 4, lc = (lane & 15) * 4;
+  float4 pk[8], pv[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { pk[p] = make_float4(0.f, 0.f, 0.f, 0.f); pv[p] = pk[p]; }     // (defined on every path: otherwise the two arrays live in scratch memory)
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const size_t grow = (size_t)(t * KT2 + lr + 4 * p);
+      pk[p] = *reinterpret_cast<const float4*>(kbase + grow * a.ldk + lc);
+      pv[p] = *reinterpret_cast<const float4*>(vbase + grow * a.ldv + lc);
+    }
+  };
+  if (wave < ntiles) fetch(wave);
+  for (int t = wave; t < ntiles; t += 4) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      *reinterpret_cast<float4*>(&Ks[(lr + 4 * p) * KLS + lc]) = pk[p];
+      *reinterpret_cast<float4*>(&Vs[(lr + 4 * p) * 64 + lc]) = pv[p];
+    }
+    if (t + 4 < ntiles) fetch(t + 4);
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 kf = *reinterpret_cast<const float4*>(&Ks[ql * KLS + 8 * j + 4 * hh]);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[j][0], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[j][1], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[j][2], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[j][3], st, 0, 0, 0);
+    }
+    if (t * KT2 + KT2 > nkv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * KT2 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= nkv) st[r] = -INFINITY;
+      }
+    }
+    float mloc = st[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(st[r] - m_new);
+      st[r] = p;
+      l_run += p;
+    }
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float v0 = Vs[key * 64 + ql];
+      const float v1 = Vs[key * 64 + 32 + ql];
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[r], o[1], 0, 0, 0);
+    }
+  }
+  // merge: every wave publishes (m, l, O) of its key share; wave w then finishes the output columns (d2 = w >> 1, registers 8 (w & 1) .. + 7)
+  const float l_wave = l_run + __shfl_xor(l_run, 32);
+  __syncthreads();                                      // every wave is done with its K | V region
+  float* Om = smem;                                     // [4 waves][32 registers][64 lanes]
+  float* Mm = smem + 4 * 32 * 64;                       // [4][64]
+  float* Lm = Mm + 4 * 64;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Om[(wave * 32 + d * 16 + r) * 64 + lane] = o[d][r];
+  Mm[wave * 64 + lane] = m_run;
+  Lm[wave * 64 + lane] = l_wave;
+  __syncthreads();
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) M = fmaxf(M, Mm[w * 64 + lane]);
+  float sc[4], L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float mw = Mm[w * 64 + lane];
+    sc[w] = mw == -INFINITY ? 0.f : expf(mw - M);
+    L += Lm[w * 64 + lane] * sc[w];
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  const int d2 = wave >> 1, r0 = 8 * (wave & 1);
+  float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh + d2 * 32;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += Om[(w * 32 + d2 * 16 + r0 + 4 * g + e) * 64 + lane] * sc[w];
+      acc[e] = v * inv;
+    }
+    *reinterpret_cast<float4*>(op + 8 * (r0 / 4 + g)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 variant.  K tile is staged as bf16 [64 keys][64 d] (row stride 72 halves = 144 B), V tile is
 // staged TRANSPOSED as bf16 [64 d][64 keys] (row stride 72) so that the A operand of O^T = V^T P^T
@@ -883,7 +1028,14 @@ __global__ __launch_bounds__(64 * NW) void k_attn_ks(AttnArgs a) {
 }
 }  // namespace
 
+int g_attn_f32_ks = 0;       // developer knob 43: 0 = k_attn_f32_ks for one or two pairs per call, 1 = never, 2 = always
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
+  // (the choice depends on the number of pairs only, like k_attn_ks': padding does not change the kernel family)
+  if (g_attn_f32_ks == 2 || (g_attn_f32_ks == 0 && a.BS <= 4)) {
+    hipLaunchKernelGGL(k_attn_f32_ks, dim3(a.npad / 32, kHeads, a.BS), dim3(256), 0, s, a);
+    g_last_kernel = "k_attn_f32_ks(";
+    return;
+  }
   dim3 grid(a.npad / QB, kHeads, a.BS), block(256);
   hipLaunchKernelGGL(k_attn_f32, grid, block, 0, s, a);
   g_last_kernel = "k_attn_f32(";

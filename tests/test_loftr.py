@@ -273,3 +273,36 @@ def test_exact_f32_gemm_on_64_row_tiles_equals_the_128_row_kernel_bitwise():
             assert np.abs(outs[320][0] - ref).max() < 2e-6 * np.abs(ref).max() * np.sqrt(K)
     finally:
         eng.lib.gn_debug_set_variant(eng.ctx, 41, 320)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arithmetic", ["exact_f32", "split_fp16"])
+def test_loftr_round5_forms_equal_the_forms_they_replace_bitwise(arithmetic, sd):
+    """Round 5 changed HOW LoFTR's forward is computed, not what: the next channel slice's halo tile prefetched into registers, the rows-per-wave
+    choice re-fitted, the stem's weights transposed in LDS, the zero-padding channel steps of the 196-channel layers skipped, and the fine level
+    run only on the windows of the matches there are, sides one behind the other (a cross half computes the side it updates).  Developer knob 42
+    = 15 selects every old form: all outputs are identical -- at a size whose grids are ragged, with the match list capped below the number of
+    matches (windows behind the cap are skipped), and on a featureless pair (no match at all: every fine-level tile leaves at once)."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.loftr import LoFTR
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f32")      # a gn_ctx to reach the process-wide developer knob
+    i0, i1 = lf.synthetic_pair(2, 136, 200)
+    flat = torch.full((136, 200), 0.5)
+    cases = [({"image0": i0.cuda(), "image1": i1.cuda()}, {}), ({"image0": i0.cuda(), "image1": i1.cuda()}, {"max_matches": 37}),
+             ({"image0": flat.cuda(), "image1": flat.cuda()}, {})]
+    try:
+        res = {}
+        for knob in (15, 0):
+            eng.lib.gn_debug_set_variant(eng.ctx, 42, knob)
+            res[knob] = []
+            for data, kw in cases:
+                m = LoFTR(state_dict=sd, arithmetic=arithmetic, **kw).to("cuda:0").eval()      # (a new context per knob: the graph is captured with it in force)
+                res[knob].append([m(data, with_ids=True) for _ in range(2)][-1])
+                del m
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 42, 0)
+    assert res[0][0]["keypoints0"].shape[0] > 100 and res[0][1]["keypoints0"].shape[0] == 37 and res[0][2]["keypoints0"].shape[0] == 0
+    for old, new in zip(res[15], res[0]):
+        assert old.keys() == new.keys()
+        for k in old:
+            assert old[k].shape == new[k].shape and torch.equal(old[k], new[k]), k
