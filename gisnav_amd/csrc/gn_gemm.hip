@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_v3(GemmArgs a) {
 // are M = 4864 rows x N = 256 / 512 columns = 76 / 152 workgroups of k_gemm_f32_v3 on 256 CUs, each a 17 us chain of MFMAs (29 us per launch for
 // 0.6 GFLOP: profiles/r05e_loftr_layers_exact_f32.txt).  Same operands, swizzle, LDS-DMA staging and k order as k_gemm_f32_v3 -- every output
 // element sums the same products in the same order: same bits --, half the rows per workgroup: wave w owns rows 32 (w >> 1) .. and columns
-// 64 (w & 1) ..; plain / bias / ReLU epilogues only (what the coarse transformer uses), compiler-scheduled.
+// 64 (w & 1) ..; plain / bias / ReLU (the coarse transformer) and column-scale / rotary / residual epilogues (the matcher in the exact-f32 mode at
+// one or two pairs per call: 32-96 workgroups of k_gemm_f32_v3, 35 us against 19 here), f32 output only; compiler-scheduled.
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
   constexpr int BM2 = 64;
@@ -387,6 +388,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
   const int col = bn + wc * 64 + c4;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  // column scale / rotary / residual (the matcher's exact-f32 mode at one or two pairs per call): k_gemm_f32_v3's expressions, term for term
+  const bool do_scale = EPI == EPI_SCALE_COLS && col < a.scale_cols;
+  const bool do_rot = EPI == EPI_ROTARY && col < a.rot_cols;
+  const int f0 = (col & 63) >> 1;
+  float2 cs8[8], sn8[8];
+  f32x4 res8[8];
+  if (EPI == EPI_ROTARY && (bn + wc * 64) < a.rot_cols) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const size_t row = (size_t)(bm + wr * 32 + it * 4 + (lane >> 4));
+      cs8[it] = *reinterpret_cast<const float2*>(a.cos_t + row * kFreq + f0);
+      sn8[it] = *reinterpret_cast<const float2*>(a.sin_t + row * kFreq + f0);
+    }
+  }
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) res8[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(bm + wr * 32 + it * 4 + (lane >> 4)) * a.ldr + col);
+  }
   f32x4 vals[8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * 4 + (lane >> 4)) * ES + c4]);
@@ -395,6 +414,21 @@ __global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
     const int row = bm + wr * 32 + it * 4 + (lane >> 4);
     f32x4 v = vals[it];
     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (EPI == EPI_SCALE_COLS) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY) {
+      if (do_rot) {
+        const float2 cs = cs8[it], sn = sn8[it];
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += res8[it];
+    }
     if (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
   }
@@ -1178,11 +1212,15 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
     return;
   }
   // small grids: 64-row tiles when 128 x 128 tiles would leave more than a third of the CUs without a workgroup (same bits: k_gemm_f32_m64)
-  if (g_gemm_m64 && (epi == EPI_BIAS || epi == EPI_PLAIN || epi == EPI_RELU) && (long long)grid.x * grid.y * grid.z <= g_gemm_m64) {
+  if (g_gemm_m64 && (epi == EPI_BIAS || epi == EPI_PLAIN || epi == EPI_RELU || epi == EPI_SCALE_COLS || epi == EPI_ROTARY || epi == EPI_RESIDUAL) &&
+      (long long)grid.x * grid.y * grid.z <= g_gemm_m64) {
     const dim3 g64(a.N / BN, a.M / 64, batch);
     g_last_kernel = "k_gemm_f32_m64<";
     if (epi == EPI_BIAS) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_BIAS>, g64, block, 0, s, a);
     else if (epi == EPI_RELU) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_RELU>, g64, block, 0, s, a);
+    else if (epi == EPI_SCALE_COLS) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_SCALE_COLS>, g64, block, 0, s, a);
+    else if (epi == EPI_ROTARY) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_ROTARY>, g64, block, 0, s, a);
+    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_RESIDUAL>, g64, block, 0, s, a);
     else hipLaunchKernelGGL(k_gemm_f32_m64<EPI_PLAIN>, g64, block, 0, s, a);
     return;
   }

@@ -411,3 +411,80 @@ def test_small_grid_projections_give_the_bits_of_the_bulk_kernel_and_the_small_g
     assert np.abs(a[3]).max() > 0.1
     _report("small_grid_tail_vs_k_ffn_fused_final_features_rel", worst)
     del eng
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_exact_f32_key_split_attention_of_one_pair_against_fp64(state_dict_np, cross):
+    """k_attn_f32_ks (round 5): BASELINE configs[1] as SURVEY.md reads it -- one pair per call in the guaranteed f32 arithmetic.  The four waves of a
+    workgroup share 32 queries and split the 32-key tiles (wave-private LDS, the next tile prefetched into registers), merged through LDS.  Ragged
+    key counts as in the fp16 twin's test (5 keys: three waves without a tile; 833: a masked last tile; 0 keys: an empty side gives zeros),
+    against fp64 at f32 accuracy and against k_attn_f32 (knob 43 = 1), selected by the number of pairs on its own."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=1, max_kpts=1024, precision="f32", state_dict=state_dict_np)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(23)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())      # noqa: E731
+    worst = 0.0
+    try:
+        for nk in ((1024, 833), (5, 1000), (64, 65), (33, 0)):
+            q, k, v = (torch.randn(2, 1024, 256, generator=g).to(dev) for _ in range(3))
+            k[1, 7] *= 6.0
+            nkv = torch.tensor(nk, dtype=torch.int32, device=dev)
+            out = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()      # (two slots: the key-split kernel; the launch table of the next test names it)
+            eng.lib.gn_debug_set_variant(eng.ctx, 43, 1)
+            old = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
+            eng.lib.gn_debug_set_variant(eng.ctx, 43, 0)
+            ref = _attn_ref64(q, k, v, nkv, cross, lambda t: t)
+            assert np.isfinite(out).all()
+            for bs in range(2):
+                kvs = bs ^ 1 if cross else bs
+                if nk[kvs] == 0:
+                    assert not out[bs].any() and not old[bs].any()
+                    continue
+                worst = max(worst, rel(out[bs], ref[bs]))
+                assert rel(out[bs], ref[bs]) < 5e-6 and rel(out[bs], old[bs]) < 2e-5, (nk, bs, rel(out[bs], ref[bs]), rel(out[bs], old[bs]))
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 43, 0)
+    _report("attn_f32_ks_rel_err_vs_fp64_cross%d" % int(cross), worst)
+    del eng
+
+
+def test_one_pair_in_the_exact_f32_mode_small_grid_kernels_against_the_oracle_and_the_bulk_kernels(state_dict_np, state_dict_t):
+    """One pair per call in GN_PREC_F32 (BASELINE configs[1] as SURVEY.md reads it): the launch table shows k_attn_f32_ks and the 64-row GEMM
+    (k_gemm_f32_m64, now also behind the rotary / column-scale / residual epilogues); correspondence indices are the oracle's; with the 64-row
+    GEMM switched off (knob 41 = 0) every output is BITWISE the same (it sums the same products in the same order as k_gemm_f32_v3); with the
+    key-split attention switched off as well (knob 43 = 1) the indices stay identical and the scores agree to f32 rounding."""
+    from gisnav_amd.engine import PoseEngine
+    _threads()
+    eng = PoseEngine(0, max_batch=1, max_kpts=1024, precision="f32", state_dict=state_dict_np)
+    m_all = t_all = 0
+    try:
+        for seed, nq, nr in ((9200, 1024, 1024), (9201, 1000, 777), (9202, 333, 1024)):
+            p = make_pair(seed, n_q=nq, n_r=nr)
+            ref = oracle_match(state_dict_t, p)
+            inp = eng.stage_inputs([p])
+            args = (inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"])
+            eng.set_kernel_timing(200)
+            idx, score, n = (t.clone() for t in eng.match(*args))
+            torch.cuda.synchronize()
+            names = [r["name"] for r in eng.kernel_table()]
+            eng.set_kernel_timing(0)
+            assert any(nm.startswith("k_attn_f32_ks") for nm in names) and any(nm.startswith("k_gemm_f32_m64") for nm in names), names
+            assert not any(nm.startswith("k_gemm_f32_v3") for nm in names), names        # every GEMM of the call is on 64-row tiles at one pair
+            d, t = _mismatches(idx.cpu().numpy()[0], int(n.cpu().numpy()[0]), ref[3].numpy())
+            m_all += d; t_all += t
+            eng.lib.gn_debug_set_variant(eng.ctx, 41, 0)
+            idx2, score2, n2 = (t.clone() for t in eng.match(*args))
+            assert torch.equal(idx, idx2) and torch.equal(score, score2) and torch.equal(n, n2)
+            eng.lib.gn_debug_set_variant(eng.ctx, 43, 1)
+            idx3, score3, n3 = (t.clone() for t in eng.match(*args))
+            k = int(n.item())
+            assert torch.equal(n, n3) and torch.equal(idx[0, :k], idx3[0, :k]) and float((score[0, :k] - score3[0, :k]).abs().max()) < 1e-5
+            eng.lib.gn_debug_set_variant(eng.ctx, 41, 320)
+            eng.lib.gn_debug_set_variant(eng.ctx, 43, 0)
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 41, 320)
+        eng.lib.gn_debug_set_variant(eng.ctx, 43, 0)
+    assert m_all == 0 and t_all > 600, (m_all, t_all)
+    _report("one_pair_exact_f32_small_grid_kernels", {"index_mismatches": m_all, "cpu_matches": t_all})
+    del eng
