@@ -1864,6 +1864,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 41) gn::g_gemm_m64 = value;
   else if (which == 42) gn::g_lf_conv_knob = value;
   else if (which == 43) gn::g_attn_f32_ks = value;
+  else if (which == 44) gn::g_gemm_r64 = value;
   else if (which == 39) ctx->sp_stop = value;
   else if (which == 35) {
     ctx->sp_ts_layer = value;

@@ -112,6 +112,7 @@ void launch_gemm_p2(int epi, const GemmArgs& a, int batch, hipStream_t s);   // 
 void launch_mfma_probe(float* out, int blocks, int iters, hipStream_t s);
 void launch_lds_dma_probe(const float* pattern, unsigned int* out, int blocks, int spin, hipStream_t s);
 extern int g_gemm_m64;
+extern int g_gemm_r64;
 extern int g_attn_f32_ks;     // developer knob 43 (gn_attention.hip launch_attention_f32)
 extern int g_lf_conv_knob;   // developer knob 42 (gn_loftr.hip lf_conv)
 extern thread_local const char* g_last_kernel;   // bench facility: rocprof-style name of the kernel the last launch_* call of THIS host thread dispatched

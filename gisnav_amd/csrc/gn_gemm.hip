@@ -434,6 +434,168 @@ __global__ __launch_bounds__(256) void k_gemm_f32_m64(GemmArgs a) {
   }
 }
 
+// k_gemm_f32_r64 (late round 5): k_gemm_f32_m64 with a FOUR-slot LDS ring -- three k-tiles in flight behind a counted s_waitcnt instead of one
+// (a 64-row workgroup computes a k-tile in ~1 k (BN2 = 64) / ~2 k cycles (128) and then waited a whole DMA latency for the next: the 74 GEMMs of a
+// one-pair call in GN_PREC_F32 took 19.7 us each for 0.3-0.8 GFLOP) -- and, for grids that still fill at most half of the chip on 64 x 128 tiles,
+// 64 x 64 tiles (BN2 = 64: wave w owns rows 32 (w >> 1) .., columns 32 (w & 1) ..).  Same operands, swizzle, k order and MFMA sequence per output
+// element as k_gemm_f32_v3: same bits.  One workgroup barrier per k-tile.  Measured (tools/small_batch.py 1 --precision f32 --table --knob 44:k): the ring alone
+// buys 19.9 -> 19.4 us per GEMM, the 64 x 64 tiles 19.9 -> 14.5 (twice the workgroups on a chip that was a quarter to a half full): shipped for those grids only.
+template <int EPI, int BN2>
+__global__ __launch_bounds__(256) void k_gemm_f32_r64(GemmArgs a) {
+  constexpr int BM2 = 64, NJ = BN2 / 64, NB = BN2 / 32, RING = 4;
+  constexpr int TILE = (BM2 + BN2) * BK;              // floats per ring slot
+  constexpr int SLAB = 4 * 32 * ES;
+  __shared__ __attribute__((aligned(16))) float smem[(RING * TILE > SLAB) ? RING * TILE : SLAB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * BM2, bn = blockIdx.x * BN2;
+  if (a.mlim != nullptr && (a.mlim_seg > 0 ? bm % a.mlim_seg : bm) >= a.mlim[0] * a.mlim_mul) return;     // GemmArgs::mlim: a tile of rows nobody will read
+  const float* A = a.A + (long long)blockIdx.z * a.strideA;
+  const float* W = a.W + (long long)blockIdx.z * a.strideW;
+  float* Y = a.Y + (long long)blockIdx.z * a.strideY;
+  const float* const A2 = a.A2;
+  const int lda = a.lda, lda2 = a.lda2, ldw = a.ldw, K1 = a.K1, K = a.K;
+  // staging: wave w brings rows [16 w, 16 w + 16) of the A tile (2 instructions of 8 rows) and rows [8 NB w, 8 NB w + 8 NB) of the B tile (NB);
+  // lane -> (row offset lane >> 3, chunk position lane & 7) fetches source chunk pos ^ f(row), f(row) = (row ^ (row >> 3)) & 7.
+  // The DMA is issued from assembly: the compiler neither sees nor waits for it (the builtin makes it drain every load in flight in front of
+  // the next LDS read), so that the ring can keep three k-tiles in flight behind a counted s_waitcnt.
+  const int dpos = lane & 7;
+  const float* asrc[2]; const float* a2src[2]; const float* wsrc[NB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + 8 * j + (lane >> 3);
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    asrc[j] = A + (size_t)(bm + row) * lda + c * 4;
+    a2src[j] = A2 ? A2 + (size_t)(bm + row) * lda2 + c * 4 - K1 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = wave * (8 * NB) + 8 * j + (lane >> 3);
+    const int c = dpos ^ ((row ^ (row >> 3)) & 7);
+    wsrc[j] = W + (size_t)(bn + row) * ldw + c * 4;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  auto dma1 = [&](const float* src, unsigned dst_floats) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + dst_floats * 4u) : "memory");
+  };
+  auto dma_tile = [&](int buf, int k0) __attribute__((always_inline)) {
+    const bool second = (A2 != nullptr) && (k0 >= K1);
+    const unsigned la_ = (unsigned)(buf * TILE + (wave_u * 16) * BK);
+    const unsigned lb_ = (unsigned)(buf * TILE + BM2 * BK + (wave_u * 8 * NB) * BK);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma1((second ? a2src[j] : asrc[j]) + k0, la_ + j * 8 * BK);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dma1(wsrc[j] + k0, lb_ + j * 8 * BK);
+  };
+  f32x16 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int hh = lane >> 5;
+  const int ra_ = wr * 32 + (lane & 31);
+  const int arow = ra_ * BK, ga = hh ^ ((ra_ ^ (ra_ >> 3)) & 7);
+  int brow[NJ], gb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int rb_ = wc * (BN2 / 2) + 32 * j + (lane & 31);
+    brow[j] = BM2 * BK + rb_ * BK; gb[j] = hh ^ ((rb_ ^ (rb_ >> 3)) & 7);
+  }
+  const int nt = K / BK;
+  constexpr int PER = 2 + NB;                       // DMA instructions per wave and k-tile
+#pragma unroll
+  for (int q = 0; q < RING - 1; ++q)
+    if (q < nt) dma_tile(q, q * BK);
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed once at most the (up to two) later tiles of this wave are still in flight; the barrier then says the same of every wave's
+    // share -- and that every wave is done with tile t - 1, whose slot the next request overwrites
+    const int later = nt - 1 - t;
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + RING - 1 < nt) dma_tile((t + RING - 1) % RING, (t + RING - 1) * BK);
+    const float* b_ = smem + (t % RING) * TILE;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(b_ + arow + 4 * ((kc << 1) ^ ga));
+      f32x4 fb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b_ + brow[j] + 4 * ((kc << 1) ^ gb[j]));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                  // every wave is done with the last tile: the slabs alias the ring
+  // epilogue: the wave's 32 x (BN2 / 2) block through its LDS slab, read back row-wise (16 (8) lanes x 16 bytes = one row segment)
+  float* slab = smem + wave * 32 * ES;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      slab[row * ES + j * 32 + (lane & 31)] = acc[j][r];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int CW = BN2 / 2, LPR = CW / 4, RPI = 64 / LPR, NIT = 32 / RPI;      // columns per wave, lanes per row segment, rows per pass, passes
+  const int c4 = (lane % LPR) * 4;
+  const int col = bn + wc * CW + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_PLAIN && a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  // column scale / rotary / residual: k_gemm_f32_v3's expressions, term for term
+  const bool do_scale = EPI == EPI_SCALE_COLS && col < a.scale_cols;
+  const bool do_rot = EPI == EPI_ROTARY && col < a.rot_cols;
+  const int f0 = (col & 63) >> 1;
+  float2 cs8[NIT], sn8[NIT];
+  f32x4 res8[NIT];
+  if (EPI == EPI_ROTARY && (bn + wc * CW) < a.rot_cols) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const size_t row = (size_t)(bm + wr * 32 + it * RPI + lane / LPR);
+      cs8[it] = *reinterpret_cast<const float2*>(a.cos_t + row * kFreq + f0);
+      sn8[it] = *reinterpret_cast<const float2*>(a.sin_t + row * kFreq + f0);
+    }
+  }
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) res8[it] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)(bm + wr * 32 + it * RPI + lane / LPR) * a.ldr + col);
+  }
+  f32x4 vals[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) vals[it] = *reinterpret_cast<const f32x4*>(&slab[(it * RPI + lane / LPR) * ES + c4]);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = bm + wr * 32 + it * RPI + lane / LPR;
+    f32x4 v = vals[it];
+    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (EPI == EPI_SCALE_COLS) {
+      if (do_scale) v *= a.scale;
+    } else if (EPI == EPI_ROTARY) {
+      if (do_rot) {
+        const float2 cs = cs8[it], sn = sn8[it];
+        f32x4 o;
+        o.x = v.x * cs.x + (-v.y) * sn.x;
+        o.y = v.y * cs.x + v.x * sn.x;
+        o.z = v.z * cs.y + (-v.w) * sn.y;
+        o.w = v.w * cs.y + v.z * sn.y;
+        v = o;
+      }
+    } else if (EPI == EPI_RESIDUAL) {
+      v += res8[it];
+    }
+    if (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // f32x3: f32-accurate GEMM on the bf16 matrix pipe.  Every f32 operand is split exactly into three
 // bf16 terms (x = xh + xm + xl, 8 + 8 + 8 mantissa bits) while its fragment sits in registers, and each
@@ -1079,6 +1241,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16x2(GemmArgs a) {
 
 thread_local int g_gemm_variant = 3;
 int g_lf_conv_knob = 0;  // developer knob 42: bit 0 = LoFTR's convolutions stage their halo tiles the way rounds 3-4 did (no register prefetch); bits 8.. = the overhead term of lf_conv's cost model x 100
+int g_gemm_r64 = 1;     // developer knob 44 (launch_gemm_f32)
 int g_gemm_m64 = 320;    // developer knob 41: the exact-f32 GEMM runs on 64-row tiles when its 128 x 128 grid has at most this many workgroups (0 = never)
 
 // Pure-MFMA ceiling probe: 4 waves per CU-resident block, 8 independent accumulators, no memory traffic.
@@ -1215,6 +1378,19 @@ void launch_gemm_f32(int epi, const GemmArgs& a, int batch, hipStream_t s) {
   if (g_gemm_m64 && (epi == EPI_BIAS || epi == EPI_PLAIN || epi == EPI_RELU || epi == EPI_SCALE_COLS || epi == EPI_ROTARY || epi == EPI_RESIDUAL) &&
       (long long)grid.x * grid.y * grid.z <= g_gemm_m64) {
     const dim3 g64(a.N / BN, a.M / 64, batch);
+    // developer knob 44: 0 = k_gemm_f32_m64 always; 1 (default) = k_gemm_f32_r64 on 64 x 64 tiles when 64 x 128 tiles leave half of the CUs idle (at most
+    // 128 workgroups: 19.9 -> 14.5 us per GEMM of a one-pair call), k_gemm_f32_m64 otherwise; 2 = the ring kernel on 64 x 128 tiles everywhere (measured:
+    // 19.4 against 19.9 us -- it is the tile count, not the ring, that pays; its 96 KB of LDS leave one workgroup per CU)
+    const bool n64 = g_gemm_r64 == 1 && (long long)g64.x * g64.y * g64.z <= 128 && a.N % 64 == 0;
+    if (n64 || g_gemm_r64 == 2) {
+      const dim3 gr(n64 ? a.N / 64 : a.N / BN, a.M / 64, batch);
+      g_last_kernel = "k_gemm_f32_r64<";
+#define GN_R64(E) do { if (n64) hipLaunchKernelGGL((k_gemm_f32_r64<E, 64>), gr, block, 0, s, a); else hipLaunchKernelGGL((k_gemm_f32_r64<E, 128>), gr, block, 0, s, a); } while (0)
+      if (epi == EPI_BIAS) GN_R64(EPI_BIAS); else if (epi == EPI_RELU) GN_R64(EPI_RELU); else if (epi == EPI_SCALE_COLS) GN_R64(EPI_SCALE_COLS);
+      else if (epi == EPI_ROTARY) GN_R64(EPI_ROTARY); else if (epi == EPI_RESIDUAL) GN_R64(EPI_RESIDUAL); else GN_R64(EPI_PLAIN);
+#undef GN_R64
+      return;
+    }
     g_last_kernel = "k_gemm_f32_m64<";
     if (epi == EPI_BIAS) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_BIAS>, g64, block, 0, s, a);
     else if (epi == EPI_RELU) hipLaunchKernelGGL(k_gemm_f32_m64<EPI_RELU>, g64, block, 0, s, a);

@@ -451,7 +451,7 @@ def test_exact_f32_key_split_attention_of_one_pair_against_fp64(state_dict_np, c
 
 def test_one_pair_in_the_exact_f32_mode_small_grid_kernels_against_the_oracle_and_the_bulk_kernels(state_dict_np, state_dict_t):
     """One pair per call in GN_PREC_F32 (BASELINE configs[1] as SURVEY.md reads it): the launch table shows k_attn_f32_ks and the 64-row GEMM
-    (k_gemm_f32_m64, now also behind the rotary / column-scale / residual epilogues); correspondence indices are the oracle's; with the 64-row
+    (k_gemm_f32_m64 / its four-slot-ring form k_gemm_f32_r64, also behind the rotary / column-scale / residual epilogues); correspondence indices are the oracle's; with the 64-row
     GEMM switched off (knob 41 = 0) every output is BITWISE the same (it sums the same products in the same order as k_gemm_f32_v3); with the
     key-split attention switched off as well (knob 43 = 1) the indices stay identical and the scores agree to f32 rounding."""
     from gisnav_amd.engine import PoseEngine
@@ -469,7 +469,7 @@ def test_one_pair_in_the_exact_f32_mode_small_grid_kernels_against_the_oracle_an
             torch.cuda.synchronize()
             names = [r["name"] for r in eng.kernel_table()]
             eng.set_kernel_timing(0)
-            assert any(nm.startswith("k_attn_f32_ks") for nm in names) and any(nm.startswith("k_gemm_f32_m64") for nm in names), names
+            assert any(nm.startswith("k_attn_f32_ks") for nm in names) and any(nm.startswith(("k_gemm_f32_m64", "k_gemm_f32_r64")) for nm in names), names
             assert not any(nm.startswith("k_gemm_f32_v3") for nm in names), names        # every GEMM of the call is on 64-row tiles at one pair
             d, t = _mismatches(idx.cpu().numpy()[0], int(n.cpu().numpy()[0]), ref[3].numpy())
             m_all += d; t_all += t

@@ -13,6 +13,9 @@ i0, i1 = olf.synthetic_pair(1, 480, 640)
 data = {"image0": i0.to(dev), "image1": i1.to(dev)}
 ref = None
 knobs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0, (25 << 8), (50 << 8), (100 << 8), 1, 0, (25 << 8), (50 << 8), (100 << 8)]
+extra = [tuple(int(x) for x in a.split(":")) for a in sys.argv[3:]]      # further process-wide knobs, which:value (e.g. 44:0 = the 64-row GEMM without its ring)
+for w, v in extra:
+    eng.lib.gn_debug_set_variant(eng.ctx, w, v)
 for knob in knobs:
     eng.lib.gn_debug_set_variant(eng.ctx, 42, knob)
     m2 = LoFTR(state_dict=olf.synthetic_state_dict(0), fine=True, graph=True, arithmetic=arith).to(dev).eval()   # (a new context: the graph is captured with the knob in force)
