@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnArgs a) {
 // workgroups at one pair; a wave stages its tile in its OWN LDS region (no workgroup barrier inside the loop) and requests the next tile into
 // registers before it computes on the current one; the four partial results meet through LDS by the log-sum-exp identity.  The same MFMA
 // instruction and per-tile arithmetic as k_attn_f32; the order in which a query's keys enter its sums differs (rounding level).
-__global__ __launch_bounds__(256) void k_attn_f32_ks(AttnArgs a) {
+template <int NW>     // waves per workgroup = key shares (4, or 8: two waves per SIMD, one's softmax under the other's MFMAs)
+__global__ __launch_bounds__(64 * NW) void k_attn_f32_ks(AttnArgs a) {
   constexpr int KT2 = 32;                                  // keys per tile here: the next tile waits in 64 registers (with 64-key tiles the kernel spilled)
   constexpr int WREG = KT2 * KLS + KT2 * 64;               // floats of one wave's K | V region
-  __shared__ __attribute__((aligned(16))) float smem[4 * 32 * 64 + 8 * 64 > 4 * WREG ? 4 * 32 * 64 + 8 * 64 : 4 * WREG];
+  __shared__ __attribute__((aligned(16))) float smem[NW * 32 * 64 + 2 * NW * 64 > NW * WREG ? NW * 32 * 64 + 2 * NW * 64 : NW * WREG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, bs = blockIdx.z;
@@ -201,13 +202,13 @@ __global__ __launch_bounds__(256) void k_attn_f32_ks(AttnArgs a) {
     }
   };
   if (wave < ntiles) fetch(wave);
-  for (int t = wave; t < ntiles; t += 4) {
+  for (int t = wave; t < ntiles; t += NW) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       *reinterpret_cast<float4*>(&Ks[(lr + 4 * p) * KLS + lc]) = pk[p];
       *reinterpret_cast<float4*>(&Vs[(lr + 4 * p) * 64 + lc]) = pv[p];
     }
-    if (t + 4 < ntiles) fetch(t + 4);
+    if (t + NW < ntiles) fetch(t + NW);
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -253,12 +254,12 @@ __global__ __launch_bounds__(256) void k_attn_f32_ks(AttnArgs a) {
       o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[r], o[1], 0, 0, 0);
     }
   }
-  // merge: every wave publishes (m, l, O) of its key share; wave w then finishes the output columns (d2 = w >> 1, registers 8 (w & 1) .. + 7)
+  // merge: every wave publishes (m, l, O) of its key share; wave w then finishes 32 / NW of the 32 output registers (d2 = w / (NW / 2), groups of 4)
   const float l_wave = l_run + __shfl_xor(l_run, 32);
   __syncthreads();                                      // every wave is done with its K | V region
-  float* Om = smem;                                     // [4 waves][32 registers][64 lanes]
-  float* Mm = smem + 4 * 32 * 64;                       // [4][64]
-  float* Lm = Mm + 4 * 64;
+  float* Om = smem;                                     // [NW waves][32 registers][64 lanes]
+  float* Mm = smem + NW * 32 * 64;                      // [NW][64]
+  float* Lm = Mm + NW * 64;
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -268,28 +269,29 @@ __global__ __launch_bounds__(256) void k_attn_f32_ks(AttnArgs a) {
   __syncthreads();
   float M = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) M = fmaxf(M, Mm[w * 64 + lane]);
-  float sc[4], L = 0.f;
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, Mm[w * 64 + lane]);
+  float sc[NW], L = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const float mw = Mm[w * 64 + lane];
     sc[w] = mw == -INFINITY ? 0.f : expf(mw - M);
     L += Lm[w * 64 + lane] * sc[w];
   }
   const float inv = L > 0.f ? 1.0f / L : 0.f;
-  const int d2 = wave >> 1, r0 = 8 * (wave & 1);
+  constexpr int G = 8 / NW;                             // groups of 4 registers per wave: 2 (NW = 4) or 1 (8)
+  const int d2 = wave / (NW / 2), g0 = (wave % (NW / 2)) * G;
   float* op = a.out + ((size_t)bs * a.npad + q0 + ql) * a.ldo + h * 64 + 4 * hh + d2 * 32;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < G; ++g) {
     float acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += Om[(w * 32 + d2 * 16 + r0 + 4 * g + e) * 64 + lane] * sc[w];
+      for (int w = 0; w < NW; ++w) v += Om[(w * 32 + d2 * 16 + 4 * (g0 + g) + e) * 64 + lane] * sc[w];
       acc[e] = v * inv;
     }
-    *reinterpret_cast<float4*>(op + 8 * (r0 / 4 + g)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(op + 8 * (g0 + g)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
@@ -1028,11 +1030,13 @@ __global__ __launch_bounds__(64 * NW) void k_attn_ks(AttnArgs a) {
 }
 }  // namespace
 
-int g_attn_f32_ks = 0;       // developer knob 43: 0 = k_attn_f32_ks for one or two pairs per call, 1 = never, 2 = always
+int g_attn_f32_ks = 0;       // developer knob 43: bits 0-1: 0 = k_attn_f32_ks for one or two pairs per call, 1 = never, 2 = always; bit 2: its eight-wave form
 void launch_attention_f32(const AttnArgs& a, hipStream_t s) {
   // (the choice depends on the number of pairs only, like k_attn_ks': padding does not change the kernel family)
-  if (g_attn_f32_ks == 2 || (g_attn_f32_ks == 0 && a.BS <= 4)) {
-    hipLaunchKernelGGL(k_attn_f32_ks, dim3(a.npad / 32, kHeads, a.BS), dim3(256), 0, s, a);
+  if ((g_attn_f32_ks & 3) == 2 || ((g_attn_f32_ks & 3) == 0 && a.BS <= 4)) {
+    // (knob 43 bit 2: eight waves per workgroup instead of four -- measured: 34.9 against 35.8 us at one pair, 62.6 against 58.0 at two: not shipped)
+    if (g_attn_f32_ks & 4) hipLaunchKernelGGL(k_attn_f32_ks<8>, dim3(a.npad / 32, kHeads, a.BS), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_attn_f32_ks<4>, dim3(a.npad / 32, kHeads, a.BS), dim3(256), 0, s, a);
     g_last_kernel = "k_attn_f32_ks(";
     return;
   }

@@ -431,6 +431,8 @@ def test_exact_f32_key_split_attention_of_one_pair_against_fp64(state_dict_np, c
             k[1, 7] *= 6.0
             nkv = torch.tensor(nk, dtype=torch.int32, device=dev)
             out = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()      # (two slots: the key-split kernel; the launch table of the next test names it)
+            eng.lib.gn_debug_set_variant(eng.ctx, 43, 4)                             # its eight-wave form (two waves per SIMD; measured, not shipped)
+            out4 = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
             eng.lib.gn_debug_set_variant(eng.ctx, 43, 1)
             old = eng.debug_attention(q, k, v, nkv, cross, 0.125).cpu().numpy()
             eng.lib.gn_debug_set_variant(eng.ctx, 43, 0)
@@ -439,8 +441,9 @@ def test_exact_f32_key_split_attention_of_one_pair_against_fp64(state_dict_np, c
             for bs in range(2):
                 kvs = bs ^ 1 if cross else bs
                 if nk[kvs] == 0:
-                    assert not out[bs].any() and not old[bs].any()
+                    assert not out[bs].any() and not old[bs].any() and not out4[bs].any()
                     continue
+                assert rel(out4[bs], ref[bs]) < 5e-6, (nk, bs, rel(out4[bs], ref[bs]))
                 worst = max(worst, rel(out[bs], ref[bs]))
                 assert rel(out[bs], ref[bs]) < 5e-6 and rel(out[bs], old[bs]) < 2e-5, (nk, bs, rel(out[bs], ref[bs]), rel(out[bs], old[bs]))
     finally:
