@@ -177,6 +177,22 @@ def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
             assert not packed, (name, packed[:8])
 
 
+def test_late_round5_kernels_hold_their_operands_in_registers(tmp_path):
+    """DESIGN 12.8.  The kernels added late in round 5 win by keeping the NEXT tile in registers while the matrix pipe works on the current one:
+    k_attn_f32_ks (its first build, on 64-key tiles, held that tile in scratch memory: 528 bytes per lane), the prefetching forms of LoFTR's
+    convolutions at the rows-per-wave counts lf_conv launches for stride 1, and the 64-row exact-f32 GEMMs.  From the disassembly of the library
+    that ships: no spill, no scratch segment, the MFMAs there; the two-workgroups-per-CU forms within 256 registers."""
+    ks = _disassemble_kernels(tmp_path, ["k_attn_f32_ksILi4E", "k_gemm_f32_r64ILi", "k_gemm_f32_m64ILi", "k_lf_convILi3ELi1E", "k_lf_conv_hILi3ELi1E", "k_lf_conv1ILb0E"])
+    assert sum("k_attn_f32_ks" in n for n in ks) == 1 and sum("k_gemm_f32_r64" in n for n in ks) >= 12 and sum("k_lf_conv" in n for n in ks) >= 12, sorted(ks)
+    for name, (meta, ins) in ks.items():
+        assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0, (name, meta)
+        assert not any(op.startswith("scratch_") for op, _ in ins), name
+        if "k_lf_conv1" not in name:
+            assert sum(op.startswith("v_mfma") for op, _ in ins) >= 12, name
+        if re.search(r"k_lf_conv(_h)?ILi3ELi1ELi[12]ELi32ELb1E", name):     # prefetching forms at one / two rows per wave: two workgroups per CU
+            assert meta["vgpr_count"] <= 256, (name, meta["vgpr_count"])
+
+
 def test_product_path_has_no_cpu_fallback():
     from gisnav_amd import _lib
     from gisnav_amd.engine import PoseEngine
