@@ -657,20 +657,36 @@ __global__ __launch_bounds__(256) void k_lf_check_finite(const float* x, long lo
 __device__ __forceinline__ float lf_conf(float s, float rmax, float rsum, float cmax, float csum) {
   return (expf(s - cmax) / csum) * (expf(s - rmax) / rsum);
 }
+constexpr int kLfU = 5;       // loads in flight per thread in the passes over the similarity matrix
 // one block per row i: max and sum of exponentials over j < L
 __global__ __launch_bounds__(256) void k_lf_row_stats(const float* sim, int ld, int L, float temp, float* rmax, float* rsum) {
   __shared__ float red[8];
   const int i = blockIdx.x, tid = threadIdx.x;
   const float* row = sim + (long long)i * ld;
+  // (late round 5, here and in the four kernels below: a thread's loads are requested kLfU at a time before the first is used -- same elements in the
+  // same order per thread, so the same bits; with one load in flight per loop iteration these passes over the 92 MB matrix ran at 1.3-2.5 TB/s: k_lf_conf_colmax 74 -> 59 us, k_lf_col_stats 63 -> below 50,
+  // the row passes -3 us each; the same treatment of k_lf_fine_attn's staging loop bought nothing -- that kernel is bound by its LDS reads)
   float m = -INFINITY;
-  for (int j = tid; j < L; j += 256) m = fmaxf(m, row[j] / temp);
+  for (int j0 = tid; j0 < L; j0 += 256 * kLfU) {
+    float x[kLfU];
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) { const int j = j0 + 256 * u; x[u] = j < L ? row[j] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) if (j0 + 256 * u < L) m = fmaxf(m, x[u] / temp);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
-  for (int j = tid; j < L; j += 256) s += expf(row[j] / temp - m);
+  for (int j0 = tid; j0 < L; j0 += 256 * kLfU) {
+    float x[kLfU];
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) { const int j = j0 + 256 * u; x[u] = j < L ? row[j] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) if (j0 + 256 * u < L) s += expf(x[u] / temp - m);
+  }
   s = wsum(s);
   if ((tid & 63) == 0) red[4 + (tid >> 6)] = s;
   __syncthreads();
@@ -682,9 +698,16 @@ __global__ __launch_bounds__(256) void k_lf_col_stats(const float* sim, int ld, 
   if (j >= L) return;
   const int i0 = sp * rows_per, i1 = min(L, i0 + rows_per);
   float m = -INFINITY, s = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const float x = sim[(long long)i * ld + j] / temp;
-    if (x > m) { s = s * expf(m - x) + 1.f; m = x; } else s += expf(x - m);
+  for (int ib = i0; ib < i1; ib += 2 * kLfU) {
+    float xv[2 * kLfU];
+#pragma unroll
+    for (int u = 0; u < 2 * kLfU; ++u) xv[u] = ib + u < i1 ? sim[(long long)(ib + u) * ld + j] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * kLfU; ++u) {
+      if (ib + u >= i1) continue;
+      const float x = xv[u] / temp;
+      if (x > m) { s = s * expf(m - x) + 1.f; m = x; } else s += expf(x - m);
+    }
   }
   pmax[(long long)sp * L + j] = m; psum[(long long)sp * L + j] = s;
 }
@@ -704,7 +727,13 @@ __global__ __launch_bounds__(256) void k_lf_conf_rowmax(const float* sim, int ld
   const float* row = sim + (long long)i * ld;
   const float rm = rmax[i], rs = rsum[i];
   float m = 0.f;
-  for (int j = tid; j < L; j += 256) m = fmaxf(m, lf_conf(row[j] / temp, rm, rs, cmax[j], csum[j]));
+  for (int j0 = tid; j0 < L; j0 += 256 * kLfU) {
+    float x[kLfU], cm[kLfU], cs[kLfU];
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) { const int j = j0 + 256 * u; const bool in = j < L; x[u] = in ? row[j] : 0.f; cm[u] = in ? cmax[j] : 0.f; cs[u] = in ? csum[j] : 1.f; }
+#pragma unroll
+    for (int u = 0; u < kLfU; ++u) if (j0 + 256 * u < L) m = fmaxf(m, lf_conf(x[u] / temp, rm, rs, cm[u], cs[u]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -717,7 +746,13 @@ __global__ __launch_bounds__(256) void k_lf_conf_colmax(const float* sim, int ld
   const int i0 = sp * rows_per, i1 = min(L, i0 + rows_per);
   const float cm = cmax[j], cs = csum[j];
   float m = 0.f;
-  for (int i = i0; i < i1; ++i) m = fmaxf(m, lf_conf(sim[(long long)i * ld + j] / temp, rmax[i], rsum[i], cm, cs));
+  for (int ib = i0; ib < i1; ib += 2 * kLfU) {
+    float xv[2 * kLfU];
+#pragma unroll
+    for (int u = 0; u < 2 * kLfU; ++u) xv[u] = ib + u < i1 ? sim[(long long)(ib + u) * ld + j] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * kLfU; ++u) if (ib + u < i1) m = fmaxf(m, lf_conf(xv[u] / temp, rmax[ib + u], rsum[ib + u], cm, cs));
+  }
   part[(long long)sp * L + j] = m;
 }
 __global__ __launch_bounds__(256) void k_lf_max_merge(const float* part, int nsplit, int L, float* out) {
@@ -739,10 +774,21 @@ __global__ __launch_bounds__(256) void k_lf_mutual(const float* sim, int ld, int
   const float* row = sim + (long long)i * ld;
   const float rm = rmax[i], rs = rsum[i], cr = crow[i];
   if (in_i)
-    for (int j = tid; j < L; j += 256) {
-      const float c = lf_conf(row[j] / temp, rm, rs, cmax[j], csum[j]);
-      const int yj = j / wc, xj = j - yj * wc;
-      if (c > thr && c == cr && c == ccol[j] && yj >= border && yj < hc - border && xj >= border && xj < wc - border) atomicMin(&best, j);
+    for (int j0 = tid; j0 < L; j0 += 256 * kLfU) {
+      float x[kLfU], cm[kLfU], cs[kLfU], cc[kLfU];
+#pragma unroll
+      for (int u = 0; u < kLfU; ++u) {
+        const int j = j0 + 256 * u; const bool in = j < L;
+        x[u] = in ? row[j] : 0.f; cm[u] = in ? cmax[j] : 0.f; cs[u] = in ? csum[j] : 1.f; cc[u] = in ? ccol[j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kLfU; ++u) {
+        const int j = j0 + 256 * u;
+        if (j >= L) continue;
+        const float c = lf_conf(x[u] / temp, rm, rs, cm[u], cs[u]);
+        const int yj = j / wc, xj = j - yj * wc;
+        if (c > thr && c == cr && c == cc[u] && yj >= border && yj < hc - border && xj >= border && xj < wc - border) atomicMin(&best, j);
+      }
     }
   __syncthreads();
   if (tid == 0) {

@@ -375,7 +375,13 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * (0 = tiled GEMM, 2 = force at any batch size), 20 k_qkv phase stamps, 21 SuperPoint split-fp16 convolutions, 23 largest number of key ranges the
  * attention of a small batch is split into (default 1 = never; 4 gives -5 % latency at batch 1 but rounds the probabilities per split), 25 start the guard word of sub-batch group value - 1 raised (tests).  Knob 1 (attention) values: 4 default,
  * 43 / 44 / 45 / 46 / 48 rejected variants kept for A/B timing, 51-55 timing probes with WRONG results, 56 the exact running maximum in every key
- * tile (the path a workgroup of the default kernel falls back to).  A bench line run with any knob set records it in `debug_variant`. */
+ * tile (the path a workgroup of the default kernel falls back to).  A bench line run with any knob set records it in `debug_variant`.
+ * Process-wide knobs of late round 5 (every context; the shipped value is 0 unless noted): 41 largest 128 x 128 grid the exact-f32 GEMM leaves to 64-row
+ * tiles (320; 0 = never), 42 LoFTR forms of rounds 3-4 (bit 0 staging without the register prefetch, bit 1 fine level over all max_matches windows
+ * with interleaved sides, bit 2 the stem with [channel][tap] weights, bit 3 multiply the zero-padding channel steps; bits 8.. the overhead term of the
+ * rows-per-wave cost model x 100), 43 exact-f32 attention of one or two pairs (bits 0-1: 0 = k_attn_f32_ks, 1 = k_attn_f32 always, 2 = k_attn_f32_ks
+ * always; bit 2 its eight-wave form), 44 exact-f32 GEMM on 64 x 64 tiles (1 = for grids of at most 128 workgroups on 64 x 128 tiles, 0 = never,
+ * 2 = the four-slot-ring kernel on 64 x 128 tiles everywhere).  All of them select between forms with identical results except 43 (f32 rounding). */
 int gn_debug_set_variant(gn_ctx* ctx, int which, int value);
 int gn_debug_mfma_probe(gn_ctx* ctx, int blocks, int iters, void* stream);
 /* LDS-DMA addressing probe (80 KB of LDS per block filled by global_load_lds, verified by ds_read):

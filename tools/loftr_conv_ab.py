@@ -27,5 +27,7 @@ for knob in knobs:
     res = tuple(out[k].cpu() for k in ("keypoints0", "keypoints1", "confidence"))
     same = "-" if ref is None else str(all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(ref, res)))
     if ref is None: ref = res
-    print(f"knob42 {knob:6d} (prefetch {'off' if knob & 1 else 'on'}, overhead {(knob >> 8) * 0.01 if knob >> 8 else (0.75 if knob & 1 else 0.25):.2f}): {dt:.3f} ms per pair, matches {int(res[0].shape[0])}, bitwise equal to the first variant: {same}", flush=True)
+    import hashlib
+    digest = hashlib.sha256(b"".join(t.numpy().tobytes() for t in res)).hexdigest()[:12]
+    print(f"[outputs sha256 {digest}] knob42 {knob:6d} (prefetch {'off' if knob & 1 else 'on'}, overhead {(knob >> 8) * 0.01 if knob >> 8 else (0.75 if knob & 1 else 0.25):.2f}): {dt:.3f} ms per pair, matches {int(res[0].shape[0])}, bitwise equal to the first variant: {same}", flush=True)
     del m2
