@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_lf_conv1(const float* in, const float* 
   __shared__ __attribute__((aligned(16))) float ws[128 * 49 + 256];
   for (int q = threadIdx.x; q < 128 * 49 + 256; q += 256) {
     float x;
-    if (q < 128 * 49) x = OLD ? w[q] : w[(q & 127) * 49 + (q >> 7)];
+    if (q < 128 * 49) x = OLD ? w[q] : w[128 * 49 + q];       // (the [tap][channel] copy lf_finalise put behind the [channel][tap] one)
     else x = q < 128 * 49 + 128 ? scale[q - 128 * 49] : shift[q - 128 * 49 - 128];
     ws[q] = x;
   }
@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void k_lf_conv1(const float* in, const float* 
       *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
     }
   } else {
+    // lane (pixel, grp) owns the channels 32 c4 + 4 grp .. + 3, c4 = 0 .. 3: the eight lanes of a pixel read 128 contiguous bytes of a tap's weights
+    // and store 128 contiguous bytes of the pixel's row per instruction (with 16 channels in a row per lane every store instruction wrote 16 bytes
+    // out of every 64)
     f32x4 acc[4];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) acc[c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -76,17 +79,18 @@ __global__ __launch_bounds__(256) void k_lf_conv1(const float* in, const float* 
     for (int t = 0; t < 49; ++t)
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + t * 128 + grp * 16 + c4 * 4);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + t * 128 + c4 * 32 + grp * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c4][e] = fmaf(w4[e], v[t], acc[c4][e]);
       }
+    float* const op = out + ((long long)blockIdx.z * Ho * Wo + pix) * 128 + grp * 4;
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + grp * 16 + c4 * 4), sh = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + 128 + grp * 16 + c4 * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + c4 * 32 + grp * 4), sh = *reinterpret_cast<const f32x4*>(ws + 128 * 49 + 128 + c4 * 32 + grp * 4);
       f32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[c4][e] * sc[e] + sh[e], 0.f);
-      *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+      *reinterpret_cast<f32x4*>(op + c4 * 32) = r;
     }
   }
 }
@@ -980,7 +984,15 @@ int lf_finalise(gn_loftr* ctx) {
     }
     int rc = lf_upload(ctx, &c.scale, scale.data(), scale.size()); if (rc != GN_OK) return rc;
     rc = lf_upload(ctx, &c.shift, shift.data(), shift.size()); if (rc != GN_OK) return rc;
-    if (ci == 0) { rc = lf_upload(ctx, &c.wf, c.hw.data(), c.hw.size()); if (rc != GN_OK) return rc; continue; }   // stem: [128][49] as it is
+    if (ci == 0) {   // stem: [128][49] as it is, and behind it the same weights as [49][128] (what k_lf_conv1<false> keeps in LDS: a coalesced copy instead of a strided gather per workgroup)
+      if (c.hw.size() != (size_t)128 * 49) return lf_fail(ctx, GN_ERR_SHAPE, "backbone.conv1.weight: expected [128][1][7][7]");
+      std::vector<float> both(c.hw);
+      both.resize(2 * c.hw.size());
+      for (int o = 0; o < 128; ++o)
+        for (int t = 0; t < 49; ++t) both[128 * 49 + t * 128 + o] = c.hw[(size_t)o * 49 + t];
+      rc = lf_upload(ctx, &c.wf, both.data(), both.size()); if (rc != GN_OK) return rc;
+      continue;
+    }
     std::vector<float> wp((size_t)c.cout * c.cin_p * taps, 0.f);     // input channels padded with zeros
     for (int o = 0; o < c.cout; ++o)
       for (int i = 0; i < c.cin; ++i)
