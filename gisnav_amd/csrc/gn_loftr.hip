@@ -115,7 +115,12 @@ struct LfConvArgs {
 // PF (round 5): the halo tile of the NEXT channel slice is requested into registers behind the first tap of the current one and written to
 // LDS at the slice boundary -- with one or two workgroups per CU nothing else hid the global latency of the staging pass (~7 us per slice
 // beside ~17 us of MFMAs at RPW = 2; profiles/r05e_loftr_layers_exact_f32.txt); same values in the same LDS places: bitwise the same output
-template <int KS, int S, int RPW, int CH, bool PF>
+// FAST (late round 5): every output-channel group has both 32-channel tiles and every 32-channel slice is whole (Cout % 64 == 0, real Cin % 32 == 0:
+// LoFTR's 128- and 256-channel layers) -- the MFMA stream of a tap is then ONE basic block: counters showed the matrix pipe busy 0.60-0.71 at 2.3 GHz, and
+// the disassembly why: the run-time tests of `two` and of the channel-step limit sat between the MFMAs, so every 32-channel step began with its two
+// ds_read_b128 and waited for them (the scheduler does not move loads across branches).  FAST requests the next step's fragments before the current
+// step's MFMAs.  Same MFMAs in the same order: same bits.
+template <int KS, int S, int RPW, int CH, bool PF, bool FAST = false>
 __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_conv(LfConvArgs a) {
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int TH = 4 * RPW, LH = (TH - 1) * S + KS, LW = 31 * S + KS, NCH = CH / 4;
@@ -124,11 +129,11 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
   const int hh = lane >> 5, ql = lane & 31;
   const int ogroups = (a.Cout + 63) / 64;
   const int img = blockIdx.z / ogroups, og = blockIdx.z % ogroups;
-  const bool two = 64 * og + 32 < a.Cout;                   // the last group of a 32 (mod 64) channel count has one tile
+  const bool two = FAST || 64 * og + 32 < a.Cout;           // the last group of a 32 (mod 64) channel count has one tile
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH;
   const int gy0 = y0 * S - PAD, gx0 = x0 * S - PAD;
   const float* in = a.in + (long long)img * a.Hin * a.Win * a.Cin;
-  const int csteps = a.Cin / 8, rsteps = (a.cin_real + 7) / 8;
+  const int csteps = a.Cin / 8, rsteps = FAST ? csteps : (a.cin_real + 7) / 8;
   const f32x4* wf = reinterpret_cast<const f32x4*>(a.wf) + lane;
   auto sw = [](int lx) { const int u = lx / S; return (u ^ (u >> 3)) & (NCH - 1); };
 
@@ -148,9 +153,9 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
   auto load_w = [&](f32x4 (&w)[NS][2], int c0_, int tap_) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (c0_ / 8 + s >= rsteps) continue;
+      if (!FAST && c0_ / 8 + s >= rsteps) continue;
       w[s][0] = wf[(size_t)(((2 * og) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
-      if (two) w[s][1] = wf[(size_t)(((2 * og + 1) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
+      if (FAST || two) w[s][1] = wf[(size_t)(((2 * og + 1) * TAPS + tap_) * csteps + (c0_ / 8 + s)) * 64];
     }
   };
   load_w(wcur, 0, 0);
@@ -214,6 +219,28 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
       const bool last_tap = tap + 1 == TAPS;
       if (!last_tap || c0 + CH < a.Cin) load_w(wnxt, last_tap ? c0 + CH : c0, last_tap ? 0 : tap + 1);
       if (PF && tap == 0 && c0 + CH < a.Cin) fetch(c0 + CH);     // behind the next tap's weights: it has two taps of MFMAs to land in
+      if (FAST) {
+        f32x4 fb2[2][RPW];
+        auto read_fb = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            const int ly = (RPW * wave + j) * S + ty, lx = ql * S + tx;
+            fb2[buf][j] = *reinterpret_cast<const f32x4*>(tile + (ly * LW + lx) * CH + (((2 * s + hh) ^ sw(lx)) * 4));
+          }
+        };
+        read_fb(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (s + 1 < NS) read_fb((s + 1) & 1, s + 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+              acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][0][e], fb2[s & 1][j][e], acc[0][j], 0, 0, 0);
+              acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][1][e], fb2[s & 1][j][e], acc[1][j], 0, 0, 0);
+            }
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         if (c0 / 8 + s >= rsteps) continue;
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(256, (PF && RPW <= 2 && S == 1) ? 2 : 1) void k_lf_
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][0][e], fb[j][e], acc[0][j], 0, 0, 0);
             if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][1][e], fb[j][e], acc[1][j], 0, 0, 0);
           }
+      }
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) { wcur[s][0] = wnxt[s][0]; wcur[s][1] = wnxt[s][1]; }
@@ -1033,6 +1061,7 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
   // ceil(workgroups / 256) rounds of RPW units each -- pick the RPW with the fewest units (layer1 at 240x320: 600 workgroups = 3 rounds of 4
   // against 1200 = 5 rounds of 2; the 1/8-resolution layers fill 96 CUs with RPW = 4 and 192 with 2)
   // (+ 0.75: the halo rows, the weight stream and the prologue a workgroup pays whatever its height -- without it RPW = 1 wins ties it loses on the GPU)
+  const bool fast = !(gn::g_lf_conv_knob & 16) && c.cout_p % 64 == 0 && a.cin_real % 32 == 0 && a.cin_real == c.cin_p;     // k_lf_conv<.., FAST> (knob 42 bit 4: off)
   const bool pf = !(gn::g_lf_conv_knob & 1);                                   // developer knob 42, bit 0: the staging form of rounds 3-4
   const double ovh = (gn::g_lf_conv_knob >> 8) ? (gn::g_lf_conv_knob >> 8) * 0.01 : (pf ? 0.25 : 0.75);    // bits 8..: the per-workgroup overhead of the cost model, in 1/100 units
   auto units = [&](int rpw) { const long long wg = (long long)((a.Wout + 31) / 32) * ((a.Hout + 4 * rpw - 1) / (4 * rpw)) * N * og; return (double)((wg + 255) / 256) * (rpw + ovh); };
@@ -1044,6 +1073,7 @@ void lf_conv(gn_loftr* ctx, const char* name, const float* in, int N, int Hin, i
     if (units(1) < units(rpw)) rpw = 1;
 #define LF_LAUNCH(KS_, S_, R_, C_) do { if (hm && pf) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_, true>), grid(R_), blk, 0, s, a); \
                                         else if (hm) hipLaunchKernelGGL((k_lf_conv_h<KS_, S_, R_, C_, false>), grid(R_), blk, 0, s, a); \
+                                        else if (pf && fast) hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_, true, true>), grid(R_), blk, 0, s, a); \
                                         else if (pf) hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_, true>), grid(R_), blk, 0, s, a); \
                                         else hipLaunchKernelGGL((k_lf_conv<KS_, S_, R_, C_, false>), grid(R_), blk, 0, s, a); } while (0)
     if (c.ks == 3) {

@@ -378,7 +378,7 @@ int gn_get_stage_ms(gn_ctx* ctx, float* host_ms, int max_stages);
  * tile (the path a workgroup of the default kernel falls back to).  A bench line run with any knob set records it in `debug_variant`.
  * Process-wide knobs of late round 5 (every context; the shipped value is 0 unless noted): 41 largest 128 x 128 grid the exact-f32 GEMM leaves to 64-row
  * tiles (320; 0 = never), 42 LoFTR forms of rounds 3-4 (bit 0 staging without the register prefetch, bit 1 fine level over all max_matches windows
- * with interleaved sides, bit 2 the stem with [channel][tap] weights, bit 3 multiply the zero-padding channel steps; bits 8.. the overhead term of the
+ * with interleaved sides, bit 2 the stem with [channel][tap] weights, bit 3 multiply the zero-padding channel steps, bit 4 no branch-free MFMA stream for the 128- / 256-channel layers; bits 8.. the overhead term of the
  * rows-per-wave cost model x 100), 43 exact-f32 attention of one or two pairs (bits 0-1: 0 = k_attn_f32_ks, 1 = k_attn_f32 always, 2 = k_attn_f32_ks
  * always; bit 2 its eight-wave form), 44 exact-f32 GEMM on 64 x 64 tiles (1 = for grids of at most 128 workgroups on 64 x 128 tiles, 0 = never,
  * 2 = the four-slot-ring kernel on 64 x 128 tiles everywhere).  All of them select between forms with identical results except 43 (f32 rounding). */
