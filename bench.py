@@ -164,15 +164,44 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
             "method": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {n_steps} steps of this script; bytes = 2 x FETCH_SIZE + WRITE_SIZE"}, None
 
 
-def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev):
+CERT_SAFETY = 4.0
+
+
+def certify_on(eng, kpts, batch, precision, certify=True):
+    """The margin certificate for a fast-mode engine (gn_set_certify(2)): eps is CALIBRATED for these weights on four pairs that are not part of any
+    timed batch (max |P_mode - P_f32| over the deciding entries x CERT_SAFETY), then every estimate() call synchronises once, reads its per-pair
+    flags and re-runs the flagged pairs on the exact-f32 kernels -- inside the timed region.  Returns the calibration record (None: f32 / off)."""
+    if precision == "f32" or not certify:
+        return None
+    cal_pairs = [make_pair(900_000 + i, n_q=kpts, n_r=kpts) for i in range(min(4, batch))]
+    cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=CERT_SAFETY)
+    eng.set_certify("rerun")
+    return cal
+
+
+def certificate_block(eng, cal):
+    if cal is None:
+        return None
+    st = eng.certify_stats()
+    return {"mode": "margin guard + exact-f32 re-run of the flagged pairs (gn_set_certify(2)); one stream synchronisation per call, inside the timed region",
+            "eps": cal["eps"], "eps_measured_max_dP": cal["measured"], "safety_factor": cal["safety"],
+            "calls": st["calls"], "pairs": st["pairs"], "pairs_flagged_margin": st["flagged_margin"], "pairs_flagged_fp16_range": st["flagged_fp16_range"],
+            "pairs_rerun_in_f32": st["rerun_pairs"], "rerun_fraction": round(st["rerun_fraction"], 6), "rerun_pairs_marginal_even_in_f32": st["f32_marginal_pairs"]}
+
+
+def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev, certify=True, substreams=1):
     """One further configuration, timed like the main one (no per-kernel events, no collectives needed: every rank runs it)."""
     eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision=precision, state_dict=sd)
+    cal = certify_on(eng, kpts, batch, precision, certify)
+    if substreams > 1:
+        eng.set_substreams(substreams)
     pairs = [make_pair(i, n_q=kpts, n_r=kpts) for i in range(batch)]
     inp = eng.stage_inputs(pairs)
     out = eng.alloc_outputs(batch)
     torch.cuda.synchronize()
     elapsed, _ = timed_steps(eng, inp, out, steps, warmup, dev)
     ok = int(out["ok"].sum().item())
+    cert = certificate_block(eng, cal)
     del eng
     torch.cuda.empty_cache()
     g, _ = gflop_per_pair(kpts, kpts)
@@ -180,10 +209,11 @@ def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev):
     peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
     return {"config": name, "batch": batch, "keypoints_per_side": kpts, "precision": precision, "steps": steps, "warmup": warmup,
             "value": round(pps, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 4), "poses_ok_per_step": ok,
-            "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak}
+            "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak,
+            "index_exact": "exact-f32 arithmetic" if precision == "f32" else "certified (margin guard, f32 re-run)" if cert else "tolerance mode", "certificate": cert}
 
 
-def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=400, hi=2500, bucket=8):
+def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=400, hi=2500, bucket=8, certify=True):
     """A ragged batch: `cv2.SIFT_create()` is unbounded (pose_node.py:122), so N and M differ per message.  `batch` pairs with N, M ~ U(lo, hi)
     per side: (a) ONE gn_estimate call padded to the batch maximum, (b) the length-bucketing scheduler (PoseEngine.estimate_bucketed: groups of `bucket`
     pairs sorted by length, each padded to its own maximum).  Same poses either way."""
@@ -191,6 +221,7 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
     nq = rs.integers(lo, hi + 1, batch); nr = rs.integers(lo, hi + 1, batch)
     kmax = ((int(max(nq.max(), nr.max())) + 127) // 128) * 128
     eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kmax, precision=precision, state_dict=sd)
+    cal = certify_on(eng, 1024, batch, precision, certify)
     pairs = [make_pair(500 + i, n_q=int(nq[i]), n_r=int(nr[i])) for i in range(batch)]
     inp = eng.stage_inputs(pairs)
     n_q = np.array([len(p.kp_q) for p in pairs]); n_r = np.array([len(p.kp_r) for p in pairs])
@@ -222,6 +253,7 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
     same = bool(torch.equal(out_a["ok"], out_b["ok"]) and torch.equal(out_a["n_match"], out_b["n_match"]) and
                 float((out_a["R"] - out_b["R"]).abs().max()) < 1e-6)
     ok = int(out_b["ok"].sum().item())
+    cert = certificate_block(eng, cal)
     del eng
     torch.cuda.empty_cache()
     real = stats["real_tokens"]
@@ -234,7 +266,8 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
                                 "padded_tokens": stats["padded_tokens_bucketed"], "padding_waste": round(1.0 - real / stats["padded_tokens_bucketed"], 4),
                                 "group_sizes_tried": tried},
             "value": round(batch / min(t_one, t_bkt), 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(min(t_one, t_bkt) * 1e3, 3),
-            "poses_ok_per_step": ok, "same_results_both_ways": same}
+            "poses_ok_per_step": ok, "same_results_both_ways": same,
+            "index_exact": "certified (margin guard, f32 re-run)" if cert else "tolerance mode", "certificate": cert}
 
 
 def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, kpts=1024, arithmetic="split_fp16"):
@@ -409,42 +442,38 @@ def run_extra_loftr(local_rank, steps, warmup, dev, h=480, w=640, fine=True, gra
     return res
 
 
-def precision_guarantee(precision: str) -> dict:
-    """Index-mismatch counts of the precision mode against the CPU restatement of the reference -- READ from the report the -m gpu parity tests wrote
-    (tests/test_gpu_round5.py -> gpurun_out/parity_r05.json, committed as profiles/r05_parity_report.json), never typed in: the report carries the
-    digest of the sources it was measured on and `same_build` says whether that is the library this run loaded."""
-    from gisnav_amd.build import source_digest
-    out = {"mode": precision, "index_exact": "guaranteed" if precision == "f32" else "tolerance mode",
-           "note": "north_star asks for bit-exact correspondence indices: GN_PREC_F32 guarantees them (f32 MFMA everywhere; extra_configs carries its batch-32 "
-                   "throughput).  The headline mode computes in the reference's CUDA arithmetic class (fp32-accurate linear layers except the two-product q/k/v "
-                   "projections named in `dtype`, half-precision SDPA); counts below are symmetric differences of the match sets, headline KERNELS "
-                   "(k_qkv<.,.,2> + k_attn_pw + composed k_ffn128, asserted from the launch table), against the CPU restatement of the reference (tests' checker)",
-           "library_source_digest": source_digest()}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_parity_report.json")
+def precision_guarantee(precision: str, cert=None) -> dict:
+    """What this run can say about `north_star`'s "correspondence indices bit-exact", and the evidence behind it -- READ from the report the -m gpu
+    parity tests wrote (tests/test_gpu_round6.py -> gpurun_out/parity_r06.json, committed as profiles/r06_parity_report.json), never typed in.  The
+    report carries the source digest of the LIBRARY it was measured on (gn_source_digest, compiled into the binary); `same_build` compares it with the
+    digest of the library THIS run loaded."""
+    from gisnav_amd import _lib
+    exact = "exact-f32 arithmetic (empirically index-exact: f32_evidence)" if precision == "f32" else \
+        "certified (margin guard, f32 re-run)" if cert else "tolerance mode"
+    out = {"mode": precision, "index_exact": exact, "certificate": cert,
+           "note": "north_star asks for bit-exact correspondence indices (pose_node.py:285-297 uses them as integers).  The fast mode computes the assignment "
+                   "scores with an arithmetic error; with the certificate on, the match head keeps the runner-up of every row / column maximum, flags every "
+                   "pair in which a decision lies within eps (calibrated: max |P_mode - P_f32| x safety) of flipping -- or whose activations left the fp16 "
+                   "range -- and the flagged pairs are run again on the exact-f32 kernels before the call returns.  Counts below: symmetric differences of "
+                   "the match sets against the CPU restatement of the reference (the tests' checker; itself UNPINNED against kornia, DESIGN 2), on the "
+                   "headline kernels (asserted from the launch table)",
+           "library_source_digest": _lib.library_digest()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_parity_report.json")
     try:
         with open(path) as f:
             rep = json.load(f)
     except (OSError, ValueError) as exc:
         out["report"] = f"not available ({exc.__class__.__name__}): no counts are claimed for this run"
         return out
-    out["report"] = "profiles/r05_parity_report.json"
+    out["report"] = "profiles/r06_parity_report.json"
     out["report_source_digest"] = rep.get("source_digest")
     out["same_build"] = rep.get("source_digest") == out["library_source_digest"]
-
-    def frac(row):
-        return f"{row['index_mismatches']} / {row['cpu_matches']}" if isinstance(row, dict) and "index_mismatches" in row else None
-    counts = {}
-    for key in ("forced_4x512_low_margin", "forced_4x512_mid_margin"):
-        t = rep.get(key) or {}
-        counts[key] = {k: frac(v) for k, v in t.items() if frac(v)}
-    for key in ("bulk_16x1024_low_margin", "bulk_16x1024_mid_margin"):
-        counts[key] = frac(rep.get(key))
-    rag = rep.get("ragged_16_pairs_u400_2500") or {}
-    counts["ragged_16_pairs_u400_2500_margin_built_weights"] = {k: frac(v) for k, v in rag.items() if frac(v)}
-    out["index_mismatches_vs_cpu_restatement"] = counts
-    out["source"] = "tests/test_gpu_round5.py (asserted: f32 = 0; headline kernels <= 1 % on low- / mid-margin weights, <= 0.1 % on the ragged bulk batch)"
+    keep = ("eps", "safety", "cpu_matches", "uncertified_index_mismatches", "certified_index_mismatches", "pairs", "pairs_flagged", "rerun_fraction", "f32_marginal_pairs")
+    out["certified_tables"] = {k[len("certified_"):]: {f: v.get(f) for f in keep} for k, v in rep.items() if k.startswith("certified_") and isinstance(v, dict)}
+    out["f32_evidence"] = {k[len("f32_"):]: v for k, v in rep.items() if k.startswith("f32_") and isinstance(v, dict)}
+    out["source"] = "tests/test_gpu_round6.py (asserted: certified = 0 mismatches and no wrong pair unflagged on every table; f32 = 0) + tools/f32_exactness_sweep.py"
     if not out["same_build"]:
-        out["warning"] = "the report was measured on other sources than the library this run loaded: re-run `pytest -m gpu tests/test_gpu_round5.py` and copy gpurun_out/parity_r05.json"
+        out["warning"] = "the report was measured on another build than the library this run loaded: re-run `pytest -m gpu tests/test_gpu_round6.py` and copy gpurun_out/parity_r06.json"
     return out
 
 
@@ -579,6 +608,8 @@ def main() -> None:
     ap.add_argument("--debug-variant", action="append", default=[], metavar="WHICH:VALUE",
                     help="developer knob: gn_debug_set_variant(which, value) before the run (timing experiments; RECORDED in the JSON line, "
                          "a line with a non-empty debug_variant is not a valid measurement)")
+    ap.add_argument("--no-certify", action="store_true", help="run the fast precision mode WITHOUT the margin certificate (gn_set_certify): round 5's tolerance-mode "
+                                                              "number; the line then says index_exact: tolerance mode")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
@@ -640,6 +671,7 @@ def main() -> None:
     for kv in args.debug_variant:
         which, value = (int(v) for v in kv.split(":"))
         eng.lib.gn_debug_set_variant(eng.ctx, which, value)
+    cert_cal = certify_on(eng, args.kpts, args.batch, args.precision, certify=not args.no_certify)
 
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
     shard = gdist.shard_range(args.batch * world, rank, world)
@@ -671,6 +703,7 @@ def main() -> None:
     else:
         elapsed, mine = elapsed1, _
     tripped, trips = eng.guard_status()
+    cert_main = certificate_block(eng, cert_cal)
 
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
     n_match_mean = float(out["n_match"].float().mean().item())
@@ -700,14 +733,18 @@ def main() -> None:
     if not args.no_extras and not args.debug_variant and world == 1:   # per-GPU side configurations: reported by the N = 1 line; an N > 1 run times the sharded headline only
         extras.append(run_extra(local_rank, sd, "BASELINE configs[1] as SURVEY.md reads it: batch-1 640x480 pair, f32 everywhere (exact-f32 MFMA GEMMs and attention)",
                                 1, args.kpts, "f32", 30, 5, dev))
-        extras.append(run_extra(local_rank, sd, "BASELINE configs[2] with exact-f32 MFMA projections/FFN (no fp16 split) + bf16 MFMA attention",
-                                args.batch, args.kpts, "bf16_attn", 6, 2, dev))
+        extras.append(run_extra(local_rank, sd, "BASELINE configs[2] with exact-f32 MFMA projections/FFN (no fp16 split) + bf16 MFMA attention (a tolerance mode: no certificate)",
+                                args.batch, args.kpts, "bf16_attn", 6, 2, dev, certify=False))
+        if cert_cal is not None:
+            extras.append(run_extra(local_rank, sd, "the headline configuration WITHOUT the certificate (round 5's tolerance-mode number: no per-call synchronisation, no re-run)",
+                                    args.batch, args.kpts, args.precision, 20, 3, dev, certify=False, substreams=nsub))
         extras.append(run_extra(local_rank, sd, f"BASELINE configs[2] in the GUARANTEED mode: batch-{args.batch}, f32 everywhere (exact-f32 MFMA GEMMs and attention) -- "
-                                                "correspondence indices bit-exact against the CPU restatement of the reference on every weight set tested, low-margin ones included",
+                                                "the arithmetic the certificate re-runs flagged pairs in; correspondence indices identical to the CPU restatement of the reference on every "
+                                                "weight set tested (counts: precision_guarantee.f32_evidence)",
                                 args.batch, args.kpts, "f32", 3, 1, dev))
-        extras.append(run_extra_ragged(local_rank, sd, args.batch, args.precision, 5, 2, dev))
+        extras.append(run_extra_ragged(local_rank, sd, args.batch, args.precision, 5, 2, dev, certify=not args.no_certify))
         extras.append(run_extra(local_rank, sd, "batch-1 640x480 pair in the headline precision (latency of one ROS message, SURVEY F5)",
-                                1, args.kpts, args.precision, 30, 5, dev))
+                                1, args.kpts, args.precision, 30, 5, dev, certify=not args.no_certify))
         extras.append(run_extra_loftr(local_rank, 10, 2, dev))
         extras.append(run_extra_loftr(local_rank, 10, 2, dev, arithmetic="split_fp16"))
         extras.append(run_extra_superpoint(local_rank, 4, 2, 1, dev))
@@ -760,7 +797,7 @@ def main() -> None:
                                         "products -- the fp16 high term of the activations (11 bits) times the 22-bit weights, one rounding more than half(fp32 Linear(x)); "
                                         "their outputs are rounded to fp16 for the attention either way (10.5 % of the q/k/v values move by one fp16 ulp, DESIGN 10.3) --; "
                                         "fp16 MFMA attention (q, k, v, p rounded to fp16 like the reference's CUDA SDPA; f32 softmax / accumulate)"}[args.precision],
-            "precision_guarantee": precision_guarantee(args.precision),
+            "precision_guarantee": precision_guarantee(args.precision, cert_main),
             "data": "synthetic",
             "inputs_resident": True,
             "debug_variant": list(args.debug_variant),

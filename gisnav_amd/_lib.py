@@ -45,6 +45,12 @@ SIGNATURES = {
     "gn_set_deferred_join": (C.c_int, [VP, C.c_int]),
     "gn_set_guard": (C.c_int, [VP, C.c_int]),
     "gn_get_guard_status": (C.c_int, [VP, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "gn_set_certify": (C.c_int, [VP, C.c_int, C.c_float, C.c_float]),
+    "gn_get_certify_stats": (C.c_int, [VP, c_i64p]),
+    "gn_reset_certify_stats": (C.c_int, [VP]),
+    "gn_calibrate_certify": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, VP]),
+    "gn_get_uncertain": (C.c_int, [VP, C.c_int, c_i32p, VP]),
+    "gn_source_digest": (C.c_char_p, []),
     "gn_vo_match": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP, VP, VP, VP, VP]),
     "gn_vo_estimate": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, c_f64p, C.c_double, C.c_int,
                                  VP, VP, VP, VP, VP, VP]),
@@ -121,8 +127,19 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    # the binary must be the one these sources build: a git-ignored .so travels with the tree, and a stale one would silently run
+    # yesterday's kernels.  GISNAV_AMD_ALLOW_STALE=1 is for developer A/B builds (tools/slp_variants.sh).
+    from .build import source_digest
+    have, want = (lib.gn_source_digest() or b"").decode(), source_digest()
+    if have != want and os.environ.get("GISNAV_AMD_ALLOW_STALE") != "1":
+        raise GnError(f"{LIB_PATH} was built from other sources (library digest {have}, tree digest {want}): run `python -m gisnav_amd.build`")
     _lib = lib
     return lib
+
+
+def library_digest() -> str:
+    """The source digest compiled into the LOADED library (gn_source_digest)."""
+    return (load().gn_source_digest() or b"").decode()
 
 
 def check(ctx, rc: int, what: str) -> None:

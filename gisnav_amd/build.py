@@ -68,6 +68,25 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+BUILD_ID_SRC = os.path.join(CSRC, "gn_build_id.hip")
+BUILD_ID_OBJ = os.path.join(CSRC, "gn_build_id.o")
+BUILD_ID_STAMP = os.path.join(CSRC, "gn_build_id.stamp")
+
+
+def _build_id(digest: str, verbose: bool) -> bool:
+    """Compile the digest into the library (gn_source_digest).  Returns True when the object was (re)built."""
+    have = open(BUILD_ID_STAMP).read().strip() if os.path.exists(BUILD_ID_STAMP) else ""
+    if have == digest and os.path.exists(BUILD_ID_OBJ):
+        return False
+    cmd = [_hipcc(), *FLAGS, f'-DGN_SOURCE_DIGEST="{digest}"', "-c", BUILD_ID_SRC, "-o", BUILD_ID_OBJ]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(BUILD_ID_STAMP, "w") as f:
+        f.write(digest + "\n")
+    return True
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, "gn_common.h"), os.path.join(HERE, "..", "include", "gisnav_amd.h")]
     objs = []
@@ -84,7 +103,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
-    if force or procs or _stale(LIB, objs):
+    new_id = _build_id(source_digest(), verbose)
+    objs.append(BUILD_ID_OBJ)
+    if force or procs or new_id or _stale(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)

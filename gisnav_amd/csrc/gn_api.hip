@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
+#include <memory>
 
 using namespace gn;
 
@@ -62,6 +64,15 @@ struct gn_ctx {
   int ovf_groups_last = 1; // number of group words the most recent matcher call used (gn_get_guard_status ORs exactly those)
   int guard = 1;           // 0 off, 1 flag (a tripped call reports zero matches), 2 flag + synchronous re-run in the f32x3 mode
   long long guard_trips = 0;   // calls that tripped (counted when observed: guard 2, or gn_get_guard_status)
+  // margin certificate (gn_set_certify): the match head keeps the runner-up of every row / column maximum and flags, per PAIR, a decision that
+  // lies within cert_eps of flipping; mode 2 reads the flags back once per call (one stream synchronisation) and re-runs the flagged pairs in the
+  // exact-f32 arithmetic (GN_PREC_F32's kernels on this context's f32 weights and f32 workspaces), which also takes over the fp16-range fallback
+  int certify = 0;             // 0 off, 1 flags only (gn_get_uncertain), 2 flags + f32 re-run of the flagged pairs
+  float cert_eps = 4.0e-3f;    // stated bound on |P_mode - P_exact| for this context's arithmetic (tools/certify_eps.py measures it)
+  float cert_eps_f32 = 1.0e-4f;   // the same for the exact-f32 kernels (GPU f32 against the torch-CPU f32 oracle: summation order only)
+  float* max0b = nullptr; float* rpart_c = nullptr; int32_t* uncert = nullptr; int32_t* uncert_host = nullptr;   // uncert_host: pinned [max_batch]
+  bool cert_inner = false;     // a certificate re-run is being enqueued (no nested certification)
+  long long cert_calls = 0, cert_pairs = 0, cert_flag_margin = 0, cert_flag_range = 0, cert_rerun = 0, cert_f32_marginal = 0;
   int attn_f16 = 0;        // GN_PREC_F16X2_F16_ATTN: q | k rows, V^T panels and the probabilities are fp16 instead of bf16 (precision itself reads F16X2_BF16_ATTN)
   int precision_api = 0;   // the gn_precision value gn_create was called with
   int feature = 0;         // GN_FEATURE_SIFT / GN_FEATURE_SUPERPOINT (gn_create_ex)
@@ -717,6 +728,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     hd.rowmax = c->rowmax; hd.rowlog = c->rowlog; hd.colmax = c->colmax; hd.collog = c->collog;
     hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
     hd.ovf = (c->planes_mode && c->guard) ? c->ovf : nullptr;
+    hd.max0b = c->max0b; hd.rpart_c = c->rpart_c; hd.uncert = c->certify ? c->uncert : nullptr;
+    hd.cert_eps = (c->precision == GN_PREC_F32) ? c->cert_eps_f32 : c->cert_eps;
     hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = c->npad;   // output stride: gn_kmax(), whatever the active size
     hd.md = c->planes_mode ? (const void*)c->md_p : (const void*)c->md; hd.md_f32 = c->planes_mode ? 0 : 1;
     hd.cpart_m = c->cpart_m; hd.cpart_s = c->cpart_s; hd.cpart_i = c->cpart_i; hd.rpart_a = c->rpart_a; hd.rpart_b = c->rpart_b; hd.tickets = c->tickets;
@@ -767,7 +780,7 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
   }
   if (ctx->precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); GN_ALLOC(attn_part, (size_t)256 * 4 * 34 * 64); GN_ALLOC(attn_tickets, 256); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
-  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np);
+  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np); GN_ALLOC(max0b, B * np); GN_ALLOC(rpart_c, B * 8 * np); GN_ALLOC(uncert, B);
   GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
   GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
@@ -779,6 +792,58 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
   ctx->lists_stride = gn::kTileListBase + 2 * (np / 128) + 8 * ((np + 255) / 256);
   GN_ALLOC(lists, B * (size_t)ctx->lists_stride);
 #undef GN_ALLOC
+  return GN_OK;
+}
+
+void shift_workspaces(gn_ctx* c, long long b0, int sign);
+
+// The exact-f32 arithmetic inside a context of another precision, for the duration of a scope: GN_PREC_F32's kernels read the f32 weights (kept in
+// every mode) and the f32 workspaces (allocated in every mode); nothing of the hm16 / 16-bit state is touched.
+struct F32Scope {
+  gn_ctx* c; int precision, planes_mode, gemm_variant, no_planes, attn_f16;
+  explicit F32Scope(gn_ctx* c_) : c(c_), precision(c_->precision), planes_mode(c_->planes_mode), gemm_variant(c_->gemm_variant), no_planes(c_->no_planes), attn_f16(c_->attn_f16) {
+    c->precision = GN_PREC_F32; c->planes_mode = 0; c->gemm_variant = 3; c->no_planes = 1; c->attn_f16 = 0;
+  }
+  ~F32Scope() { c->precision = precision; c->planes_mode = planes_mode; c->gemm_variant = gemm_variant; c->no_planes = no_planes; c->attn_f16 = attn_f16; }
+};
+
+// gn_set_certify(2): read the per-pair flags of the call that was just enqueued on `s` (synchronises s), then run every maximal run of
+// flagged pairs [b0, b0 + n) again through `rerun(b0, n)` with the context switched to the exact-f32 arithmetic and every per-pair workspace
+// pointer moved to pair b0.  Counts what it saw (gn_get_certify_stats).
+template <typename F> int certify_rerun(gn_ctx* ctx, int B, hipStream_t s, F&& rerun) {
+  GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GN_HIP(hipStreamSynchronize(s));
+  ++ctx->cert_calls; ctx->cert_pairs += B;
+  std::vector<int> flagged;
+  for (int b = 0; b < B; ++b) {
+    const int f = ctx->uncert_host[b];
+    if (f == 1) ++ctx->cert_flag_margin; else if (f == 2) ++ctx->cert_flag_range;
+    if (f != 0) flagged.push_back(b);
+  }
+  if (flagged.empty()) return GN_OK;
+  if (ctx->precision == GN_PREC_F32) { ctx->cert_f32_marginal += (long long)flagged.size(); return GN_OK; }   // already the exact arithmetic: counted, nothing better to run
+  int rc = GN_OK;
+  {
+    F32Scope f32(ctx);
+    const bool ig = ctx->in_group; unsigned int* const ovf = ctx->ovf;
+    ctx->cert_inner = true; ctx->in_group = true; ctx->ovf = ctx->ovf_base;
+    for (size_t k = 0; k < flagged.size() && rc == GN_OK;) {
+      size_t e = k + 1;
+      while (e < flagged.size() && flagged[e] == flagged[e - 1] + 1) ++e;
+      const int b0 = flagged[k], n = (int)(e - k);
+      shift_workspaces(ctx, b0, +1);
+      rc = rerun(b0, n);
+      shift_workspaces(ctx, b0, -1);
+      ctx->cert_rerun += n;
+      k = e;
+    }
+    ctx->cert_inner = false; ctx->in_group = ig; ctx->ovf = ovf;
+  }
+  if (rc != GN_OK) return rc;
+  // the re-run's own flags (stated for cert_eps_f32): how many of the pairs are marginal even in exact f32 -- counted, reported, not acted upon
+  GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GN_HIP(hipStreamSynchronize(s));
+  for (int b : flagged) if (ctx->uncert_host[b] != 0) ++ctx->cert_f32_marginal;
   return GN_OK;
 }
 
@@ -796,7 +861,7 @@ int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
 
 extern "C" {
 
-const char* gn_version(void) { return "gisnav_amd 0.2.0 gfx950"; }
+// gn_version / gn_source_digest: gn_build_id.hip (carries the digest of the sources this binary was built from)
 
 const char* gn_last_error(const gn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -833,6 +898,8 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   if (hipHostMalloc((void**)&ctx->ovf_host, (16 + 4096 + 16) * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
   memset(ctx->ovf_host, 0, (16 + 4096 + 16) * sizeof(unsigned int));
   ctx->tile_feedback = reinterpret_cast<unsigned long long*>(ctx->ovf_host + 16 + 4096);   // [8] x 8 bytes behind the counters (8-byte aligned)
+  if (hipHostMalloc((void**)&ctx->uncert_host, (size_t)max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  memset(ctx->uncert_host, 0, (size_t)max_batch * sizeof(int32_t));
   ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
@@ -882,6 +949,7 @@ void gn_destroy(gn_ctx* ctx) {
   for (void* p : ctx->allocs) hipFree(p);
   for (void* p : ctx->ws_allocs) hipFree(p);
   if (ctx->ovf_host) hipHostFree(ctx->ovf_host);
+  if (ctx->uncert_host) hipHostFree(ctx->uncert_host);
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
@@ -1045,7 +1113,19 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
   rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
                    (hipStream_t)stream);
   if (rc != GN_OK) return rc;
-  if (ctx->planes_mode && ctx->guard == 2) {
+  if (ctx->certify == 2 && !ctx->in_group && !ctx->cert_inner) {
+    // certified mode: read this call's per-pair flags (one stream synchronisation -- the reference's call site synchronises right after the
+    // matcher anyway, pose_node.py:296-297) and run the flagged pairs again on the exact-f32 kernels; covers the fp16-range fallback too
+    const int kw = kfmt == GN_KPT_LAF ? 6 : kfmt == GN_KPT_RECORD ? kRecordFloats : 4;
+    const int in_dim = ctx->feature == GN_FEATURE_SIFT ? kInDim : kDim;
+    const size_t km = (size_t)ctx->npad;
+    rc = certify_rerun(ctx, B, (hipStream_t)stream, [&](int b0, int n) {
+      return run_matcher(ctx, n, kpt_format, desc_q ? desc_q + (size_t)b0 * stride_q * in_dim : nullptr, kpt_q + (size_t)b0 * stride_q * kw, n_q + b0, stride_q,
+                         desc_r ? desc_r + (size_t)b0 * stride_r * in_dim : nullptr, kpt_r + (size_t)b0 * stride_r * kw, n_r + b0, stride_r,
+                         idx + (size_t)b0 * km * 2, score + (size_t)b0 * km, n_match + b0, (hipStream_t)stream);
+    });
+    if (rc != GN_OK) return rc;
+  } else if (ctx->planes_mode && ctx->guard == 2 && ctx->certify != 2) {
     // guarded mode: observe the domain word of THIS call (one stream synchronisation -- the reference's call site synchronises
     // right after the matcher anyway, pose_node.py:296-297) and, if an activation left the fp16 range, run the call again with
     // every operand split exactly into three bf16 terms (the f32x3 mode: f32 range, f32 accuracy), on the f32 workspaces
@@ -1089,6 +1169,96 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
   if (tripped && ctx->guard == 1) ++ctx->guard_trips;
   if (last_call_tripped) *last_call_tripped = tripped;
   if (trips_total) *trips_total = ctx->guard_trips;
+  return GN_OK;
+}
+
+int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32) {
+  if (!ctx || mode < 0 || mode > 2) return GN_ERR_ARG;
+  ctx->certify = mode;
+  if (eps >= 0.f) ctx->cert_eps = eps;
+  if (eps_f32 >= 0.f) ctx->cert_eps_f32 = eps_f32;
+  return GN_OK;
+}
+
+int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
+                         const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                         const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                         float safety, float floor_eps, float* measured_host, float* eps_host, void* stream) {
+  int rc = check_fwd(ctx, B, stride_q, stride_r);
+  if (rc != GN_OK) return rc;
+  if (!(safety >= 1.f) || !(floor_eps >= 0.f)) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: safety must be >= 1, floor_eps >= 0");
+  if (ctx->precision == GN_PREC_F32) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: this context already computes in exact f32");
+  if (ctx->n_sub > 1 || ctx->overlap) { const int rcf = gn_flush(ctx, stream); if (rcf != GN_OK) return rcf; }
+  GN_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t np = (size_t)ctx->npad_run, n = (size_t)B * np;
+  int32_t* nm = nullptr;
+  GN_HIP(hipMalloc((void**)&nm, (size_t)B * sizeof(int32_t)));
+  std::vector<float> best[2], second[2];
+  std::vector<int32_t> nv(2 * (size_t)B);
+  unsigned int tripped = 0u;
+  for (int pass = 0; pass < 2 && rc == GN_OK; ++pass) {
+    std::unique_ptr<F32Scope> f32;
+    if (pass == 1) f32.reset(new F32Scope(ctx));
+    const bool ig = ctx->in_group; ctx->in_group = true;       // (no nested certification, ovf_groups_last untouched)
+    rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, ctx->e_idx, ctx->e_score, nm, s);
+    ctx->in_group = ig;
+    if (rc != GN_OK) break;
+    best[pass].resize(n); second[pass].resize(n);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(best[pass].data(), ctx->max0, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(second[pass].data(), ctx->max0b, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(nv.data(), ctx->nvalid, nv.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (pass == 0 && ctx->planes_mode && ctx->guard && hipMemcpy(&tripped, ctx->ovf, 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = GN_ERR_HIP;
+  }
+  hipFree(nm);
+  if (rc != GN_OK) return rc == GN_ERR_HIP ? fail(ctx, rc, "gn_calibrate_certify: a HIP call failed") : rc;
+  if (tripped) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: the sample left the fp16 range of this precision mode (nothing to calibrate: such calls are re-run as a whole)");
+  // largest difference between the two arithmetics over the entries a decision looks at: every valid row's best score and runner-up,
+  // restricted -- when there is a threshold -- to rows that come within 1 (in log units) of it in either arithmetic
+  const float L = ctx->threshold > 0.f ? logf(ctx->threshold) : -INFINITY;
+  double mx = 0.0; long long rows = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n0 = nv[2 * b], n1 = nv[2 * b + 1];
+    if (n0 < 2 || n1 < 2) continue;
+    for (int i = 0; i < n0; ++i) {
+      const size_t o = (size_t)b * np + i;
+      const float bf = best[0][o], be = best[1][o], sf = second[0][o], se = second[1][o];
+      if (!(std::max(bf, be) >= L - 1.f)) continue;
+      ++rows;
+      const double d1 = std::fabs((double)bf - be), d2 = std::fabs((double)sf - se);
+      if (std::isfinite(d1)) mx = std::max(mx, d1); else mx = INFINITY;
+      if (std::isfinite(d2)) mx = std::max(mx, d2);
+    }
+  }
+  if (!std::isfinite(mx)) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: non-finite scores in the sample");
+  if (rows == 0) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: no row of the sample comes near the threshold (nothing to measure)");
+  const float eps = std::max(floor_eps, safety * (float)mx);
+  ctx->cert_eps = eps;
+  if (measured_host) *measured_host = (float)mx;
+  if (eps_host) *eps_host = eps;
+  return GN_OK;
+}
+
+int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8) {
+  if (!ctx || !out8) return GN_ERR_ARG;
+  out8[0] = ctx->cert_calls; out8[1] = ctx->cert_pairs; out8[2] = ctx->cert_flag_margin; out8[3] = ctx->cert_flag_range;
+  out8[4] = ctx->cert_rerun; out8[5] = ctx->cert_f32_marginal; out8[6] = ctx->certify; out8[7] = 0;
+  return GN_OK;
+}
+
+int gn_reset_certify_stats(gn_ctx* ctx) {
+  if (!ctx) return GN_ERR_ARG;
+  ctx->cert_calls = ctx->cert_pairs = ctx->cert_flag_margin = ctx->cert_flag_range = ctx->cert_rerun = ctx->cert_f32_marginal = 0;
+  return GN_OK;
+}
+
+int gn_get_uncertain(gn_ctx* ctx, int B, int32_t* host_flags, void* stream) {
+  if (!ctx || !host_flags || B < 1 || B > ctx->max_batch) return GN_ERR_ARG;
+  if (!ctx->certify) return fail(ctx, GN_ERR_ARG, "gn_get_uncertain: the certificate is off (gn_set_certify)");
+  GN_HIP(hipSetDevice(ctx->device));
+  GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  memcpy(host_flags, ctx->uncert_host, (size_t)B * sizeof(int32_t));
   return GN_OK;
 }
 
@@ -1142,6 +1312,7 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   mv(c->qkb, T2 * 2 * kDim); mv(c->vtb, T2 * kDim);
   mv(c->rowmax, np); mv(c->rowlog, np); mv(c->colmax, np); mv(c->collog, np); mv(c->max0, np); mv(c->m0, np); mv(c->m1, np);
   mv(c->cpart_m, (np / 32) * np); mv(c->cpart_s, (np / 32) * np); mv(c->cpart_i, (np / 32) * np); mv(c->rpart_a, 8 * np); mv(c->rpart_b, 8 * np); mv(c->tickets, 2);
+  mv(c->max0b, np); mv(c->rpart_c, 8 * np); mv(c->uncert, 1);
   // match lists and the PnP masks are strided by the context's padded maximum (gn_kmax), whatever the active size
   const long long km = c->npad;
   mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
@@ -1203,7 +1374,17 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   // default: the caller's stream continues only after every group is done -- inputs may be released and outputs read in
   // stream order, like any other call.  gn_set_deferred_join(1) leaves the join to gn_flush (consecutive calls then pipeline
   // inside each group's stream; the caller keeps the INPUT buffers alive until it has flushed).
-  if (!ctx->defer_join) { const int rcj = gn_flush(ctx, stream); if (rcj != GN_OK && rc_all == GN_OK) rc_all = rcj; }
+  if (!ctx->defer_join || ctx->certify == 2) { const int rcj = gn_flush(ctx, stream); if (rcj != GN_OK && rc_all == GN_OK) rc_all = rcj; }
+  if (ctx->certify == 2 && rc_all == GN_OK) {
+    // the groups are joined: one read-back of the call's per-pair flags, then matcher + gather + PnP of the flagged pairs again in exact f32
+    rc_all = certify_rerun(ctx, B, s, [&](int q0, int n) {
+      return estimate_impl(ctx, n, kpt_format,
+                           desc_q ? desc_q + (size_t)q0 * stride_q * in_dim : nullptr, kpt_q + (size_t)q0 * stride_q * kw, n_q + q0, stride_q,
+                           desc_r ? desc_r + (size_t)q0 * stride_r * in_dim : nullptr, kpt_r + (size_t)q0 * stride_r * kw, n_r + q0, stride_r,
+                           dem ? dem + (size_t)q0 * H * W : nullptr, H, W, K9, min_matches,
+                           R + (size_t)q0 * 9, t + (size_t)q0 * 3, n_match + q0, n_inliers + q0, ok + q0, s);
+    });
+  }
   return rc_all;
 }
 
@@ -1704,7 +1885,7 @@ int64_t gn_debug_read(gn_ctx* ctx, const char* name, void* host_out, int64_t max
       {"x", ctx->x, T * kDim}, {"qkv", ctx->qkv, T * 3 * kDim}, {"ctx", ctx->ctx, T * kDim}, {"msg", ctx->msg, T * kDim},
       {"h", ctx->h, T * 2 * kDim}, {"md", ctx->md, T * kDim}, {"ls", ctx->ls, T}, {"sim", ctx->sim, ctx->sim ? B * np * np : 0},
       {"rowmax", ctx->rowmax, B * np}, {"rowlog", ctx->rowlog, B * np}, {"colmax", ctx->colmax, B * np},
-      {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
+      {"collog", ctx->collog, B * np}, {"max0", ctx->max0, B * np}, {"max0b", ctx->max0b, B * np}, {"uncert", ctx->uncert, B}, {"m0", ctx->m0, B * np}, {"m1", ctx->m1, B * np},
       {"extent", ctx->extent, B * 4}, {"nvalid", ctx->nvalid, B * 2}, {"e_mkp", ctx->e_mkp, B * np * 2},
       {"e_obj", ctx->e_obj, B * np * 3}, {"e_score", ctx->e_score, B * np},
       {"hyp", ctx->hyp_ws, B * 16 * (sizeof(gn::HypResult) / 4)},

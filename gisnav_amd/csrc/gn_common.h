@@ -272,6 +272,12 @@ struct HeadArgs {
   float* rpart_a; float* rpart_b;                      // [B][8][npad] row partials per column split: (max, sum) or (best score, column as int bits)
   unsigned int* tickets;    // [B][2] arrival counters of the two sweeps, zero between calls
   long long* dbg_ts;        // developer: nullptr, or [2][B][npad / 128][8 splits][8] s_memtime phase stamps
+  // margin certificate (gn_set_certify): the second sweep also keeps the RUNNER-UP of every row / column maximum; the last workgroup of a pair
+  // raises uncert[b] when a decision of that pair lies within the stated arithmetic error of flipping (see k_head_fused)
+  float* max0b;             // [B][npad] runner-up score of every row
+  float* rpart_c;           // [B][8][npad] row partials per column split: runner-up
+  int32_t* uncert;          // [B] out: 0 certified, 1 a decision inside the margin, 2 the fp16-range guard tripped; nullptr = no certificate
+  float cert_eps;           // bound on |P_this mode - P_exact| the certificate is stated for
 };
 void launch_match_head(const HeadArgs& a, hipStream_t s);
 void launch_match_head_fused(const HeadArgs& a, hipStream_t s);

@@ -150,10 +150,12 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
   const size_t ro = (size_t)b * a.npad;
   if (tid == 0) base_s = 0;
   __syncthreads();
+  // (the five-pass developer form keeps no runner-ups: with a certificate requested every pair that has matches to decide reports "uncertain")
   if (n0 < 2 || n1 < 2 || (a.ovf != nullptr && *a.ovf != 0u)) {  // kornia LightGlueMatcher._no_match; or the f16x2 domain guard tripped (gn_common.h)
-    if (tid == 0) a.n_match[b] = 0;
+    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = (n0 < 2 || n1 < 2) ? 0 : 2; }
     return;
   }
+  if (tid == 0 && a.uncert) a.uncert[b] = 1;
   for (int i0 = 0; i0 < n0; i0 += 256) {
     const int i = i0 + tid;
     bool valid = false; int j = 0; float sc = 0.f;
@@ -254,7 +256,7 @@ template <bool F32, int SWEEP, int ABL = 0>   // ABL, timing-only ablations (wro
 __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kHeadTile];
   __shared__ int s_last;
-  __shared__ float xch[3][2][4][64];   // [tile % 3][value][row quarter][column of the tile]: column partials of the four row quarters
+  __shared__ float xch[3][3][4][64];   // [tile % 3][value][row quarter][column of the tile]: column partials of the four row quarters (value 2: sweep 2's runner-up)
   __shared__ f32x4 rowc[kHeadRows];    // SWEEP 2: (rowmax, rowlog, logsigmoid matchability, -) of the workgroup's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave & 3, wc = wave >> 2;       // row quarter (32 rows), column half (32 columns of every tile)
@@ -332,10 +334,10 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   unsigned rvalid = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) rvalid |= (irow0 + (r & 3) + 8 * (r >> 2) < n0 ? 1u : 0u) << r;
-  float ra[16], rbv[16];        // SWEEP 1: running row max / sum;  SWEEP 2: row best score (ra) / best column (rj)
+  float ra[16], rbv[16];        // SWEEP 1: running row max / sum;  SWEEP 2: row best score (ra) / best column (rj) / runner-up score (rbv)
   int rj[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { ra[r] = SWEEP == 1 ? kLseEmpty : -INFINITY; rbv[r] = 0.f; rj[r] = 0x7fffffff; }
+  for (int r = 0; r < 16; ++r) { ra[r] = SWEEP == 1 ? kLseEmpty : -INFINITY; rbv[r] = SWEEP == 1 ? 0.f : -INFINITY; rj[r] = 0x7fffffff; }
   if (ntile > 0) stage_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
     if (SWEEP == 2) { cm = a.colmax[ro + j]; cl = a.collog[ro + j]; lj = a.ls[(size_t)(2 * b + 1) * np + j]; }
     float c0[2], c1[2]; int ci[2];                        // two interleaved column chains (even / odd registers)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { c0[e] = SWEEP == 1 ? kLseEmpty : -INFINITY; c1[e] = 0.f; ci[e] = 0x7fffffff; }
+    for (int e = 0; e < 2; ++e) { c0[e] = SWEEP == 1 ? kLseEmpty : -INFINITY; c1[e] = SWEEP == 1 ? 0.f : -INFINITY; ci[e] = 0x7fffffff; }   // sweep 2: c1 = the chain's runner-up
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = acc.c[0][r] + acc.c[1][r];           // small terms + main term
@@ -376,6 +378,11 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
       } else {
         const f32x4 rc = rowc[lrow0 + (r & 3) + 8 * (r >> 2)];
         const float p = score_at(v, rc[0], rc[1], cm, cl, rc[2], lj);
+        // runner-up of the row / of the column chain: max(second, min(best so far, this one)) -- two instructions per direction, no index
+        // (an exact tie leaves runner-up == best: gap 0, which the certificate treats as undecided)
+        const float pr = cvalid ? p : -INFINITY, pc = (cvalid & rv) ? p : -INFINITY;
+        rbv[r] = fmaxf(rbv[r], fminf(ra[r], pr));
+        c1[r & 1] = fmaxf(c1[r & 1], fminf(c0[r & 1], pc));
         const bool take = cvalid & ((p > ra[r]) | (rj[r] == 0x7fffffff));
         ra[r] = take ? p : ra[r]; rj[r] = take ? j : rj[r];
         const bool takec = cvalid & rv & ((p > c0[r & 1]) | (ci[r & 1] == 0x7fffffff));
@@ -391,10 +398,13 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
       lse_merge(c0[0], c1[0], om, os);
       if (hh == 0) { *xm = c0[0]; *xs = c1[0]; }
     } else {
+      float* const x2 = &xch[t % 3][2][wq][32 * wc + ql];
+      c1[0] = fmaxf(fmaxf(c1[0], c1[1]), fminf(c0[0], c0[1]));           // runner-up of the union: the larger runner-up, or the smaller best
       if (arg_better(c0[1], ci[1], c0[0], ci[0])) { c0[0] = c0[1]; ci[0] = ci[1]; }
-      const float ov = __shfl_xor(c0[0], 32); const int oi = __shfl_xor(ci[0], 32);
+      const float ov = __shfl_xor(c0[0], 32); const int oi = __shfl_xor(ci[0], 32); const float o2 = __shfl_xor(c1[0], 32);
+      c1[0] = fmaxf(fmaxf(c1[0], o2), fminf(c0[0], ov));
       if (arg_better(ov, oi, c0[0], ci[0])) { c0[0] = ov; ci[0] = oi; }
-      if (hh == 0) { *xm = c0[0]; *xs = __int_as_float(ci[0]); }
+      if (hh == 0) { *xm = c0[0]; *xs = __int_as_float(ci[0]); *x2 = c1[0]; }
     }
   };
   // one partial per (row block, column): wave 0 merges the four row quarters' values of tile tt (in increasing row order)
@@ -408,13 +418,14 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
       for (int w = 1; w < 4; ++w) lse_merge(m, sm, xch[par][0][w][lane], xch[par][1][w][lane]);
       if (j < np) { st_dev(a.cpart_m + po, m); st_dev(a.cpart_s + po, sm); }
     } else {
-      float bv = xch[par][0][0][lane]; int bi = __float_as_int(xch[par][1][0][lane]);
+      float bv = xch[par][0][0][lane]; int bi = __float_as_int(xch[par][1][0][lane]); float b2 = xch[par][2][0][lane];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
         const float ov = xch[par][0][w][lane]; const int oi = __float_as_int(xch[par][1][w][lane]);
+        b2 = fmaxf(fmaxf(b2, xch[par][2][w][lane]), fminf(bv, ov));
         if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
       }
-      if (j < np) { st_dev(a.cpart_m + po, bv); st_dev(a.cpart_i + po, bi); }
+      if (j < np) { st_dev(a.cpart_m + po, bv); st_dev(a.cpart_i + po, bi); st_dev(a.cpart_s + po, b2); }   // (cpart_s: sweep 1's sums were consumed by sweep 1's last workgroup)
     }
   };
   // Both waves of a SIMD run the SAME phase at the same time (MFMAs of tile t, then its VALU work): tools/probes/overlap.hip measures
@@ -436,11 +447,13 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   __syncthreads();
   float* const red0 = reinterpret_cast<float*>(smem);                 // [128 rows][65]
   float* const red1 = red0 + kHeadRows * 65;
+  float* const red2 = red1 + kHeadRows * 65;                           // sweep 2: runner-ups
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = lrow0 + (r & 3) + 8 * (r >> 2), slot = 32 * wc + ql;
     red0[row * 65 + slot] = ra[r];
     red1[row * 65 + slot] = SWEEP == 1 ? rbv[r] : __int_as_float(rj[r]);
+    if (SWEEP == 2) red2[row * 65 + slot] = rbv[r];
   }
   __syncthreads();
   {
@@ -457,20 +470,22 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
         else { st_dev(a.rpart_a + pr, m); st_dev(a.rpart_b + pr, sm); }
       }
     } else {
-      float bv = -INFINITY; int bj = 0x7fffffff;
+      float bv = -INFINITY; int bj = 0x7fffffff; float b2 = -INFINITY;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const float ov = red0[row * 65 + 16 * part + k]; const int oj = __float_as_int(red1[row * 65 + 16 * part + k]);
+        b2 = fmaxf(fmaxf(b2, red2[row * 65 + 16 * part + k]), fminf(bv, ov));
         if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; }
       }
 #pragma unroll
       for (int o = 1; o < 4; o <<= 1) {
-        const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o);
+        const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o); const float o2 = __shfl_xor(b2, o);
+        b2 = fmaxf(fmaxf(b2, o2), fminf(bv, ov));
         if (arg_better(ov, oj, bv, bj)) { bv = ov; bj = oj; }
       }
       if (part == 0 && i < np) {
-        if (S == 1) { if (i < n0) { st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv); } }
-        else { st_dev(a.rpart_a + pr, bv); st_dev(a.rpart_b + pr, __int_as_float(bj)); }
+        if (S == 1) { if (i < n0) { st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv); st_dev(a.max0b + ro + i, b2); } }
+        else { st_dev(a.rpart_a + pr, bv); st_dev(a.rpart_b + pr, __int_as_float(bj)); st_dev(a.rpart_c + pr, b2); }
       }
     }
   }
@@ -492,11 +507,12 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   // in increasing (column split / row) order
   int* const m1s = reinterpret_cast<int*>(smem) + 64;     // sweep 2: the column arg-max of the pair stays in LDS for the mutual check
   for (int i = tid; S > 1 && i < n0; i += 512) {
-    float pa[kHeadMaxSplit], pb[kHeadMaxSplit];
+    float pa[kHeadMaxSplit], pb[kHeadMaxSplit], pc[kHeadMaxSplit];
 #pragma unroll
     for (int e = 0; e < kHeadMaxSplit; ++e) {
       const size_t pr = ((size_t)b * kHeadMaxSplit + min(e, S - 1)) * np + i;
       pa[e] = ld_dev(a.rpart_a + pr); pb[e] = ld_dev(a.rpart_b + pr);
+      pc[e] = SWEEP == 2 ? ld_dev(a.rpart_c + pr) : 0.f;
     }
     if (SWEEP == 1) {
       float m = -INFINITY, sm = 0.f;
@@ -504,31 +520,52 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
       for (int e = 0; e < kHeadMaxSplit; ++e) if (e < S) lse_merge(m, sm, pa[e], pb[e]);
       a.rowmax[ro + i] = m; a.rowlog[ro + i] = logf(sm);
     } else {
-      float bv = -INFINITY; int bj = 0x7fffffff;
+      float bv = -INFINITY; int bj = 0x7fffffff; float b2 = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < kHeadMaxSplit; ++e) if (e < S && arg_better(pa[e], __float_as_int(pb[e]), bv, bj)) { bv = pa[e]; bj = __float_as_int(pb[e]); }
-      st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv);
+      for (int e = 0; e < kHeadMaxSplit; ++e) {
+        if (e >= S) continue;
+        b2 = fmaxf(fmaxf(b2, pc[e]), fminf(bv, pa[e]));
+        if (arg_better(pa[e], __float_as_int(pb[e]), bv, bj)) { bv = pa[e]; bj = __float_as_int(pb[e]); }
+      }
+      st_dev(a.m0 + ro + i, bj); st_dev(a.max0 + ro + i, bv); st_dev(a.max0b + ro + i, b2);
     }
   }
+  // The margin certificate (gn_set_certify; kornia consumes `match_indices` as exact integers, pose_node.py:285-297).  With eps a bound on
+  // |P - P_exact| over the entries that take part in a decision and L = log(filter_threshold), the pair's match list is the exact
+  // arithmetic's list whenever (a) every row whose best score is >= L - eps leads its runner-up by more than 2 eps, (b) the same for every
+  // column, and (c) no row's best score lies within eps of L: an exact-arithmetic match (i, j) has P[i][j] > L - eps, so by (a) / (b) it is
+  // the row's and the column's arg-max here too, and by (c) it passes the threshold here; conversely a match here keeps both arg-maxima (the
+  // gaps exceed twice the error) and stays above L.  (For filter_threshold >= 0.5 -- PoseNode's value -- (a) and (b) follow from (c): a
+  // score above 0.5 e^eps leaves less than 0.5 e^-eps for every other entry of its row and column.)  Anything else sets `unc`.
+  const bool cert = a.uncert != nullptr && a.cert_eps >= 0.f;
+  const float Lth = a.threshold > 0.f ? logf(a.threshold) : -INFINITY;
+  int unc = 0;
   for (int j = tid; j < n1; j += 512) {
-    float m = -INFINITY, sm = 0.f; int bi = 0x7fffffff;
+    float m = -INFINITY, sm = 0.f; int bi = 0x7fffffff; float m2 = -INFINITY;
     for (int p0 = 0; p0 < nparts; p0 += 16) {     // partials in increasing row order: a strict comparison keeps the lowest row on ties
-      float pm[16], ps[16];
+      float pm[16], ps[16], p2[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const size_t po = ((size_t)b * npart + min(p0 + e, nparts - 1)) * np + j;
         pm[e] = ld_dev(a.cpart_m + po);
         ps[e] = SWEEP == 1 ? ld_dev(a.cpart_s + po) : __int_as_float(ld_dev(a.cpart_i + po));
+        p2[e] = SWEEP == 2 ? ld_dev(a.cpart_s + po) : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         if (p0 + e >= nparts) continue;
         if (SWEEP == 1) lse_merge(m, sm, pm[e], ps[e]);
-        else if (arg_better(pm[e], __float_as_int(ps[e]), m, bi)) { m = pm[e]; bi = __float_as_int(ps[e]); }
+        else {
+          m2 = fmaxf(fmaxf(m2, p2[e]), fminf(m, pm[e]));
+          if (arg_better(pm[e], __float_as_int(ps[e]), m, bi)) { m = pm[e]; bi = __float_as_int(ps[e]); }
+        }
       }
     }
     if (SWEEP == 1) { a.colmax[ro + j] = m; a.collog[ro + j] = logf(sm); }
-    else { a.m1[ro + j] = bi; m1s[j] = bi; }
+    else {
+      a.m1[ro + j] = bi; m1s[j] = bi;
+      if (cert && m >= Lth - a.cert_eps && !(m - m2 > 2.f * a.cert_eps)) unc = 1;     // (b)
+    }
   }
   stamp(5);
   if (SWEEP == 1) return;
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   if (tid == 0) *base_s = 0;
   __syncthreads();
   if (nomatch || (a.ovf != nullptr && *a.ovf != 0u)) {
-    if (tid == 0) a.n_match[b] = 0;
+    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = nomatch ? 0 : 2; }   // 2: an activation left the fp16 range -- nothing of this call can be certified
     return;
   }
   for (int ib = 0; ib < n0; ib += 512) {
@@ -548,8 +585,14 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
     bool valid = false; int j = 0; float sc = 0.f;
     if (i < n0) {
       j = ld_dev(a.m0 + ro + i);
-      sc = expf(ld_dev(a.max0 + ro + i));
+      const float best = ld_dev(a.max0 + ro + i);
+      sc = expf(best);
       valid = (m1s[j] == i) && (sc > a.threshold);
+      if (cert) {
+        const float second = ld_dev(a.max0b + ro + i);
+        if (best >= Lth - a.cert_eps && !(best - second > 2.f * a.cert_eps)) unc = 1;   // (a)
+        if (fabsf(best - Lth) <= a.cert_eps) unc = 1;                                    // (c)
+      }
     }
     const unsigned long long bal = __ballot(valid);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -567,6 +610,10 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.n_match[b] = *base_s;
+  if (a.uncert) {
+    const int any = __syncthreads_or(unc);
+    if (tid == 0) a.uncert[b] = (cert && any) ? 1 : 0;
+  }
   stamp(6);
 }
 

@@ -177,6 +177,43 @@ class PoseEngine:
         _lib.check(self.ctx, self.lib.gn_get_guard_status(self.ctx, self._stream(), C.byref(last), C.byref(total)), "gn_get_guard_status")
         return bool(last.value), int(total.value)
 
+    # ------------------------------------------------------------------ margin certificate (gn_set_certify)
+    def set_certify(self, mode, eps: Optional[float] = None, eps_f32: Optional[float] = None) -> None:
+        """"off" | "flag" | "rerun" (0 / 1 / 2).  "rerun": every match() / estimate() call synchronises once, and the pairs in which a decision
+        lies within `eps` of flipping (or whose activations left the fp16 range) are run again on the exact-f32 kernels before the call
+        returns -- correspondence indices are then the exact arithmetic's (pose_node.py:285-297 consumes them as exact integers)."""
+        m = {"off": 0, "flag": 1, "rerun": 2}.get(mode, mode)
+        _lib.check(self.ctx, self.lib.gn_set_certify(self.ctx, int(m), -1.0 if eps is None else float(eps), -1.0 if eps_f32 is None else float(eps_f32)),
+                   "gn_set_certify")
+
+    def calibrate_certify(self, inputs: dict, safety: float = 4.0, floor_eps: float = 1.0e-5) -> Dict[str, float]:
+        """gn_calibrate_certify on staged inputs (the dict of stage_inputs / RecordStager.stage): measures max |P_mode - P_f32| over the deciding
+        entries of the sample and sets eps = max(floor_eps, safety * that).  Returns {"measured": ..., "eps": ...}."""
+        B = inputs["kpt_q"].shape[0]
+        m, e = C.c_float(0.0), C.c_float(0.0)
+        rc = self.lib.gn_calibrate_certify(self.ctx, B, inputs["kpt_format"],
+                                           _ptr(inputs.get("desc_q")), _ptr(inputs["kpt_q"]), _ptr(inputs["n_q"]), inputs["kpt_q"].shape[1],
+                                           _ptr(inputs.get("desc_r")), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["kpt_r"].shape[1],
+                                           float(safety), float(floor_eps), C.byref(m), C.byref(e), self._stream())
+        _lib.check(self.ctx, rc, "gn_calibrate_certify")
+        return {"measured": float(m.value), "eps": float(e.value), "safety": float(safety)}
+
+    def certify_stats(self, reset: bool = False) -> Dict[str, int]:
+        buf = (C.c_int64 * 8)()
+        _lib.check(self.ctx, self.lib.gn_get_certify_stats(self.ctx, buf), "gn_get_certify_stats")
+        if reset:
+            _lib.check(self.ctx, self.lib.gn_reset_certify_stats(self.ctx), "gn_reset_certify_stats")
+        keys = ("calls", "pairs", "flagged_margin", "flagged_fp16_range", "rerun_pairs", "f32_marginal_pairs", "mode")
+        d = {k: int(buf[i]) for i, k in enumerate(keys)}
+        d["rerun_fraction"] = (d["rerun_pairs"] / d["pairs"]) if d["pairs"] else 0.0
+        return d
+
+    def uncertain(self, B: int) -> np.ndarray:
+        """Per-pair flags of the most recent matcher call (0 certified, 1 margin, 2 fp16 range); synchronises the stream."""
+        out = np.zeros(B, np.int32)
+        _lib.check(self.ctx, self.lib.gn_get_uncertain(self.ctx, int(B), out.ctypes.data_as(_lib.c_i32p), self._stream()), "gn_get_uncertain")
+        return out
+
     def __del__(self):
         ctx, self.ctx = getattr(self, "ctx", None), None
         if ctx:

@@ -104,6 +104,45 @@ def synthetic_state_dict(seed: int = 0, n_layers: int = N_LAYERS, qk_gain: float
     return sd
 
 
+def default_init_state_dict(seed: int = 0, n_layers: int = N_LAYERS, feature: str = "sift") -> Dict[str, np.ndarray]:
+    """A third weight family: every tensor as PyTorch's own constructors would leave it -- `nn.Linear`: weight and bias
+    ~ U(-1 / sqrt(in), 1 / sqrt(in)) (kaiming_uniform with a = sqrt(5)); `nn.LayerNorm`: weight 1, bias 0 -- i.e. what
+    `kornia.feature.LightGlue("sift")` holds before `sift_lightglue.pth` is loaded (pose_node.py:109-121).  Nothing is hand-shrunk: each block
+    rewrites the residual stream completely, activations take whatever range nine un-trained layers give them, and the assignment matrix
+    is nearly flat -- with filter_threshold 0 every mutual arg-max is a match and most of them have a small margin.  A look at a realistic
+    dynamic range through the fp16 split, the fp16 attention and the guards; not a model that finds true correspondences."""
+    rng = np.random.default_rng(50_000 + seed)
+    d = DESC_DIM
+    sd: Dict[str, np.ndarray] = {}
+
+    def linear(name, out, inp):
+        b = inp ** -0.5
+        sd[name + ".weight"] = _uniform(rng, (out, inp), b)
+        sd[name + ".bias"] = _uniform(rng, (out,), b)
+
+    if feature == "sift":
+        linear("input_proj", d, INPUT_DIM)
+        sd["posenc.Wr.weight"] = _uniform(rng, (HEAD_DIM // 2, 4), 4 ** -0.5)
+    else:
+        sd["posenc.Wr.weight"] = _uniform(rng, (HEAD_DIM // 2, 2), 2 ** -0.5)
+    for i in range(n_layers):
+        for blk, lins in (("self_attn", (("Wqkv", 3 * d, d), ("out_proj", d, d))), ("cross_attn", (("to_qk", d, d), ("to_v", d, d), ("to_out", d, d)))):
+            p = f"transformers.{i}.{blk}"
+            for name, o, k in lins:
+                linear(f"{p}.{name}", o, k)
+            linear(p + ".ffn.0", 2 * d, 2 * d)
+            sd[p + ".ffn.1.weight"] = np.ones(2 * d, np.float32)
+            sd[p + ".ffn.1.bias"] = np.zeros(2 * d, np.float32)
+            linear(p + ".ffn.3", d, 2 * d)
+    for i in range(n_layers):
+        linear(f"log_assignment.{i}.final_proj", d, d)
+        linear(f"log_assignment.{i}.matchability", 1, d)
+    for i in range(n_layers - 1):
+        linear(f"token_confidence.{i}.token.0", 1, d)
+    sd["confidence_thresholds"] = np.clip(0.8 + 0.1 * np.exp(-4.0 * np.arange(n_layers) / n_layers), 0, 1).astype(np.float32)
+    return sd
+
+
 def canonical_key(k: str) -> str:
     """Checkpoint spelling ``self_attn.{i}.*`` -> kornia's ``transformers.{i}.self_attn.*``."""
     for kind in ("self_attn", "cross_attn"):

@@ -100,7 +100,7 @@ enum gn_kpt_format {
  * RootSIFT itself to raw SIFT descriptors. */
 #define GN_DESC_ROOTSIFT 0x100
 
-/* Library / build info: "gisnav_amd <ver> gfx950". */
+/* Library / build info: "gisnav_amd <ver> gfx950 src:<source digest>". */
 const char* gn_version(void);
 /* Human-readable text for the last failure on this context (or global if ctx is NULL). */
 const char* gn_last_error(const gn_ctx* ctx);
@@ -119,6 +119,41 @@ int gn_set_guard(gn_ctx* ctx, int mode);
 /* Synchronises `stream`; *last_call_tripped = 1 if the most recent matcher run on this context left the fp16 range,
  * *trips_total = number of tripped calls observed so far (either pointer may be NULL). */
 int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, int64_t* trips_total);
+
+/* The margin certificate of the correspondence indices.  kornia's LightGlueMatcher returns `match_indices` that PoseNode uses as exact
+ * integers (ros/gisnav/gisnav/core/pose_node.py:285-297); the fast precision modes compute the assignment scores P with an arithmetic
+ * error, so a decision whose margin is smaller than that error may come out differently from the exact-f32 arithmetic.  With the certificate
+ * on, the match head keeps the runner-up of every row / column maximum of P and reports, per PAIR, whether every decision of that pair
+ * is safe: (a) every row whose best score is >= log(filter_threshold) - eps leads its runner-up by more than 2 eps, (b) the same for every
+ * column, (c) no row's best score lies within eps of log(filter_threshold).  eps is the stated bound on |P_mode - P_exact| for the
+ * entries that decide (measured per weight set by tools/certify_eps.py / PoseEngine.calibrate_certify; pass < 0 to keep the current
+ * value).  A pair that satisfies (a)-(c) has exactly the exact arithmetic's match list (proof in DESIGN.md).
+ *   mode 0  off (default): no flags are written;
+ *   mode 1  flags only, stream-ordered, no host synchronisation: gn_get_uncertain reads them;
+ *   mode 2  certified results: gn_match / gn_estimate synchronise the stream once per call, read the flags and run every flagged pair
+ *           again -- matcher, and for gn_estimate also gather + PnP -- on GN_PREC_F32's kernels (the context keeps f32 weights and f32
+ *           workspaces in every mode).  A call whose activations left the fp16 range is flagged as a whole (flag value 2), so this mode
+ *           also takes over gn_set_guard(2)'s fallback.  In a GN_PREC_F32 context nothing is re-run: the flags (for eps_f32) are counted.
+ * Results of a pair do not depend on which other pairs were re-run. */
+int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32);
+/* out8: calls certified, pairs certified, pairs flagged for margin, pairs flagged for fp16 range, pairs re-run in exact f32,
+ * re-run (or, in an f32 context, original) pairs that are marginal even for eps_f32, current mode, reserved. */
+int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8);
+int gn_reset_certify_stats(gn_ctx* ctx);
+/* Measure eps for THIS context's weights and precision mode on a sample batch (arguments as gn_match): the batch is matched twice -- in the
+ * context's arithmetic and on the exact-f32 kernels -- and eps = max(floor_eps, safety * max |P_mode - P_f32|) over the best score and the
+ * runner-up of every valid row that comes within 1 of log(filter_threshold) in either arithmetic (all rows when the threshold is 0).
+ * Synchronises; sets the context's eps and returns the measured maximum and eps through the two host pointers (either may be NULL).  Call
+ * it once after loading a checkpoint, on representative pairs; safety >= 1 is the stated safety factor (the Python mirror uses 4). */
+int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
+                         const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
+                         const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
+                         float safety, float floor_eps, float* measured_host, float* eps_host, void* stream);
+/* Synchronises `stream`; host_flags[b] of the most recent matcher call: 0 certified, 1 a decision inside the margin, 2 fp16 range left. */
+int gn_get_uncertain(gn_ctx* ctx, int B, int32_t* host_flags, void* stream);
+/* 16 hex digits over every source file and compile flag the loaded binary was built from (gisnav_amd.build.source_digest() computes the
+ * same value from the tree; gisnav_amd._lib.load refuses a library whose digest differs from its tree's). */
+const char* gn_source_digest(void);
 
 /* Create a context on HIP device `device` sized for batches of up to max_batch pairs with up
  * to max_kpts keypoints per side (rounded up to a multiple of 128 internally). */

@@ -97,9 +97,52 @@ def posenc(wr: Tensor, x: Tensor) -> Tensor:
     return emb.repeat_interleave(2, dim=-1)
 
 
+# Arithmetic class of the attention.  "fp32": what kornia's Attention computes on CPU (the default, and what every parity test compares
+# with).  "half_sdpa": a CPU EMULATION of the branch PoseNode takes when `torch.cuda.is_available()` (pose_node.py:81, 108-121 put the matcher
+# on "cuda"): kornia 0.7.2's Attention then casts q, k, v to half and calls F.scaled_dot_product_attention (flash kernel: q k^T and P v on
+# fp16 operands with f32 accumulation, the probabilities rounded to fp16 before P v, the output rounded to fp16), and the cross block runs it
+# twice (once per direction) instead of sharing one `sim`.  [EXT, restated; no CUDA device here to pin it on.]  Used only to give the fast
+# GPU modes' mismatch counts their context: how many correspondence indices the REFERENCE'S OWN CPU -> CUDA move flips on the same inputs.
+ATTENTION_MODE = "fp32"
+
+
+class attention_mode:
+    """with attention_mode("half_sdpa"): ...   (test infrastructure; module-wide switch, restored on exit)"""
+
+    def __init__(self, mode: str):
+        assert mode in ("fp32", "half_sdpa"), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global ATTENTION_MODE
+        self.prev, ATTENTION_MODE = ATTENTION_MODE, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global ATTENTION_MODE
+        ATTENTION_MODE = self.prev
+
+
+def _half(t: Tensor) -> Tensor:
+    return t.to(torch.float16).to(torch.float32)
+
+
+def _sdpa_half(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
+    """Flash-style half SDPA emulated in f32: operands and probabilities rounded to fp16, f32 accumulation, fp16 output."""
+    q, k, v = _half(q), _half(k), _half(v)
+    sim = torch.einsum("...id,...jd->...ij", q, k) * scale
+    m = sim.max(-1, keepdim=True).values
+    p = torch.exp(sim - m)
+    den = p.sum(-1, keepdim=True)
+    out = torch.einsum("...ij,...jd->...id", _half(p), v) / den
+    return _half(out)
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
     """fp32 softmax(q k^T / sqrt(d)) v -- what kornia's Attention computes on CPU."""
     s = q.shape[-1] ** -0.5
+    if ATTENTION_MODE == "half_sdpa":
+        return _sdpa_half(q, k, v, s)
     sim = torch.einsum("...id,...jd->...ij", q, k) * s
     attn = F.softmax(sim, -1)
     return torch.einsum("...ij,...jd->...id", attn, v)
@@ -131,12 +174,15 @@ def cross_block(sd: Dict[str, Tensor], i: int, x0: Tensor, x1: Tensor) -> Tuple[
     heads = lambda t: t.unflatten(-1, (NUM_HEADS, -1)).transpose(1, 2)  # noqa: E731
     qk0, qk1 = heads(lin("to_qk", x0)), heads(lin("to_qk", x1))
     v0, v1 = heads(lin("to_v", x0)), heads(lin("to_v", x1))
-    qk0, qk1 = qk0 * scale ** 0.5, qk1 * scale ** 0.5
-    sim = torch.einsum("bhid, bhjd -> bhij", qk0, qk1)
-    attn01 = F.softmax(sim, dim=-1)
-    attn10 = F.softmax(sim.transpose(-2, -1).contiguous(), dim=-1)
-    m0 = torch.einsum("bhij, bhjd -> bhid", attn01, v1)
-    m1 = torch.einsum("bhji, bhjd -> bhid", attn10.transpose(-2, -1), v0)
+    if ATTENTION_MODE == "half_sdpa":   # kornia CrossBlock with flash: two SDPA calls on the UNSCALED qk (SDPA applies 1 / sqrt(d) itself)
+        m0, m1 = _sdpa_half(qk0, qk1, v1, scale), _sdpa_half(qk1, qk0, v0, scale)
+    else:
+        qk0, qk1 = qk0 * scale ** 0.5, qk1 * scale ** 0.5
+        sim = torch.einsum("bhid, bhjd -> bhij", qk0, qk1)
+        attn01 = F.softmax(sim, dim=-1)
+        attn10 = F.softmax(sim.transpose(-2, -1).contiguous(), dim=-1)
+        m0 = torch.einsum("bhij, bhjd -> bhid", attn01, v1)
+        m1 = torch.einsum("bhji, bhjd -> bhid", attn10.transpose(-2, -1), v0)
     m0, m1 = (t.transpose(1, 2).flatten(start_dim=-2) for t in (m0, m1))
     m0, m1 = lin("to_out", m0), lin("to_out", m1)
     x0 = x0 + _ffn(sd, p, torch.cat([x0, m0], -1))

@@ -30,7 +30,28 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/gisnav_amd.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "python binding and header disagree"
-    assert lib.gn_version().decode().endswith("gfx950")
+    # the binary is bound to its sources: the digest of every csrc file, the public header and the compile flags is compiled into
+    # the library, gn_version() shows it, and _lib.load() has just compared it with the tree's
+    assert lib.gn_version().decode() == "gisnav_amd 0.3.0 gfx950 src:" + build.source_digest()
+    assert _lib.library_digest() == build.source_digest() == lib.gn_source_digest().decode()
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
+    """A git-ignored libgisnav_amd.so travels with the tree to the GPU box: if it was built before the last source edit it would silently run
+    yesterday's kernels.  `_lib.load` compares the digest compiled into the binary with the digest of the tree and refuses on a mismatch
+    (GISNAV_AMD_ALLOW_STALE=1: developer A/B builds only).  Simulated by making the tree's digest differ, in a child interpreter."""
+    import subprocess
+    import sys
+    from gisnav_amd import build
+    build.build(verbose=False)
+    code = ("import gisnav_amd.build as b; b.source_digest = lambda: '0' * 16\n"
+            "from gisnav_amd import _lib\n"
+            "try:\n    _lib.load(); print('LOADED')\nexcept _lib.GnError as e:\n    print('REFUSED', 'built from other sources' in str(e))\n")
+    env = {k: v for k, v in os.environ.items() if k != "GISNAV_AMD_ALLOW_STALE"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env, timeout=300)
+    assert "REFUSED True" in r.stdout, (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=dict(env, GISNAV_AMD_ALLOW_STALE="1"), timeout=300)
+    assert "LOADED" in r.stdout, (r.stdout, r.stderr[-500:])
 
 
 def test_shipped_device_code_has_no_low_lane_opsel_packed_fma(tmp_path):
