@@ -72,6 +72,15 @@ struct gn_ctx {
   float cert_eps_f32 = 1.0e-4f;   // the same for the exact-f32 kernels (GPU f32 against the torch-CPU f32 oracle: summation order only)
   float* max0b = nullptr; float* rpart_c = nullptr; int32_t* uncert = nullptr; int32_t* uncert_host = nullptr;   // uncert_host: pinned [max_batch]
   bool cert_inner = false;     // a certificate re-run is being enqueued (no nested certification)
+  // mode 3 (deferred): gn_estimate leaves the flags of call n in a pinned slot behind an event and resolves them -- reads them, re-runs the flagged
+  // pairs from the SAVED arguments -- after call n + 1 has been enqueued (or in gn_flush), so the host never waits for an idle GPU
+  struct CertPending {
+    bool active = false; hipEvent_t ev = nullptr; int32_t* flags = nullptr;   // flags: pinned [max_batch]
+    int B = 0, kpt_format = 0, stride_q = 0, stride_r = 0, H = 0, W = 0, min_matches = 0, npad_run = 0;
+    const float *desc_q = nullptr, *kpt_q = nullptr, *desc_r = nullptr, *kpt_r = nullptr; const int32_t *n_q = nullptr, *n_r = nullptr; const uint8_t* dem = nullptr;
+    double K9[9] = {0}; double *R = nullptr, *t = nullptr; int32_t *n_match = nullptr, *n_inliers = nullptr; uint8_t* ok = nullptr;
+  } cert_pend[2];
+  int cert_slot = 0;
   long long cert_calls = 0, cert_pairs = 0, cert_flag_margin = 0, cert_flag_range = 0, cert_rerun = 0, cert_f32_marginal = 0;
   int attn_f16 = 0;        // GN_PREC_F16X2_F16_ATTN: q | k rows, V^T panels and the probabilities are fp16 instead of bf16 (precision itself reads F16X2_BF16_ATTN)
   int precision_api = 0;   // the gn_precision value gn_create was called with
@@ -810,13 +819,16 @@ struct F32Scope {
 // gn_set_certify(2): read the per-pair flags of the call that was just enqueued on `s` (synchronises s), then run every maximal run of
 // flagged pairs [b0, b0 + n) again through `rerun(b0, n)` with the context switched to the exact-f32 arithmetic and every per-pair workspace
 // pointer moved to pair b0.  Counts what it saw (gn_get_certify_stats).
-template <typename F> int certify_rerun(gn_ctx* ctx, int B, hipStream_t s, F&& rerun) {
-  GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  GN_HIP(hipStreamSynchronize(s));
+template <typename F> int certify_rerun(gn_ctx* ctx, int B, hipStream_t s, F&& rerun, const int32_t* flags_ready = nullptr) {
+  if (!flags_ready) {
+    GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    GN_HIP(hipStreamSynchronize(s));
+    flags_ready = ctx->uncert_host;
+  }
   ++ctx->cert_calls; ctx->cert_pairs += B;
   std::vector<int> flagged;
   for (int b = 0; b < B; ++b) {
-    const int f = ctx->uncert_host[b];
+    const int f = flags_ready[b];
     if (f == 1) ++ctx->cert_flag_margin; else if (f == 2) ++ctx->cert_flag_range;
     if (f != 0) flagged.push_back(b);
   }
@@ -900,6 +912,10 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   ctx->tile_feedback = reinterpret_cast<unsigned long long*>(ctx->ovf_host + 16 + 4096);   // [8] x 8 bytes behind the counters (8-byte aligned)
   if (hipHostMalloc((void**)&ctx->uncert_host, (size_t)max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
   memset(ctx->uncert_host, 0, (size_t)max_batch * sizeof(int32_t));
+  for (auto& pd : ctx->cert_pend) {
+    if (hipHostMalloc((void**)&pd.flags, (size_t)max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "certificate slots: allocation failed"); }
+  }
   ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   for (int i = 0; i < 256; ++i) hipEventCreate(&ctx->ev[i]);
   ctx->ev_ready = true;
@@ -950,6 +966,7 @@ void gn_destroy(gn_ctx* ctx) {
   for (void* p : ctx->ws_allocs) hipFree(p);
   if (ctx->ovf_host) hipHostFree(ctx->ovf_host);
   if (ctx->uncert_host) hipHostFree(ctx->uncert_host);
+  for (auto& pd : ctx->cert_pend) { if (pd.flags) hipHostFree(pd.flags); if (pd.ev) hipEventDestroy(pd.ev); }
   if (ctx->ev_ready) for (int i = 0; i < 256; ++i) hipEventDestroy(ctx->ev[i]);
   for (hipEvent_t e : ctx->kev) hipEventDestroy(e);
   for (void* p : ctx->sift_allocs) hipFree(p);
@@ -1113,8 +1130,8 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
   rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, idx, score, n_match,
                    (hipStream_t)stream);
   if (rc != GN_OK) return rc;
-  if (ctx->certify == 2 && !ctx->in_group && !ctx->cert_inner) {
-    // certified mode: read this call's per-pair flags (one stream synchronisation -- the reference's call site synchronises right after the
+  if (ctx->certify >= 2 && !ctx->in_group && !ctx->cert_inner) {
+    // certified mode (3 = deferred exists for gn_estimate's sub-batch-stream path only; everywhere else it is 2): read this call's per-pair flags (one stream synchronisation -- the reference's call site synchronises right after the
     // matcher anyway, pose_node.py:296-297) and run the flagged pairs again on the exact-f32 kernels; covers the fp16-range fallback too
     const int kw = kfmt == GN_KPT_LAF ? 6 : kfmt == GN_KPT_RECORD ? kRecordFloats : 4;
     const int in_dim = ctx->feature == GN_FEATURE_SIFT ? kInDim : kDim;
@@ -1125,7 +1142,7 @@ int gn_match(gn_ctx* ctx, int B, int kpt_format,
                          idx + (size_t)b0 * km * 2, score + (size_t)b0 * km, n_match + b0, (hipStream_t)stream);
     });
     if (rc != GN_OK) return rc;
-  } else if (ctx->planes_mode && ctx->guard == 2 && ctx->certify != 2) {
+  } else if (ctx->planes_mode && ctx->guard == 2 && ctx->certify < 2) {
     // guarded mode: observe the domain word of THIS call (one stream synchronisation -- the reference's call site synchronises
     // right after the matcher anyway, pose_node.py:296-297) and, if an activation left the fp16 range, run the call again with
     // every operand split exactly into three bf16 terms (the f32x3 mode: f32 range, f32 accuracy), on the f32 workspaces
@@ -1173,7 +1190,9 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
 }
 
 int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32) {
-  if (!ctx || mode < 0 || mode > 2) return GN_ERR_ARG;
+  if (!ctx || mode < 0 || mode > 3) return GN_ERR_ARG;
+  if (ctx->certify == 3 && mode != 3 && (ctx->cert_pend[0].active || ctx->cert_pend[1].active))
+    return fail(ctx, GN_ERR_ARG, "gn_set_certify: deferred certificates are still open -- gn_flush first");
   ctx->certify = mode;
   if (eps >= 0.f) ctx->cert_eps = eps;
   if (eps_f32 >= 0.f) ctx->cert_eps_f32 = eps_f32;
@@ -1325,6 +1344,28 @@ int estimate_impl(gn_ctx* ctx, int B, int kpt_format,
                   const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,
                   const uint8_t* dem, int H, int W, const double* K9, int min_matches,
                   double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream);
+
+// deferred certificate: wait for the flags of the pending call in `slot` (its kernels are behind at most one later call on the GPU), re-run
+// its flagged pairs from the saved arguments on `s`
+int cert_resolve(gn_ctx* ctx, int slot, hipStream_t s) {
+  gn_ctx::CertPending& p = ctx->cert_pend[slot];
+  if (!p.active) return GN_OK;
+  p.active = false;
+  GN_HIP(hipEventSynchronize(p.ev));
+  const int kw = (p.kpt_format & 0xff) == GN_KPT_LAF ? 6 : (p.kpt_format & 0xff) == GN_KPT_RECORD ? kRecordFloats : 4;
+  const int in_dim = ctx->feature == GN_FEATURE_SIFT ? kInDim : kDim;
+  const int np_now = ctx->npad_run;
+  ctx->npad_run = p.npad_run;
+  const int rc = certify_rerun(ctx, p.B, s, [&](int q0, int n) {
+    return estimate_impl(ctx, n, p.kpt_format,
+                         p.desc_q ? p.desc_q + (size_t)q0 * p.stride_q * in_dim : nullptr, p.kpt_q + (size_t)q0 * p.stride_q * kw, p.n_q + q0, p.stride_q,
+                         p.desc_r ? p.desc_r + (size_t)q0 * p.stride_r * in_dim : nullptr, p.kpt_r + (size_t)q0 * p.stride_r * kw, p.n_r + q0, p.stride_r,
+                         p.dem ? p.dem + (size_t)q0 * p.H * p.W : nullptr, p.H, p.W, p.K9, p.min_matches,
+                         p.R + (size_t)q0 * 9, p.t + (size_t)q0 * 3, p.n_match + q0, p.n_inliers + q0, p.ok + q0, s);
+  }, p.flags);
+  ctx->npad_run = np_now;
+  return rc;
+}
 }  // namespace
 
 int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
@@ -1374,6 +1415,22 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
   // default: the caller's stream continues only after every group is done -- inputs may be released and outputs read in
   // stream order, like any other call.  gn_set_deferred_join(1) leaves the join to gn_flush (consecutive calls then pipeline
   // inside each group's stream; the caller keeps the INPUT buffers alive until it has flushed).
+  if (ctx->certify == 3 && rc_all == GN_OK) {
+    // deferred certificate: join the groups (stream order only), leave this call's flags in a pinned slot behind an event, and resolve the
+    // PREVIOUS call now that this one is queued -- the host waits for call n while the GPU already works on call n + 1
+    for (int g = 0; g < 8; ++g)
+      if (ctx->sub_pending[g]) { GN_HIP(hipStreamWaitEvent(s, ctx->ev_join[g], 0)); ctx->sub_pending[g] = false; }
+    const int slot = ctx->cert_slot;
+    gn_ctx::CertPending& p = ctx->cert_pend[slot];
+    if (p.active) { const int rcr = cert_resolve(ctx, slot, s); if (rcr != GN_OK) return rcr; }     // (cannot happen in the alternating order; kept for safety)
+    GN_HIP(hipMemcpyAsync(p.flags, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    GN_HIP(hipEventRecord(p.ev, s));
+    p.active = true; p.B = B; p.kpt_format = kpt_format; p.stride_q = stride_q; p.stride_r = stride_r; p.H = H; p.W = W; p.min_matches = min_matches;
+    p.npad_run = ctx->npad_run; p.desc_q = desc_q; p.kpt_q = kpt_q; p.n_q = n_q; p.desc_r = desc_r; p.kpt_r = kpt_r; p.n_r = n_r; p.dem = dem;
+    memcpy(p.K9, K9, sizeof p.K9); p.R = R; p.t = t; p.n_match = n_match; p.n_inliers = n_inliers; p.ok = ok;
+    ctx->cert_slot ^= 1;
+    return cert_resolve(ctx, slot ^ 1, s);
+  }
   if (!ctx->defer_join || ctx->certify == 2) { const int rcj = gn_flush(ctx, stream); if (rcj != GN_OK && rc_all == GN_OK) rc_all = rcj; }
   if (ctx->certify == 2 && rc_all == GN_OK) {
     // the groups are joined: one read-back of the call's per-pair flags, then matcher + gather + PnP of the flagged pairs again in exact f32
@@ -1492,6 +1549,11 @@ int gn_flush(gn_ctx* ctx, void* stream) {
     if (ctx->pnp_pending[i]) { GN_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_pnp[i], 0)); ctx->pnp_pending[i] = false; }
   for (int g = 0; g < 8; ++g)
     if (ctx->sub_pending[g]) { GN_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join[g], 0)); ctx->sub_pending[g] = false; }
+  if (!ctx->cert_inner)
+    for (int k = 0; k < 2; ++k) {       // deferred certificates still open: the older one first
+      const int rc = cert_resolve(ctx, ctx->cert_slot ^ k, (hipStream_t)stream);
+      if (rc != GN_OK) return rc;
+    }
   return GN_OK;
 }
 

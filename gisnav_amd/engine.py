@@ -181,8 +181,12 @@ class PoseEngine:
     def set_certify(self, mode, eps: Optional[float] = None, eps_f32: Optional[float] = None) -> None:
         """"off" | "flag" | "rerun" (0 / 1 / 2).  "rerun": every match() / estimate() call synchronises once, and the pairs in which a decision
         lies within `eps` of flipping (or whose activations left the fp16 range) are run again on the exact-f32 kernels before the call
-        returns -- correspondence indices are then the exact arithmetic's (pose_node.py:285-297 consumes them as exact integers)."""
-        m = {"off": 0, "flag": 1, "rerun": 2}.get(mode, mode)
+        returns -- correspondence indices are then the exact arithmetic's (pose_node.py:285-297 consumes them as exact integers).
+        "deferred" (3; estimate() with sub-batch streams): the flags of call n are read -- and its flagged pairs re-run -- after call n + 1 has been
+        enqueued, so the host never waits for an idle GPU.  Contract: the inputs AND outputs of call n stay alive and untouched until call n + 1 has
+        returned or flush() was called (alternate two output dicts); results of call n are final from then on."""
+        m = {"off": 0, "flag": 1, "rerun": 2, "deferred": 3}.get(mode, mode)
+        self._certify_mode, self._last_out_ptr = int(m), None
         _lib.check(self.ctx, self.lib.gn_set_certify(self.ctx, int(m), -1.0 if eps is None else float(eps), -1.0 if eps_f32 is None else float(eps_f32)),
                    "gn_set_certify")
 
@@ -412,12 +416,18 @@ class PoseEngine:
 
     def flush(self) -> None:
         _lib.check(self.ctx, self.lib.gn_flush(self.ctx, self._stream()), "gn_flush")
+        self._last_out_ptr = None
 
     def estimate(self, inputs: dict, K: np.ndarray, min_matches: int = MIN_MATCHES, out: Optional[dict] = None):
         """gn_estimate on staged inputs: PoseNode._pose lines 246-308 for the whole batch."""
         B = inputs["kpt_q"].shape[0]
         if out is None:
             out = self.alloc_outputs(B)
+        if getattr(self, "_certify_mode", 0) == 3:
+            if self._last_out_ptr == out["R"].data_ptr():
+                raise _lib.GnError("deferred certificate: this call would write the outputs of the previous call, whose flagged pairs may still be re-run -- "
+                                   "alternate two output dicts, or flush() between the calls")
+            self._last_out_ptr = out["R"].data_ptr()
         dem = inputs.get("dem")
         H, W = (dem.shape[1], dem.shape[2]) if dem is not None else (0, 0)
         K9 = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))

