@@ -169,12 +169,13 @@ CERT_SAFETY = 4.0
 
 
 def certify_on(eng, kpts, batch, precision, certify=True):
-    """The margin certificate for a fast-mode engine (gn_set_certify(2)): eps is CALIBRATED for these weights on four pairs that are not part of any
+    """The margin certificate for a fast-mode engine (gn_set_certify(2)): eps is CALIBRATED for these weights on one batch of pairs that are not part of any
     timed batch (max |P_mode - P_f32| over the deciding entries x CERT_SAFETY), then every estimate() call synchronises once, reads its per-pair
     flags and re-runs the flagged pairs on the exact-f32 kernels -- inside the timed region.  Returns the calibration record (None: f32 / off)."""
     if precision == "f32" or not certify:
         return None
-    cal_pairs = [make_pair(900_000 + i, n_q=kpts, n_r=kpts) for i in range(min(4, batch))]
+    # (as many pairs as a timed call holds: the kernel family, and with it the arithmetic whose error is measured, follows the grid size)
+    cal_pairs = [make_pair(900_000 + i, n_q=kpts, n_r=kpts) for i in range(batch)]
     cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=CERT_SAFETY)
     eng.set_certify("rerun")
     return cal
@@ -191,17 +192,24 @@ def certificate_block(eng, cal):
             "pairs_rerun_in_f32": st["rerun_pairs"], "rerun_fraction": round(st["rerun_fraction"], 6), "rerun_pairs_marginal_even_in_f32": st["f32_marginal_pairs"]}
 
 
-def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev, certify=True, substreams=1):
+def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev, certify=True, substreams=1, ffn_products=3, filter_threshold=0.5):
     """One further configuration, timed like the main one (no per-kernel events, no collectives needed: every rank runs it)."""
-    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision=precision, state_dict=sd)
+    eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kpts, precision=precision, state_dict=sd, filter_threshold=filter_threshold)
+    if precision.startswith("f16x2"):
+        eng.set_ffn_products(ffn_products)
     cal = certify_on(eng, kpts, batch, precision, certify)
-    if substreams > 1:
-        eng.set_substreams(substreams)
     pairs = [make_pair(i, n_q=kpts, n_r=kpts) for i in range(batch)]
     inp = eng.stage_inputs(pairs)
     out = eng.alloc_outputs(batch)
+    outs = out
+    if substreams > 1:
+        eng.set_substreams(substreams)
+        if cal is not None:      # as in the headline: the certificate resolved one call later, two alternating output sets
+            eng.set_certify("deferred")
+            cal["resolution"] = "deferred by one call (gn_set_certify(3)); two alternating output sets"
+            outs = [out, eng.alloc_outputs(batch)]
     torch.cuda.synchronize()
-    elapsed, _ = timed_steps(eng, inp, out, steps, warmup, dev)
+    elapsed, _ = timed_steps(eng, inp, outs, steps, warmup, dev)
     ok = int(out["ok"].sum().item())
     cert = certificate_block(eng, cal)
     del eng
@@ -212,6 +220,7 @@ def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev, 
     return {"config": name, "batch": batch, "keypoints_per_side": kpts, "precision": precision, "steps": steps, "warmup": warmup,
             "value": round(pps, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 4), "poses_ok_per_step": ok,
             "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak,
+            "block_tail_partial_products": ffn_products if precision.startswith("f16x2") else None,
             "index_exact": "exact-f32 arithmetic" if precision == "f32" else "certified (margin guard, f32 re-run)" if cert else "tolerance mode", "certificate": cert}
 
 
@@ -612,6 +621,9 @@ def main() -> None:
                          "a line with a non-empty debug_variant is not a valid measurement)")
     ap.add_argument("--no-certify", action="store_true", help="run the fast precision mode WITHOUT the margin certificate (gn_set_certify): round 5's tolerance-mode "
                                                               "number; the line then says index_exact: tolerance mode")
+    ap.add_argument("--ffn-products", type=int, default=0, choices=[0, 2, 3],
+                    help="fp16 partial products of the block tail's GEMMs on bulk grids (gn_set_ffn_products): 3 = f32-accurate split (rounds 1-5), 2 = activations' "
+                         "high term only (reported as an extra configuration); default 3")
     ap.add_argument("--sync-certify", action="store_true", help="certificate resolved inside every call (one host synchronisation per step) instead of one call later")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -674,6 +686,11 @@ def main() -> None:
     for kv in args.debug_variant:
         which, value = (int(v) for v in kv.split(":"))
         eng.lib.gn_debug_set_variant(eng.ctx, which, value)
+    # default 3: the f32-accurate fast pass.  Two products are ~7 % faster per step and ten times less accurate (eps): under the certificate the indices stay
+    # exact either way, but the share of pairs that must be re-run in f32 grows with eps on anything but wide-margin weights -- an opt-in
+    ffn_products = args.ffn_products or 3
+    if args.precision.startswith("f16x2"):
+        eng.set_ffn_products(ffn_products)         # (before the calibration: eps is measured for the arithmetic that runs)
     cert_cal = certify_on(eng, args.kpts, args.batch, args.precision, certify=not args.no_certify)
 
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
@@ -716,6 +733,7 @@ def main() -> None:
     else:
         elapsed, mine = elapsed1, _
     tripped, trips = eng.guard_status()
+    fused_status = eng.fused_projection_status()
     cert_main = certificate_block(eng, cert_cal)
 
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
@@ -751,6 +769,17 @@ def main() -> None:
         if cert_cal is not None:
             extras.append(run_extra(local_rank, sd, "the headline configuration WITHOUT the certificate (round 5's tolerance-mode number: no per-call synchronisation, no re-run)",
                                     args.batch, args.kpts, args.precision, 20, 3, dev, certify=False, substreams=nsub))
+        if cert_cal is not None:
+            # what the certificate costs when decisions are NOT far from flipping: the same configuration on the tests' mid-margin weight family
+            # (filter_threshold 0.01: tests/test_gpu_round6.py) -- flagged pairs are re-run in exact f32 inside the timed region -- and the opt-in
+            # two-product block tail (a third less matrix work in the tail, ten times the eps) on both weight sets
+            mid = synthetic_state_dict(0, ffn_out_std=1.2e-3, final_scale=12.0, matchability_bias=2.0, matchability_std=0.05)
+            extras.append(run_extra(local_rank, sd, "the headline configuration with the block tail on TWO partial products (gn_set_ffn_products(2), opt-in): bench weights",
+                                    args.batch, args.kpts, args.precision, 20, 3, dev, substreams=nsub, ffn_products=2))
+            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights (decisions close to flipping: re-runs inside the timed region), three products",
+                                    args.batch, args.kpts, args.precision, 6, 2, dev, substreams=nsub, ffn_products=3, filter_threshold=0.01))
+            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights, two products",
+                                    args.batch, args.kpts, args.precision, 6, 2, dev, substreams=nsub, ffn_products=2, filter_threshold=0.01))
         extras.append(run_extra(local_rank, sd, f"BASELINE configs[2] in the GUARANTEED mode: batch-{args.batch}, f32 everywhere (exact-f32 MFMA GEMMs and attention) -- "
                                                 "the arithmetic the certificate re-runs flagged pairs in; correspondence indices identical to the CPU restatement of the reference on every "
                                                 "weight set tested (counts: precision_guarantee.f32_evidence)",
@@ -835,6 +864,9 @@ def main() -> None:
             "mean_matches_per_pair": round(n_match_mean, 1),
             "result_records_gathered": int(rec.shape[0]),
             "f16x2_guard": {"tripped_in_last_step": bool(tripped), "trips_observed": int(trips)},
+            "fused_projection_selfcheck": {1: "passed: bitwise equal to the separate k_qkv launches on these weights (checked at the first call)",
+                                           0: "FAILED: fusion switched off for this context", -1: "not applicable / not run"}.get(fused_status),
+            "block_tail_partial_products": ffn_products if args.precision.startswith("f16x2") else None,
             "end_to_end": {"algorithmic_gflop_per_pair": round(g_pair, 2), "attention_gflop_per_pair": round(g_attn, 2),
                            "achieved_tflops_per_gpu": round(e2e_tf, 1), "peak_tflops": e2e_peak, "frac": round(e2e_tf / e2e_peak, 4),
                            "attention_only_frac": round(pairs_per_s / world * g_attn / 1e3 / e2e_peak, 4),

@@ -141,11 +141,16 @@ struct gn_ctx {
                            // at once) while >= 90 % of the tiles hold tokens, else one workgroup per CU walking the list (3 % slower per tile on a batch without
                            // padding, 20 % faster on a ragged one; identical bits).  2: always walk.  3: never walk.
   int ncu = 256;           // compute units of ctx->device (grids of the walking kernels)
+  int fused_proj_status = -1;   // self-check of the projection fused behind the block tail (selfcheck_fused_projection): -1 not run / not applicable to this
+                                // context, 1 bitwise equal to the separate k_qkv launches, 0 differed -> qkv_in_tail switched off for this context
+  bool fused_proj_pending = true;   // run the self-check at the next forward call (set by every weight (re)load)
   int qkv_in_tail = 1;     // knob 32.  1 (default): on bulk grids the block tail k_ffn128 also computes the NEXT block's attention input projection from the rows
                            // it has just produced (k_ffn128<., ., ., 1 / 2>: no k_qkv launch, no read-back of the residual stream); 0: separate k_qkv launches
   int skinny = 1;          // knob 33.  1 (default): calls of one or two pairs run the attention input projections and the block
                            // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow; + 4: not the projections; + 8: not the tail;
                            // >> 4: kernel variant (tools/skinny_ab.py)
+  int ffn_products = 3;    // gn_set_ffn_products: fp16 partial products of the block tail's two GEMMs on bulk grids (k_ffn128, composed form): 3 = f32-accurate split,
+                           // 2 = the activations' fp16 high term only (meant to run under the margin certificate)
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
   unsigned long long* tile_feedback = nullptr;   // pinned host [8]: (all tiles << 32 | valid tiles) written by k_tile_lists of sub-batch group g's last call
   int* lists = nullptr; long long lists_stride = 0;   // work lists (launch_tile_lists), lists_stride ints per pair
@@ -565,6 +570,7 @@ bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const
     f.walk = c->use_lists == 2 || (c->use_lists == 1 && tail_should_walk(c));
     f.ncu = c->ncu;
     f.composed = comp ? 1 : 0;
+    f.products = (comp && c->ffn_products == 2) ? 2 : 3;
     const bool fuse_qkv = next != nullptr && c->qkv_in_tail && comp && ffn_selects_128(f) && gn::g_ffn_ablate == 0 && c->attn_f16 && c->qkv_products != 3 && !c->qkv_stamps &&
                           c->precision != GN_PREC_F32 && c->attn_variant >= 1 && qkv_projection_applies(c, *next, T, np, vt_perm) && !(vt_perm & 2);
     if (fuse_qkv) {
@@ -583,7 +589,7 @@ bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const
     launch_ffn_fused(f, s);
     if (rec) {
       hipEventRecord(c->kev[2 * c->kused + 1], s);
-      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + ((fold && !comp) ? 256.0 * 256.0 : 0.0));   // composed: the flops the kernel's own formulation needs
+      c->kflops[c->kused] = 2.0 * T * (512.0 * 512.0 + 256.0 * 512.0 + ((fold && !comp) ? 256.0 * 256.0 : 0.0));   // composed: the flops the kernel's own formulation needs (algorithmic: whatever the number of partial products)
       c->kbytes[c->kused] = 4.0 * T * (256.0 + 256.0 + 256.0 + 256.0) + 4.0 * (512.0 * 512.0 + 256.0 * 512.0);   // x, msg, residual rows in; x out; weights once
       if (fuse_qkv) {     // + the projection (k_qkv's figures without its read of the rows)
         const double N = next_cross ? 2.0 * kDim : 3.0 * kDim;
@@ -806,6 +812,99 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
 
 void shift_workspaces(gn_ctx* c, long long b0, int sign);
 
+// words of two device arrays that differ (16-byte granules; one atomic per wave that saw a difference)
+__global__ void k_count_diff(const uint4* a, const uint4* b, size_t n, unsigned int* cnt) {
+  bool d = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 x = a[i], y = b[i];
+    d |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+  }
+  const unsigned long long bal = __ballot(d);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(cnt, (unsigned int)__popcll(bal));
+}
+
+// the NEXT block's attention input projection fused behind k_ffn128 (knob 32, on by default) once miscomputed in a way that moved
+// with unrelated edits (DESIGN_HISTORY; the epilogue is pinned scalar arithmetic since) -- so every context PROVES the fused form against the separate
+// k_qkv launches on ITS weights before it is used: the first forward call after a weight (re)load runs, on pseudo-random token rows in the context's own
+// workspaces, the block tail with the projection fused (self and cross form, one-tile and walking form) and tail + k_qkv separately, and compares the
+// q | k rows and V^T panels bit for bit.  Any difference switches the fusion off for this context (gn_fused_projection_status).  ~60 ms, once.
+int selfcheck_fused_projection(gn_ctx* c) {
+  gn_ctx* ctx = c;
+  c->fused_proj_pending = false;
+  c->fused_proj_status = -1;
+  const int np = c->npad;
+  GN_HIP(hipDeviceSynchronize());        // (nothing of an earlier call may still be using the workspaces)
+  if (!c->planes_mode || !c->qkv_in_tail || !c->attn_f16 || c->qkv_products == 3 || !c->ffn_compose || c->ffn_fused != 3 || !c->x_planes_only || c->n_layers < 1 ||
+      !c->qkv_fused || !c->rot4 || !c->lists || !c->msg_p || !c->h_p || c->feature < 0 || gn::g_ffn_ablate != 0 || gn::g_ffn_shape != 0) return GN_OK;
+  int B = (256 * 128 + 2 * np - 1) / (2 * np);          // the smallest batch whose grid selects k_ffn128 (>= 256 tiles of 128 tokens)
+  if (B > c->max_batch) return GN_OK;                   // this context never runs the bulk kernels
+  const int T = B * 2 * np;
+  std::vector<float> h((size_t)T * kDim);
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 40) & 0xFFFF) * (1.0f / 32768.0f) - 1.0f; };   // U(-1, 1), 16 bits
+  for (int pass = 0; pass < 2; ++pass) {
+    for (auto& v : h) v = 1.5f * rnd();
+    float* dst = pass == 0 ? c->x : c->ctx;
+    GN_HIP(hipMemcpy(dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    launch_split_hm16(dst, pass == 0 ? c->x_p : c->ctx_p, T, kDim, 1.0f, 0);
+  }
+  {
+    std::vector<float> cs((size_t)T * kFreq), sn((size_t)T * kFreq);
+    for (size_t i = 0; i < cs.size(); ++i) { const float th = 3.14159265f * rnd(); cs[i] = cosf(th); sn[i] = sinf(th); }
+    GN_HIP(hipMemcpy(c->cos_t, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+    GN_HIP(hipMemcpy(c->sin_t, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice));
+    launch_rot_table(c->cos_t, c->sin_t, c->rot4, T, (long long)c->Tmax, 0);
+    std::vector<int32_t> nv(2 * (size_t)B, np);
+    GN_HIP(hipMemcpy(c->nvalid, nv.data(), nv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    launch_tile_lists(c->nvalid, 2 * B, np, c->lists, nullptr, 0);
+  }
+  const size_t xbytes = (size_t)T * kDim * 4, qbytes = (size_t)T * 2 * kDim * 2, vbytes = (size_t)T * kDim * 2;
+  uint16_t* const keep_q = c->h_p;                                      // (k_ffn128 never writes the hidden tensor to memory: h_p is free scratch, 2 KB per token)
+  uint16_t* const keep_v = c->h_p + (size_t)T * 2 * kDim;
+  GN_HIP(hipMemcpy(c->msg_p, c->x_p, xbytes, hipMemcpyDeviceToDevice));  // the rows every run starts from (the tail updates x_p in place)
+  unsigned int* cnt = c->ovf_base + 12;                                 // (words 9..15 of the guard block are unused)
+  GN_HIP(hipMemset(cnt, 0, sizeof(unsigned int)));
+  const int lists0 = c->use_lists, fused0 = c->qkv_in_tail, guard0 = c->guard; const bool kt0 = c->ktiming; const int lc0 = c->launch_count, sa0 = c->stop_after;
+  c->ktiming = false; c->stop_after = 0; c->guard = 0;
+  bool applicable = true;
+  const int nblk = c->n_layers > 1 ? 1 : 0;
+  for (int cross = 0; cross < 2 && applicable; ++cross)
+    for (int walk = 0; walk < 2 && applicable; ++walk) {
+      const Block& tail = cross ? c->self_blk[0] : c->cross_blk[0];     // (any tail will do; the projection is the OTHER kind's)
+      const Block* next = cross ? &c->cross_blk[0] : &c->self_blk[nblk];
+      c->use_lists = walk ? 2 : 3;
+      GN_HIP(hipMemcpyAsync(c->x_p, c->msg_p, xbytes, hipMemcpyDeviceToDevice, 0));
+      GN_HIP(hipMemsetAsync(c->qkb, 0, qbytes, 0)); GN_HIP(hipMemsetAsync(c->vtb, 0, vbytes, 0));
+      c->qkv_in_tail = 1;
+      if (!ffn(c, tail, T, 0, false, next, cross != 0, np, 1)) { applicable = false; break; }
+      GN_HIP(hipMemcpyAsync(keep_q, c->qkb, qbytes, hipMemcpyDeviceToDevice, 0));
+      GN_HIP(hipMemcpyAsync(keep_v, c->vtb, vbytes, hipMemcpyDeviceToDevice, 0));
+      GN_HIP(hipMemcpyAsync(c->x_p, c->msg_p, xbytes, hipMemcpyDeviceToDevice, 0));
+      GN_HIP(hipMemsetAsync(c->qkb, 0, qbytes, 0)); GN_HIP(hipMemsetAsync(c->vtb, 0, vbytes, 0));
+      c->qkv_in_tail = 0;
+      ffn(c, tail, T, 0, false, next, cross != 0, np, 1);
+      if (!qkv_projection(c, *next, cross != 0, T, np, 1, 0)) { applicable = false; break; }
+      hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const uint4*>(keep_q), reinterpret_cast<const uint4*>(c->qkb), (cross ? qbytes / 2 : qbytes) / 16, cnt);
+      hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const uint4*>(keep_v), reinterpret_cast<const uint4*>(c->vtb), vbytes / 16, cnt);
+    }
+  c->use_lists = lists0; c->qkv_in_tail = fused0; c->guard = guard0; c->ktiming = kt0; c->launch_count = lc0; c->stop_after = sa0;
+  unsigned int diffs = 0;
+  GN_HIP(hipStreamSynchronize(0));
+  GN_HIP(hipMemcpy(&diffs, cnt, sizeof diffs, hipMemcpyDeviceToHost));
+  // leave the workspaces as a fresh context has them
+  GN_HIP(hipMemset(c->x_p, 0, xbytes)); GN_HIP(hipMemset(c->ctx_p, 0, xbytes)); GN_HIP(hipMemset(c->msg_p, 0, xbytes)); GN_HIP(hipMemset(c->h_p, 0, qbytes + vbytes));
+  GN_HIP(hipMemset(c->qkb, 0, qbytes)); GN_HIP(hipMemset(c->vtb, 0, vbytes)); GN_HIP(hipMemset(c->x, 0, xbytes)); GN_HIP(hipMemset(c->ctx, 0, xbytes));
+  GN_HIP(hipMemset(cnt, 0, sizeof(unsigned int)));
+  if (!applicable) return GN_OK;
+  c->fused_proj_status = diffs == 0 ? 1 : 0;
+  if (diffs != 0) {
+    c->qkv_in_tail = 0;
+    fprintf(stderr, "[gisnav_amd] the projection fused behind the block tail differs from the separate k_qkv launches in %u 16-byte words on this context's weights: "
+                    "fusion switched off for this context (results stay correct, ~4 %% slower)\n", diffs);
+  }
+  return GN_OK;
+}
+
 // The exact-f32 arithmetic inside a context of another precision, for the duration of a scope: GN_PREC_F32's kernels read the f32 weights (kept in
 // every mode) and the f32 workspaces (allocated in every mode); nothing of the hm16 / 16-bit state is touched.
 struct F32Scope {
@@ -866,7 +965,10 @@ int check_fwd(gn_ctx* ctx, int B, int stride_q, int stride_r) {
   if (stride_q < 1 || stride_r < 1 || stride_q > ctx->npad || stride_r > ctx->npad)
     return fail(ctx, GN_ERR_ARG, "keypoint stride exceeds max_kpts of this context");
   if (gn_missing_tensors(ctx) != 0) return fail(ctx, GN_ERR_WEIGHTS, "weights not fully loaded");
-  return ensure_composed(ctx);      // (host work on the first call after a (re)load only)
+  const int rc_c = ensure_composed(ctx);      // (host work on the first call after a (re)load only)
+  if (rc_c != GN_OK) return rc_c;
+  if (ctx->fused_proj_pending && !ctx->in_group && !ctx->cert_inner) return selfcheck_fused_projection(ctx);
+  return GN_OK;
 }
 
 }  // namespace
@@ -1109,7 +1211,7 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
   } else {
     return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
   }
-  if (rc == GN_OK) ctx->loaded[name] = true;
+  if (rc == GN_OK) { ctx->loaded[name] = true; ctx->fused_proj_pending = true; }
   return rc;
 }
 
@@ -1186,6 +1288,14 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
   if (tripped && ctx->guard == 1) ++ctx->guard_trips;
   if (last_call_tripped) *last_call_tripped = tripped;
   if (trips_total) *trips_total = ctx->guard_trips;
+  return GN_OK;
+}
+
+int gn_fused_projection_status(const gn_ctx* ctx) { return ctx ? ctx->fused_proj_status : GN_ERR_ARG; }
+
+int gn_set_ffn_products(gn_ctx* ctx, int products) {
+  if (!ctx || (products != 2 && products != 3)) return GN_ERR_ARG;
+  ctx->ffn_products = products;
   return GN_OK;
 }
 
@@ -1374,6 +1484,12 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
                 const uint8_t* dem, int H, int W, const double* K9, int min_matches,
                 double* R, double* t, int32_t* n_match, int32_t* n_inliers, uint8_t* ok, void* stream) {
   if (!ctx) return fail(nullptr, GN_ERR_ARG, "null context");
+  if (ctx->fused_proj_pending && ctx->npad > 0 && gn_missing_tensors(ctx) == 0) {      // (the sub-batch groups below skip it: their workspace pointers are shifted)
+    GN_HIP(hipSetDevice(ctx->device));
+    int rcs = ensure_composed(ctx);
+    if (rcs == GN_OK) rcs = selfcheck_fused_projection(ctx);
+    if (rcs != GN_OK) return rcs;
+  }
   const int groups = std::min(ctx->n_sub, B);
   if (groups <= 1 || ctx->overlap)
     return estimate_impl(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, dem, H, W, K9, min_matches,

@@ -144,6 +144,7 @@ struct FfnArgs {
   // k_ffn128 with the NEXT block's attention input projection fused behind the tail (round 5): the tile's new residual rows go from the epilogue's
   // registers into LDS as the projection's token operand (no 64 MB round trip through HBM, no second launch).  Same arithmetic, operand order and
   // outputs as k_qkv<., true, 2> (gn_qkv.hip: fp16 outputs, two partial products): bit-identical q | k rows and V^T panels.
+  int products = 3;                        // k_ffn128, composed form: 3 = the f32-accurate split (three fp16 partial products per GEMM), 2 = activations' high term only (gn_set_ffn_products)
   int qkv = 0;                             // 0: none; 1: the self block's Wqkv + rotary; 2: the cross block's to_qk | to_v
   const uint16_t* q_wf = nullptr; float q_acc_scale = 1.f; const float* q_bias = nullptr;   // QkvArgs::wf / acc_scale / bias
   const float* q_rot4 = nullptr; long long q_rot_stride = 0;                               // QkvArgs::rot4 / rot_stride (qkv == 1)

@@ -50,8 +50,14 @@ __device__ __forceinline__ float resid_hi(unsigned int h, float y) { float r; as
 // COMP: out_proj is composed into ffn.0 at load time (W1' = [W1_x | W1_m Wo], b1' = b1 + W1_m bo: gn_api.hip build_composed) -- no GEMM 0, no message
 // tile: GEMM 1 runs over [x | ctx], all sixteen k-tiles through the ring
 // QKV (round 5): 1 / 2 = the NEXT block's attention input projection (self: Wqkv + rotary; cross: to_qk | to_v) runs on the tile's new rows behind the epilogue
-template <int ABL, bool COMP, bool LOOP = false, int QKV = 0>   // LOOP: the workgroup walks the work list (one workgroup per CU); timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
+// PROD (round 6): 3 = every GEMM on the three partial products of the hm16 split (W_m X_h + W_h X_m + W_h X_h: f32-accurate); 2 = the products with the
+// activations' fp16 HIGH term only (W_m X_h + W_h X_h: 22-bit weights x 11-bit activations, f32 accumulate) -- the arithmetic of the attention input
+// projections since round 4, one rounding of the GEMM inputs to fp16, which the fp16 attention beside it applies to q, k, v and the probabilities anyway.
+// A third of the matrix-pipe work of both GEMMs, half of the token-fragment reads, no residual split of the hidden tile.  Meant to run under the margin
+// certificate (gn_set_certify), which makes the correspondence indices independent of the fast pass's arithmetic; composed form only.
+template <int ABL, bool COMP, bool LOOP = false, int QKV = 0, int PROD = 3>   // LOOP: the workgroup walks the work list (one workgroup per CU); timing-only ablations (bits): 1 no weight loads inside the loops, 2 no token-row loads inside the loops, 4 no GELU polynomial, 16 no barriers inside the k-loops; 8 = s_memtime stamps per phase into a.dbg_ts (results stay valid)
 __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
+  static_assert(PROD == 3 || (PROD == 2 && COMP), "two partial products: composed form only");
   constexpr int NJ = 4, NI = 4, NO = 2, NW = 4, TM = 128;
   constexpr int KT = TM * 128;            // bytes of one 32-wide k-tile of 128 token rows (hm16: 128 B per row)
   constexpr int RING = 8 * KT;            // two staging slots behind the message tile
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
   auto read_b = [&](int g, int tile_off, int ks, int j) __attribute__((always_inline)) {
     const int off = tile_off + (j >> 1) * 8192;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) bq[g % 3][pl] = *reinterpret_cast<const f16x8*>(smem + bo[off >> 16][j & 1][2 * ks + pl] + (off & 65535));
+    for (int pl = 0; pl < (PROD == 2 ? 1 : 2); ++pl) bq[g % 3][pl] = *reinterpret_cast<const f16x8*>(smem + bo[off >> 16][j & 1][2 * ks + pl] + (off & 65535));
   };
   // a lane's accumulator registers 8 ks' .. 8 ks' + 7 of tile (., j) ARE one 16-byte B-operand fragment of a following transposed
   // GEMM (whose weight columns are permuted to this order in the re-layout): publishing costs two ds_write_b128 per fragment.
@@ -187,14 +193,18 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
 #pragma unroll
       for (int e = 0; e < 8; e += 2) { amax = fmaxf(amax, fmaxf(fabsf(gy[e]), fabsf(gy[e + 1]))); gh[e >> 1] = pack16<true>(gy[e], gy[e + 1]); }
     } else if (st == 19) {
+      if constexpr (PROD == 3) {
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) { gt[e] = resid_lo(gh[e >> 1], gy[e]); gt[e + 1] = resid_hi(gh[e >> 1], gy[e + 1]); }
+        for (int e = 0; e < 8; e += 2) { gt[e] = resid_lo(gh[e >> 1], gy[e]); gt[e + 1] = resid_hi(gh[e >> 1], gy[e + 1]); }
+      }
     } else if (st == 20) {
     } else if (st == 21) {
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) gm[e >> 1] = pack16<true>(gt[e], gt[e + 1]);
       *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp] + (off + (j >> 1) * 8192)) = make_uint4(gh[0], gh[1], gh[2], gh[3]);
-      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + (off + (j >> 1) * 8192)) = make_uint4(gm[0], gm[1], gm[2], gm[3]);
+      if constexpr (PROD == 3) {      // (two products: the next GEMM reads the high terms only)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) gm[e >> 1] = pack16<true>(gt[e], gt[e + 1]);
+        *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + (off + (j >> 1) * 8192)) = make_uint4(gm[0], gm[1], gm[2], gm[3]);
+      }
     }
   };
 
@@ -369,15 +379,18 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+          if (PROD == 2 && p == 1) continue;            // (W_h X_m: not in the two-product form)
           const int mj = 4 * p + i;       // MFMA number inside the j-step
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[n2 % RA][i][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+          // the memory instructions of the k-step, one per MFMA gap: three products: gaps 2 | 5, 10 | 7 of the j-step's 12; two products: 2 | 1, 9 | 3 of its 8 (mj 4..7 do not exist)
+          constexpr int kLa0 = PROD == 3 ? 5 : 1, kLa1 = PROD == 3 ? 10 : 9, kSl = PROD == 3 ? 7 : 3;
           if ((COMP || n >= 8) && ks == 0 && n + 1 < 16 && mj == 2) stage_write(n + 1, j);
-          if (!(ABL & 1) && (mj == 5 || mj == 10) && n2 >= 1 && n2 + RA - 1 < 32) {
-            const int u = 2 * j + (mj == 10 ? 1 : 0);   // 0..7 -> (i, term)
+          if (!(ABL & 1) && (mj == kLa0 || mj == kLa1) && n2 >= 1 && n2 + RA - 1 < 32) {
+            const int u = 2 * j + (mj == kLa1 ? 1 : 0);   // 0..7 -> (i, term)
             load_a((n2 - 1) % RA, n2 + RA - 1, u >> 1, u & 1);
           }
-          if (!(ABL & 2) && ks == 0 && (COMP || n + 3 >= 9) && n + 3 < 16 && mj == 7) stage_load(n + 3, j);     // (x tiles 9, 10 are requested during the last message k-tiles)
-          if (n2 == 29 && mj == 7 && j == 0) cst_a = *reinterpret_cast<const uint4*>((tid < 128 ? a.ln_g : a.ln_b - 512) + 4 * tid);
+          if (!(ABL & 2) && ks == 0 && (COMP || n + 3 >= 9) && n + 3 < 16 && mj == kSl) stage_load(n + 3, j);     // (x tiles 9, 10 are requested during the last message k-tiles)
+          if (n2 == 29 && mj == kSl && j == 0) cst_a = *reinterpret_cast<const uint4*>((tid < 128 ? a.ln_g : a.ln_b - 512) + 4 * tid);
           GN_PIN();
         }
     }
@@ -578,14 +591,17 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
     unsigned int hw[8], mw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { amax = fmaxf(amax, fmaxf(fabsf(y[k][0]), fabsf(y[k][1]))); hw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(y[k], f16x2v)); }
+    if constexpr (PROD == 3) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = (f32x2v){resid_lo(hw[k], y[k][0]), resid_hi(hw[k], y[k][1])};
+      for (int k = 0; k < 8; ++k) t[k] = (f32x2v){resid_lo(hw[k], y[k][0]), resid_hi(hw[k], y[k][1])};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
+      for (int k = 0; k < 8; ++k) mw[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t[k], f16x2v));
+    }
 #pragma unroll
     for (int ksp = 0; ksp < 2; ++ksp) {
       *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp] + ((j >> 1) * 8192)) = make_uint4(hw[4 * ksp], hw[4 * ksp + 1], hw[4 * ksp + 2], hw[4 * ksp + 3]);
-      *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + ((j >> 1) * 8192)) = make_uint4(mw[4 * ksp], mw[4 * ksp + 1], mw[4 * ksp + 2], mw[4 * ksp + 3]);
+      if constexpr (PROD == 3)
+        *reinterpret_cast<uint4*>(smem + pb[j & 1][2 * ksp + 1] + ((j >> 1) * 8192)) = make_uint4(mw[4 * ksp], mw[4 * ksp + 1], mw[4 * ksp + 2], mw[4 * ksp + 3]);
     }
   };
 #pragma unroll
@@ -635,12 +651,26 @@ __global__ __launch_bounds__(256) void k_ffn128(FfnArgs a_in) {
         for (int p = 0; p < 3; ++p)
 #pragma unroll
           for (int o = 0; o < NO; ++o) {
-            const int m = 6 * j + 2 * p + o;
+            if (PROD == 2 && p == 1) continue;            // (W_h H_m: not in the two-product form)
             acc2[o][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[c % RG][o][p == 0 ? 1 : 0], bq[g % 3][p == 1 ? 1 : 0], acc2[o][j], 0, 0, 0);
-            // the VALU stage of the next quarter's fragment (token tile w4, k-step ks) that shares this MFMA's gap
-            if (fill && m < 22) gelu_stage(m, q + 1, w4, ks);
-            if (q == 3 && m == 2 && !LOOP) res_load(cc);      // (walking form: the registers are not there, all residual rows are requested in the epilogue)
-            if (!(ABL & 1) && m % 6 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 6) >> 1, (m / 6) & 1);
+            if constexpr (PROD == 3) {
+              const int m = 6 * j + 2 * p + o;
+              // the VALU stage of the next quarter's fragment (token tile w4, k-step ks) that shares this MFMA's gap
+              if (fill && m < 22) gelu_stage(m, q + 1, w4, ks);
+              if (q == 3 && m == 2 && !LOOP) res_load(cc);      // (walking form: the registers are not there, all residual rows are requested in the epilogue)
+              if (!(ABL & 1) && m % 6 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 6) >> 1, (m / 6) & 1);
+            } else {
+              // sixteen MFMA gaps per (quarter, k-step) for the fragment's twenty stages (no residual split): the light neighbours share a gap
+              const int m = 4 * j + (p == 2 ? 2 : 0) + o;
+              if (fill) {
+                constexpr int first[16] = {0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18};
+                constexpr int second[16] = {-1, -1, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1, -1, 15, 17, 21};
+                gelu_stage(first[m], q + 1, w4, ks);
+                if (second[m] >= 0) gelu_stage(second[m], q + 1, w4, ks);
+              }
+              if (q == 3 && m == 2 && !LOOP) res_load(cc);
+              if (!(ABL & 1) && m % 4 == 3 && c >= 1 && c + RG - 1 < 32) load_g((c - 1) % RG, c + RG - 1, (m / 4) >> 1, (m / 4) & 1);
+            }
             GN_PIN();
           }
       }
@@ -908,6 +938,17 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
   FfnArgs b = a;
   if (!walk) b.tiles = nullptr;
   if (walk || ablate != 0) b.nvalid = nullptr;
+  if (a.composed && a.products == 2 && (ablate == 0 || ablate == 8)) {      // two partial products (round 6): composed form only
+#define GN_F2(Q) do { if (ablate == 8) hipLaunchKernelGGL((k_ffn128<8, true, false, Q, 2>), grid, block, 0, s, b); \
+                      else if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, Q, 2>), grid, block, 0, s, b); \
+                      else hipLaunchKernelGGL((k_ffn128<0, true, false, Q, 2>), grid, block, 0, s, b); } while (0)
+    const int qv = ablate == 0 ? a.qkv : 0;
+    if (qv == 1) { GN_F2(1); g_last_kernel = walk ? "k_ffn128<0, true, true, 1, 2>" : "k_ffn128<0, true, false, 1, 2>"; }
+    else if (qv == 2) { GN_F2(2); g_last_kernel = walk ? "k_ffn128<0, true, true, 2, 2>" : "k_ffn128<0, true, false, 2, 2>"; }
+    else { GN_F2(0); g_last_kernel = walk ? "k_ffn128<0, true, true, 0, 2>" : "k_ffn128<0, true, false, 0, 2>"; }
+#undef GN_F2
+    return;
+  }
   if (a.composed && a.qkv != 0 && ablate == 0) {      // the next block's attention input projection behind the tail (a.qkv: 1 self, 2 cross)
     if (a.qkv == 1) {
       if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, 1>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true, false, 1>), grid, block, 0, s, b);

@@ -190,6 +190,15 @@ class PoseEngine:
         _lib.check(self.ctx, self.lib.gn_set_certify(self.ctx, int(m), -1.0 if eps is None else float(eps), -1.0 if eps_f32 is None else float(eps_f32)),
                    "gn_set_certify")
 
+    def fused_projection_status(self) -> int:
+        """gn_fused_projection_status: 1 the projection fused behind the block tail was checked bitwise equal to the separate launches on this context's
+        weights, 0 it differed and was switched off, -1 not run yet / not applicable."""
+        return int(self.lib.gn_fused_projection_status(self.ctx))
+
+    def set_ffn_products(self, products: int) -> None:
+        """gn_set_ffn_products: 3 (default, f32-accurate) or 2 (activations' fp16 high term only; run it under set_certify)."""
+        _lib.check(self.ctx, self.lib.gn_set_ffn_products(self.ctx, int(products)), "gn_set_ffn_products")
+
     def calibrate_certify(self, inputs: dict, safety: float = 4.0, floor_eps: float = 1.0e-5) -> Dict[str, float]:
         """gn_calibrate_certify on staged inputs (the dict of stage_inputs / RecordStager.stage): measures max |P_mode - P_f32| over the deciding
         entries of the sample and sets eps = max(floor_eps, safety * that).  Returns {"measured": ..., "eps": ...}."""

@@ -130,12 +130,26 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
  * value).  A pair that satisfies (a)-(c) has exactly the exact arithmetic's match list (proof in DESIGN.md).
  *   mode 0  off (default): no flags are written;
  *   mode 1  flags only, stream-ordered, no host synchronisation: gn_get_uncertain reads them;
+ *   mode 3  as mode 2, but gn_estimate with sub-batch streams resolves call n's flags after call n + 1 has been enqueued (or in gn_flush): the caller keeps
+ *           the inputs AND outputs of call n untouched until then (two alternating output sets); no host wait on an idle GPU;
  *   mode 2  certified results: gn_match / gn_estimate synchronise the stream once per call, read the flags and run every flagged pair
  *           again -- matcher, and for gn_estimate also gather + PnP -- on GN_PREC_F32's kernels (the context keeps f32 weights and f32
  *           workspaces in every mode).  A call whose activations left the fp16 range is flagged as a whole (flag value 2), so this mode
  *           also takes over gn_set_guard(2)'s fallback.  In a GN_PREC_F32 context nothing is re-run: the flags (for eps_f32) are counted.
  * Results of a pair do not depend on which other pairs were re-run. */
 int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32);
+/* Arithmetic of the block tail (ffn.0 -> LayerNorm -> GELU -> ffn.3 with out_proj folded in; kornia `x + ffn(cat[x, msg])`) on bulk grids in the f16x2
+ * modes: 3 (default) = every operand as two fp16 terms, three partial products, f32-accurate; 2 = the activations' fp16 HIGH term only (22-bit weights x
+ * 11-bit activations, f32 accumulation: the arithmetic of the attention input projections, and the rounding the fp16 attention applies to q, k, v anyway) --
+ * a third less matrix-pipe work.  The error of the assignment scores grows (gn_calibrate_certify measures it), so this setting is meant to run under the
+ * margin certificate (gn_set_certify(2 / 3)), which makes the returned correspondence indices independent of the fast pass's arithmetic.  Small grids
+ * (fewer than 256 tiles of 128 tokens) keep three products. */
+int gn_set_ffn_products(gn_ctx* ctx, int products);
+/* On bulk grids the block-tail kernel also computes the next block's attention input projection (one launch and one pass over the residual rows
+ * less).  Every context proves that fused form against the separate launches on its own weights before using it: at the first forward call after
+ * a weight (re)load both forms run on pseudo-random rows and their outputs are compared bit for bit (~60 ms, once); a difference switches the
+ * fusion off for the context.  Returns 1 = checked equal, 0 = differed (fusion off), -1 = not run yet / not applicable (small contexts, other modes). */
+int gn_fused_projection_status(const gn_ctx* ctx);
 /* out8: calls certified, pairs certified, pairs flagged for margin, pairs flagged for fp16 range, pairs re-run in exact f32,
  * re-run (or, in an f32 context, original) pairs that are marginal even for eps_f32, current mode, reserved. */
 int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8);
@@ -144,7 +158,8 @@ int gn_reset_certify_stats(gn_ctx* ctx);
  * context's arithmetic and on the exact-f32 kernels -- and eps = max(floor_eps, safety * max |P_mode - P_f32|) over the best score and the
  * runner-up of every valid row that comes within 1 of log(filter_threshold) in either arithmetic (all rows when the threshold is 0).
  * Synchronises; sets the context's eps and returns the measured maximum and eps through the two host pointers (either may be NULL).  Call
- * it once after loading a checkpoint, on representative pairs; safety >= 1 is the stated safety factor (the Python mirror uses 4). */
+ * it once after loading a checkpoint, on representative pairs, IN A BATCH OF THE SIZE THE REAL CALLS HAVE (the kernel family -- and with it the arithmetic
+ * whose error is being measured -- follows the grid size); safety >= 1 is the stated safety factor (the Python mirror uses 4). */
 int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
                          const float* desc_q, const float* kpt_q, const int32_t* n_q, int stride_q,
                          const float* desc_r, const float* kpt_r, const int32_t* n_r, int stride_r,

@@ -177,8 +177,11 @@ def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
                     assert not touched, f"{name}: {op} touches v[{lo}:{hi}] {k - j} instructions behind the score MFMA that writes it"
     # (tag, MFMAs in the code, spilled VGPRs at most, scratch instructions at most): the one-tile tail alone, with the self / cross projection fused behind it
     # (round 5: + 768 / 512 MFMAs), and the walking form
-    for tag, nmf, spills, scratch in (("k_ffn128ILi0ELb1ELb0ELi0E", 2304, 2, 5), ("k_ffn128ILi0ELb1ELb0ELi1E", 3072, 3, 5), ("k_ffn128ILi0ELb1ELb0ELi2E", 2816, 19, 12),
-                                      ("k_ffn128ILi0ELb1ELb1ELi0E", 2304, 22, 21)):
+    # round 6: the last template parameter is the number of partial products (3: n1 = 1536 MFMAs in GEMM 1, 2304 in the tail; 2: 1024 / 1536)
+    for tag, nmf, n1, ntail, spills, scratch in (("k_ffn128ILi0ELb1ELb0ELi0ELi3E", 2304, 1536, 2304, 2, 5), ("k_ffn128ILi0ELb1ELb0ELi1ELi3E", 3072, 1536, 2304, 3, 5),
+                                                 ("k_ffn128ILi0ELb1ELb0ELi2ELi3E", 2816, 1536, 2304, 19, 12), ("k_ffn128ILi0ELb1ELb1ELi0ELi3E", 2304, 1536, 2304, 22, 21),
+                                                 ("k_ffn128ILi0ELb1ELb0ELi0ELi2E", 1536, 1024, 1536, 4, 6), ("k_ffn128ILi0ELb1ELb0ELi1ELi2E", 2304, 1024, 1536, 4, 6),
+                                                 ("k_ffn128ILi0ELb1ELb0ELi2ELi2E", 2048, 1024, 1536, 6, 8)):
         (name,) = [n for n in ks if tag in n]
         meta, ins = ks[name]
         assert meta["agpr_count"] == 256 and meta["vgpr_count"] == 512, meta
@@ -188,13 +191,13 @@ def test_shipped_asm_dependent_kernels_are_tamper_evident(tmp_path):
         sc = [j for j, (op, _) in enumerate(ins) if op.startswith("scratch_")]
         assert len(sc) <= scratch, (name, len(sc))
         if "Lb0ELi" in tag:     # the one-tile forms the bench runs: nothing from scratch memory inside the first GEMM's weight stream, nor inside the projection's
-            assert not any(mf[0] < j < mf[1535] for j in sc), (name, sc, mf[0], mf[1535])
-            assert not any(j > mf[2304] for j in sc if nmf > 2304), (name, sc, mf[2304])
-        if nmf > 2304:
+            assert not any(mf[0] < j < mf[n1 - 1] for j in sc), (name, sc, mf[0], mf[n1 - 1])
+            assert not any(j > mf[ntail] for j in sc if nmf > ntail), (name, sc, mf[ntail])
+        if nmf > ntail:
             # round 5: the fused projection's epilogue is written component by component -- with the f32x4 expressions of k_qkv hipcc
             # emitted `v_pk_mul_f32 D, s[n:n+1], V op_sel_hi:[0,1]`, and the one-tile self form then stored garbage in (o.z, o.w) of lanes 12..15 /
             # 28..31 (deterministic; gone with scalar arithmetic).  No packed f32 arithmetic behind the projection's first MFMA (the tail's own row-wise epilogue, in front of it, keeps its v_pk_fma_f32).
-            packed = [(j, op) for j, (op, _) in enumerate(ins) if j > mf[2304] and op.startswith("v_pk_") and op.endswith("_f32")]
+            packed = [(j, op) for j, (op, _) in enumerate(ins) if j > mf[ntail] and op.startswith("v_pk_") and op.endswith("_f32")]
             assert not packed, (name, packed[:8])
 
 
