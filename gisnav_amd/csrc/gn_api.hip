@@ -2024,11 +2024,19 @@ int gn_sp_detect_and_describe(gn_ctx* ctx, const float* gray01, int B, int H, in
     for (int i = 1; i < 12; ++i) hm16_io = hm16_io && ctx->sp[i].wfh != nullptr;
     ctx->sp_enc_hm16 = hm16_io;
     ctx->sp_enc_fp16 = !hm16_io && split && ctx->sp_split == 2 && gn::g_sp_conv_h == 2 && ctx->sp[7].wfh != nullptr;
+    // round 6: in the split-fp16 mode the first convolution is evaluated inside the second one's halo staging (k_sp_conv_s16<., ., true>): its
+    // full-resolution 64-channel map -- 0.53 GB of records per 1080p frame -- is neither written nor read; same bits (knob 46 = 0: two launches)
+    const bool fuse1 = hm16_io && gn::g_sp_fuse1 && gn::g_sp_conv_s == 2 && ctx->sp[1].cin == 64 && ctx->sp[1].cout_pad == 64 && ctx->sp[1].taps == 9 && ctx->sp_stop != 1 &&
+                       !(ctx->sp_ts_layer == 1 && ctx->sp_ts != nullptr);
+    if (fuse1) {
+      sp_conv_fused1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, n, H, W, ctx->sp[1].b, Y, ctx->sp[1].cout_pad, s, ctx->sp[1].wfh, ctx->sp[1].acc_scale, ctx->ovf_base + 8);
+    } else {
     sp_conv1(gray01 + (size_t)b0 * H * W, ctx->sp[0].wf, ctx->sp[0].b, X, n, H, W, s,
              hm16_io ? 2 : (split && ctx->sp_split == 2 && ctx->sp[1].wfh != nullptr ? 1 : 0), ctx->ovf_base + 8);
     // the three 2 x 2 max-pools are fused into the epilogues of the convolutions in front of them (the full-resolution 64-channel map of
     // block 0 alone is 0.5 GB per 1080p image: writing it and reading it back was a quarter of the extractor's HBM traffic)
     conv(1, X, Y, n, H, W, 1, 1);                                                                   // block 0 -> Y [H/2][W/2][64]
+    }
     conv(2, Y, X, n, H / 2, W / 2, 1);     conv(3, X, Y, n, H / 2, W / 2, 1, 1);                    // block 1 -> Y [H/4][W/4][64]
     conv(4, Y, X, n, H / 4, W / 4, 1);     conv(5, X, Y, n, H / 4, W / 4, 1, 1);                    // block 2 -> Y [H/8][W/8][128]
     conv(6, Y, X, n, h, w, 1);             conv(7, X, Y, n, h, w, 1);                               // block 3 -> Y = encoder output
@@ -2224,6 +2232,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 42) gn::g_lf_conv_knob = value;
   else if (which == 43) gn::g_attn_f32_ks = value;
   else if (which == 44) gn::g_gemm_r64 = value;
+  else if (which == 46) gn::g_sp_fuse1 = value;
   else if (which == 39) ctx->sp_stop = value;
   else if (which == 35) {
     ctx->sp_ts_layer = value;

@@ -353,7 +353,10 @@ void sift_sort_dedup(int B, SiftKeypoint* kp, long long kp_stride, int* counters
 
 // ---- SuperPoint extractor (gn_superpoint.hip) ------------------------------------------------------------------
 void sp_weight_fragments(const float* w, int Cout, int Cin, int taps, int Cout_pad, float* out);   // host arrays
-void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half = 0, unsigned int* ovf = nullptr);   // out_half: 0 f32, 1 fp16, 2 hm16 records (guarded by ovf)
+void sp_conv1(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, int out_half = 0, unsigned int* ovf = nullptr);
+void sp_conv_fused1(const float* gray, const float* w1, const float* b1, int B, int H, int W, const float* bias, float* out, int Cout_pad, hipStream_t s,
+                    const uint16_t* wfh, float acc_scale, unsigned int* ovf);   // layers 0 + 1 in one launch (split-fp16 mode, hm16 records out, 2 x 2 max-pool fused)
+extern int g_sp_fuse1;   // out_half: 0 f32, 1 fp16, 2 hm16 records (guarded by ovf)
 extern int g_sp_conv_s, g_sp_nms_fused, g_sp_select_stream;
 void sp_weight_fragments_hm16(const float* w, int Cout, int Cin, int taps, int Cout_pad, float scale, uint16_t* out);   // host arrays; out: 2 * Cout_pad * taps * Cin halfs
 void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, const float* bias, float* out, int Cout_pad, int taps, int relu, hipStream_t s,

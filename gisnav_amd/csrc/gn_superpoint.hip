@@ -144,6 +144,9 @@ struct ConvArgs {
   unsigned int* ovf;                         // HM variant: raised when an input activation does not fit fp16 (the caller re-runs the exact path)
   long long* dbg_ts;                         // developer: s_memtime stamps of k_sp_conv_s's phases, [workgroup][32] (tools/sp_phases.py), or nullptr
   int in_half, out_half;                     // GN_SP_FP16 only: the layer reads / writes its NHWC activations as fp16 (half the HBM traffic of the full-resolution layers)
+  // k_sp_conv_s16<., ., true> (round 6): the network's FIRST convolution (1 -> 64, 3 x 3 + ReLU) is evaluated while the halo tile is staged, from the
+  // gray image itself -- `in` is then unused, Cin = 64
+  const float* img = nullptr; const float* w1 = nullptr; const float* b1 = nullptr;   // [B][H][W] f32 image, conv1a weight [64][9], bias [64]
 };
 
 // grid (tiles_x, tiles_y, B * Cout/64)
@@ -862,15 +865,26 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
 // three 4 KB buffers, across the slice boundaries (they do not depend on the tile), and are waited for with a counted vmcnt.  LDS pixel layout:
 // 64 bytes = pieces 2 pl + hh at position piece ^ ((lx >> 2) & 3) (k_sp_conv_h's).  Same products, but the k order is (slice of 16, tap) instead
 // of (slice of 32, tap, k-step): results equal k_sp_conv_s's to f32 rounding, not bitwise.
-template <bool POOL, bool OUTHM>
-__global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
+// FUSE1 (round 6): this is the network's SECOND convolution and the first one (1 -> 64 channels, 3 x 3, ReLU) is not a launch of its own
+// any more: its 64-channel full-resolution map -- 0.53 GB of hm16 records per 1080p frame, written by k_sp_conv1 and read straight back here -- never
+// exists.  A slice's halo tile (10 x 34 pixels x 16 channels) is COMPUTED into LDS from a 12 x 36 patch of the gray image: per pixel and channel the fma
+// chain of k_sp_conv1 (bias, then the nine taps in order), ReLU, the fp16 split of its record format -- the same bits in the same LDS positions the
+// LDS-DMA would have delivered, so everything downstream is bitwise what the two launches give.  Pixels outside the image are zero records (this
+// convolution's zero padding), not first-layer values.
+template <bool POOL, bool OUTHM, bool FUSE1 = false>
+__global__ __launch_bounds__(256, FUSE1 ? 4 : 3) void k_sp_conv_s16(ConvArgs a) {
   constexpr int RPW = 2, TH = 8, LW = TW + 2, LH = TH + 2, TAPS = 9;
   constexpr int NSEG = 3, TAIL = 2;                 // 16 pixels per staging instruction; 34 = 16 + 16 + 2
   constexpr int NROW = (LH + 3) / 4;
   constexpr int TILE_B = ((LH * LW * 64 + 1023) / 1024) * 1024;
   constexpr int PSTR = 256 + 16, SLAB = (POOL ? 16 : 32) * PSTR;
-  constexpr int SMEM = TILE_B + 3 * 4096 > 4 * SLAB ? TILE_B + 3 * 4096 : 4 * SLAB;
+  constexpr int PW = LW + 2, PH = LH + 2;           // FUSE1: image patch (the halo tile's own 3 x 3 neighbourhood)
+  constexpr int FUSE_B = FUSE1 ? (PH * PW + 64 * 9 + 64) * 4 : 0;
+  constexpr int SMEM0 = TILE_B + 3 * 4096 > 4 * SLAB ? TILE_B + 3 * 4096 : 4 * SLAB;
+  constexpr int SMEM = SMEM0 + ((FUSE_B + 15) / 16) * 16;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+  float* const patch = reinterpret_cast<float*>(smem + SMEM0);      // [PH][PW], origin (y0 - 2, x0 - 2), zeros outside the image
+  float* const ws1 = patch + PH * PW;                               // [64 channels][9 taps], then [64] biases
   unsigned char* const tb = smem;
   unsigned char* const wbuf = smem + TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -921,7 +935,65 @@ __global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
       }
     }
   };
-  stage_issue(0);
+  float amax1 = 0.f;
+  // FUSE1: the halo tile of slice c0 computed from the image patch.  Thread -> the 8-channel half (tid & 1) of pixels (tid >> 1) + 128 k: the half's 72
+  // weights and 8 biases are read once per slice and serve the thread's three pixels
+  auto stage_compute = [&](int c0) __attribute__((always_inline)) {
+    const int half = tid & 1;
+    const float* const wsl = ws1 + (c0 + 8 * half) * 9;       // the half's 8 x 9 weights (contiguous), read four channels at a time: 36 floats = 9 x 16 bytes
+    const float* const bsl = ws1 + 576 + c0 + 8 * half;
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+      const int p = (tid >> 1) + 128 * k;
+      if (p < LH * LW) {
+        const int r = p / LW, lx = p - r * LW;
+        const int gy = y0 + r - 1, gx = x0 + lx - 1;
+        unsigned char* const dst = tb + (r * LW + lx) * 64;
+        const int ph = ((0 + half) ^ fsw(lx)) * 16, pm = ((2 + half) ^ fsw(lx)) * 16;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+          float v[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) v[t] = patch[(r + t / 3) * PW + lx + t % 3];
+          h16x8 hv, mv;
+#pragma unroll
+          for (int g4 = 0; g4 < 2; ++g4) {
+            f32x4 w4[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) w4[q] = *reinterpret_cast<const f32x4*>(wsl + 36 * g4 + 4 * q);
+            const f32x4 b4v = *reinterpret_cast<const f32x4*>(bsl + 4 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float acc1 = b4v[e];
+#pragma unroll
+              for (int t = 0; t < 9; ++t) acc1 = fmaf(w4[(9 * e + t) >> 2][(9 * e + t) & 3], v[t], acc1);
+              const float f = fmaxf(acc1, 0.f);
+              amax1 = fmaxf(amax1, f);
+              hv[4 * g4 + e] = (_Float16)f;
+              mv[4 * g4 + e] = (_Float16)(f - (float)hv[4 * g4 + e]);
+            }
+          }
+          *reinterpret_cast<h16x8*>(dst + ph) = hv;
+          *reinterpret_cast<h16x8*>(dst + pm) = mv;
+        } else {
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(dst + ph) = z;
+          *reinterpret_cast<uint4*>(dst + pm) = z;
+        }
+      }
+    }
+  };
+  if constexpr (FUSE1) {
+    const float* const im = a.img + (size_t)img * a.H * a.W;
+    for (int q = tid; q < PH * PW; q += 256) {
+      const int py = q / PW, px = q - py * PW, gy = y0 - 2 + py, gx = x0 - 2 + px;
+      patch[q] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? im[(size_t)gy * a.W + gx] : 0.f;
+    }
+    for (int q = tid; q < 64 * 9 + 64; q += 256) ws1[q] = q < 576 ? a.w1[q] : a.b1[q - 576];
+    __syncthreads();
+    stage_compute(0);
+  } else {
+    stage_issue(0);
+  }
   weights_dma(0, 0, 0);
   weights_dma(1, 0, 1);
   // (behind the first requests, in the shadow of their latency)
@@ -980,7 +1052,7 @@ __global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
     }
     if (more) {
       __syncthreads();      // every wave is done with this slice's tile
-      stage_issue(c0 + 16);
+      if constexpr (FUSE1) stage_compute(c0 + 16); else stage_issue(c0 + 16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -993,7 +1065,7 @@ __global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) b4[i][g] = *reinterpret_cast<const f32x4*>(a.bias + 64 * og + 32 * i + 8 * g + 4 * hh);
   const float ascale = a.acc_scale;
-  float amax = 0.f;
+  float amax = FUSE1 ? amax1 : 0.f;                    // (the first layer's values were rounded to fp16 too: they are in the same guard)
   constexpr bool out_hm = OUTHM;
   const float relu_lo = a.relu ? 0.f : -INFINITY;
   unsigned char* const slab = smem + wave * SLAB;
@@ -1796,6 +1868,15 @@ void sp_conv(const float* in, int B, int H, int W, int Cin, const float* wf, con
   }
   if (taps == 9) hipLaunchKernelGGL((k_sp_conv<9, 0, 3, false>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_sp_conv<1, 0, 3, false>), grid, dim3(256), 0, s, a);
+}
+// layers 0 + 1 of the split-fp16 mode in ONE launch (k_sp_conv_s16<true, true, true>): gray image in, pooled hm16 records of layer 1 out
+int g_sp_fuse1 = 1;    // developer knob 46: 0 = k_sp_conv1 + k_sp_conv_s16 as two launches (the round-5 form; bitwise the same results)
+void sp_conv_fused1(const float* gray, const float* w1, const float* b1, int B, int H, int W, const float* bias, float* out, int Cout_pad, hipStream_t s,
+                    const uint16_t* wfh, float acc_scale, unsigned int* ovf) {
+  ConvArgs a; a.in = nullptr; a.H = H; a.W = W; a.Cin = 64; a.wf = nullptr; a.bias = bias; a.out = out; a.Cout = Cout_pad; a.relu = 1;
+  a.wfh = wfh; a.acc_scale = acc_scale; a.ovf = ovf; a.in_half = 2; a.out_half = 2; a.dbg_ts = nullptr; a.img = gray; a.w1 = w1; a.b1 = b1;
+  const dim3 g8((W + TW - 1) / TW, (H + 7) / 8, B * (Cout_pad / 64));
+  hipLaunchKernelGGL((k_sp_conv_s16<true, true, true>), g8, dim3(256), 0, s, a);
 }
 void sp_pool(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);

@@ -374,3 +374,37 @@ def test_superpoint_fp16_kernel_of_round5_against_the_one_it_replaces():
             assert np.array_equal(new[0], again[0]) and all(np.array_equal(a, b) for a, b in zip(new[1], again[1]))
     finally:
         eng.lib.gn_debug_set_variant(eng.ctx, 24, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 1080, 1920), (3, 248, 328), (1, 64, 40)])
+def test_first_convolution_fused_into_the_second_gives_the_same_bits(shape):
+    """Round 6: in the split-fp16 mode the network's first convolution (1 -> 64) is evaluated inside the halo staging of the second
+    (k_sp_conv_s16<true, true, true>: the 0.53 GB-per-1080p-frame map between them is never written).  Same fma chain, same fp16 split, same LDS
+    positions as k_sp_conv1 + LDS-DMA staging: score map, NMS map, keypoints, scores and descriptors are IDENTICAL to the two-launch form (knob 46 = 0)
+    -- at the bench's frame size, at a size with ragged tiles on both axes, and at one smaller than a tile -- and repeatable."""
+    from gisnav_amd.engine import PoseEngine
+    from gisnav_amd.superpoint import SuperPoint
+    from oracle import superpoint as osp
+    eng = PoseEngine(0, max_batch=1, max_kpts=128, precision="f16x2_f16_attn", feature="superpoint")
+    sp = SuperPoint(engine=eng, max_keypoints=512, state_dict=osp.synthetic_state_dict(0))
+    img = torch.from_numpy(np.random.default_rng(21).random(shape, dtype=np.float32)).cuda()
+    npx = shape[0] * shape[1] * shape[2]
+
+    def run(fuse):
+        eng.lib.gn_debug_set_variant(eng.ctx, 46, fuse)
+        out = sp.detect_and_describe_device(img)
+        torch.cuda.synchronize()
+        return (eng.debug_read("sp_scores", npx).copy(), eng.debug_read("sp_nms", npx).copy(), [o.cpu().numpy().copy() if hasattr(o, "cpu") else np.asarray(o) for o in out])
+
+    try:
+        two = run(0)
+        one = run(1)
+        again = run(1)
+    finally:
+        eng.lib.gn_debug_set_variant(eng.ctx, 46, 1)
+    assert np.array_equal(two[0].view(np.uint32), one[0].view(np.uint32)), "score map differs"
+    assert np.array_equal(two[1].view(np.uint32), one[1].view(np.uint32))
+    for a, b, c in zip(two[2], one[2], again[2]):
+        assert np.array_equal(a, b) and np.array_equal(b, c)
+    assert float(one[0].max()) > 0.0
