@@ -341,6 +341,7 @@ def run_extra_superpoint(local_rank, batch, steps, warmup, dev, h=1080, w=1920, 
            "superpoint_frac_of_issue_ceiling": round((1.0 if fp16 else 3.0) * 345.0 / (t_sp / steps / (2 * batch)) / 1e3 / PEAK_16BIT_MFMA_TFLOPS, 4),
            "mean_keypoints": float(np.mean(n)), "mean_matches": float(out["n_match"].float().mean().item()), "poses_ok": int(out["ok"].sum().item()),
            "note": "random-init networks: keypoints / matches are whatever the untrained detector yields; the model named by configs[4] is not in the reference tree"}
+    res["_pose"] = (out["R"].cpu().numpy().copy(), out["t"].cpu().numpy().copy(), out["ok"].cpu().numpy().copy().astype(bool))     # (popped by main: the pose delta between the arithmetics)
     del sp, eng
     torch.cuda.empty_cache()
     return res
@@ -794,6 +795,20 @@ def main() -> None:
         # the same two at configs[3]'s per-GPU batch (32 pairs: the extractor still runs four frames per pass, the matcher and the PnP stage run once)
         extras.append(run_extra_superpoint(local_rank, 32, 2, 1, dev))
         extras.append(run_extra_superpoint(local_rank, 32, 2, 1, dev, arithmetic="fp16"))
+        # what the 16-bit convolution operands do to the POSE: the same 32 frame / tile pairs through both extractors, everything
+        # behind them identical -- per pair |R_fp16 - R_split|_F and |t_fp16 - t_split| / |t_split| over the pairs that yield a pose both ways
+        (Ra, ta, oka), (Rb, tb, okb) = extras[-2]["_pose"], extras[-1]["_pose"]
+        both = oka & okb
+        if both.any():
+            dR = np.linalg.norm((Ra - Rb)[both].reshape(-1, 9), axis=1)
+            dt = np.linalg.norm((ta - tb)[both].reshape(-1, 3), axis=1) / np.maximum(np.linalg.norm(ta[both].reshape(-1, 3), axis=1), 1e-12)
+            extras[-1]["pose_delta_vs_f32_accurate_extractor"] = {"pairs_with_a_pose_both_ways": int(both.sum()), "pairs": int(len(both)),
+                                                                  "dR_frobenius": {"median": float(np.median(dR)), "max": float(dR.max())},
+                                                                  "dt_relative": {"median": float(np.median(dt)), "max": float(dt.max())}}
+        else:
+            extras[-1]["pose_delta_vs_f32_accurate_extractor"] = {"pairs_with_a_pose_both_ways": 0, "pairs": int(len(both))}
+        for e in extras:
+            e.pop("_pose", None)
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps

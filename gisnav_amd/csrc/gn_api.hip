@@ -2172,7 +2172,7 @@ int gn_debug_attention(gn_ctx* ctx, int BS, int npad, int cross, float qscale, c
   AttnArgs a; a.ovf = nullptr;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
   a.nvalid = nkv; a.npad = npad; a.cross = cross; a.qscale = qscale; a.BS = BS;
-  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr; a.half_fmt = ctx->attn_f16;
+  a.qb = a.kb = a.vt = nullptr; a.ldqb = a.ldkb = 0; a.outp = nullptr; a.half_fmt = ctx->attn_f16; a.ncu = ctx->ncu;
   const long long cap = (long long)ctx->max_batch * 2 * ctx->npad;
   if (ctx->precision != GN_PREC_F32 && ctx->attn_variant >= 1 && ctx->qkb && ctx->vtb && (long long)BS * npad <= cap) {
     // the production kernel (k_attn_bf16_v5) on the layouts the projection epilogues would have written

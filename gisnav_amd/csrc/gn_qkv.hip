@@ -241,8 +241,15 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
 // pairs are index-identical, and the launches drop from 87 / 62 us to 72 / 53 us (tools/qkv2_study.py, profiles/r04_qkv2_study.json).
 // Developer knob 27 = 3 restores the third product.  (The block tail and the match head keep all three: their outputs are f32-accurate values.)
 int device_cu_count() {
-  int dev = 0; hipDeviceProp_t pr;
-  return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  // per device id, filled on first use (hipGetDeviceProperties on every launch was slow; a process-wide static was wrong with several devices)
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+  return n;
 }
 void launch_qkv(const QkvArgs& a, bool cross, hipStream_t s) {
   const int ncu = a.ncu > 0 ? a.ncu : device_cu_count();

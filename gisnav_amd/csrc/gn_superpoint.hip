@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void k_sp_conv_s(ConvArgs a) {
 // LDS-DMA would have delivered, so everything downstream is bitwise what the two launches give.  Pixels outside the image are zero records (this
 // convolution's zero padding), not first-layer values.
 template <bool POOL, bool OUTHM, bool FUSE1 = false>
-__global__ __launch_bounds__(256, FUSE1 ? 4 : 3) void k_sp_conv_s16(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void k_sp_conv_s16(ConvArgs a) {
   constexpr int RPW = 2, TH = 8, LW = TW + 2, LH = TH + 2, TAPS = 9;
   constexpr int NSEG = 3, TAIL = 2;                 // 16 pixels per staging instruction; 34 = 16 + 16 + 2
   constexpr int NROW = (LH + 3) / 4;

@@ -456,7 +456,11 @@ class PoseEngine:
         batch of messages spread widely, and one gn_estimate call pads every pair to the batch maximum (attention cost grows with the
         SQUARE of the padded length).  The pairs are sorted by max(n_q, n_r) (host-side counts: no device read), run as groups of
         `bucket_pairs` consecutive pairs each padded to ITS maximum (gn_set_active_kpts), and the results are returned in the caller's
-        order.  Results do not depend on the padding (tests), so they equal the single padded call's.  Returns (out, stats)."""
+        order.  Results do not depend on the padding (tests).  They DO depend, at rounding level, on the number of pairs per call: calls of one or
+        two pairs (and sub-stream groups of that size) run the small-grid kernel family, whose summation order differs from the bulk kernels' -- a
+        remainder bucket of one or two pairs therefore gives the same matches and poses up to rounding, not the same bits, as one padded call
+        (tests/test_gpu_round6.py).  With the certificate on (set_certify) the correspondence indices are the exact arithmetic's either
+        way.  Returns (out, stats)."""
         n_q_host = np.asarray(n_q_host).astype(np.int64)
         n_r_host = np.asarray(n_r_host).astype(np.int64)
         B = len(n_q_host)

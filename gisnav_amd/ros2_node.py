@@ -104,8 +104,14 @@ def make_node_class():
         def _pose_image_cb(self, msg) -> None:
             if self._camera_info is None:                      # narrow_types: no result until both inputs exist (_decorators.py:117-160)
                 return
-            wire = ortho_stereo_image_from_ros(msg)
-            pose = self._impl.estimate(self._camera_info, wire)
+            # one malformed message (a non-mono8 raster, a short keypoint buffer, more keypoints than the context can grow to) must not kill the node:
+            # exceptions of the conversion and of the estimator are logged and the message is dropped
+            try:
+                wire = ortho_stereo_image_from_ros(msg)
+                pose = self._impl.estimate(self._camera_info, wire)
+            except Exception as exc:  # noqa: BLE001
+                self.get_logger().warning(f"pose_image message dropped: {exc.__class__.__name__}: {exc}")
+                return
             if pose is None:
                 self.get_logger().warning(f"no pose ({self._impl.last_num_matches} matches)")
                 return
@@ -113,7 +119,7 @@ def make_node_class():
             if fields is None:
                 self.get_logger().warning("camera centre outside the reference raster - no pose")
                 return
-            out = PoseWithCovarianceStamped()
+            out = PoseWithCovarianceStamped()      # covariance stays all-zero, as in the reference (pose_node.py:478-495 fills pose and header only)
             out.header.frame_id = "earth"
             out.header.stamp.sec, out.header.stamp.nanosec = wire.query_stamp.sec, wire.query_stamp.nanosec
             p, q = fields["position"], fields["orientation"]

@@ -271,6 +271,27 @@ def test_every_bulk_context_proves_the_fused_projection_on_its_own_weights(state
         del eng
 
 
+def test_bucketed_remainder_of_one_or_two_pairs_gives_the_same_matches(state_dict_np):
+    """the kernel family follows the number of pairs per call, so estimate_bucketed's remainder bucket of one or two pairs runs other
+    kernels than a single padded call.  Documented as equal up to rounding; here: 10 and 9 pairs with bucket_pairs = 4 (remainders 2 and 1) give the
+    same match counts, inlier counts and poses (1e-6) as one call."""
+    from gisnav_amd.engine import PoseEngine
+    for B in (10, 9):
+        rs = np.random.default_rng(B)
+        nq = rs.integers(300, 1000, B); nr = rs.integers(300, 1000, B)
+        pairs = [make_pair(9500 + i, n_q=int(nq[i]), n_r=int(nr[i])) for i in range(B)]
+        eng = PoseEngine(0, max_batch=B, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+        inp = eng.stage_inputs(pairs)
+        want = {k: v.clone() for k, v in eng.estimate(inp, K_MATRIX).items()}
+        got, stats = eng.estimate_bucketed(inp, K_MATRIX, np.array([len(p.kp_q) for p in pairs]), np.array([len(p.kp_r) for p in pairs]), bucket_pairs=4)
+        torch.cuda.synchronize()
+        assert stats["groups"] == 3 and int(want["ok"].sum()) >= B - 1
+        assert torch.equal(got["n_match"], want["n_match"]) and torch.equal(got["ok"], want["ok"]) and torch.equal(got["n_inliers"], want["n_inliers"]), B
+        ok = want["ok"].bool()
+        assert float((got["R"][ok] - want["R"][ok]).abs().max()) < 1e-6 and float((got["t"][ok] - want["t"][ok]).abs().max()) < 1e-4, B
+        del eng
+
+
 def test_deferred_certificate_resolves_one_call_later_with_the_same_results():
     """gn_set_certify(3): with sub-batch streams the flags of call n are read after call n + 1 has been enqueued.  A stream of six calls over two
     alternating input batches and two alternating output sets (mid-margin weights: some pairs flagged, some not) gives, after the flush, exactly what
