@@ -1,4 +1,5 @@
-// Batched PnP + RANSAC + Rodrigues on gfx950: one 64-lane wavefront per frame<->tile pair.
+// Batched PnP + RANSAC + Rodrigues on gfx950: k_pnp_hyp = one single-wave workgroup per (pair, RANSAC hypothesis) -- the cv::RNG stream does not depend on
+// the models, so the <= 10 hypotheses of a pair run concurrently --, k_pnp_refine = one wave per pair (best-model replay, initial guess, LM, Rodrigues).
 //
 // Stands in for `cv2.solvePnPRansac(obj, img, K, zeros(4,1), useExtrinsicGuess=False,
 // iterationsCount=10)` + `cv2.Rodrigues` as called by `compute_pose`

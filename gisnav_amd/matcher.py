@@ -22,7 +22,7 @@ _DEFAULTS = {"n_layers": N_LAYERS, "filter_threshold": 0.1, "depth_confidence": 
 
 class LightGlueMatcher:
     def __init__(self, feature_name: str = "sift", params: Optional[Dict] = None, *,
-                 state_dict=None, max_kpts: int = 4096, precision: str = "f32"):
+                 state_dict=None, max_kpts: int = 4096, precision: str = "f32", certify: bool = True, certify_calibration_calls: int = 8):
         if feature_name not in ("sift", "superpoint"):
             raise NotImplementedError("LightGlue('sift') is what PoseNode uses (pose_node.py:110); 'superpoint' (256-d descriptors, BASELINE configs[4]) "
                                       "is the other variant built here")
@@ -38,6 +38,11 @@ class LightGlueMatcher:
             state_dict = self._find_pretrained(feature_name)    # kornia loads the pretrained checkpoint in its constructor (pose_node.py:109-121 passes none)
         self._state_dict = state_dict
         self._max_kpts, self._precision = max_kpts, precision
+        # fast precision modes: correspondence indices certified against the exact-f32 arithmetic (gn_set_certify: pairs with a decision inside
+        # the calibrated error margin are re-run in f32 before the call returns).  eps is calibrated on the first calls' own inputs (each of them
+        # is matched a second time in f32: 4 x the largest difference seen), then frozen.
+        self._certify = bool(certify) and precision != "f32"
+        self._cal_left, self._cal_eps = int(certify_calibration_calls), 0.0
         self._engine: Optional[PoseEngine] = None
 
     @staticmethod
@@ -98,7 +103,13 @@ class LightGlueMatcher:
         l1, l2 = f(lafs1).reshape(1, -1, 6), f(lafs2).reshape(1, -1, 6)
         n1 = torch.full((1,), d1.shape[1], dtype=torch.int32, device=dev)     # (a fill kernel on the stream, not a blocking pageable upload)
         n2 = torch.full((1,), d2.shape[1], dtype=torch.int32, device=dev)
-        idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, _lib.GN_KPT_LAF | 0x100)   # 0x100: descriptors are already normalised by the caller
+        fmt = _lib.GN_KPT_LAF | 0x100          # 0x100: descriptors are already normalised by the caller
+        if self._certify and self._cal_left > 0:
+            cal = self._engine.calibrate_certify(dict(desc_q=d1, kpt_q=l1, n_q=n1, desc_r=d2, kpt_r=l2, n_r=n2, kpt_format=fmt))
+            self._cal_eps = max(self._cal_eps, cal["eps"])
+            self._cal_left -= 1
+            self._engine.set_certify("rerun", eps=self._cal_eps)
+        idx, score, n_match = self._engine.match(d1, l1, n1, d2, l2, n2, fmt)
         # the D2H sync the reference has at pose_node.py:296-297 -- through a pinned word (pageable reads of a few bytes were measured to stall for
         # ~90 ms every few dozen calls on the MI355X boxes, tools/bench_seams.py)
         if getattr(self, "_n_host", None) is None:

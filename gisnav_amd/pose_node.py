@@ -27,13 +27,18 @@ class PoseNode:
     CONFIDENCE_THRESHOLD = 0.5   # pose_node.py:60
     MIN_MATCHES = MIN_MATCHES    # pose_node.py:63
 
-    def __init__(self, state_dict, extractor: Optional[Callable] = None, device: int = 0, max_kpts: int = 4096, precision: str = "f32"):
+    def __init__(self, state_dict, extractor: Optional[Callable] = None, device: int = 0, max_kpts: int = 4096, precision: str = "f32",
+                 certify: bool = True, certify_calibration_calls: int = 8):
         self._engine = PoseEngine(device, max_batch=1, max_kpts=max_kpts, precision=precision, state_dict=state_dict,
                                   n_layers=9, filter_threshold=self.CONFIDENCE_THRESHOLD, guard="sync")
         if extractor is None:
             from .sift import SIFT
             extractor = SIFT(engine=self._engine, max_keypoints=max_kpts).as_extractor()
         self._extractor = extractor
+        # fast precision modes: the correspondence indices are certified against the exact-f32 arithmetic (gn_set_certify(2)); eps is calibrated on
+        # the first messages' own inputs (each is matched a second time in f32), 4 x the largest difference seen, then frozen
+        self._certify = bool(certify) and precision != "f32"
+        self._cal_left, self._cal_eps = int(certify_calibration_calls), 0.0
         self._cached_stamp_kps_desc = None
         self._cached_n_r = 0
         self.camera_info: Optional[CameraInfo] = None
@@ -98,6 +103,10 @@ class PoseNode:
                       desc_r=None, kpt_r=rec_r_t, n_r=n_r_t, dem=self._dem_dev[1], kpt_format=_lib.GN_KPT_RECORD)
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)
         try:
+            if self._certify and self._cal_left > 0 and n >= 2 and self._cached_n_r >= 2:
+                self._cal_eps = max(self._cal_eps, eng.calibrate_certify(inputs)["eps"])
+                self._cal_left -= 1
+                eng.set_certify("rerun", eps=self._cal_eps)
             eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES, out=self._out)
         finally:
             eng.set_active_kpts(eng.kmax)                   # sticky context state: restore
