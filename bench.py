@@ -102,10 +102,12 @@ def kernel_rows(table, steps, precision):
         peak = PEAK_F32_MFMA_TFLOPS if f32_pipe else PEAK_16BIT_MFMA_TFLOPS
         two = r["name"].startswith("k_qkv") and r["name"].rstrip(">").endswith(", 2")         # attention input projections: two partial products (gn_qkv.hip)
         mult = 1 if (attn or f32_pipe) else 6 if r["name"].startswith("k_gemm_f32x3") else 2 if two else 3   # matrix-pipe flops issued per algorithmic flop
-        if r["name"].startswith("k_ffn128") and r["name"].rstrip(">").endswith((", 1", ", 2")):      # block tail (3 products) + the next block's projection (2 products) in one launch
+        if r["name"].startswith("k_ffn128"):      # k_ffn128<ABL, COMP, LOOP, QKV, PROD>: block tail on PROD partial products (+ the next block's projection, 2 products, in the same launch)
+            prm = r["name"][r["name"].index("<") + 1:].rstrip(">").split(", ")
+            qkv, prod = (int(prm[3]), int(prm[4])) if len(prm) >= 5 else (0, 3)
             tail = 2.0 * (512 * 512 + 256 * 512)
-            proj = 2.0 * 256 * (768 if r["name"].rstrip(">").endswith(", 1") else 512)
-            mult = round((3 * tail + 2 * proj) / (tail + proj), 4)
+            proj = 2.0 * 256 * (768 if qkv == 1 else 512 if qkv == 2 else 0)
+            mult = round((prod * tail + 2 * proj) / (tail + proj), 4)
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
         rows.append({"name": r["name"], "launches_per_step": round(n / steps, 2), "avg_launch_us": round(r["ms"] * 1e3 / n, 2),
                      "share_of_timed_kernel_time": round(r["ms"] / total_ms, 4),
@@ -116,7 +118,7 @@ def kernel_rows(table, steps, precision):
     return rows
 
 
-def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
+def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1, certify_eps: float = 0.0):
     """HBM bytes per kernel from two rocprofv3 PMC passes over this same script (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass),
     --kernel-trace only.  FETCH_SIZE counts 64 B per 128-B request on gfx950 for wide coalesced reads: doubled (MI355X_MICROARCH.md)."""
     exe = shutil.which("rocprofv3")
@@ -133,6 +135,9 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
                    "--no-cpu-baseline", "--no-traffic", "--no-extras", "--no-stream", "--no-rccl-check", "--substreams", "1"]     # one pass, full-batch launches: the configuration of the kernel table
             for kv in args.debug_variant:
                 cmd += ["--debug-variant", kv]
+            cmd += ["--certify-eps", repr(certify_eps)] if certify_eps > 0.0 else ["--no-certify"] if args.no_certify else []
+            if args.ffn_products:
+                cmd += ["--ffn-products", str(args.ffn_products)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -168,12 +173,15 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1):
 CERT_SAFETY = 4.0
 
 
-def certify_on(eng, kpts, batch, precision, certify=True):
+def certify_on(eng, kpts, batch, precision, certify=True, eps=0.0):
     """The margin certificate for a fast-mode engine (gn_set_certify(2)): eps is CALIBRATED for these weights on one batch of pairs that are not part of any
     timed batch (max |P_mode - P_f32| over the deciding entries x CERT_SAFETY), then every estimate() call synchronises once, reads its per-pair
     flags and re-runs the flagged pairs on the exact-f32 kernels -- inside the timed region.  Returns the calibration record (None: f32 / off)."""
     if precision == "f32" or not certify:
         return None
+    if eps > 0.0:      # profiling pass: the eps a full run calibrated
+        eng.set_certify("rerun", eps=eps)
+        return {"eps": eps, "measured": None, "safety": None}
     # (as many pairs as a timed call holds: the kernel family, and with it the arithmetic whose error is measured, follows the grid size)
     cal_pairs = [make_pair(900_000 + i, n_q=kpts, n_r=kpts) for i in range(batch)]
     cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=CERT_SAFETY)
@@ -625,6 +633,8 @@ def main() -> None:
     ap.add_argument("--ffn-products", type=int, default=0, choices=[0, 2, 3],
                     help="fp16 partial products of the block tail's GEMMs on bulk grids (gn_set_ffn_products): 3 = f32-accurate split (rounds 1-5), 2 = activations' "
                          "high term only (reported as an extra configuration); default 3")
+    ap.add_argument("--certify-eps", type=float, default=0.0, help="profiling passes: use this eps instead of calibrating (the calibration's f32 pass and the "
+                                                                     "fused-projection self-check are set-up work that a rocprofv3 pass over few steps would count as steps)")
     ap.add_argument("--sync-certify", action="store_true", help="certificate resolved inside every call (one host synchronisation per step) instead of one call later")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -692,7 +702,9 @@ def main() -> None:
     ffn_products = args.ffn_products or 3
     if args.precision.startswith("f16x2"):
         eng.set_ffn_products(ffn_products)         # (before the calibration: eps is measured for the arithmetic that runs)
-    cert_cal = certify_on(eng, args.kpts, args.batch, args.precision, certify=not args.no_certify)
+    if args.certify_eps > 0.0:
+        eng.lib.gn_debug_set_variant(eng.ctx, 47, 1)      # (a profiling pass: no self-check launches among the steps; the full run's line carries its verdict)
+    cert_cal = certify_on(eng, args.kpts, args.batch, args.precision, certify=not args.no_certify, eps=args.certify_eps)
 
     # this rank's contiguous shard of the global batch, staged into HBM before the timed region
     shard = gdist.shard_range(args.batch * world, rank, world)
@@ -828,7 +840,7 @@ def main() -> None:
         dom = max(dom_family, key=lambda m: m["share_of_timed_kernel_time"]) if dom_family else None
         traffic, traffic_err = (None, "skipped")
         if not args.no_traffic and world == 1:
-            traffic, traffic_err = measure_traffic(args)
+            traffic, traffic_err = measure_traffic(args, certify_eps=(cert_main or {}).get("eps", 0.0))
         comp_mb = compulsory_mb_per_pair(args.kpts, args.kpts) * args.batch + 47.5   # + the f32 weights once per step (cache-resident in practice)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",

@@ -2233,6 +2233,7 @@ int gn_debug_set_variant(gn_ctx* ctx, int which, int value) {
   else if (which == 43) gn::g_attn_f32_ks = value;
   else if (which == 44) gn::g_gemm_r64 = value;
   else if (which == 46) gn::g_sp_fuse1 = value;
+  else if (which == 47) { ctx->fused_proj_pending = value == 0; }   // 1: skip the fused-projection self-check of the next forward call (profiling passes: its launches are set-up, not steps)
   else if (which == 39) ctx->sp_stop = value;
   else if (which == 35) {
     ctx->sp_ts_layer = value;

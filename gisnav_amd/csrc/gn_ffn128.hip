@@ -952,10 +952,10 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
   if (a.composed && a.qkv != 0 && ablate == 0) {      // the next block's attention input projection behind the tail (a.qkv: 1 self, 2 cross)
     if (a.qkv == 1) {
       if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, 1>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true, false, 1>), grid, block, 0, s, b);
-      g_last_kernel = walk ? "k_ffn128<0, true, true, 1>" : "k_ffn128<0, true, false, 1>";
+      g_last_kernel = walk ? "k_ffn128<0, true, true, 1, 3>" : "k_ffn128<0, true, false, 1, 3>";
     } else {
       if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true, 2>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true, false, 2>), grid, block, 0, s, b);
-      g_last_kernel = walk ? "k_ffn128<0, true, true, 2>" : "k_ffn128<0, true, false, 2>";
+      g_last_kernel = walk ? "k_ffn128<0, true, true, 2, 3>" : "k_ffn128<0, true, false, 2, 3>";
     }
     return;
   }
@@ -965,7 +965,7 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
       case 136: hipLaunchKernelGGL((k_ffn128<136, true>), grid, block, 0, s, b); break;
       default: if (walk) hipLaunchKernelGGL((k_ffn128<0, true, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, true>), grid, block, 0, s, b); break;
     }
-    g_last_kernel = walk ? "k_ffn128<0, true, true, 0>" : "k_ffn128<0, true, false, 0>";
+    g_last_kernel = walk ? "k_ffn128<0, true, true, 0, 3>" : "k_ffn128<0, true, false, 0, 3>";
     return;
   }
   switch (ablate) {
@@ -973,7 +973,7 @@ void launch_ffn128(const FfnArgs& a, int ablate, hipStream_t s) {
     case 136: hipLaunchKernelGGL((k_ffn128<136, false>), grid, block, 0, s, b); break;
     default: if (walk) hipLaunchKernelGGL((k_ffn128<0, false, true>), grid, block, 0, s, b); else hipLaunchKernelGGL((k_ffn128<0, false>), grid, block, 0, s, b); break;
   }
-  g_last_kernel = walk ? "k_ffn128<0, false, true, 0>" : "k_ffn128<0, false, false, 0>";
+  g_last_kernel = walk ? "k_ffn128<0, false, true, 0, 3>" : "k_ffn128<0, false, false, 0, 3>";
 }
 
 }  // namespace gn

@@ -278,9 +278,10 @@ def test_projection_fused_into_the_block_tail_gives_the_bits_of_the_separate_lau
                     got[fused] = (idx.cpu().numpy().copy(), score.cpu().numpy().copy(), n.cpu().numpy().copy(), md, out["R"].cpu().numpy().copy(), tab)
             eng.lib.gn_debug_set_variant(eng.ctx, 32, 1)
             a, b = got[1], got[0]
-            nf = sum(v for k, v in a[5].items() if k.startswith("k_ffn128") and k.rstrip(">").endswith((", 1", ", 2")))
+            fused_tail = lambda k: k.startswith("k_ffn128") and k.rstrip(">").split(", ")[3] in ("1", "2")      # noqa: E731  (k_ffn128<ABL, COMP, LOOP, QKV, PROD>)
+            nf = sum(v for k, v in a[5].items() if fused_tail(k))
             assert nf == 17 and sum(v for k, v in a[5].items() if k.startswith("k_qkv")) == 1, a[5]
-            assert sum(v for k, v in b[5].items() if k.startswith("k_qkv")) == 18 and not any(k.rstrip(">").endswith((", 1", ", 2")) for k in b[5] if k.startswith("k_ffn128")), b[5]
+            assert sum(v for k, v in b[5].items() if k.startswith("k_qkv")) == 18 and not any(fused_tail(k) for k in b[5]), b[5]
             assert np.array_equal(a[2], b[2]) and a[2].max() > 300, (label, lists)
             for p in range(16):
                 k = int(a[2][p])

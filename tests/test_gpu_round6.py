@@ -129,7 +129,7 @@ def test_certified_indices_equal_the_oracle_on_every_weight_family(name, shape, 
         names = [r["name"] for r in eng.kernel_table()]
         eng.set_kernel_timing(0)
         assert any(n.startswith("k_ffn128") for n in names) and any(n.startswith("k_attn_pw") for n in names), names
-        assert all((n.count(",") == 4) == (products == 2) for n in names if n.startswith("k_ffn128")), names      # k_ffn128<., ., ., QKV, 2>: the two-product instantiations
+        assert all(n.rstrip(">").split(", ")[4] == str(products) for n in names if n.startswith("k_ffn128")), names      # k_ffn128<ABL, COMP, LOOP, QKV, PROD>
         flags = eng.uncertain(B)
         m0, t0, per = _diff(idx_h, n_h, refs)
         unflagged_wrong = [b for b in range(B) if per[b] and not flags[b]]
@@ -231,7 +231,7 @@ def test_two_product_block_tail_is_repeatable_and_close_to_the_three_product_for
         idx, n = _match(eng, inp)
         names = [r["name"] for r in eng.kernel_table() if r["name"].startswith("k_ffn128")]
         eng.set_kernel_timing(0)
-        assert len(names) >= 2 and all((nm.count(",") == 4) == (products == 2) for nm in names), names
+        assert len(names) >= 2 and all(nm.rstrip(">").split(", ")[4] == str(products) for nm in names), names
         md = eng.debug_read("max0", 16 * 1024).copy()          # best assignment score of every row
         got.setdefault(products, []).append((idx, n, md))
     a, b, c = got[3][0], got[2][0], got[2][1]

@@ -11,10 +11,12 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | grep '^{"metric' | tail -1 > $O/${TAG}_bench_n1.json
-rm -rf $O/${TAG}_prof && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --substreams 1 > /dev/null 2>&1
+# the profiling passes run the same certified configuration with the eps the full run calibrated (--certify-eps: no calibration pass, no self-check launches among the steps)
+EPS=$(python -c "import json;print(json.load(open('$O/${TAG}_bench_n1.json'))['precision_guarantee']['certificate']['eps'])")
+rm -rf $O/${TAG}_prof && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --no-stream --substreams 1 --certify-eps $EPS > /dev/null 2>&1
 cp $(ls $O/${TAG}_prof/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats.csv
 rm -rf $O/${TAG}_prof
-rm -rf $O/${TAG}_pmc_MFMA && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-extras --substreams 1 > /dev/null 2>&1
+rm -rf $O/${TAG}_pmc_MFMA && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --certify-eps $EPS --no-stream --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-extras --substreams 1 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_pmc_mfma_raw.json
 rm -rf $O/${TAG}_pmc_MFMA
 python - <<PY
