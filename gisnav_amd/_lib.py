@@ -48,6 +48,7 @@ SIGNATURES = {
     "gn_set_certify": (C.c_int, [VP, C.c_int, C.c_float, C.c_float]),
     "gn_set_ffn_products": (C.c_int, [VP, C.c_int]),
     "gn_fused_projection_status": (C.c_int, [VP]),
+    "gn_device_numa_node": (C.c_int, [C.c_int]),
     "gn_get_certify_stats": (C.c_int, [VP, c_i64p]),
     "gn_reset_certify_stats": (C.c_int, [VP]),
     "gn_calibrate_certify": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, VP]),

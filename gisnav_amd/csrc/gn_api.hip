@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <cctype>
 #include <algorithm>
 #include <memory>
 
@@ -1363,6 +1364,19 @@ int gn_get_guard_status(gn_ctx* ctx, void* stream, int32_t* last_call_tripped, i
   if (last_call_tripped) *last_call_tripped = tripped;
   if (trips_total) *trips_total = ctx->guard_trips;
   return GN_OK;
+}
+
+int gn_device_numa_node(int device) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+  for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
 }
 
 int gn_fused_projection_status(const gn_ctx* ctx) { return ctx ? ctx->fused_proj_status : GN_ERR_ARG; }

@@ -39,6 +39,25 @@ def _dev_tensor(t, dtype, device) -> torch.Tensor:
     return t.contiguous()
 
 
+def numa_cpus(node: int):
+    """CPU ids of NUMA node `node` (/sys/devices/system/node/node<N>/cpulist, e.g. "0-31,128-159"), or None."""
+    try:
+        with open(f"/sys/devices/system/node/node{int(node)}/cpulist") as f:
+            return parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None
+
+
+def parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus or None
+
+
 class RecordStager:
     """Input side of a STREAM of new frame<->tile pairs (pose_node.py:207-213, 254-265): the raw `query_sift` / reference keypoint payloads
     (532-byte KEYPOINT_DTYPE records) and the DEM rasters of a batch are copied -- bytes, no unpacking -- into pinned host buffers and
@@ -54,12 +73,30 @@ class RecordStager:
     overwritten without waiting.
     """
 
-    def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3, copy_threads: int = 4):
+    def __init__(self, engine: "PoseEngine", max_batch: int, max_kpts: int, dem_hw: Tuple[int, int], depth: int = 3, copy_threads: int = 4,
+                 numa: Optional[str] = "auto"):
+        import os
         from concurrent.futures import ThreadPoolExecutor
+        # one rank per GPU: the copy threads of a rank stay on the cores of its GPU's NUMA node (VERDICT r5 item 7: host staging is ~6 ms of memcpy
+        # per 5.8 ms step and rank; eight unpinned pools wander over both sockets).  "auto": gn_device_numa_node; None: leave the threads alone.
+        self.numa_node, cpus = -1, None
+        if numa == "auto":
+            self.numa_node = int(engine.lib.gn_device_numa_node(engine.device.index or 0))
+            cpus = numa_cpus(self.numa_node) if self.numa_node >= 0 else None
+            if cpus:
+                cpus = (cpus & os.sched_getaffinity(0)) or None      # never outside what the launcher allowed this process
+
+        def _pin():
+            if cpus:
+                try:
+                    os.sched_setaffinity(0, cpus)
+                except OSError:
+                    pass
+        self._pin = _pin
         self.eng, self.B, self.K, self.depth = engine, int(max_batch), int(max_kpts), int(depth)
         # the pinned-memory copies of a batch (35 MB at 32 x 1024 keypoints per side) run on a few host threads: one thread's memcpy
         # (~6 GB/s) would be slower than the GPU's step; numpy releases the GIL inside the copies
-        self._pool = ThreadPoolExecutor(max_workers=max(1, int(copy_threads))) if copy_threads > 1 else None
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(copy_threads)), initializer=_pin) if copy_threads > 1 else None
         dev, (H, W) = engine.device, dem_hw
         self.copy_stream = torch.cuda.Stream(device=dev)
         mk = lambda shape, dt, **kw: torch.empty(shape, dtype=dt, **kw)  # noqa: E731

@@ -150,6 +150,10 @@ int gn_set_ffn_products(gn_ctx* ctx, int products);
  * a weight (re)load both forms run on pseudo-random rows and their outputs are compared bit for bit (~60 ms, once); a difference switches the
  * fusion off for the context.  Returns 1 = checked equal, 0 = differed (fusion off), -1 = not run yet / not applicable (small contexts, other modes). */
 int gn_fused_projection_status(const gn_ctx* ctx);
+/* NUMA node of HIP device `device` (its PCI function's /sys/bus/pci/devices/<bus id>/numa_node), or -1 when the platform does not say.  The host side pins
+ * the staging threads of a rank to that node's cores (gisnav_amd.engine.RecordStager): with one rank per GPU, eight staging pools otherwise share whatever
+ * cores the scheduler picks. */
+int gn_device_numa_node(int device);
 /* out8: calls certified, pairs certified, pairs flagged for margin, pairs flagged for fp16 range, pairs re-run in exact f32,
  * re-run (or, in an f32 context, original) pairs that are marginal even for eps_f32, current mode, reserved. */
 int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8);

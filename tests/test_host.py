@@ -425,3 +425,9 @@ def test_two_process_gloo_rank_identity_gather():
         p.join(60)
         assert p.exitcode == 0
     assert all(ids == ["0:gpu0", "1:gpu1"] for _, ids in res)
+
+
+def test_cpulist_parser_of_the_staging_threads_numa_pinning():
+    from gisnav_amd.engine import parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parse_cpulist("5") == {5} and parse_cpulist("") is None
