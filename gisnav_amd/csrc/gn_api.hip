@@ -1433,22 +1433,24 @@ int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
   // largest difference between the two arithmetics over the entries a decision looks at: every valid row's best score and runner-up,
   // restricted -- when there is a threshold -- to rows that come within 1 (in log units) of it in either arithmetic
   const float L = ctx->threshold > 0.f ? logf(ctx->threshold) : -INFINITY;
-  double mx = 0.0; long long rows = 0;
+  double mx = 0.0, mx_all = 0.0; long long rows = 0, rows_all = 0;
   for (int b = 0; b < B; ++b) {
     const int n0 = nv[2 * b], n1 = nv[2 * b + 1];
     if (n0 < 2 || n1 < 2) continue;
     for (int i = 0; i < n0; ++i) {
       const size_t o = (size_t)b * np + i;
       const float bf = best[0][o], be = best[1][o], sf = second[0][o], se = second[1][o];
-      if (!(std::max(bf, be) >= L - 1.f)) continue;
-      ++rows;
       const double d1 = std::fabs((double)bf - be), d2 = std::fabs((double)sf - se);
-      if (std::isfinite(d1)) mx = std::max(mx, d1); else mx = INFINITY;
-      if (std::isfinite(d2)) mx = std::max(mx, d2);
+      const double d = std::max(std::isfinite(d1) ? d1 : (double)INFINITY, std::isfinite(d2) ? d2 : 0.0);
+      ++rows_all; mx_all = std::max(mx_all, d);
+      if (!(std::max(bf, be) >= L - 1.f)) continue;
+      ++rows; mx = std::max(mx, d);
     }
   }
+  // (a sample without any row near the threshold -- every decision far away -- still calibrates: over all rows, which only makes eps larger)
+  if (rows == 0) { mx = mx_all; rows = rows_all; }
   if (!std::isfinite(mx)) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: non-finite scores in the sample");
-  if (rows == 0) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: no row of the sample comes near the threshold (nothing to measure)");
+  if (rows == 0) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: the sample holds no pair with at least two keypoints per side (nothing to measure)");
   const float eps = std::max(floor_eps, safety * (float)mx);
   ctx->cert_eps = eps;
   if (measured_host) *measured_host = (float)mx;

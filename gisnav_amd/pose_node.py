@@ -104,9 +104,12 @@ class PoseNode:
         eng.set_active_kpts(max(n, self._cached_n_r, 1))    # pad to what this pair needs, not to max_kpts (results do not depend on it)
         try:
             if self._certify and self._cal_left > 0 and n >= 2 and self._cached_n_r >= 2:
-                self._cal_eps = max(self._cal_eps, eng.calibrate_certify(inputs)["eps"])
-                self._cal_left -= 1
-                eng.set_certify("rerun", eps=self._cal_eps)
+                try:
+                    self._cal_eps = max(self._cal_eps, eng.calibrate_certify(inputs)["eps"])
+                    self._cal_left -= 1
+                    eng.set_certify("rerun", eps=self._cal_eps)
+                except _lib.GnError:      # (a sample that cannot calibrate -- it left the fp16 range -- : the next message tries again)
+                    pass
             eng.estimate(inputs, np.asarray(camera_info.k, np.float64).reshape(3, 3), self.MIN_MATCHES, out=self._out)
         finally:
             eng.set_active_kpts(eng.kmax)                   # sticky context state: restore

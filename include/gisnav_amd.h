@@ -160,7 +160,8 @@ int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8);
 int gn_reset_certify_stats(gn_ctx* ctx);
 /* Measure eps for THIS context's weights and precision mode on a sample batch (arguments as gn_match): the batch is matched twice -- in the
  * context's arithmetic and on the exact-f32 kernels -- and eps = max(floor_eps, safety * max |P_mode - P_f32|) over the best score and the
- * runner-up of every valid row that comes within 1 of log(filter_threshold) in either arithmetic (all rows when the threshold is 0).
+ * runner-up of every valid row that comes within 1 of log(filter_threshold) in either arithmetic (all rows when the threshold is 0, or when no row
+ * of the sample comes that close).
  * Synchronises; sets the context's eps and returns the measured maximum and eps through the two host pointers (either may be NULL).  Call
  * it once after loading a checkpoint, on representative pairs, IN A BATCH OF THE SIZE THE REAL CALLS HAVE (the kernel family -- and with it the arithmetic
  * whose error is being measured -- follows the grid size); safety >= 1 is the stated safety factor (the Python mirror uses 4). */

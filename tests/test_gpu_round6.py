@@ -328,6 +328,48 @@ def test_deferred_certificate_resolves_one_call_later_with_the_same_results():
     del eng
 
 
+def test_mirrors_certify_by_themselves_in_the_fast_mode():
+    """The drop-in objects (seams B1 and B3) in the FAST precision on low-margin weights (filter_threshold 0: every mutual arg-max is a match,
+    hundreds of them with a small margin): `LightGlueMatcher(..., precision=headline)` and `PoseNode(..., precision=headline)` calibrate on their first calls and certify every
+    call -- the matcher's indices equal the oracle's on every one of six messages, the node's match count and pose equal an exact-f32 node's."""
+    from gisnav_amd import wire
+    from gisnav_amd.matcher import LightGlueMatcher
+    from gisnav_amd.pose_node import PoseNode
+    from oracle import lightglue_sift as lg
+    _threads()
+    sd = synthetic_state_dict(0, **LOW_MARGIN)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    th = 0.0
+    m = LightGlueMatcher("sift", params={"n_layers": 9, "filter_threshold": th, "depth_confidence": -1, "width_confidence": -1}, state_dict=sd,
+                         max_kpts=512, precision=HEADLINE).to("cuda:0").eval()
+    tq = torch.from_numpy
+    for i in range(6):
+        p = make_pair(9700 + i, n_q=400 + 17 * i, n_r=512)
+        laf_q = lg.laf_from_center_scale_ori(tq(p.kp_q).unsqueeze(0), tq(p.size_q)[None, :, None, None], tq(p.angle_q)[None, :, None])
+        laf_r = lg.laf_from_center_scale_ori(tq(p.kp_r).unsqueeze(0), tq(p.size_r)[None, :, None, None], tq(p.angle_r)[None, :, None])
+        dq, dr = lg.rootsift(tq(p.desc_q)), lg.rootsift(tq(p.desc_r))
+        dists, idx = m(dq.cuda(), dr.cuda(), laf_q.cuda(), laf_r.cuda())
+        want = oracle_match(tsd, p, filter_threshold=th)[3].numpy()
+        assert np.array_equal(idx.cpu().numpy(), want), i
+    st = m._engine.certify_stats()
+    assert st["mode"] == 2 and st["calls"] == 6 and m._cal_left == 2 and m._cal_eps > 0.0, st
+
+    class Node(PoseNode):
+        CONFIDENCE_THRESHOLD = th
+    p = make_pair(9720, n_q=500, n_r=512)
+    res = {}
+    for prec in ("f32", HEADLINE):
+        node = Node(sd, lambda ref: (p.kp_r, p.desc_r, p.size_r, p.angle_r), max_kpts=512, precision=prec)
+        node.camera_info = wire.CameraInfo(k=K_MATRIX.reshape(-1), height=480, width=640)
+        node.pose_image = wire.OrthoStereoImage(query_sift=wire.pack_keypoints(p.kp_q, p.size_q, p.angle_q, p.desc_q),
+                                                reference=wire.ImageMsg(p.ref, wire.Stamp(3, 0)), dem=wire.ImageMsg(p.dem, wire.Stamp(3, 0)))
+        r = node.pose()
+        res[prec] = (node.last_num_matches, r)
+    assert res["f32"][0] == res[HEADLINE][0] == len(oracle_match(tsd, p, filter_threshold=th)[3])
+    if res["f32"][1] is not None:
+        assert res[HEADLINE][1] is not None and np.linalg.norm(res["f32"][1][0] - res[HEADLINE][1][0]) < 1e-9 and np.linalg.norm(res["f32"][1][1] - res[HEADLINE][1][1]) < 1e-6
+
+
 def test_bench_n2_launch_path_on_one_gpu():
     """the sharded path under the driver every round.  `python bench.py --gpus 2` spawns its two ranks itself (gloo, both on
     cuda:0): contiguous shards, the weight broadcast, barriers, max-over-ranks timing, the all-gather of result records."""
