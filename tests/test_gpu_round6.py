@@ -328,6 +328,58 @@ def test_deferred_certificate_resolves_one_call_later_with_the_same_results():
     del eng
 
 
+def test_gathered_rerun_of_scattered_pairs_equals_the_exact_f32_mode_for_every_input_format():
+    """Scattered flagged pairs are gathered into a staging block and re-run as one f32 batch (certify_rerun).  Mid-margin weights, 16 x 512, some pairs
+    flagged and some not: for XYSA keypoints + descriptor arrays, for LAF keypoints, and for raw 532-byte wire records (descriptors inside the
+    records, no descriptor arrays) the certified match lists -- and, through estimate(), match counts and poses -- equal an exact-f32 context's."""
+    from gisnav_amd import _lib, wire
+    from gisnav_amd.engine import PoseEngine
+    sd, _, th = _family("mid_margin")
+    pairs = [make_pair(9800 + i, n_q=512 - 3 * i, n_r=512) for i in range(16)]
+    cal = [make_pair(9860 + i, n_q=500, n_r=512) for i in range(16)]
+
+    def record_inputs(eng, ps):
+        base = eng.stage_inputs(ps)
+        rec = lambda kp, sz, an, ds: np.frombuffer(wire.pack_keypoints(kp, sz, an, ds), dtype=np.float32).reshape(-1, 133)      # noqa: E731
+        rq = np.zeros((len(ps), 512, 133), np.float32); rr = np.zeros((len(ps), 512, 133), np.float32)
+        for b, p in enumerate(ps):
+            rq[b, : len(p.kp_q)] = rec(p.kp_q, p.size_q, p.angle_q, p.desc_q); rr[b, : len(p.kp_r)] = rec(p.kp_r, p.size_r, p.angle_r, p.desc_r)
+        d = dict(base)
+        d.update(desc_q=None, desc_r=None, kpt_q=torch.from_numpy(rq).to(eng.device), kpt_r=torch.from_numpy(rr).to(eng.device), kpt_format=_lib.GN_KPT_RECORD)
+        return d
+
+    e32 = PoseEngine(0, max_batch=16, max_kpts=512, precision="f32", state_dict=sd, filter_threshold=th)
+    eng = PoseEngine(0, max_batch=16, max_kpts=512, precision=HEADLINE, state_dict=sd, filter_threshold=th)
+    eng.calibrate_certify(eng.stage_inputs(cal), safety=SAFETY)
+    eng.set_certify("rerun")
+    seen_scattered = False
+    for fmt in ("xysa", "record"):
+        i32 = e32.stage_inputs(pairs) if fmt == "xysa" else record_inputs(e32, pairs)
+        inp = eng.stage_inputs(pairs) if fmt == "xysa" else record_inputs(eng, pairs)
+        a = e32.match(i32["desc_q"], i32["kpt_q"], i32["n_q"], i32["desc_r"], i32["kpt_r"], i32["n_r"], i32["kpt_format"])
+        eng.set_certify("flag")
+        eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"], inp["kpt_format"])
+        flags = eng.uncertain(16)
+        fl = np.flatnonzero(flags)
+        print(fmt, "flags", flags.tolist())
+        seen_scattered |= len(fl) >= 2 and (fl[-1] - fl[0] + 1) != len(fl)
+        eng.set_certify("rerun")
+        b = eng.match(inp["desc_q"], inp["kpt_q"], inp["n_q"], inp["desc_r"], inp["kpt_r"], inp["n_r"], inp["kpt_format"])
+        torch.cuda.synchronize()
+        assert torch.equal(a[2], b[2]), (fmt, a[2], b[2], flags)
+        for p in range(16):
+            k = int(a[2][p])
+            assert torch.equal(a[0][p, :k], b[0][p, :k]), (fmt, p, flags)
+        wa, wb = e32.estimate(i32, K_MATRIX), eng.estimate(inp, K_MATRIX)
+        torch.cuda.synchronize()
+        assert torch.equal(wa["n_match"], wb["n_match"]) and torch.equal(wa["ok"], wb["ok"]), fmt
+        ok = wa["ok"].bool()
+        if bool(ok.any()):
+            assert float((wa["R"][ok] - wb["R"][ok]).abs().max()) < 1e-6 and float((wa["t"][ok] - wb["t"][ok]).abs().max()) < 1e-3, fmt
+    assert seen_scattered, "the sample never produced scattered flags: the gathered path was not exercised"
+    del eng, e32
+
+
 def test_mirrors_certify_by_themselves_in_the_fast_mode():
     """The drop-in objects (seams B1 and B3) in the FAST precision on low-margin weights (filter_threshold 0: every mutual arg-max is a match,
     hundreds of them with a small margin): `LightGlueMatcher(..., precision=headline)` and `PoseNode(..., precision=headline)` calibrate on their first calls and certify every
