@@ -118,7 +118,7 @@ def kernel_rows(table, steps, precision):
     return rows
 
 
-def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1, certify_eps: float = 0.0):
+def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1, certify_eps: str = ""):
     """HBM bytes per kernel from two rocprofv3 PMC passes over this same script (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass),
     --kernel-trace only.  FETCH_SIZE counts 64 B per 128-B request on gfx950 for wide coalesced reads: doubled (MI355X_MICROARCH.md)."""
     exe = shutil.which("rocprofv3")
@@ -135,9 +135,8 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1, certify_eps
                    "--no-cpu-baseline", "--no-traffic", "--no-extras", "--no-stream", "--no-rccl-check", "--substreams", "1"]     # one pass, full-batch launches: the configuration of the kernel table
             for kv in args.debug_variant:
                 cmd += ["--debug-variant", kv]
-            cmd += ["--certify-eps", repr(certify_eps)] if certify_eps > 0.0 else ["--no-certify"] if args.no_certify else []
-            if args.ffn_products:
-                cmd += ["--ffn-products", str(args.ffn_products)]
+            cmd += ["--certify-eps", certify_eps] if certify_eps else ["--no-certify"] if args.no_certify else []
+            cmd += ["--ffn-products", str(args.ffn_products)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -173,19 +172,30 @@ def measure_traffic(args, steps_prof: int = 2, warmup_prof: int = 1, certify_eps
 CERT_SAFETY = 4.0
 
 
-def certify_on(eng, kpts, batch, precision, certify=True, eps=0.0):
+def certify_on(eng, kpts, batch, precision, certify=True, eps=""):
     """The margin certificate for a fast-mode engine (gn_set_certify(2)): eps is CALIBRATED for these weights on one batch of pairs that are not part of any
     timed batch (max |P_mode - P_f32| over the deciding entries x CERT_SAFETY), then every estimate() call synchronises once, reads its per-pair
     flags and re-runs the flagged pairs on the exact-f32 kernels -- inside the timed region.  Returns the calibration record (None: f32 / off)."""
     if precision == "f32" or not certify:
         return None
-    if eps > 0.0:      # profiling pass: the eps a full run calibrated
-        eng.set_certify("rerun", eps=eps)
-        return {"eps": eps, "measured": None, "safety": None}
+    if eps:      # profiling pass: the eps a full run calibrated -- "E", or "E3,E2,LEVEL" for the automatic block-tail level (and the level that run settled on)
+        v = [float(x) for x in str(eps).split(",")]
+        eng.set_certify("rerun", eps=v[0])
+        if len(v) == 3:
+            eng.set_ffn_level_eps(v[1], v[0], int(v[2]))
+        return {"eps": v[0], "measured": None, "safety": None}
     # (as many pairs as a timed call holds: the kernel family, and with it the arithmetic whose error is measured, follows the grid size)
     cal_pairs = [make_pair(900_000 + i, n_q=kpts, n_r=kpts) for i in range(batch)]
     cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=CERT_SAFETY)
     eng.set_certify("rerun")
+    if "eps_two_products" in cal:
+        # automatic block-tail level: it starts on three products and moves after a window of 64 certified pairs; let it settle on pairs outside every timed batch
+        inp = eng.stage_inputs(cal_pairs)
+        out = eng.alloc_outputs(batch)
+        for _ in range(max(2, -(-128 // batch))):
+            eng.estimate(inp, K_MATRIX, out=out)
+        torch.cuda.synchronize()
+        eng.certify_stats(reset=True)
     return cal
 
 
@@ -193,7 +203,14 @@ def certificate_block(eng, cal):
     if cal is None:
         return None
     st = eng.certify_stats()
-    return {"mode": "margin guard + exact-f32 re-run of the flagged pairs (gn_set_certify(2)); one stream synchronisation per call, inside the timed region",
+    lv = eng.ffn_level()
+    auto = "eps_two_products" in cal
+    return {"block_tail_level": None if not auto else {
+                "setting": "automatic (gn_set_ffn_products(0)): two partial products while that flags no more pairs than three would (1 in 64 tolerated), else three",
+                "level_now": lv["level"], "certified_calls_on_two_products": lv["calls_two_products"], "certified_calls_on_three_products": lv["calls_three_products"],
+                "switches": lv["switches"], "eps_two_products": cal["eps_two_products"], "eps_three_products": cal["eps_three_products"]},
+            "profile_eps_arg": ("%r,%r,%d" % (cal["eps_three_products"], cal["eps_two_products"], lv["level"])) if auto else repr(cal["eps"]),
+            "mode": "margin guard + exact-f32 re-run of the flagged pairs (gn_set_certify(2)); one stream synchronisation per call, inside the timed region",
             "resolution": cal.get("resolution", "inside every call"),
             "eps": cal["eps"], "eps_measured_max_dP": cal["measured"], "safety_factor": cal["safety"],
             "calls": st["calls"], "pairs": st["pairs"], "pairs_flagged_margin": st["flagged_margin"], "pairs_flagged_fp16_range": st["flagged_fp16_range"],
@@ -228,7 +245,7 @@ def run_extra(local_rank, sd, name, batch, kpts, precision, steps, warmup, dev, 
     return {"config": name, "batch": batch, "keypoints_per_side": kpts, "precision": precision, "steps": steps, "warmup": warmup,
             "value": round(pps, 2), "unit": "pairs/s (this rank's GPU)", "ms_per_step": round(elapsed / steps * 1e3, 4), "poses_ok_per_step": ok,
             "end_to_end_tflops": round(pps * g / 1e3, 1), "end_to_end_frac_of_peak": round(pps * g / 1e3 / peak, 4), "peak_tflops": peak,
-            "block_tail_partial_products": ffn_products if precision.startswith("f16x2") else None,
+            "block_tail_partial_products": (ffn_products or "automatic") if precision.startswith("f16x2") else None,
             "index_exact": "exact-f32 arithmetic" if precision == "f32" else "certified (margin guard, f32 re-run)" if cert else "tolerance mode", "certificate": cert}
 
 
@@ -632,8 +649,9 @@ def main() -> None:
                                                               "number; the line then says index_exact: tolerance mode")
     ap.add_argument("--ffn-products", type=int, default=0, choices=[0, 2, 3],
                     help="fp16 partial products of the block tail's GEMMs on bulk grids (gn_set_ffn_products): 3 = f32-accurate split (rounds 1-5), 2 = activations' "
-                         "high term only (reported as an extra configuration); default 3")
-    ap.add_argument("--certify-eps", type=float, default=0.0, help="profiling passes: use this eps instead of calibrating (the calibration's f32 pass and the "
+                         "high term only, 0 (default) = the level follows the certificate's flags (two products only while they flag no more pairs than three would); "
+                         "the fixed levels are reported as extra configurations")
+    ap.add_argument("--certify-eps", type=str, default="", help="profiling passes: use this eps instead of calibrating (the calibration's f32 pass and the "
                                                                      "fused-projection self-check are set-up work that a rocprofv3 pass over few steps would count as steps)")
     ap.add_argument("--sync-certify", action="store_true", help="certificate resolved inside every call (one host synchronisation per step) instead of one call later")
     ap.add_argument("--share-gpu", action="store_true", help="dry-run aid: every rank uses cuda:0 (with --backend gloo)")
@@ -697,12 +715,13 @@ def main() -> None:
     for kv in args.debug_variant:
         which, value = (int(v) for v in kv.split(":"))
         eng.lib.gn_debug_set_variant(eng.ctx, which, value)
-    # default 3: the f32-accurate fast pass.  Two products are ~7 % faster per step and ten times less accurate (eps): under the certificate the indices stay
-    # exact either way, but the share of pairs that must be re-run in f32 grows with eps on anything but wide-margin weights -- an opt-in
-    ffn_products = args.ffn_products or 3
+    # default 0: the level follows the certificate.  Two products are ~7 % faster per step and ten times less accurate (eps): under the certificate the indices
+    # stay exact either way, but the share of pairs that must be re-run in f32 grows with eps on anything but wide-margin weights -- so the
+    # context counts what each level's certificate flags and uses two products only while that costs no extra re-runs (without the certificate: three)
+    ffn_products = args.ffn_products
     if args.precision.startswith("f16x2"):
         eng.set_ffn_products(ffn_products)         # (before the calibration: eps is measured for the arithmetic that runs)
-    if args.certify_eps > 0.0:
+    if args.certify_eps:
         eng.lib.gn_debug_set_variant(eng.ctx, 47, 1)      # (a profiling pass: no self-check launches among the steps; the full run's line carries its verdict)
     cert_cal = certify_on(eng, args.kpts, args.batch, args.precision, certify=not args.no_certify, eps=args.certify_eps)
 
@@ -787,11 +806,15 @@ def main() -> None:
             # (filter_threshold 0.01: tests/test_gpu_round6.py) -- flagged pairs are re-run in exact f32 inside the timed region -- and the opt-in
             # two-product block tail (a third less matrix work in the tail, ten times the eps) on both weight sets
             mid = synthetic_state_dict(0, ffn_out_std=1.2e-3, final_scale=12.0, matchability_bias=2.0, matchability_std=0.05)
-            extras.append(run_extra(local_rank, sd, "the headline configuration with the block tail on TWO partial products (gn_set_ffn_products(2), opt-in): bench weights",
+            extras.append(run_extra(local_rank, sd, "the headline configuration with the block tail FIXED on three partial products (gn_set_ffn_products(3): the f32-accurate fast pass of rounds 1-5): bench weights",
+                                    args.batch, args.kpts, args.precision, 20, 3, dev, substreams=nsub, ffn_products=3))
+            extras.append(run_extra(local_rank, sd, "the headline configuration with the block tail FIXED on two partial products (gn_set_ffn_products(2)): bench weights",
                                     args.batch, args.kpts, args.precision, 20, 3, dev, substreams=nsub, ffn_products=2))
-            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights (decisions close to flipping: re-runs inside the timed region), three products",
+            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights (decisions close to flipping: re-runs inside the timed region), AUTOMATIC block-tail level as in the headline",
+                                    args.batch, args.kpts, args.precision, 6, 2, dev, substreams=nsub, ffn_products=0, filter_threshold=0.01))
+            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights, fixed on three products",
                                     args.batch, args.kpts, args.precision, 6, 2, dev, substreams=nsub, ffn_products=3, filter_threshold=0.01))
-            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights, two products",
+            extras.append(run_extra(local_rank, mid, "the headline configuration on MID-MARGIN weights, fixed on two products",
                                     args.batch, args.kpts, args.precision, 6, 2, dev, substreams=nsub, ffn_products=2, filter_threshold=0.01))
         extras.append(run_extra(local_rank, sd, f"BASELINE configs[2] in the GUARANTEED mode: batch-{args.batch}, f32 everywhere (exact-f32 MFMA GEMMs and attention) -- "
                                                 "the arithmetic the certificate re-runs flagged pairs in; correspondence indices identical to the CPU restatement of the reference on every "
@@ -840,7 +863,7 @@ def main() -> None:
         dom = max(dom_family, key=lambda m: m["share_of_timed_kernel_time"]) if dom_family else None
         traffic, traffic_err = (None, "skipped")
         if not args.no_traffic and world == 1:
-            traffic, traffic_err = measure_traffic(args, certify_eps=(cert_main or {}).get("eps", 0.0))
+            traffic, traffic_err = measure_traffic(args, certify_eps=(cert_main or {}).get("profile_eps_arg", ""))
         comp_mb = compulsory_mb_per_pair(args.kpts, args.kpts) * args.batch + 47.5   # + the f32 weights once per step (cache-resident in practice)
         line = {
             "metric": "matched frame-pairs/sec + PnP poses/sec, 640x480 cam-vs-tile",
@@ -893,7 +916,7 @@ def main() -> None:
             "f16x2_guard": {"tripped_in_last_step": bool(tripped), "trips_observed": int(trips)},
             "fused_projection_selfcheck": {1: "passed: bitwise equal to the separate k_qkv launches on these weights (checked at the first call)",
                                            0: "FAILED: fusion switched off for this context", -1: "not applicable / not run"}.get(fused_status),
-            "block_tail_partial_products": ffn_products if args.precision.startswith("f16x2") else None,
+            "block_tail_partial_products": (ffn_products or "automatic: see precision_guarantee.certificate.block_tail_level") if args.precision.startswith("f16x2") else None,
             "end_to_end": {"algorithmic_gflop_per_pair": round(g_pair, 2), "attention_gflop_per_pair": round(g_attn, 2),
                            "achieved_tflops_per_gpu": round(e2e_tf, 1), "peak_tflops": e2e_peak, "frac": round(e2e_tf / e2e_peak, 4),
                            "attention_only_frac": round(pairs_per_s / world * g_attn / 1e3 / e2e_peak, 4),
@@ -947,7 +970,8 @@ def main() -> None:
                                  "flops_per_byte": round(ai, 1)},
                 "note": "achieved = algorithmic flops per launch (2 x M x N x K of the GEMMs inside the kernel) / average launch duration from HIP events recorded "
                         "around every launch on the launch stream in THIS run; peak = dense 16-bit MFMA.  The split-fp16 arithmetic issues 3 MFMA flops per "
-                        "algorithmic flop, so the kernel's own issue ceiling is peak / 3 (frac_of_issue_ceiling).  `kernel` is the name rocprofv3 prints "
+                        "algorithmic flop (2 on the block tail's two-product level and in the attention input projections: mfma_flops_issued_per_algorithmic_flop), so "
+                        "the kernel's own issue ceiling is peak / that factor (frac_of_issue_ceiling).  `kernel` is the name rocprofv3 prints "
                         "(profiles/*kernel_stats*.csv).  Measured in this run's single-stream pass (config.single_stream_ms_per_step): with sub-batch "
                         "streams two groups' launches run concurrently and a launch's elapsed time is no longer its own (tools/collect_profiles.sh "
                         "profiles the same single-stream configuration: --substreams 1)."}

@@ -47,6 +47,8 @@ SIGNATURES = {
     "gn_get_guard_status": (C.c_int, [VP, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "gn_set_certify": (C.c_int, [VP, C.c_int, C.c_float, C.c_float]),
     "gn_set_ffn_products": (C.c_int, [VP, C.c_int]),
+    "gn_get_ffn_level": (C.c_int, [VP, C.POINTER(C.c_int32), c_f32p, c_f32p, c_i64p]),
+    "gn_set_ffn_level_eps": (C.c_int, [VP, C.c_float, C.c_float, C.c_int]),
     "gn_fused_projection_status": (C.c_int, [VP]),
     "gn_device_numa_node": (C.c_int, [C.c_int]),
     "gn_get_certify_stats": (C.c_int, [VP, c_i64p]),

@@ -71,14 +71,14 @@ struct gn_ctx {
   int certify = 0;             // 0 off, 1 flags only (gn_get_uncertain), 2 flags + f32 re-run of the flagged pairs
   float cert_eps = 4.0e-3f;    // stated bound on |P_mode - P_exact| for this context's arithmetic (tools/certify_eps.py measures it)
   float cert_eps_f32 = 1.0e-4f;   // the same for the exact-f32 kernels (GPU f32 against the torch-CPU f32 oracle: summation order only)
-  float* max0b = nullptr; float* rpart_c = nullptr; int32_t* uncert = nullptr; int32_t* uncert_host = nullptr;   // uncert_host: pinned [max_batch]
+  float* max0b = nullptr; float* rpart_c = nullptr; int32_t* uncert = nullptr; int32_t* uncert_alt = nullptr; int32_t* uncert_host = nullptr;   // uncert_host: pinned [2 * max_batch] (flags | the other level's flags)
   bool cert_inner = false;     // a certificate re-run is being enqueued (no nested certification)
   void* cert_stage = nullptr; size_t cert_stage_bytes = 0;      // staging block of the gathered re-run (certify_rerun), grown on demand
   // mode 3 (deferred): gn_estimate leaves the flags of call n in a pinned slot behind an event and resolves them -- reads them, re-runs the flagged
   // pairs from the SAVED arguments -- after call n + 1 has been enqueued (or in gn_flush), so the host never waits for an idle GPU
   struct CertPending {
     bool active = false; hipEvent_t ev = nullptr; int32_t* flags = nullptr;   // flags: pinned [max_batch]
-    int B = 0, kpt_format = 0, stride_q = 0, stride_r = 0, H = 0, W = 0, min_matches = 0, npad_run = 0;
+    int B = 0, kpt_format = 0, stride_q = 0, stride_r = 0, H = 0, W = 0, min_matches = 0, npad_run = 0, level = 0;
     const float *desc_q = nullptr, *kpt_q = nullptr, *desc_r = nullptr, *kpt_r = nullptr; const int32_t *n_q = nullptr, *n_r = nullptr; const uint8_t* dem = nullptr;
     double K9[9] = {0}; double *R = nullptr, *t = nullptr; int32_t *n_match = nullptr, *n_inliers = nullptr; uint8_t* ok = nullptr;
   } cert_pend[2];
@@ -151,6 +151,11 @@ struct gn_ctx {
   int skinny = 1;          // knob 33.  1 (default): calls of one or two pairs run the attention input projections and the block
                            // tail as CU-split small-grid kernels (gn_skinny.hip); 0: never; 2: whenever the shapes allow; + 4: not the projections; + 8: not the tail;
                            // >> 4: kernel variant (tools/skinny_ab.py)
+  // gn_set_ffn_products(0) -- the level follows the certificate: with eps calibrated for both levels (cert_eps_lvl[0 / 1] = two / three products, < 0 = not
+  // calibrated) every head launch also evaluates the OTHER level's certificate on the same scores (uncert_alt); over windows of >= 64 certified pairs the
+  // context counts the pairs each level flags and runs the next window on two products only when that flags at most 1 pair in 64 more than three products
+  // would (a re-run in exact f32 costs ~4 block-tail passes of the pair, the two-product pass saves ~7 % of one).  Starts on three products.
+  int auto_level = 3; float cert_eps_lvl[2] = {-1.f, -1.f}; long long auto_pairs = 0, auto_wide = 0, auto_narrow = 0, auto_calls_lvl[2] = {0, 0}, auto_switches = 0;
   int ffn_products = 3;    // gn_set_ffn_products: fp16 partial products of the block tail's two GEMMs on bulk grids (k_ffn128, composed form): 3 = f32-accurate split,
                            // 2 = the activations' fp16 high term only (meant to run under the margin certificate)
   int qkv_products = 2;    // knob 27: fp16 partial products of the attention input projections (2 or 3), per context
@@ -547,6 +552,10 @@ template <typename F> bool timed_launch(gn_ctx* c, hipStream_t s, double flops, 
   return true;
 }
 
+inline bool ffn_auto(const gn_ctx* c) { return c->ffn_products == 0 && c->cert_eps_lvl[0] >= 0.f && c->cert_eps_lvl[1] >= 0.f && c->certify >= 2; }
+inline int ffn_level(const gn_ctx* c) { return c->ffn_products == 0 ? (ffn_auto(c) ? c->auto_level : 3) : c->ffn_products; }
+inline float cert_eps_now(const gn_ctx* c) { return ffn_auto(c) ? c->cert_eps_lvl[c->auto_level - 2] : c->cert_eps; }
+
 bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const Block* next = nullptr, bool next_cross = false, int np = 0, int vt_perm = 0) {
   if (skinny_applies(c, T, np) && !(c->skinny & 8) && c->ffn_fused == 3 && c->ffn_compose && tail_folds_out_proj(c, blk, T) && blk.wfc && blk.b1c && !blk.comp_dirty && blk.ffn3.wfn &&
       c->h && c->ctx_p && gn::g_ffn_ablate == 0 && gn::g_ffn_shape == 0) {
@@ -572,7 +581,7 @@ bool ffn(gn_ctx* c, const Block& blk, int T, hipStream_t s, bool keep_f32, const
     f.walk = c->use_lists == 2 || (c->use_lists == 1 && tail_should_walk(c));
     f.ncu = c->ncu;
     f.composed = comp ? 1 : 0;
-    f.products = (comp && c->ffn_products == 2) ? 2 : 3;
+    f.products = (comp && ffn_level(c) == 2) ? 2 : 3;
     const bool fuse_qkv = next != nullptr && c->qkv_in_tail && comp && ffn_selects_128(f) && gn::g_ffn_ablate == 0 && c->attn_f16 && c->qkv_products != 3 && !c->qkv_stamps &&
                           c->precision != GN_PREC_F32 && c->attn_variant >= 1 && qkv_projection_applies(c, *next, T, np, vt_perm) && !(vt_perm & 2);
     if (fuse_qkv) {
@@ -746,7 +755,8 @@ int run_matcher(gn_ctx* c, int B, int kpt_format,
     hd.m0 = c->m0; hd.max0 = c->max0; hd.m1 = c->m1;
     hd.ovf = (c->planes_mode && c->guard) ? c->ovf : nullptr;
     hd.max0b = c->max0b; hd.rpart_c = c->rpart_c; hd.uncert = c->certify ? c->uncert : nullptr;
-    hd.cert_eps = (c->precision == GN_PREC_F32) ? c->cert_eps_f32 : c->cert_eps;
+    hd.cert_eps = (c->precision == GN_PREC_F32) ? c->cert_eps_f32 : cert_eps_now(c);
+    if (hd.uncert && c->precision != GN_PREC_F32 && ffn_auto(c)) { hd.uncert_alt = c->uncert_alt; hd.cert_eps_alt = c->cert_eps_lvl[3 - c->auto_level]; }
     hd.idx = idx; hd.score = score; hd.n_match = n_match; hd.kmax = c->npad;   // output stride: gn_kmax(), whatever the active size
     hd.md = c->planes_mode ? (const void*)c->md_p : (const void*)c->md; hd.md_f32 = c->planes_mode ? 0 : 1;
     hd.cpart_m = c->cpart_m; hd.cpart_s = c->cpart_s; hd.cpart_i = c->cpart_i; hd.rpart_a = c->rpart_a; hd.rpart_b = c->rpart_b; hd.tickets = c->tickets;
@@ -797,7 +807,7 @@ int alloc_workspace(gn_ctx* ctx, int max_kpts) {
   }
   if (ctx->precision != GN_PREC_F32) { GN_ALLOC(qkb, T * 2 * kDim); GN_ALLOC(vtb, T * kDim); GN_ALLOC(attn_part, (size_t)256 * 4 * 34 * 64); GN_ALLOC(attn_tickets, 256); }
   GN_ALLOC(rowmax, B * np); GN_ALLOC(rowlog, B * np); GN_ALLOC(colmax, B * np); GN_ALLOC(collog, B * np);
-  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np); GN_ALLOC(max0b, B * np); GN_ALLOC(rpart_c, B * 8 * np); GN_ALLOC(uncert, B);
+  GN_ALLOC(max0, B * np); GN_ALLOC(m0, B * np); GN_ALLOC(m1, B * np); GN_ALLOC(max0b, B * np); GN_ALLOC(rpart_c, B * 8 * np); GN_ALLOC(uncert, B); GN_ALLOC(uncert_alt, B);
   GN_ALLOC(cpart_m, B * (np / 32) * np); GN_ALLOC(cpart_s, B * (np / 32) * np); GN_ALLOC(cpart_i, B * (np / 32) * np); GN_ALLOC(rpart_a, B * 8 * np); GN_ALLOC(rpart_b, B * 8 * np); GN_ALLOC(tickets, B * 2);
   GN_ALLOC(e_idx, B * np * 2); GN_ALLOC(e_score, B * np); GN_ALLOC(e_mkp, B * np * 2); GN_ALLOC(e_obj, B * np * 3);
   GN_ALLOC(vo_norm2, T); GN_ALLOC(vo_nn_idx, B * np * 2); GN_ALLOC(vo_nn_dist, B * np * 2); GN_ALLOC(vo_good, B * np);
@@ -909,6 +919,21 @@ int selfcheck_fused_projection(gn_ctx* c) {
 
 // The exact-f32 arithmetic inside a context of another precision, for the duration of a scope: GN_PREC_F32's kernels read the f32 weights (kept in
 // every mode) and the f32 workspaces (allocated in every mode); nothing of the hm16 / 16-bit state is touched.
+
+// gn_set_ffn_products(0): one certified call's flags (those of the level it ran on, and the other level's from the same scores) into the window
+void ffn_level_update(gn_ctx* c, int B, const int32_t* flags, const int32_t* alt, int lvl) {      // lvl: the level the call ran on (a deferred call's: saved with it)
+  if (!ffn_auto(c) || c->precision == GN_PREC_F32 || lvl < 2 || lvl > 3) return;
+  ++c->auto_calls_lvl[lvl - 2];
+  int nf = 0, na = 0;
+  for (int b = 0; b < B; ++b) { nf += flags[b] == 1; na += alt[b] == 1; }
+  c->auto_pairs += B; c->auto_wide += lvl == 2 ? nf : na; c->auto_narrow += lvl == 2 ? na : nf;
+  if (c->auto_pairs < 64) return;
+  const int next = (c->auto_wide - c->auto_narrow) * 64 <= c->auto_pairs ? 2 : 3;
+  if (next != c->auto_level) ++c->auto_switches;
+  c->auto_level = next;
+  c->auto_pairs = c->auto_wide = c->auto_narrow = 0;
+}
+
 struct F32Scope {
   gn_ctx* c; int precision, planes_mode, gemm_variant, no_planes, attn_f16;
   explicit F32Scope(gn_ctx* c_) : c(c_), precision(c_->precision), planes_mode(c_->planes_mode), gemm_variant(c_->gemm_variant), no_planes(c_->no_planes), attn_f16(c_->attn_f16) {
@@ -943,12 +968,14 @@ CertView cert_view_at(const CertView& v, const CertShape& h, size_t b) {
 // block first (device-to-device copies of their inputs), run as ONE batch on workspace slots 0 .. nf - 1, and their outputs scattered back: a
 // batched f32 call costs ~0.8 ms per pair where one- and two-pair calls cost 1.7 / 1.2 (round 6: mid-margin weights 1.26 k -> 1.9 k certified pairs/s).
 // Counts what it saw (gn_get_certify_stats).
-template <typename F> int certify_rerun(gn_ctx* ctx, int B, hipStream_t s, const CertShape& h, const CertView& v, F&& run, const int32_t* flags_ready = nullptr) {
+template <typename F> int certify_rerun(gn_ctx* ctx, int B, hipStream_t s, const CertShape& h, const CertView& v, F&& run, const int32_t* flags_ready = nullptr, int flags_level = 0) {
   if (!flags_ready) {
     GN_HIP(hipMemcpyAsync(ctx->uncert_host, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (ffn_auto(ctx)) GN_HIP(hipMemcpyAsync(ctx->uncert_host + ctx->max_batch, ctx->uncert_alt, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     GN_HIP(hipStreamSynchronize(s));
     flags_ready = ctx->uncert_host;
   }
+  ffn_level_update(ctx, B, flags_ready, flags_ready + ctx->max_batch, flags_level ? flags_level : ctx->auto_level);     // (both callers lay the other level's flags max_batch entries behind)
   ++ctx->cert_calls; ctx->cert_pairs += B;
   std::vector<int> flagged;
   for (int b = 0; b < B; ++b) {
@@ -1086,10 +1113,10 @@ int gn_create_ex(int device, int max_batch, int max_kpts, int precision, int fea
   if (hipHostMalloc((void**)&ctx->ovf_host, (16 + 4096 + 16) * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
   memset(ctx->ovf_host, 0, (16 + 4096 + 16) * sizeof(unsigned int));
   ctx->tile_feedback = reinterpret_cast<unsigned long long*>(ctx->ovf_host + 16 + 4096);   // [8] x 8 bytes behind the counters (8-byte aligned)
-  if (hipHostMalloc((void**)&ctx->uncert_host, (size_t)max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
-  memset(ctx->uncert_host, 0, (size_t)max_batch * sizeof(int32_t));
+  if (hipHostMalloc((void**)&ctx->uncert_host, (size_t)2 * max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "hipHostMalloc failed"); }
+  memset(ctx->uncert_host, 0, (size_t)2 * max_batch * sizeof(int32_t));
   for (auto& pd : ctx->cert_pend) {
-    if (hipHostMalloc((void**)&pd.flags, (size_t)max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&pd.flags, (size_t)2 * max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming) != hipSuccess) { gn_destroy(ctx); return fail(nullptr, GN_ERR_HIP, "certificate slots: allocation failed"); }
   }
   ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1382,8 +1409,25 @@ int gn_device_numa_node(int device) {
 int gn_fused_projection_status(const gn_ctx* ctx) { return ctx ? ctx->fused_proj_status : GN_ERR_ARG; }
 
 int gn_set_ffn_products(gn_ctx* ctx, int products) {
-  if (!ctx || (products != 2 && products != 3)) return GN_ERR_ARG;
+  if (!ctx || (products != 0 && products != 2 && products != 3)) return GN_ERR_ARG;
+  if (products != ctx->ffn_products) { ctx->auto_level = 3; ctx->auto_pairs = ctx->auto_wide = ctx->auto_narrow = 0; }
   ctx->ffn_products = products;
+  return GN_OK;
+}
+
+int gn_set_ffn_level_eps(gn_ctx* ctx, float eps2, float eps3, int level) {
+  if (!ctx || !(eps2 >= 0.f) || !(eps3 >= 0.f) || (level != 2 && level != 3)) return GN_ERR_ARG;
+  ctx->cert_eps_lvl[0] = std::max(eps2, eps3); ctx->cert_eps_lvl[1] = eps3;
+  ctx->auto_level = level; ctx->auto_pairs = ctx->auto_wide = ctx->auto_narrow = 0;
+  return GN_OK;
+}
+
+int gn_get_ffn_level(gn_ctx* ctx, int32_t* level, float* eps2, float* eps3, int64_t* out4) {
+  if (!ctx) return GN_ERR_ARG;
+  if (level) *level = ffn_level(ctx);
+  if (eps2) *eps2 = ctx->cert_eps_lvl[0];
+  if (eps3) *eps3 = ctx->cert_eps_lvl[1];
+  if (out4) { out4[0] = ctx->auto_calls_lvl[0]; out4[1] = ctx->auto_calls_lvl[1]; out4[2] = ctx->auto_switches; out4[3] = ffn_auto(ctx) ? 1 : 0; }
   return GN_OK;
 }
 
@@ -1411,21 +1455,27 @@ int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
   const size_t np = (size_t)ctx->npad_run, n = (size_t)B * np;
   int32_t* nm = nullptr;
   GN_HIP(hipMalloc((void**)&nm, (size_t)B * sizeof(int32_t)));
-  std::vector<float> best[2], second[2];
+  // passes: the context's arithmetic -- on BOTH block-tail levels under gn_set_ffn_products(0) -- then the exact-f32 kernels
+  const int setting = ctx->ffn_products;
+  const int n_lv = setting == 0 ? 2 : 1;
+  const int lv[2] = {setting == 0 ? 2 : setting, 3};
+  std::vector<float> best[3], second[3];
   std::vector<int32_t> nv(2 * (size_t)B);
   unsigned int tripped = 0u;
-  for (int pass = 0; pass < 2 && rc == GN_OK; ++pass) {
+  for (int pass = 0; pass <= n_lv && rc == GN_OK; ++pass) {
     std::unique_ptr<F32Scope> f32;
-    if (pass == 1) f32.reset(new F32Scope(ctx));
+    if (pass == n_lv) f32.reset(new F32Scope(ctx)); else ctx->ffn_products = lv[pass];
     const bool ig = ctx->in_group; ctx->in_group = true;       // (no nested certification, ovf_groups_last untouched)
     rc = run_matcher(ctx, B, kpt_format, desc_q, kpt_q, n_q, stride_q, desc_r, kpt_r, n_r, stride_r, ctx->e_idx, ctx->e_score, nm, s);
-    ctx->in_group = ig;
+    ctx->in_group = ig; ctx->ffn_products = setting;
     if (rc != GN_OK) break;
     best[pass].resize(n); second[pass].resize(n);
+    unsigned int trip = 0u;
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(best[pass].data(), ctx->max0, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(second[pass].data(), ctx->max0b, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(nv.data(), ctx->nvalid, nv.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        (pass == 0 && ctx->planes_mode && ctx->guard && hipMemcpy(&tripped, ctx->ovf, 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = GN_ERR_HIP;
+        (pass < n_lv && ctx->planes_mode && ctx->guard && hipMemcpy(&trip, ctx->ovf, 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = GN_ERR_HIP;
+    tripped |= trip;
   }
   hipFree(nm);
   if (rc != GN_OK) return rc == GN_ERR_HIP ? fail(ctx, rc, "gn_calibrate_certify: a HIP call failed") : rc;
@@ -1433,28 +1483,37 @@ int gn_calibrate_certify(gn_ctx* ctx, int B, int kpt_format,
   // largest difference between the two arithmetics over the entries a decision looks at: every valid row's best score and runner-up,
   // restricted -- when there is a threshold -- to rows that come within 1 (in log units) of it in either arithmetic
   const float L = ctx->threshold > 0.f ? logf(ctx->threshold) : -INFINITY;
-  double mx = 0.0, mx_all = 0.0; long long rows = 0, rows_all = 0;
-  for (int b = 0; b < B; ++b) {
-    const int n0 = nv[2 * b], n1 = nv[2 * b + 1];
-    if (n0 < 2 || n1 < 2) continue;
-    for (int i = 0; i < n0; ++i) {
-      const size_t o = (size_t)b * np + i;
-      const float bf = best[0][o], be = best[1][o], sf = second[0][o], se = second[1][o];
-      const double d1 = std::fabs((double)bf - be), d2 = std::fabs((double)sf - se);
-      const double d = std::max(std::isfinite(d1) ? d1 : (double)INFINITY, std::isfinite(d2) ? d2 : 0.0);
-      ++rows_all; mx_all = std::max(mx_all, d);
-      if (!(std::max(bf, be) >= L - 1.f)) continue;
-      ++rows; mx = std::max(mx, d);
+  float eps_of[2] = {0.f, 0.f}, mx_of[2] = {0.f, 0.f};
+  for (int k = 0; k < n_lv; ++k) {
+    double mx = 0.0, mx_all = 0.0; long long rows = 0, rows_all = 0;
+    for (int b = 0; b < B; ++b) {
+      const int n0 = nv[2 * b], n1 = nv[2 * b + 1];
+      if (n0 < 2 || n1 < 2) continue;
+      for (int i = 0; i < n0; ++i) {
+        const size_t o = (size_t)b * np + i;
+        const float bf = best[k][o], be = best[n_lv][o], sf = second[k][o], se = second[n_lv][o];
+        const double d1 = std::fabs((double)bf - be), d2 = std::fabs((double)sf - se);
+        const double d = std::max(std::isfinite(d1) ? d1 : (double)INFINITY, std::isfinite(d2) ? d2 : 0.0);
+        ++rows_all; mx_all = std::max(mx_all, d);
+        if (!(std::max(bf, be) >= L - 1.f)) continue;
+        ++rows; mx = std::max(mx, d);
+      }
     }
+    // (a sample without any row near the threshold -- every decision far away -- still calibrates: over all rows, which only makes eps larger)
+    if (rows == 0) { mx = mx_all; rows = rows_all; }
+    if (!std::isfinite(mx)) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: non-finite scores in the sample");
+    if (rows == 0) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: the sample holds no pair with at least two keypoints per side (nothing to measure)");
+    mx_of[k] = (float)mx; eps_of[k] = std::max(floor_eps, safety * (float)mx);
   }
-  // (a sample without any row near the threshold -- every decision far away -- still calibrates: over all rows, which only makes eps larger)
-  if (rows == 0) { mx = mx_all; rows = rows_all; }
-  if (!std::isfinite(mx)) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: non-finite scores in the sample");
-  if (rows == 0) return fail(ctx, GN_ERR_ARG, "gn_calibrate_certify: the sample holds no pair with at least two keypoints per side (nothing to measure)");
-  const float eps = std::max(floor_eps, safety * (float)mx);
-  ctx->cert_eps = eps;
-  if (measured_host) *measured_host = (float)mx;
-  if (eps_host) *eps_host = eps;
+  if (setting == 0) {
+    // the wider level's bound is never stated tighter than the narrower one's (a sample can happen to show the opposite)
+    ctx->cert_eps_lvl[1] = eps_of[1]; ctx->cert_eps_lvl[0] = std::max(eps_of[0], eps_of[1]);
+    ctx->auto_level = 3; ctx->auto_pairs = ctx->auto_wide = ctx->auto_narrow = 0;
+  }
+  const int rep = n_lv - 1;       // reported: the three-product level's values under the automatic setting (gn_get_ffn_level returns both eps)
+  ctx->cert_eps = eps_of[rep];
+  if (measured_host) *measured_host = mx_of[rep];
+  if (eps_host) *eps_host = eps_of[rep];
   return GN_OK;
 }
 
@@ -1468,6 +1527,7 @@ int gn_get_certify_stats(gn_ctx* ctx, int64_t* out8) {
 int gn_reset_certify_stats(gn_ctx* ctx) {
   if (!ctx) return GN_ERR_ARG;
   ctx->cert_calls = ctx->cert_pairs = ctx->cert_flag_margin = ctx->cert_flag_range = ctx->cert_rerun = ctx->cert_f32_marginal = 0;
+  ctx->auto_calls_lvl[0] = ctx->auto_calls_lvl[1] = ctx->auto_switches = 0;
   return GN_OK;
 }
 
@@ -1531,7 +1591,7 @@ void shift_workspaces(gn_ctx* c, long long b0, int sign) {
   mv(c->qkb, T2 * 2 * kDim); mv(c->vtb, T2 * kDim);
   mv(c->rowmax, np); mv(c->rowlog, np); mv(c->colmax, np); mv(c->collog, np); mv(c->max0, np); mv(c->m0, np); mv(c->m1, np);
   mv(c->cpart_m, (np / 32) * np); mv(c->cpart_s, (np / 32) * np); mv(c->cpart_i, (np / 32) * np); mv(c->rpart_a, 8 * np); mv(c->rpart_b, 8 * np); mv(c->tickets, 2);
-  mv(c->max0b, np); mv(c->rpart_c, 8 * np); mv(c->uncert, 1);
+  mv(c->max0b, np); mv(c->rpart_c, 8 * np); mv(c->uncert, 1); mv(c->uncert_alt, 1);
   // match lists and the PnP masks are strided by the context's padded maximum (gn_kmax), whatever the active size
   const long long km = c->npad;
   mv(c->e_idx, km * 2); mv(c->e_score, km); mv(c->e_mkp, km * 2); mv(c->e_obj, km * 3);
@@ -1561,7 +1621,7 @@ int cert_resolve(gn_ctx* ctx, int slot, hipStream_t s) {
   const int rc = certify_rerun(ctx, p.B, s, shp, view, [&](const CertView& w, int n) {
     return estimate_impl(ctx, n, p.kpt_format, w.desc_q, w.kpt_q, w.n_q, p.stride_q, w.desc_r, w.kpt_r, w.n_r, p.stride_r, w.dem, p.H, p.W, p.K9, p.min_matches,
                          w.R, w.t, w.n_match, w.n_inliers, w.ok, s);
-  }, p.flags);
+  }, p.flags, p.level);
   ctx->npad_run = np_now;
   return rc;
 }
@@ -1629,8 +1689,10 @@ int gn_estimate(gn_ctx* ctx, int B, int kpt_format,
     gn_ctx::CertPending& p = ctx->cert_pend[slot];
     if (p.active) { const int rcr = cert_resolve(ctx, slot, s); if (rcr != GN_OK) return rcr; }     // (cannot happen in the alternating order; kept for safety)
     GN_HIP(hipMemcpyAsync(p.flags, ctx->uncert, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (ffn_auto(ctx)) GN_HIP(hipMemcpyAsync(p.flags + ctx->max_batch, ctx->uncert_alt, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    else memset(p.flags + ctx->max_batch, 0, (size_t)B * sizeof(int32_t));
     GN_HIP(hipEventRecord(p.ev, s));
-    p.active = true; p.B = B; p.kpt_format = kpt_format; p.stride_q = stride_q; p.stride_r = stride_r; p.H = H; p.W = W; p.min_matches = min_matches;
+    p.active = true; p.level = ffn_auto(ctx) ? ctx->auto_level : -1; p.B = B; p.kpt_format = kpt_format; p.stride_q = stride_q; p.stride_r = stride_r; p.H = H; p.W = W; p.min_matches = min_matches;
     p.npad_run = ctx->npad_run; p.desc_q = desc_q; p.kpt_q = kpt_q; p.n_q = n_q; p.desc_r = desc_r; p.kpt_r = kpt_r; p.n_r = n_r; p.dem = dem;
     memcpy(p.K9, K9, sizeof p.K9); p.R = R; p.t = t; p.n_match = n_match; p.n_inliers = n_inliers; p.ok = ok;
     ctx->cert_slot ^= 1;

@@ -279,6 +279,8 @@ struct HeadArgs {
   float* rpart_c;           // [B][8][npad] row partials per column split: runner-up
   int32_t* uncert;          // [B] out: 0 certified, 1 a decision inside the margin, 2 the fp16-range guard tripped; nullptr = no certificate
   float cert_eps;           // bound on |P_this mode - P_exact| the certificate is stated for
+  int32_t* uncert_alt = nullptr;   // [B] out (optional): the same test for cert_eps_alt -- what the OTHER block-tail level's certificate would say about these
+  float cert_eps_alt = -1.f;       // scores (gn_set_ffn_products(0): the context weighs the two levels' re-run fractions against each other); 0 / 1
 };
 void launch_match_head(const HeadArgs& a, hipStream_t s);
 void launch_match_head_fused(const HeadArgs& a, hipStream_t s);

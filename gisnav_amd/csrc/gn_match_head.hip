@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void k_compact(HeadArgs a) {
   __syncthreads();
   // (the five-pass developer form keeps no runner-ups: with a certificate requested every pair that has matches to decide reports "uncertain")
   if (n0 < 2 || n1 < 2 || (a.ovf != nullptr && *a.ovf != 0u)) {  // kornia LightGlueMatcher._no_match; or the f16x2 domain guard tripped (gn_common.h)
-    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = (n0 < 2 || n1 < 2) ? 0 : 2; }
+    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = (n0 < 2 || n1 < 2) ? 0 : 2; if (a.uncert_alt) a.uncert_alt[b] = 0; }
     return;
   }
   if (tid == 0 && a.uncert) a.uncert[b] = 1;
+  if (tid == 0 && a.uncert_alt) a.uncert_alt[b] = 1;
   for (int i0 = 0; i0 < n0; i0 += 256) {
     const int i = i0 + tid;
     bool valid = false; int j = 0; float sc = 0.f;
@@ -538,8 +539,9 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   // gaps exceed twice the error) and stays above L.  (For filter_threshold >= 0.5 -- PoseNode's value -- (a) and (b) follow from (c): a
   // score above 0.5 e^eps leaves less than 0.5 e^-eps for every other entry of its row and column.)  Anything else sets `unc`.
   const bool cert = a.uncert != nullptr && a.cert_eps >= 0.f;
+  const bool cert2 = cert && a.uncert_alt != nullptr && a.cert_eps_alt >= 0.f;      // the same three tests for a second eps (HeadArgs::uncert_alt)
   const float Lth = a.threshold > 0.f ? logf(a.threshold) : -INFINITY;
-  int unc = 0;
+  int unc = 0, unc2 = 0;
   for (int j = tid; j < n1; j += 512) {
     float m = -INFINITY, sm = 0.f; int bi = 0x7fffffff; float m2 = -INFINITY;
     for (int p0 = 0; p0 < nparts; p0 += 16) {     // partials in increasing row order: a strict comparison keeps the lowest row on ties
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
     else {
       a.m1[ro + j] = bi; m1s[j] = bi;
       if (cert && m >= Lth - a.cert_eps && !(m - m2 > 2.f * a.cert_eps)) unc = 1;     // (b)
+      if (cert2 && m >= Lth - a.cert_eps_alt && !(m - m2 > 2.f * a.cert_eps_alt)) unc2 = 1;
     }
   }
   stamp(5);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   if (tid == 0) *base_s = 0;
   __syncthreads();
   if (nomatch || (a.ovf != nullptr && *a.ovf != 0u)) {
-    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = nomatch ? 0 : 2; }   // 2: an activation left the fp16 range -- nothing of this call can be certified
+    if (tid == 0) { a.n_match[b] = 0; if (a.uncert) a.uncert[b] = nomatch ? 0 : 2; if (a.uncert_alt) a.uncert_alt[b] = 0; }   // 2: an activation left the fp16 range -- nothing of this call can be certified
     return;
   }
   for (int ib = 0; ib < n0; ib += 512) {
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
         const float second = ld_dev(a.max0b + ro + i);
         if (best >= Lth - a.cert_eps && !(best - second > 2.f * a.cert_eps)) unc = 1;   // (a)
         if (fabsf(best - Lth) <= a.cert_eps) unc = 1;                                    // (c)
+        if (cert2 && ((best >= Lth - a.cert_eps_alt && !(best - second > 2.f * a.cert_eps_alt)) || fabsf(best - Lth) <= a.cert_eps_alt)) unc2 = 1;
       }
     }
     const unsigned long long bal = __ballot(valid);
@@ -613,6 +617,10 @@ __global__ __launch_bounds__(512) void k_head_fused(HeadArgs a) {
   if (a.uncert) {
     const int any = __syncthreads_or(unc);
     if (tid == 0) a.uncert[b] = (cert && any) ? 1 : 0;
+    if (a.uncert_alt) {
+      const int any2 = __syncthreads_or(unc2);
+      if (tid == 0) a.uncert_alt[b] = (cert2 && any2) ? 1 : 0;
+    }
   }
   stamp(6);
 }

@@ -232,9 +232,24 @@ class PoseEngine:
         weights, 0 it differed and was switched off, -1 not run yet / not applicable."""
         return int(self.lib.gn_fused_projection_status(self.ctx))
 
-    def set_ffn_products(self, products: int) -> None:
-        """gn_set_ffn_products: 3 (default, f32-accurate) or 2 (activations' fp16 high term only; run it under set_certify)."""
-        _lib.check(self.ctx, self.lib.gn_set_ffn_products(self.ctx, int(products)), "gn_set_ffn_products")
+    def set_ffn_products(self, products) -> None:
+        """gn_set_ffn_products: 3 (default, f32-accurate), 2 (activations' fp16 high term only; run it under set_certify), or "auto" (0): the level
+        follows the certificate -- calibrate_certify then measures eps for both levels, and under set_certify("rerun" / "deferred") the context runs on
+        two products only while that flags (at most 1 pair in 64) no more pairs than three products would.  Indices do not depend on the level."""
+        p = 0 if products in ("auto", 0) else int(products)
+        self._ffn_auto = p == 0
+        _lib.check(self.ctx, self.lib.gn_set_ffn_products(self.ctx, p), "gn_set_ffn_products")
+
+    def set_ffn_level_eps(self, eps_two: float, eps_three: float, level: int = 3) -> None:
+        """gn_set_ffn_level_eps: both levels' eps as an earlier calibrate_certify (same weights, same batch size) measured them, and the level to start on."""
+        _lib.check(self.ctx, self.lib.gn_set_ffn_level_eps(self.ctx, float(eps_two), float(eps_three), int(level)), "gn_set_ffn_level_eps")
+
+    def ffn_level(self) -> Dict[str, float]:
+        """gn_get_ffn_level: the level the next call runs on, the calibrated eps of both levels, and how many certified calls ran on each."""
+        lvl, e2, e3, buf = C.c_int32(0), C.c_float(0.0), C.c_float(0.0), (C.c_int64 * 4)()
+        _lib.check(self.ctx, self.lib.gn_get_ffn_level(self.ctx, C.byref(lvl), C.byref(e2), C.byref(e3), buf), "gn_get_ffn_level")
+        return {"level": int(lvl.value), "eps_two_products": float(e2.value), "eps_three_products": float(e3.value),
+                "calls_two_products": int(buf[0]), "calls_three_products": int(buf[1]), "switches": int(buf[2]), "automatic": bool(buf[3])}
 
     def calibrate_certify(self, inputs: dict, safety: float = 4.0, floor_eps: float = 1.0e-5) -> Dict[str, float]:
         """gn_calibrate_certify on staged inputs (the dict of stage_inputs / RecordStager.stage): measures max |P_mode - P_f32| over the deciding
@@ -246,7 +261,11 @@ class PoseEngine:
                                            _ptr(inputs.get("desc_r")), _ptr(inputs["kpt_r"]), _ptr(inputs["n_r"]), inputs["kpt_r"].shape[1],
                                            float(safety), float(floor_eps), C.byref(m), C.byref(e), self._stream())
         _lib.check(self.ctx, rc, "gn_calibrate_certify")
-        return {"measured": float(m.value), "eps": float(e.value), "safety": float(safety)}
+        lv = self.ffn_level()
+        d = {"measured": float(m.value), "eps": float(e.value), "safety": float(safety)}
+        if getattr(self, "_ffn_auto", False):      # set_ffn_products("auto"): both levels were measured; measured / eps are the three-product level's
+            d["eps_two_products"], d["eps_three_products"] = lv["eps_two_products"], lv["eps_three_products"]
+        return d
 
     def certify_stats(self, reset: bool = False) -> Dict[str, int]:
         buf = (C.c_int64 * 8)()

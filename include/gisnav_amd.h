@@ -143,8 +143,19 @@ int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32);
  * 11-bit activations, f32 accumulation: the arithmetic of the attention input projections, and the rounding the fp16 attention applies to q, k, v anyway) --
  * a third less matrix-pipe work.  The error of the assignment scores grows (gn_calibrate_certify measures it), so this setting is meant to run under the
  * margin certificate (gn_set_certify(2 / 3)), which makes the returned correspondence indices independent of the fast pass's arithmetic.  Small grids
- * (fewer than 256 tiles of 128 tokens) keep three products. */
+ * (fewer than 256 tiles of 128 tokens) keep three products.
+ * 0 = the level FOLLOWS THE CERTIFICATE (needs gn_set_certify(2 / 3) and a gn_calibrate_certify made under this setting, which measures eps for both
+ * levels; three products otherwise): every matcher call also evaluates the other level's certificate on its scores, the context counts over windows
+ * of >= 64 certified pairs how many pairs each level flags, and runs the next window on two products only when that would flag at most 1 pair in 64
+ * more than three products (a flagged pair costs an exact-f32 re-run, ~4 fast passes; the two-product pass saves ~7 % of one).  Starts on three
+ * products.  The returned indices do not depend on the level (both are certified against the same exact arithmetic); scores differ within eps. */
 int gn_set_ffn_products(gn_ctx* ctx, int products);
+/* The level the next call runs on (2 / 3), the eps calibrated for each (< 0: not calibrated), and out4 = {certified calls that ran on two products, on three
+ * products, level switches, 1 when the automatic setting is in effect} since gn_reset_certify_stats.  Any pointer may be NULL. */
+int gn_get_ffn_level(gn_ctx* ctx, int32_t* level, float* eps2, float* eps3, int64_t* out4);
+/* The two levels' eps and the level to start on, stated by the caller instead of measured (values a gn_calibrate_certify of the same weights and
+ * batch size returned earlier: a process that restarts need not repeat the calibration's exact-f32 pass). */
+int gn_set_ffn_level_eps(gn_ctx* ctx, float eps2, float eps3, int level);
 /* On bulk grids the block-tail kernel also computes the next block's attention input projection (one launch and one pass over the residual rows
  * less).  Every context proves that fused form against the separate launches on its own weights before using it: at the first forward call after
  * a weight (re)load both forms run on pseudo-random rows and their outputs are compared bit for bit (~60 ms, once); a difference switches the

@@ -160,6 +160,66 @@ def test_certified_indices_equal_the_oracle_on_every_weight_family(name, shape, 
         assert m0 == 0 and st["rerun_pairs"] == 0, row       # the bench's weights: nothing to re-run, the fast kernels' result stands
 
 
+@pytest.mark.parametrize("name,mode", [("margin_built", "rerun"), ("mid_margin", "rerun"), ("margin_built", "deferred"), ("mid_margin", "deferred")])
+def test_automatic_block_tail_level_follows_the_certificates_flags(name, mode):
+    """gn_set_ffn_products(0): eps is calibrated for both levels; the context starts on three products, evaluates both levels' certificates on every call's
+    scores and moves to two products after a window of 64 certified pairs only when that flags no more pairs than three products would.  Margin-built
+    (bench) weights: nothing is flagged on either level -> two products from the fifth 16-pair call on.  Mid-margin weights: two products would flag most
+    pairs -> it stays on three.  Either way, and whatever the level of a call, the certified indices are the oracle's (match(), synchronous certificate)
+    and the poses an exact-f32 context's (estimate() on two sub-batch streams, certificate resolved one call later)."""
+    from gisnav_amd.engine import PoseEngine
+    sd, _, th = _family(name)
+    pairs, cal_pairs, B, K = _pairs("16x1024")
+    eng = PoseEngine(0, max_batch=B, max_kpts=K, precision=HEADLINE, state_dict=sd, filter_threshold=th)
+    eng.set_ffn_products("auto")
+    cal = eng.calibrate_certify(eng.stage_inputs(cal_pairs), safety=SAFETY)
+    assert cal["eps_two_products"] >= cal["eps_three_products"] == cal["eps"] > 0.0, cal
+    assert eng.ffn_level()["level"] == 3            # (no certificate yet: three products)
+    inp = eng.stage_inputs(pairs)
+    levels, wrong = [], []
+    if mode == "rerun":
+        refs = _refs(name, "16x1024")
+        eng.set_certify("rerun")
+        eng.certify_stats(reset=True)
+        for _ in range(7):
+            levels.append(eng.ffn_level()["level"])
+            idx_c, n_c = _match(eng, inp)
+            wrong.append(_diff(idx_c, n_c, refs)[0])
+    else:
+        ref = PoseEngine(0, max_batch=B, max_kpts=K, precision="f32", state_dict=sd, filter_threshold=th)
+        want = {k: v.clone() for k, v in ref.estimate(ref.stage_inputs(pairs), K_MATRIX).items()}
+        torch.cuda.synchronize()
+        del ref
+        eng.set_substreams(2)
+        eng.set_certify("deferred")
+        eng.certify_stats(reset=True)
+        outs = [eng.alloc_outputs(B), eng.alloc_outputs(B)]
+        for i in range(8):
+            levels.append(eng.ffn_level()["level"])
+            eng.estimate(inp, K_MATRIX, out=outs[i % 2])
+        eng.flush()
+        torch.cuda.synchronize()
+        for o in outs:        # (calls 7 and 8: on two products for the margin-built weights)
+            wrong.append(sum(int(not torch.equal(o[k], want[k])) for k in ("n_match", "ok", "n_inliers", "R", "t")))
+        eng.set_certify("rerun")
+        eng.set_substreams(1)
+    lv = eng.ffn_level()
+    st = eng.certify_stats()
+    row = {"levels_of_the_calls": levels, "eps_two_products": cal["eps_two_products"], "eps_three_products": cal["eps_three_products"], "level_after": lv["level"],
+           "calls_on_two_products": lv["calls_two_products"], "calls_on_three_products": lv["calls_three_products"], "switches": lv["switches"],
+           "rerun_fraction": st["rerun_fraction"], "mismatches_per_call": wrong, "mode": mode}
+    print(name, row)
+    _report(f"automatic_level_16x1024_{name}_{mode}", row)
+    ok_auto = lv["automatic"]
+    del eng
+    assert ok_auto and levels[0] == 3, row
+    assert all(w == 0 for w in wrong), row
+    if name == "margin_built":
+        assert lv["level"] == 2 and levels[-1] == 2 and lv["calls_two_products"] >= 2 and lv["switches"] == 1 and st["rerun_pairs"] == 0, row
+    else:
+        assert lv["level"] == 3 and lv["calls_two_products"] == 0 and lv["switches"] == 0 and st["rerun_pairs"] > 0, row
+
+
 @pytest.mark.parametrize("name,shape", [("low_margin", "16x1024"), ("mid_margin", "16x1024"), ("default_init", "8x1024")])
 def test_exact_f32_mode_on_the_bulk_tables(name, shape):
     """GN_PREC_F32 had only ever been run on low- / mid-margin weights at 4 x 512 (1.9 k matches).  The bulk tables and the default-init family:

@@ -11,8 +11,8 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | grep '^{"metric' | tail -1 > $O/${TAG}_bench_n1.json
-# the profiling passes run the same certified configuration with the eps the full run calibrated (--certify-eps: no calibration pass, no self-check launches among the steps)
-EPS=$(python -c "import json;print(json.load(open('$O/${TAG}_bench_n1.json'))['precision_guarantee']['certificate']['eps'])")
+# the profiling passes run the same certified configuration with the eps (both block-tail levels' and the level the run settled on) the full run calibrated (--certify-eps: no calibration pass, no self-check launches among the steps)
+EPS=$(python -c "import json;print(json.load(open('$O/${TAG}_bench_n1.json'))['precision_guarantee']['certificate']['profile_eps_arg'])")
 rm -rf $O/${TAG}_prof && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --no-stream --substreams 1 --certify-eps $EPS > /dev/null 2>&1
 cp $(ls $O/${TAG}_prof/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats.csv
 rm -rf $O/${TAG}_prof
