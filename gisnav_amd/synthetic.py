@@ -84,7 +84,8 @@ def make_pair(pair_index: int, n_q: int = 1024, n_r: int = 1024, h: int = IMG_H,
     cam_pos = np.array([centre[0], centre[1], -height])  # camera above the tile (world z points "down")
     t = (-R @ cam_pos).reshape(3, 1)
 
-    z = dem[np.floor(kp_r[:, 1]).astype(int), np.floor(kp_r[:, 0]).astype(int)].astype(np.float64)
+    # (uniform(0, h) rounded to float32 can land on h itself -- one pair in a few thousand: the lookup clamps, the coordinate stays)
+    z = dem[np.minimum(np.floor(kp_r[:, 1]).astype(int), h - 1), np.minimum(np.floor(kp_r[:, 0]).astype(int), w - 1)].astype(np.float64)
     world = np.column_stack([kp_r.astype(np.float64), z])
     cam = world @ R.T + t.T
     uv = (cam[:, :2] / cam[:, 2:3]) * np.array([K_MATRIX[0, 0], K_MATRIX[1, 1]]) + np.array([K_MATRIX[0, 2], K_MATRIX[1, 2]])
