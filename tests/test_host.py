@@ -217,6 +217,38 @@ def test_late_round5_kernels_hold_their_operands_in_registers(tmp_path):
             assert meta["vgpr_count"] <= 256, (name, meta["vgpr_count"])
 
 
+def test_skinny_kernels_wait_for_their_lds_dma_rows_before_reading_them(tmp_path):
+    """the small-grid kernels stage their token rows with `global_load_lds_dwordx4` written in assembly and wait for them with a hand-counted
+    `s_waitcnt vmcnt(N)` = "everything but the N weight loads issued since" (gn_skinny.hip stage_wait).  That count is only right while the compiler leaves
+    exactly those loads between the DMA and the wait: a load it sank below the wait would make the wait too weak and the first ds_read would see rows that
+    have not landed.  Checked on the code that ships: walking every k_skinny_* kernel in program order, a staged group of DMA rows must have been retired
+    by a wait whose N does not exceed the vector-memory instructions issued since the group's last row, before any LDS read follows."""
+    ks = _disassemble_kernels(tmp_path, ["k_skinny_"])
+    checked = 0
+    for name, (_, ins) in ks.items():
+        if not any(op.startswith("global_load_lds") for op, _ in ins):
+            continue
+        outstanding, since, groups = False, 0, 0
+        for j, (op, args) in enumerate(ins):
+            if op.startswith("global_load_lds"):
+                if not outstanding:
+                    groups += 1
+                outstanding, since = True, 0
+            elif op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load", "global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "buffer_atomic")):
+                since += 1
+            elif op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", " ".join(args))
+                if m and outstanding and int(m.group(1)) <= since:
+                    outstanding = False
+            elif op.startswith(("ds_read", "ds_load")):
+                assert not outstanding, (name, j, "an LDS read follows LDS-DMA rows that no s_waitcnt has retired", since)
+            elif op in ("s_endpgm", "s_branch", "s_setpc_b64"):
+                outstanding, since = False, 0
+        assert groups >= 1 and not outstanding, (name, groups)
+        checked += 1
+    assert checked >= 6, sorted(ks)
+
+
 def test_product_path_has_no_cpu_fallback():
     from gisnav_amd import _lib
     from gisnav_amd.engine import PoseEngine
