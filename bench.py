@@ -508,7 +508,7 @@ def precision_guarantee(precision: str, cert=None) -> dict:
     keep = ("eps", "safety", "cpu_matches", "uncertified_index_mismatches", "certified_index_mismatches", "pairs", "pairs_flagged", "rerun_fraction", "f32_marginal_pairs")
     out["certified_tables"] = {k[len("certified_"):]: {f: v.get(f) for f in keep} for k, v in rep.items() if k.startswith("certified_") and isinstance(v, dict)}
     out["f32_evidence"] = {k[len("f32_"):]: v for k, v in rep.items() if k.startswith("f32_") and isinstance(v, dict)}
-    out["source"] = "tests/test_gpu_round6.py (asserted: certified = 0 mismatches and no wrong pair unflagged on every table; f32 = 0) + tools/f32_exactness_sweep.py"
+    out["source"] = "tests/test_gpu_round6.py (asserted: certified = 0 mismatches and no wrong pair unflagged on every table; f32 = 0 on those tables) + tools/f32_exactness_sweep.py (many weight sets; asserted: the exact-f32 mode differs from the CPU restatement only in pairs its own certificate marks as holding a decision within 1e-4, and the certified fast mode only where the f32 mode does)"
     if not out["same_build"]:
         out["warning"] = "the report was measured on another build than the library this run loaded: re-run `pytest -m gpu tests/test_gpu_round6.py` and copy gpurun_out/parity_r06.json"
     return out
