@@ -211,7 +211,7 @@ def certificate_block(eng, cal):
                 "switches": lv["switches"], "eps_two_products": cal["eps_two_products"], "eps_three_products": cal["eps_three_products"]},
             "profile_eps_arg": ("%r,%r,%d" % (cal["eps_three_products"], cal["eps_two_products"], lv["level"])) if auto else repr(cal["eps"]),
             "mode": "margin guard + exact-f32 re-run of the flagged pairs (gn_set_certify(2)); one stream synchronisation per call, inside the timed region",
-            "resolution": cal.get("resolution", "inside every call"),
+            "resolution": cal.get("resolution", "inside every call"), "eps_by_calibration_shape": cal.get("eps_by_calibration_shape"),
             "eps": cal["eps"], "eps_measured_max_dP": cal["measured"], "safety_factor": cal["safety"],
             "calls": st["calls"], "pairs": st["pairs"], "pairs_flagged_margin": st["flagged_margin"], "pairs_flagged_fp16_range": st["flagged_fp16_range"],
             "pairs_rerun_in_f32": st["rerun_pairs"], "rerun_fraction": round(st["rerun_fraction"], 6), "rerun_pairs_marginal_even_in_f32": st["f32_marginal_pairs"]}
@@ -258,6 +258,17 @@ def run_extra_ragged(local_rank, sd, batch, precision, steps, warmup, dev, lo=40
     kmax = ((int(max(nq.max(), nr.max())) + 127) // 128) * 128
     eng = PoseEngine(local_rank, max_batch=batch, max_kpts=kmax, precision=precision, state_dict=sd)
     cal = certify_on(eng, 1024, batch, precision, certify)
+    if cal is not None:
+        # eps belongs to the grid it was measured on (the kernel family follows the grid): a ragged stream runs several -- the padded call and the buckets --
+        # so it is measured on each of them and the LARGEST is stated for all
+        by_shape = {f"{batch}x1024": cal["eps"]}
+        for b, k in ((batch, kmax), (16, 1536), (8, 1536)):
+            c2 = eng.calibrate_certify(eng.stage_inputs([make_pair(910_000 + i, n_q=k, n_r=k) for i in range(b)]), safety=CERT_SAFETY)
+            by_shape[f"{b}x{k}"] = c2["eps"]
+            if c2["eps"] > cal["eps"]:
+                cal["eps"], cal["measured"] = c2["eps"], c2["measured"]
+        cal["eps_by_calibration_shape"] = {k: round(v, 7) for k, v in by_shape.items()}
+        eng.set_certify("rerun", eps=cal["eps"])
     pairs = [make_pair(500 + i, n_q=int(nq[i]), n_r=int(nr[i])) for i in range(batch)]
     inp = eng.stage_inputs(pairs)
     n_q = np.array([len(p.kp_q) for p in pairs]); n_r = np.array([len(p.kp_r) for p in pairs])
