@@ -5,7 +5,7 @@ f32 MFMA summation order differs from torch-CPU's, so exactness of the f32 mode 
 through (a) the exact-f32 mode and (b) the headline mode with the calibrated certificate in re-run mode, each against the oracle, and counts
 matches / index mismatches / flagged pairs.  Writes gpurun_out/f32_sweep_r06.json and merges the totals into gpurun_out/parity_r06.json.
 
-    python tools/f32_exactness_sweep.py [seeds=11] [pairs=16]
+    python tools/f32_exactness_sweep.py [seeds=11] [pairs=16] [block-tail products=2]
 """
 import json
 import os
@@ -88,7 +88,8 @@ def main():
             print(fam, "seed", s, {k: v for k, v in tot.items() if k != "eps"}, f"{time.time() - t0:.0f} s", flush=True)
         out["families"][fam] = tot
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "f32_sweep_r06.json"), "w") as f:
+    sfx = "_tail2" if products == 2 else ""       # (a second run on the two-product block tail adds its own keys; the f32 columns repeat)
+    with open(os.path.join(ROOT, "gpurun_out", f"f32_sweep_r06{sfx}.json"), "w") as f:
         json.dump(out, f, indent=1)
     path = os.path.join(ROOT, "gpurun_out", "parity_r06.json")
     rep = {}
@@ -98,8 +99,9 @@ def main():
     if rep.get("source_digest") != out["source_digest"]:
         rep = {"source_digest": out["source_digest"]}
     for fam, tot in out["families"].items():
-        rep[f"f32_sweep_16x1024_{fam}"] = {k: v for k, v in tot.items() if k.startswith(("f32_", "cpu_", "seeds", "pairs"))}
-        rep[f"certified_sweep_16x1024_{fam}"] = {"cpu_matches": tot["cpu_matches"], "uncertified_index_mismatches": tot["headline_uncertified_index_mismatches"],
+        if not sfx:
+            rep[f"f32_sweep_16x1024_{fam}"] = {k: v for k, v in tot.items() if k.startswith(("f32_", "cpu_", "seeds", "pairs"))}
+        rep[f"certified_sweep_16x1024_{fam}{sfx}"] = {"cpu_matches": tot["cpu_matches"], "uncertified_index_mismatches": tot["headline_uncertified_index_mismatches"],
                                                  "certified_index_mismatches": tot["headline_certified_index_mismatches"], "pairs": tot["pairs"],
                                                  "pairs_flagged": tot["headline_pairs_flagged"], "rerun_fraction": round(tot["headline_pairs_flagged"] / max(tot["pairs"], 1), 4),
                                                  "eps": f"{min(tot['eps'])} .. {max(tot['eps'])} (calibrated per weight set)", "safety": 4.0, "block_tail_partial_products": products}
