@@ -482,6 +482,59 @@ def test_mirrors_certify_by_themselves_in_the_fast_mode():
         assert res[HEADLINE][1] is not None and np.linalg.norm(res["f32"][1][0] - res[HEADLINE][1][0]) < 1e-9 and np.linalg.norm(res["f32"][1][1] - res[HEADLINE][1][1]) < 1e-6
 
 
+@pytest.mark.parametrize("products", [3, 2])
+def test_certified_matches_are_permutation_equivariant_at_the_bench_size(products):
+    """A size-independent property at BASELINE configs[2]'s full size (32 pairs x 1024 keypoints per side), on discriminating weights: re-ordering the
+    keypoints of either side re-orders the sums inside every attention row and every score panel, so the FAST arithmetic's scores move in their last
+    bits and near-threshold decisions flip (the uncertified difference is counted); the certified match sets must be the same set of (query keypoint,
+    reference keypoint) correspondences -- both are the exact arithmetic's -- except in pairs that are marginal even for the exact-f32 re-run
+    (a decision within 1e-4: there f32's own summation order decides; counted by the library, bounded here)."""
+    from gisnav_amd.engine import PoseEngine
+    sd, _, th = _family("mid_margin")
+    B, K = 32, 1024
+    pairs = [make_pair(71_000 + i, n_q=K - 3 * (i % 7), n_r=K - 5 * (i % 5)) for i in range(B)]
+    eng = PoseEngine(0, max_batch=B, max_kpts=K, precision=HEADLINE, state_dict=sd, filter_threshold=th)
+    eng.set_ffn_products(products)
+    eng.calibrate_certify(eng.stage_inputs([make_pair(72_000 + i, n_q=K, n_r=K - 24) for i in range(B)]), safety=SAFETY)
+    inp = eng.stage_inputs(pairs)
+    rs = np.random.default_rng(5)
+    nq, nr = inp["n_q"].cpu().numpy(), inp["n_r"].cpu().numpy()
+    perm_q = [rs.permutation(int(n)) for n in nq]
+    perm_r = [rs.permutation(int(n)) for n in nr]
+    shuf = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    for b in range(B):     # row i of the shuffled side = row perm[i] of the original
+        for side, perm in (("q", perm_q[b]), ("r", perm_r[b])):
+            ix = torch.from_numpy(perm).to(inp["kpt_q"].device)
+            shuf[f"desc_{side}"][b, : len(perm)] = inp[f"desc_{side}"][b, ix]
+            shuf[f"kpt_{side}"][b, : len(perm)] = inp[f"kpt_{side}"][b, ix]
+
+    def sets(idx, n, mapped):
+        out = []
+        for b in range(B):
+            m = idx[b, : int(n[b])]
+            out.append({(int(perm_q[b][q]), int(perm_r[b][c])) for q, c in m} if mapped else {(int(q), int(c)) for q, c in m})
+        return out
+
+    res = {}
+    for mode in ("flag", "rerun"):
+        eng.set_certify(mode)
+        eng.certify_stats(reset=True)
+        a = sets(*_match(eng, inp), mapped=False)
+        st_a = eng.certify_stats()
+        b_ = sets(*_match(eng, shuf), mapped=True)
+        st_b = eng.certify_stats()
+        res[mode] = {"differences": sum(len(x ^ y) for x, y in zip(a, b_)), "pairs_differing": sum(1 for x, y in zip(a, b_) if x != y), "matches": sum(len(x) for x in a),
+                     "rerun_pairs": st_b["rerun_pairs"], "f32_marginal_pairs": st_b["f32_marginal_pairs"], "first_call_rerun_pairs": st_a["rerun_pairs"]}
+    row = {"pairs": B, "keypoints_per_side": K, "block_tail_partial_products": products, "uncertified": res["flag"], "certified": res["rerun"]}
+    print(row)
+    _report("permutation_equivariance_32x1024_mid_margin" + ("_tail2" if products == 2 else ""), row)
+    del eng
+    assert res["rerun"]["matches"] > 1500 and res["rerun"]["rerun_pairs"] > 0, row           # (discriminating: some pairs were re-run)
+    assert res["rerun"]["pairs_differing"] <= res["rerun"]["f32_marginal_pairs"], row
+    if res["rerun"]["f32_marginal_pairs"] == 0:
+        assert res["rerun"]["differences"] == 0, row
+
+
 def test_bench_n2_launch_path_on_one_gpu():
     """the sharded path under the driver every round.  `python bench.py --gpus 2` spawns its two ranks itself (gloo, both on
     cuda:0): contiguous shards, the weight broadcast, barriers, max-over-ranks timing, the all-gather of result records."""
