@@ -535,6 +535,40 @@ def test_certified_matches_are_permutation_equivariant_at_the_bench_size(product
         assert res["rerun"]["differences"] == 0, row
 
 
+def test_certified_matches_transpose_when_the_two_sides_are_swapped():
+    """Second size-independent property at 32 x 1024, mid-margin weights: LightGlue is symmetric in its two inputs (shared weights, bidirectional cross
+    attention, row- and column-wise log-softmax, mutual check), so matching (reference, query) must return the transposed correspondences.  The two calls
+    run different sums in a different order (side 0 and side 1 trade places in every kernel); the certified sets must agree except in pairs that are
+    marginal even in exact f32."""
+    from gisnav_amd.engine import PoseEngine
+    sd, _, th = _family("mid_margin")
+    B, K = 32, 1024
+    pairs = [make_pair(73_000 + i, n_q=K - 3 * (i % 7), n_r=K - 5 * (i % 5)) for i in range(B)]
+    eng = PoseEngine(0, max_batch=B, max_kpts=K, precision=HEADLINE, state_dict=sd, filter_threshold=th)
+    eng.calibrate_certify(eng.stage_inputs([make_pair(72_000 + i, n_q=K, n_r=K - 24) for i in range(B)]), safety=SAFETY)
+    inp = eng.stage_inputs(pairs)
+    swp = dict(inp, desc_q=inp["desc_r"], kpt_q=inp["kpt_r"], n_q=inp["n_r"], desc_r=inp["desc_q"], kpt_r=inp["kpt_q"], n_r=inp["n_q"])
+    res = {}
+    for mode in ("flag", "rerun"):
+        eng.set_certify(mode)
+        eng.certify_stats(reset=True)
+        ia, na = _match(eng, inp)
+        ib, nb = _match(eng, swp)
+        st = eng.certify_stats()
+        a = [{(int(q), int(c)) for q, c in ia[b, : int(na[b])]} for b in range(B)]
+        t = [{(int(c), int(q)) for q, c in ib[b, : int(nb[b])]} for b in range(B)]
+        res[mode] = {"differences": sum(len(x ^ y) for x, y in zip(a, t)), "pairs_differing": sum(1 for x, y in zip(a, t) if x != y), "matches": sum(len(x) for x in a),
+                     "rerun_pairs": st["rerun_pairs"], "f32_marginal_pairs": st["f32_marginal_pairs"]}
+    row = {"pairs": B, "keypoints_per_side": K, "uncertified": res["flag"], "certified": res["rerun"]}
+    print(row)
+    _report("swap_symmetry_32x1024_mid_margin", row)
+    del eng
+    assert res["rerun"]["matches"] > 1500 and res["rerun"]["rerun_pairs"] > 0, row
+    assert res["rerun"]["pairs_differing"] <= res["rerun"]["f32_marginal_pairs"], row
+    if res["rerun"]["f32_marginal_pairs"] == 0:
+        assert res["rerun"]["differences"] == 0, row
+
+
 def test_bench_n2_launch_path_on_one_gpu():
     """the sharded path under the driver every round.  `python bench.py --gpus 2` spawns its two ranks itself (gloo, both on
     cuda:0): contiguous shards, the weight broadcast, barriers, max-over-ranks timing, the all-gather of result records."""
