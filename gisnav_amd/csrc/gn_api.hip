@@ -1313,7 +1313,11 @@ int gn_load_tensor(gn_ctx* ctx, const char* name_c, const float* host, const int
   } else {
     return fail(ctx, GN_ERR_NAME, "unknown tensor " + name);
   }
-  if (rc == GN_OK) { ctx->loaded[name] = true; ctx->fused_proj_pending = true; }
+  if (rc == GN_OK) {
+    ctx->loaded[name] = true; ctx->fused_proj_pending = true;
+    // a calibration belongs to the weights it was measured on: the automatic block-tail level goes back to "not calibrated" (three products, cert_eps)
+    ctx->cert_eps_lvl[0] = ctx->cert_eps_lvl[1] = -1.f; ctx->auto_level = 3; ctx->auto_pairs = ctx->auto_wide = ctx->auto_narrow = 0;
+  }
   return rc;
 }
 

@@ -148,7 +148,8 @@ int gn_set_certify(gn_ctx* ctx, int mode, float eps, float eps_f32);
  * levels; three products otherwise): every matcher call also evaluates the other level's certificate on its scores, the context counts over windows
  * of >= 64 certified pairs how many pairs each level flags, and runs the next window on two products only when that would flag at most 1 pair in 64
  * more than three products (a flagged pair costs an exact-f32 re-run, ~4 fast passes; the two-product pass saves ~7 % of one).  Starts on three
- * products.  The returned indices do not depend on the level (both are certified against the same exact arithmetic); scores differ within eps. */
+ * products.  The returned indices do not depend on the level (both are certified against the same exact arithmetic); scores differ within eps.
+ * gn_load_tensor discards the two levels' calibration (three products until gn_calibrate_certify / gn_set_ffn_level_eps is called again). */
 int gn_set_ffn_products(gn_ctx* ctx, int products);
 /* The level the next call runs on (2 / 3), the eps calibrated for each (< 0: not calibrated), and out4 = {certified calls that ran on two products, on three
  * products, level switches, 1 when the automatic setting is in effect} since gn_reset_certify_stats.  Any pointer may be NULL. */

@@ -220,6 +220,25 @@ def test_automatic_block_tail_level_follows_the_certificates_flags(name, mode):
         assert lv["level"] == 3 and lv["calls_two_products"] == 0 and lv["switches"] == 0 and st["rerun_pairs"] > 0, row
 
 
+def test_a_weight_reload_discards_the_two_levels_calibration(state_dict_np):
+    """A calibration belongs to the weights it was measured on: gn_load_tensor puts the automatic block-tail level back to "not calibrated" (three products,
+    the single stated eps); gn_set_ffn_level_eps states both eps again without the calibration pass."""
+    from gisnav_amd.engine import PoseEngine
+    eng = PoseEngine(0, max_batch=16, max_kpts=1024, precision=HEADLINE, state_dict=state_dict_np)
+    eng.set_ffn_products("auto")
+    cal = eng.calibrate_certify(eng.stage_inputs(_pairs("16x1024")[1]), safety=SAFETY)
+    eng.set_certify("rerun")
+    lv = eng.ffn_level()
+    assert lv["automatic"] and lv["eps_two_products"] == cal["eps_two_products"] > 0.0, lv
+    eng.load_state_dict(state_dict_np)
+    lv = eng.ffn_level()
+    assert not lv["automatic"] and lv["level"] == 3 and lv["eps_two_products"] < 0.0 and lv["eps_three_products"] < 0.0, lv
+    eng.set_ffn_level_eps(cal["eps_two_products"], cal["eps_three_products"], level=2)
+    lv = eng.ffn_level()
+    assert lv["automatic"] and lv["level"] == 2, lv
+    del eng
+
+
 @pytest.mark.parametrize("name,shape", [("low_margin", "16x1024"), ("mid_margin", "16x1024"), ("default_init", "8x1024")])
 def test_exact_f32_mode_on_the_bulk_tables(name, shape):
     """GN_PREC_F32 had only ever been run on low- / mid-margin weights at 4 x 512 (1.9 k matches).  The bulk tables and the default-init family:
