@@ -779,6 +779,17 @@ def main() -> None:
     fused_status = eng.fused_projection_status()
     cert_main = certificate_block(eng, cert_cal)
 
+    # what the block tail of THIS run computed in (the `dtype` text names the three-product form; the automatic level may have chosen two)
+    tail_note = ""
+    if args.precision.startswith("f16x2"):
+        lvl = (cert_main or {}).get("block_tail_level")
+        two = lvl["certified_calls_on_two_products"] if lvl else (1 if ffn_products == 2 else 0)
+        tot = (lvl["certified_calls_on_two_products"] + lvl["certified_calls_on_three_products"]) if lvl else 1
+        if two:
+            tail_note = (f" || BLOCK TAIL (ffn.0 -> LayerNorm -> GELU -> ffn.3 with out_proj folded in) in this run: TWO partial products -- the activations' fp16 high "
+                         f"term x the 22-bit weights, f32 accumulate, the arithmetic of the attention input projections -- in {two} of {tot} certified calls"
+                         + (": the level the margin certificate chose (gn_set_ffn_products(0), DESIGN 10.2)" if lvl else " (gn_set_ffn_products(2))")
+                         + "; the correspondence indices are certified against the exact-f32 arithmetic on either level")
     n_ok_all = gdist.sum_over_ranks(float(out["ok"].sum().item()), dev)
     n_match_mean = float(out["n_match"].float().mean().item())
     # the synthetic pairs are built so that every one yields a pose: a step that produced (almost) none has run a broken hot path, and its time is not a measurement
@@ -899,7 +910,7 @@ def main() -> None:
                                         "partial products, f32 accumulate; fp16-range guard active); attention INPUT projections (q, k, v: 18 of 66 launches) on 2 partial "
                                         "products -- the fp16 high term of the activations (11 bits) times the 22-bit weights, one rounding more than half(fp32 Linear(x)); "
                                         "their outputs are rounded to fp16 for the attention either way (10.5 % of the q/k/v values move by one fp16 ulp, DESIGN 10.3) --; "
-                                        "fp16 MFMA attention (q, k, v, p rounded to fp16 like the reference's CUDA SDPA; f32 softmax / accumulate)"}[args.precision],
+                                        "fp16 MFMA attention (q, k, v, p rounded to fp16 like the reference's CUDA SDPA; f32 softmax / accumulate)"}[args.precision] + tail_note,
             "precision_guarantee": precision_guarantee(args.precision, cert_main),
             "data": "synthetic",
             "inputs_resident": True,
